@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""bench.py -- pooled-lookups/sec + achieved HBM GB/s of the embedding-lookup hot path.
+
+    python bench.py --gpus 1 --steps K --warmup W          (default: N=1, finishes in minutes)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch of synthetic input: the fused multi-table
+EmbeddingBag(sum) lookup (libpimemb.so, HIP) for the 26 Criteo-Kaggle tables, dim 16 fp32,
+B = 39292 bags per table, one index per bag (BASELINE.json configs[1], SURVEY.md section 8 row D "C2").
+Inputs are resident in HBM before the timed region; NBATCH distinct index batches and output
+buffers are rotated so a step never re-reads the previous step's rows out of the 256 MiB
+Infinity Cache (working set per rotation > 1 GB).
+
+N > 1 (one process per GPU, RCCL): tables are sharded by table id across ranks; each rank owns B
+samples; per step: all_to_all indices in -> local fused lookup -> all_to_all pooled rows out
+(SURVEY.md section 8 row E).  Weak scaling: B per rank is fixed, so global batch = N * B.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--batch", type=int, default=None, help="bags per table per rank (default 39292)")
+    ap.add_argument("--nbatch", type=int, default=8, help="distinct index batches rotated through")
+    ap.add_argument("--index-dist", choices=["uniform", "zipf"], default="uniform")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    return ap.parse_args()
+
+
+def make_tables_on_gpu(torch, eng, rows_list, dim, device, seed=0, keep_host=False):
+    """W_t ~ U(-sqrt(1/N_t), sqrt(1/N_t)), generated on the GPU and handed to the engine
+    device-to-device (no 2 GB host round trip)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    host = []
+    for t, n in enumerate(rows_list):
+        a = float(np.sqrt(1.0 / n))
+        w = torch.empty((n, dim), dtype=torch.float32, device=device)
+        w.uniform_(-a, a, generator=g)
+        eng.load_table(t, w)
+        if keep_host:
+            host.append(w.cpu().numpy())
+        del w
+    torch.cuda.empty_cache()
+    return host
+
+
+def make_batches(pel, rows_list, B, nbatch, dist, seed=1):
+    rng = np.random.default_rng(seed)
+    gen = pel.workloads.uniform_indices if dist == "uniform" else pel.workloads.zipf_indices
+    batches = []
+    off = pel.workloads.fixed_offsets(B, 1)
+    for _ in range(nbatch):
+        batches.append(([gen(rng, n, B) for n in rows_list], [off] * len(rows_list)))
+    return batches
+
+
+def cpu_baseline(pel, host_tables, batch, seconds):
+    """The oracle (kind "port": scalar C restatement, 1 thread) timed on this host on a bounded
+    sample of the same workload: whole batches of the C2 shape until ~`seconds` have elapsed."""
+    from oracle import oracle
+    idx, off = batch
+    oracle.c_lookup_tables(host_tables, idx, off)      # warm
+    n, t0 = 0, time.perf_counter()
+    while True:
+        oracle.c_lookup_tables(host_tables, idx, off)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 2000:
+            break
+    lookups = n * sum(o.shape[0] for o in off)
+    return {"value": lookups / el, "unit": "pooled-lookups/s", "cores": 1, "kind": "port",
+            "sample": f"{n} batches of the bench workload (26 tables x {off[0].shape[0]} bags, L=1) "
+                      f"through oracle/emb_oracle.c in {el:.1f} s, host has {os.cpu_count()} cpus"}
+
+
+def run_single(args):
+    import torch
+    import pim_embedding_lookup_amd as pel
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    rows_list = pel.workloads.KAGGLE_ROWS
+    dim = pel.workloads.KAGGLE_DIM
+    B = args.batch or pel.workloads.KAGGLE_BATCH
+    T = len(rows_list)
+    eng = pel.EmbeddingEngine(device=0, max_tables=T)
+    want_cpu = not args.no_cpu_baseline
+    host_tables = make_tables_on_gpu(torch, eng, rows_list, dim, dev, keep_host=want_cpu)
+    batches = make_batches(pel, rows_list, B, args.nbatch, args.index_dist)
+
+    plans = []
+    for idx, off in batches:
+        d_idx = [torch.from_numpy(i.view(np.int32)).to(dev) for i in idx]
+        d_off = [torch.from_numpy(o.view(np.int32)).to(dev) for o in off]
+        d_out = [torch.empty((B, dim), dtype=torch.float32, device=dev) for _ in range(T)]
+        plans.append(eng.plan(list(range(T)), d_idx, d_off, d_out))
+    alg_bytes, n_bags, n_idx = plans[0].bytes()
+
+    stream = torch.cuda.current_stream(dev)
+    sh = stream.cuda_stream
+    for i in range(args.warmup):
+        plans[i % len(plans)].launch(sh)
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for i in range(args.steps):
+        plans[i % len(plans)].launch(sh)
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    kernel_us = dev_ms * 1000.0 / args.steps          # avg launch duration on the launch stream
+
+    # parity spot check of what was just timed (one table of the last batch) against the oracle
+    result = {
+        "metric": "pooled-lookups/sec + achieved HBM GB/s, 26-table dim-16 Kaggle, 1/2/4/8 GPU",
+        "value": args.steps * n_bags / wall,
+        "unit": "pooled-lookups/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": wall * 1000.0 / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "C2: 26 Criteo-Kaggle tables, dim 16 fp32, B=%d bags/table, L=1, "
+                               "u32 indices+offsets, %s indices, %d rotating batches" %
+                               (B, args.index_dist, len(plans)),
+                   "tables": T, "dim": dim, "bags_per_table": B, "pooling": 1,
+                   "table_bytes": eng.stats()["table_bytes"], "parallelism": "single"},
+        "roofline": {"bound": "hbm", "achieved": alg_bytes / (kernel_us * 1e-6) / 1e9,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": alg_bytes / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                     "traffic": None, "kernel_us": kernel_us, "algorithmic_bytes": alg_bytes},
+    }
+    if want_cpu:
+        result["cpu_baseline"] = cpu_baseline(pel, host_tables, batches[0], args.cpu_seconds)
+    print(json.dumps(result))
+    for p in plans:
+        p.destroy()
+    eng.close()
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        from importlib import import_module
+        import_module("pim-embedding-lookup_amd.dist_bench").run(args, HBM_PEAK_GBS)
+    else:
+        run_single(args)
+
+
+if __name__ == "__main__":
+    main()

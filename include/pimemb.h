@@ -1,0 +1,229 @@
+/*
+ * pimemb.h -- C ABI of the MI355X-native embedding-lookup engine (libpimemb.so).
+ *
+ * Drop-in boundary for the ONE hot path of UBC-ECE-Sasha/PIM-Embedding-Lookup: the multi-table
+ * EmbeddingBag(sum) lookup that the reference offloads to UPMEM DPUs behind `populate_mram` /
+ * `lookup` (upmem/include/emb_host.h:136, :234; built into emblib.so by upmem/Makefile:122-124).
+ * Plain pointers and sizes only: no torch, no C++ types.  All functions are `extern "C"`.
+ *
+ * Two groups of entry points:
+ *   (1) the runtime-shaped native API `emb_*` -- shapes are arguments, errors are return codes
+ *       (the reference bakes NR_TABLES/NR_COLS/MAX_NR_BATCHES/MAX_INDICES_PER_BATCH in with -D,
+ *       upmem/Makefile:69-81, and exit()s on error, emb_host.h:87-90,157);
+ *   (2) the two reference signatures, byte-for-byte, so existing callers of emblib.so relink
+ *       unchanged: `populate_mram`, `lookup` (+ `emb_configure` replacing the -D macros).
+ *
+ * Paths cited as upmem/... are relative to the reference checkout.
+ */
+#ifndef PIMEMB_H
+#define PIMEMB_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------ */
+/* status codes (the reference has none: DPU_ASSERT aborts, emb_host.h:157; lookup returns 0)  */
+/* ------------------------------------------------------------------------------------------ */
+#define EMB_OK 0
+#define EMB_ERR_INVALID (-1)     /* bad argument (null pointer, unknown table, bad dtype/dim ...) */
+#define EMB_ERR_NOMEM (-2)       /* host or HBM allocation failed (replaces enomem(), emb_host.h:87) */
+#define EMB_ERR_DEVICE (-3)      /* HIP runtime error, text in emb_last_error() */
+#define EMB_ERR_UNSUPPORTED (-4) /* e.g. row bytes not a multiple of 16 or wider than 1 KiB */
+#define EMB_ERR_RANGE (-5)       /* emb_validate_inputs found an out-of-range index / bad offsets */
+
+/* element type of a table as it sits in HBM; pooled output is always fp32 [bag][dim]
+ * (emb_host.h:210 writes float final_results[k*NR_COLS + j]) */
+typedef enum emb_dtype {
+    EMB_F32 = 0,     /* fp32 rows, fp32 accumulate: nn.EmbeddingBag(sum) parity target */
+    EMB_F16 = 1,     /* fp16 rows, fp32 accumulate (BASELINE config C5) */
+    EMB_FIXED32 = 2  /* int32 x1e9 fixed point, int32 wrap-around accumulate, out = (float)acc/1e9:
+                        the reference's own arithmetic, emb_dpu_lookup.c:114 + emb_host.h:210 */
+} emb_dtype;
+
+/* width of indices AND offsets: uint32 at the reference ABI (emb_host.h:234), int64 at torch's */
+typedef enum emb_index_type { EMB_IDX_U32 = 0, EMB_IDX_I64 = 1 } emb_index_type;
+
+/* where caller buffers live */
+typedef enum emb_memspace {
+    EMB_MEM_HOST = 0,   /* host pointers: the engine copies in/out (reference behaviour) */
+    EMB_MEM_DEVICE = 1  /* HBM pointers on the engine's GPU: zero-copy, nothing leaves the device */
+} emb_memspace;
+
+typedef struct emb_engine emb_engine; /* opaque; replaces the global `struct dpu_set_t *dpu_set`,
+                                         emb_host.h:33 */
+typedef struct emb_plan emb_plan;     /* opaque; a prepared multi-table lookup (descriptors in HBM) */
+
+typedef struct emb_config {
+    int32_t device;      /* HIP device ordinal; -1 = current device */
+    uint32_t max_tables; /* table ids are 0 .. max_tables-1 (NR_TABLES, upmem/Makefile:69-81) */
+    uint32_t flags;      /* reserved, 0 */
+} emb_config;
+
+/*
+ * One table's share of a batched lookup -- what emb_host.h:234 passes as indices[t], offsets[t],
+ * final_results[t], with the lengths made explicit (the reference always sends the compile-time
+ * maxima, emb_host.h:282-283).
+ *   offsets[b] = first position of bag b in `indices`; bag b ends at offsets[b+1]; the LAST bag
+ *   ends at n_indices (emb_dpu_lookup.c:109-110; torch include_last_offset=False).
+ *   Empty bag -> zeros (emb_dpu_lookup.c:108).  Duplicate indices are summed each time.
+ *   offsets == NULL with fixed_pooling = L > 0 means offsets[b] = b*L (load_generator.c:88).
+ *   pooled: float[n_bags][dim], row-major (emb_host.h:210).
+ */
+typedef struct emb_lookup_desc {
+    uint32_t table_id;
+    uint32_t fixed_pooling;
+    const void *indices; /* uint32[n_indices] or int64[n_indices] */
+    const void *offsets; /* uint32[n_bags] or int64[n_bags] (same width as indices), or NULL */
+    uint64_t n_indices;
+    uint64_t n_bags;
+    float *pooled;
+} emb_lookup_desc;
+
+/* counters + stage times; the six stage fields mirror dpu_runtime_totals (emb_host.h:41-48) and the
+ * six latencies lookup() prints when latency_print == 1 (emb_host.h:395-402) */
+typedef struct emb_stats {
+    uint64_t n_lookup_calls;     /* emb_lookup + emb_lookup_batched + emb_plan_launch + lookup() */
+    uint64_t n_kernel_launches;
+    uint64_t n_bags;             /* pooled (table, bag) outputs produced */
+    uint64_t n_indices;          /* rows gathered */
+    uint64_t table_bytes;        /* HBM held by tables */
+    double us_copy_in_indices;   /* "Indices and offsets copying latency" */
+    double us_copy_in_lengths;   /* "Query copying latency" (descriptor upload here) */
+    double us_launch;            /* "Dpu launch latency" (kernel, host-synchronous paths only) */
+    double us_copy_out;          /* "Results copy latency" */
+    double us_post_process;      /* "Callback prep latency" -- 0: conversion is fused in the kernel */
+    double us_sync;              /* "DPU sync latency" */
+} emb_stats;
+
+/* ------------------------------------------------------------------------------------------ */
+/* (1) native API                                                                              */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Thread-local text of the last error returned on this thread ("" if none). */
+const char *emb_last_error(void);
+
+/* Library / build identification, e.g. "pimemb 0.1 gfx950". */
+const char *emb_version(void);
+
+/* Create an engine on one GPU.  Replaces the first-call dpu_alloc + dpu_load (emb_host.h:155-160). */
+int emb_create(const emb_config *cfg, emb_engine **out);
+
+/* Free every table and workspace.  The reference has no destroy function (emb_host.h:33). */
+int emb_destroy(emb_engine *e);
+
+/* Upload one whole table, row-major [nr_rows][dim] of `dtype`, into HBM (synchronous copy, like
+ * DPU_XFER_DEFAULT at emb_host.h:173).  Replaces NR_COLS populate_mram calls and the dead
+ * row->column split alloc_buffers (emb_host.h:101-122).  Re-loading a table id replaces it. */
+int emb_load_table(emb_engine *e, uint32_t table_id, uint64_t nr_rows, uint32_t dim, emb_dtype dtype,
+                   const void *rows, emb_memspace space);
+
+/* Allocate a table without filling it (for emb_load_table_column / device-side initialisation). */
+int emb_alloc_table(emb_engine *e, uint32_t table_id, uint64_t nr_rows, uint32_t dim, emb_dtype dtype);
+
+/* Upload ONE column of an EMB_FIXED32 table -- populate_mram's unit of transfer
+ * (emb_host.h:136,167-173: one int32[nr_rows] slice per (table, col)). */
+int emb_load_table_column(emb_engine *e, uint32_t table_id, uint32_t col, const int32_t *column,
+                          uint64_t nr_rows);
+
+/* HBM address / shape of a loaded table (for zero-copy initialisation or inspection). */
+int emb_table_info(emb_engine *e, uint32_t table_id, void **device_rows, uint64_t *nr_rows,
+                   uint32_t *dim, emb_dtype *dtype);
+
+/* The north star's lookup(table_id, offsets, indices) -> pooled_rows, one table.
+ * `stream` is a hipStream_t (NULL = the default stream).  With EMB_MEM_HOST the call copies in,
+ * runs and copies out synchronously; with EMB_MEM_DEVICE it only enqueues work on `stream`. */
+int emb_lookup(emb_engine *e, uint32_t table_id, const void *indices, uint64_t n_indices,
+               const void *offsets, uint64_t n_bags, float *pooled, emb_index_type itype,
+               emb_memspace space, void *stream);
+
+/* All tables in ONE fused kernel launch -- the counterpart of lookup() at emb_host.h:234, which
+ * serves every table per call.  descs: host array of n_descs entries (any subset/order of tables,
+ * a table may appear more than once). */
+int emb_lookup_batched(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs,
+                       emb_index_type itype, emb_memspace space, void *stream);
+
+/* Prepared lookup over DEVICE buffers: descriptors are resolved and uploaded once, every launch is
+ * then a single kernel enqueue (graph-capturable: no allocation, copy or sync inside). */
+int emb_plan_create(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs,
+                    emb_index_type itype, emb_plan **out);
+int emb_plan_launch(emb_plan *p, void *stream);
+int emb_plan_destroy(emb_plan *p);
+/* Algorithmic bytes one launch of the plan moves:
+ * sum_t n_idx*(dim*elem + idx) + n_bags*off + n_bags*dim*4. */
+int emb_plan_bytes(const emb_plan *p, uint64_t *algorithmic_bytes, uint64_t *n_bags,
+                   uint64_t *n_indices);
+/* Time `iters` back-to-back launches with HIP events on `stream` after `warmup` untimed ones;
+ * *avg_us = mean device time per launch. */
+int emb_plan_time(emb_plan *p, void *stream, uint32_t warmup, uint32_t iters, float *avg_us);
+
+/* Debug-only input check (the reference never checks: an out-of-range index is a wild MRAM read,
+ * emb_dpu_lookup.c:113).  Counts indices >= nr_rows and non-monotone / out-of-range offsets over
+ * DEVICE or HOST buffers; returns EMB_ERR_RANGE if *n_bad > 0. */
+int emb_validate_inputs(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs,
+                        emb_index_type itype, emb_memspace space, uint64_t *n_bad);
+
+int emb_get_stats(emb_engine *e, emb_stats *out);
+int emb_reset_stats(emb_engine *e);
+
+/* Device-memory helpers so callers without a HIP binding (ctypes, cgo, JNI) can keep inputs and
+ * outputs resident in HBM. */
+int emb_device_alloc(emb_engine *e, size_t bytes, void **out);
+int emb_device_free(emb_engine *e, void *ptr);
+int emb_copy_to_device(emb_engine *e, void *dst_device, const void *src_host, size_t bytes);
+int emb_copy_to_host(emb_engine *e, void *dst_host, const void *src_device, size_t bytes);
+int emb_memset_device(emb_engine *e, void *dst_device, int value, size_t bytes);
+int emb_synchronize(emb_engine *e, void *stream);
+int emb_device_of(emb_engine *e, int32_t *device);
+
+/* ------------------------------------------------------------------------------------------ */
+/* (2) reference-compatible entry points (same names, argument meaning and return values)      */
+/* ------------------------------------------------------------------------------------------ */
+
+struct dpu_set_t; /* opaque here; the reference returns its global DPU set, emb_host.h:182 */
+
+/* emb_host.h:41-48 */
+typedef struct dpu_runtime_totals {
+    double execution_time_prepare;
+    double execution_time_populate_copy_in;
+    double execution_time_copy_in;
+    double execution_time_copy_out;
+    double execution_time_aggregate_result;
+    double execution_time_launch;
+} dpu_runtime_totals;
+
+/* Runtime replacement for -DNR_TABLES -DNR_COLS -DMAX_NR_BATCHES -DMAX_INDICES_PER_BATCH
+ * (upmem/Makefile:69-81).  If never called, the same-named environment variables are read on the
+ * first populate_mram (run.sh:40-45 exports exactly these).  Calling it again after tables were
+ * loaded drops them (a reference rebuild does the same). */
+int emb_configure(uint32_t nr_tables, uint32_t nr_cols, uint32_t max_nr_batches,
+                  uint32_t max_indices_per_batch);
+
+/* emb_host.h:136.  Uploads int32 fixed-point column `col` of table `table_id` (nr_rows entries).
+ * First call creates the process-global engine (emb_host.h:155-160).  `runtime` may be NULL
+ * (load_generator.c:34); if not, execution_time_populate_copy_in accumulates milliseconds.
+ * Returns the engine handle as the opaque pointer lookup() expects; NULL on error. */
+struct dpu_set_t *populate_mram(uint32_t table_id, uint64_t nr_rows, uint32_t col,
+                                int32_t *table_data, dpu_runtime_totals *runtime);
+
+/* emb_host.h:234.  indices[t]: uint32[MAX_INDICES_PER_BATCH*MAX_NR_BATCHES]; offsets[t]:
+ * uint32[MAX_NR_BATCHES] bag starts (last bag runs to INDICES_LEN, emb_dpu_lookup.c:109);
+ * final_results[t]: float[MAX_NR_BATCHES*NR_COLS] row-major [bag][col] (emb_host.h:210), all HOST
+ * pointers owned by the caller.  Synchronous.  latency_print == 1 prints the six stage latencies
+ * (emb_host.h:395-402).  Always returns NULL like the reference (emb_host.h:403); on error the text
+ * is in emb_last_error() and final_results is untouched. */
+int32_t *lookup(uint32_t **indices, uint32_t **offsets, float **final_results,
+                void *dpu_set_ptr_untyped, int64_t latency_print);
+
+/* The engine behind the compat entry points (NULL before the first populate_mram). */
+emb_engine *emb_compat_engine(void);
+/* Tear the process-global compat engine down (tests; the reference never frees it). */
+int emb_compat_reset(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIMEMB_H */

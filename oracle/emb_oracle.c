@@ -1,0 +1,217 @@
+/*
+ * emb_oracle.c -- CPU ORACLE for the embedding-lookup hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is the checker, never the product: only tests/, __graft_entry__.smoke() and
+ * bench.py's `cpu_baseline` leg may build, load or call it.  The shipped library
+ * (pim-embedding-lookup_amd/csrc) has no CPU path and never links this file.
+ *
+ * What it restates (reference = /root/reference, paths relative to it):
+ *   - bag bounds, "last bag runs to indices_len", empty bag = 0, duplicates summed:
+ *       upmem/src/dpu/emb_dpu_lookup.c:106-116
+ *   - the int32 wrap-around accumulate of one (table, column) DPU:
+ *       upmem/src/dpu/emb_dpu_lookup.c:108,112-114
+ *   - fixed-point -> float conversion and the [bag][col] output layout:
+ *       upmem/include/emb_host.h:207-212  (final[k*C+j] = (float)tmp[j][k] / pow(10,9))
+ *   - row-major table indexing `index*nr_cols + t` and the acceptance tolerance
+ *       |out*1e9 - sum| <= 1000:  upmem/src/load_generator.c:40-65 (:54, :58)
+ *   - the fp32 path the north star names as the parity target, nn.EmbeddingBag(mode="sum"):
+ *       out[b,:] = sum_{p in [off[b], off[b+1])} W[idx[p],:], accumulated in index order,
+ *       the last bag ending at n_idx (torch include_last_offset=False).  The reference only
+ *       names this call on its CLI lines (README.md:6,10,14; upmem/run.sh:72-82,111-121);
+ *       the Python that makes it lives in empty submodules (.gitmodules:7-12).
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - The reference C cannot be built here (UPMEM SDK + PIM-common submodule absent), so no
+ *     reference-binary outputs exist; the reference ships no asserting test for this path.
+ *   - Pinned against (1) the reference's one known-answer vector (upmem/c_test.py:40,55-57 ->
+ *     every bag = [10,20,...,80]) and (2) fixtures generated in the build container from
+ *     torch 2.10 CPU torch.nn.functional.embedding_bag(mode="sum"), the third-party routine the
+ *     north star names (tests/golden/gen_golden.py, fixtures committed under tests/golden/).
+ *
+ * Quirks of the DPU program deliberately NOT restated: the
+ * writeback that drops the last bag for odd nr_batches (emb_dpu_lookup.c:118-123) and the
+ * unsynchronised tasklet writeback.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- index helpers: the C ABI of the reference uses uint32 (emb_host.h:234), torch uses int64 ---- */
+static inline uint64_t ld_index(const void *p, int is64, uint64_t i) {
+    return is64 ? (uint64_t)((const int64_t *)p)[i] : (uint64_t)((const uint32_t *)p)[i];
+}
+
+/* end of bag b: offsets[b+1], or n_idx for the last bag (emb_dpu_lookup.c:109-110) */
+static inline uint64_t bag_end(const void *offsets, int is64, uint64_t b, uint64_t n_bags,
+                               uint64_t n_idx) {
+    return (b + 1 < n_bags) ? ld_index(offsets, is64, b + 1) : n_idx;
+}
+
+/* IEEE binary16 -> binary32, exact (gcc 11 on this image has no _Float16 for x86-64) */
+static inline float half_to_float(uint16_t h) {
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1fu;
+    uint32_t man = h & 0x3ffu;
+    uint32_t bits;
+    if (exp == 0) {
+        if (man == 0) {
+            bits = sign;
+        } else { /* subnormal: normalise */
+            int e = -1;
+            do {
+                man <<= 1;
+                e++;
+            } while (!(man & 0x400u));
+            man &= 0x3ffu;
+            bits = sign | ((uint32_t)(127 - 15 - e) << 23) | (man << 13);
+        }
+    } else if (exp == 31) {
+        bits = sign | 0x7f800000u | (man << 13);
+    } else {
+        bits = sign | ((exp + 127 - 15) << 23) | (man << 13);
+    }
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+
+/*
+ * fp32 EmbeddingBag(sum).  table: row-major [nr_rows][dim] fp32.  out: [n_bags][dim] fp32.
+ * Accumulation is strictly in index order starting from +0.0f, one fp32 add per gathered
+ * element -- the order a sequential CPU EmbeddingBag uses and the order the HIP kernel keeps.
+ * Returns 0, or -1 if an index is out of range (the reference does not check: SURVEY App. B.4).
+ */
+int oracle_bag_sum_f32(const float *table, uint64_t nr_rows, uint32_t dim, const void *indices,
+                       uint64_t n_idx, const void *offsets, uint64_t n_bags, int idx_is64,
+                       float *out) {
+    for (uint64_t b = 0; b < n_bags; b++) {
+        float *o = out + b * dim;
+        for (uint32_t d = 0; d < dim; d++) o[d] = 0.0f; /* emb_dpu_lookup.c:108 */
+        uint64_t p = ld_index(offsets, idx_is64, b);
+        uint64_t e = bag_end(offsets, idx_is64, b, n_bags, n_idx);
+        for (; p < e; p++) {
+            uint64_t r = ld_index(indices, idx_is64, p);
+            if (r >= nr_rows) return -1;
+            const float *w = table + r * dim;
+            for (uint32_t d = 0; d < dim; d++) o[d] = o[d] + w[d];
+        }
+    }
+    return 0;
+}
+
+/* fp16 storage, fp32 accumulate/output (BASELINE config C5). */
+int oracle_bag_sum_f16(const uint16_t *table, uint64_t nr_rows, uint32_t dim, const void *indices,
+                       uint64_t n_idx, const void *offsets, uint64_t n_bags, int idx_is64,
+                       float *out) {
+    for (uint64_t b = 0; b < n_bags; b++) {
+        float *o = out + b * dim;
+        for (uint32_t d = 0; d < dim; d++) o[d] = 0.0f;
+        uint64_t p = ld_index(offsets, idx_is64, b);
+        uint64_t e = bag_end(offsets, idx_is64, b, n_bags, n_idx);
+        for (; p < e; p++) {
+            uint64_t r = ld_index(indices, idx_is64, p);
+            if (r >= nr_rows) return -1;
+            const uint16_t *w = table + r * dim;
+            for (uint32_t d = 0; d < dim; d++) o[d] = o[d] + half_to_float(w[d]);
+        }
+    }
+    return 0;
+}
+
+/*
+ * One DPU = one (table, column): int32 wrap-around sums over a column-major slice.
+ * Restates emb_dpu_lookup.c:106-116 without its tasklet striding (the result per bag does not
+ * depend on which tasklet computes it).  column: int32[nr_rows]; results: int32[n_bags].
+ */
+int oracle_dpu_column_i32(const int32_t *column, uint64_t nr_rows, const uint32_t *indices,
+                          uint32_t indices_len, const uint32_t *offsets, uint32_t nr_batches,
+                          int32_t *results) {
+    for (uint32_t i = 0; i < nr_batches; i++) {
+        uint32_t acc = 0; /* unsigned arithmetic == int32 two's-complement wrap */
+        uint32_t p = offsets[i];
+        uint32_t e = (i + 1 < nr_batches) ? offsets[i + 1] : indices_len;
+        for (; p < e; p++) {
+            uint32_t ind = indices[p];
+            if (ind >= nr_rows) return -1;
+            acc += (uint32_t)column[ind]; /* :113-114 8-byte read + select == column[ind] */
+        }
+        results[i] = (int32_t)acc;
+    }
+    return 0;
+}
+
+/* emb_host.h:207-212: final[k*C + j] = (float)tmp[j][k] / pow(10,9)  (float -> double divide -> float) */
+void oracle_post_process(const int32_t *tmp_col_major /* [nr_cols][nr_batches] */, uint32_t nr_cols,
+                         uint32_t nr_batches, float *final_results /* [nr_batches][nr_cols] */) {
+    for (uint32_t j = 0; j < nr_cols; j++)
+        for (uint32_t k = 0; k < nr_batches; k++)
+            final_results[(uint64_t)k * nr_cols + j] =
+                (float)((double)(float)tmp_col_major[(uint64_t)j * nr_batches + k] / pow(10, 9));
+}
+
+/*
+ * Whole reference `lookup` for one table held ROW-major int32 [nr_rows][nr_cols] (the layout
+ * load_generator.c:54 indexes and alloc_buffers, emb_host.h:101-122, splits into columns):
+ * per-column DPU sums followed by post_process.  out: float[nr_batches][nr_cols].
+ */
+int oracle_lookup_fixed32(const int32_t *table_row_major, uint64_t nr_rows, uint32_t nr_cols,
+                          const uint32_t *indices, uint32_t indices_len, const uint32_t *offsets,
+                          uint32_t nr_batches, float *out) {
+    for (uint32_t i = 0; i < nr_batches; i++) {
+        uint32_t p0 = offsets[i];
+        uint32_t e = (i + 1 < nr_batches) ? offsets[i + 1] : indices_len;
+        for (uint32_t t = 0; t < nr_cols; t++) {
+            uint32_t acc = 0;
+            for (uint32_t p = p0; p < e; p++) {
+                uint32_t ind = indices[p];
+                if (ind >= nr_rows) return -1;
+                acc += (uint32_t)table_row_major[(uint64_t)ind * nr_cols + t];
+            }
+            out[(uint64_t)i * nr_cols + t] = (float)((double)(float)(int32_t)acc / pow(10, 9));
+        }
+    }
+    return 0;
+}
+
+/*
+ * Acceptance criterion of load_generator.c:40-65 (validate_result), with its two indexing slips
+ * repaired (offsets[j+1] read past the end for the last bag, :50; `j==nr_batches` never true, :51):
+ * returns the number of (bag, col) cells with |results*1e9 - int32 sum| > 1000.
+ */
+uint64_t oracle_validate_result(const int32_t *table_row_major, uint32_t nr_cols,
+                                const uint32_t *indices, uint32_t indices_len,
+                                const uint32_t *offsets, uint32_t nr_batches,
+                                const float *results) {
+    uint64_t bad = 0;
+    for (uint32_t j = 0; j < nr_batches; j++) {
+        uint32_t p0 = offsets[j];
+        uint32_t e = (j + 1 < nr_batches) ? offsets[j + 1] : indices_len;
+        for (uint32_t t = 0; t < nr_cols; t++) {
+            int32_t tmp = 0;
+            for (uint32_t p = p0; p < e; p++)
+                tmp = (int32_t)((uint32_t)tmp +
+                                (uint32_t)table_row_major[(uint64_t)indices[p] * nr_cols + t]);
+            if (fabs((double)results[(uint64_t)j * nr_cols + t] * pow(10, 9) - (double)tmp) > 1000.0)
+                bad++;
+        }
+    }
+    return bad;
+}
+
+/*
+ * Multi-table driver used as bench.py's cpu_baseline ("port", scalar, 1 core): T tables of the
+ * same dim, per-table pointers exactly as emb_host.h:234 passes them (indices[t], offsets[t],
+ * final_results[t]).
+ */
+int oracle_lookup_tables_f32(uint32_t n_tables, const float *const *tables,
+                             const uint64_t *nr_rows, uint32_t dim, const void *const *indices,
+                             const uint64_t *n_idx, const void *const *offsets,
+                             const uint64_t *n_bags, int idx_is64, float *const *out) {
+    for (uint32_t t = 0; t < n_tables; t++) {
+        int rc = oracle_bag_sum_f32(tables[t], nr_rows[t], dim, indices[t], n_idx[t], offsets[t],
+                                    n_bags[t], idx_is64, out[t]);
+        if (rc) return rc;
+    }
+    return 0;
+}

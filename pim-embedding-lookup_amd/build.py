@@ -1,0 +1,40 @@
+"""Build recipe for libpimemb.so (hipcc, gfx950 only).  Used by __graft_entry__.build()."""
+from __future__ import annotations
+
+import os
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC_DIR = os.path.join(PKG_DIR, "csrc")
+LIB_PATH = os.path.join(PKG_DIR, "lib", "libpimemb.so")
+SOURCES = ["pimemb_kernels.hip", "pimemb_engine.cpp", "pimemb_compat.cpp", "pimemb_internal.h",
+           "Makefile", os.path.join("..", "..", "include", "pimemb.h")]
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    built = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(os.path.join(CSRC_DIR, s)) > built for s in SOURCES)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP kernels + C-ABI into pim-embedding-lookup_amd/lib/libpimemb.so (in-tree, so
+    the built library travels to the GPU box with the repo snapshot)."""
+    if force:
+        subprocess.check_call(["make", "-C", CSRC_DIR, "clean"], stdout=subprocess.DEVNULL)
+    if force or is_stale():
+        cmd = ["make", "-C", CSRC_DIR, "-j4"]
+        if verbose:
+            subprocess.check_call(cmd)
+        else:
+            res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if res.returncode != 0:
+                raise RuntimeError("building libpimemb.so failed:\n" + res.stdout)
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libpimemb.so missing after build")
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(verbose=True))

@@ -1,0 +1,740 @@
+// pimemb_engine.cpp -- host side of libpimemb.so: the `emb_*` C ABI declared in include/pimemb.h.
+//
+// Replaces the host runtime of the reference, upmem/include/emb_host.h:
+//   populate_mram (:136-183)  -> emb_alloc_table / emb_load_table / emb_load_table_column
+//   lookup        (:234-404)  -> emb_lookup / emb_lookup_batched / emb_plan_*
+//   post_process  (:186-222)  -> gone (conversion and [bag][col] layout are fused in the kernel)
+// There is NO CPU compute path in this file: every lookup is a HIP kernel launch; if the GPU or
+// the runtime is unavailable the call fails with EMB_ERR_DEVICE.
+#include <atomic>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "pimemb_internal.h"
+
+using pimemb::DevDesc;
+using pimemb::LaunchGeom;
+
+namespace {
+
+thread_local std::string g_last_error;
+using pimemb::fail;
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess)                                                               \
+            return fail(_e == hipErrorOutOfMemory ? EMB_ERR_NOMEM : EMB_ERR_DEVICE,         \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,    \
+                        __LINE__);                                                          \
+    } while (0)
+
+double now_us() {
+    using namespace std::chrono;
+    return duration<double, std::micro>(steady_clock::now().time_since_epoch()).count();
+}
+
+size_t elem_size(emb_dtype d) { return d == EMB_F16 ? 2 : 4; }
+size_t index_size(emb_index_type t) { return t == EMB_IDX_I64 ? 8 : 4; }
+
+struct Table {
+    void *rows = nullptr;
+    uint64_t nr_rows = 0;
+    uint32_t dim = 0;
+    emb_dtype dtype = EMB_F32;
+    LaunchGeom geom{};
+    size_t bytes = 0;
+};
+
+// One slot of the descriptor ring used by transient (non-plan) launches: the pinned host copy and
+// the HBM copy must both outlive the asynchronous upload + kernel, so a slot is reused only after
+// its event has completed.
+struct DescSlot {
+    DevDesc *h = nullptr;
+    DevDesc *d = nullptr;
+    uint32_t cap = 0;
+    hipEvent_t done = nullptr;
+    bool pending = false;
+};
+constexpr int kSlots = 4;
+
+}  // namespace
+
+struct emb_engine {
+    int device = 0;
+    std::vector<Table> tables;
+    std::mutex mu;  // guards tables / workspaces; launches on device buffers do not take it
+    DescSlot slots[kSlots];
+    int next_slot = 0;
+    // staging for EMB_MEM_HOST calls
+    char *h_stage = nullptr;
+    size_t h_stage_cap = 0;
+    char *d_stage = nullptr;
+    size_t d_stage_cap = 0;
+    unsigned long long *d_bad = nullptr;
+    // stats
+    std::atomic<uint64_t> n_lookup_calls{0}, n_kernel_launches{0}, n_bags{0}, n_indices{0};
+    uint64_t table_bytes = 0;
+    double us_copy_in_indices = 0, us_copy_in_lengths = 0, us_launch = 0, us_copy_out = 0,
+           us_sync = 0;
+};
+
+struct PlanGroup {
+    DevDesc *d_descs = nullptr;
+    uint32_t n = 0;
+    uint32_t max_tiles = 0;
+    emb_dtype dtype = EMB_F32;
+    LaunchGeom geom{};
+};
+
+struct emb_plan {
+    emb_engine *e = nullptr;
+    emb_index_type itype = EMB_IDX_U32;
+    std::vector<PlanGroup> groups;
+    uint64_t bytes = 0, n_bags = 0, n_indices = 0;
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) {
+            switched = hipSetDevice(dev) == hipSuccess;
+        }
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+
+// Resolve user descriptors against the engine's tables and split them into launch groups that
+// share (dtype, dim).  `base_indices/offsets/out`: if non-null, pointers are taken from these
+// per-desc overrides (staged copies) instead of the user's.
+struct Resolved {
+    std::vector<DevDesc> descs;       // grouped, contiguous per group
+    std::vector<PlanGroup> groups;    // d_descs left null; n / max_tiles / dtype / geom filled
+    std::vector<uint32_t> order;      // descs[i] came from user desc order[i]
+    uint64_t bytes = 0, n_bags = 0, n_indices = 0;
+};
+
+int resolve(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs, emb_index_type itype,
+            const std::vector<const void *> *st_indices, const std::vector<const void *> *st_offsets,
+            const std::vector<float *> *st_out, Resolved *r) {
+    if (itype != EMB_IDX_U32 && itype != EMB_IDX_I64) return fail(EMB_ERR_INVALID, "bad index type");
+    std::map<std::pair<int, uint32_t>, std::vector<uint32_t>> by_shape;
+    for (uint32_t i = 0; i < n_descs; i++) {
+        const emb_lookup_desc &u = descs[i];
+        if (u.table_id >= e->tables.size() || e->tables[u.table_id].rows == nullptr)
+            return fail(EMB_ERR_INVALID, "desc %u: table %u is not loaded", i, u.table_id);
+        if (u.n_bags > 0 && u.pooled == nullptr) return fail(EMB_ERR_INVALID, "desc %u: pooled is NULL", i);
+        if (u.n_indices > 0 && u.indices == nullptr)
+            return fail(EMB_ERR_INVALID, "desc %u: indices is NULL", i);
+        if (u.offsets == nullptr) {
+            if (u.n_bags > 0 && u.fixed_pooling == 0)
+                return fail(EMB_ERR_INVALID, "desc %u: offsets is NULL and fixed_pooling is 0", i);
+            if ((uint64_t)u.fixed_pooling * u.n_bags != u.n_indices)
+                return fail(EMB_ERR_INVALID, "desc %u: fixed_pooling*n_bags != n_indices", i);
+        }
+        const Table &t = e->tables[u.table_id];
+        by_shape[{(int)t.dtype, t.dim}].push_back(i);
+    }
+    const size_t isz = index_size(itype);
+    for (auto &kv : by_shape) {
+        PlanGroup g;
+        g.dtype = (emb_dtype)kv.first.first;
+        g.n = (uint32_t)kv.second.size();
+        const Table &t0 = e->tables[descs[kv.second[0]].table_id];
+        g.geom = t0.geom;
+        for (uint32_t i : kv.second) {
+            const emb_lookup_desc &u = descs[i];
+            const Table &t = e->tables[u.table_id];
+            uint64_t tiles = (u.n_bags + g.geom.bags_per_tile - 1) / g.geom.bags_per_tile;
+            if (tiles > 0x7fffffffull) return fail(EMB_ERR_UNSUPPORTED, "desc %u: too many bags", i);
+            DevDesc d{};
+            d.weights = t.rows;
+            d.indices = st_indices ? (*st_indices)[i] : u.indices;
+            d.offsets = st_offsets ? (*st_offsets)[i] : u.offsets;
+            d.out = st_out ? (*st_out)[i] : u.pooled;
+            d.n_idx = u.n_indices;
+            d.n_bags = u.n_bags;
+            d.nr_rows = t.nr_rows;
+            d.fixed_pooling = u.offsets ? 0u : u.fixed_pooling;
+            d.n_tiles = (uint32_t)tiles;
+            if (d.n_tiles > g.max_tiles) g.max_tiles = d.n_tiles;
+            r->descs.push_back(d);
+            r->order.push_back(i);
+            r->n_bags += u.n_bags;
+            r->n_indices += u.n_indices;
+            // algorithmic bytes, SURVEY.md section 8 row D
+            r->bytes += u.n_indices * ((uint64_t)t.dim * elem_size(t.dtype) + isz) +
+                        (u.offsets ? u.n_bags * isz : 0) + u.n_bags * (uint64_t)t.dim * 4;
+        }
+        r->groups.push_back(g);
+    }
+    return EMB_OK;
+}
+
+int launch_groups(emb_engine *e, const std::vector<PlanGroup> &groups, emb_index_type itype,
+                  hipStream_t s) {
+    for (const PlanGroup &g : groups) {
+        HIP_TRY(pimemb::launch_bag_sum(g.d_descs, g.n, g.max_tiles, g.dtype, itype, g.geom, s));
+        e->n_kernel_launches.fetch_add(1, std::memory_order_relaxed);
+    }
+    return EMB_OK;
+}
+
+int ensure_slot(DescSlot &sl, uint32_t n) {
+    if (sl.pending) {
+        HIP_TRY(hipEventSynchronize(sl.done));
+        sl.pending = false;
+    }
+    if (sl.cap < n) {
+        if (sl.h) (void)hipHostFree(sl.h);
+        if (sl.d) (void)hipFree(sl.d);
+        sl.h = nullptr;
+        sl.d = nullptr;
+        sl.cap = 0;
+        uint32_t cap = n < 64 ? 64 : n;
+        HIP_TRY(hipHostMalloc((void **)&sl.h, sizeof(DevDesc) * cap, hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void **)&sl.d, sizeof(DevDesc) * cap));
+        sl.cap = cap;
+    }
+    if (!sl.done) HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    return EMB_OK;
+}
+
+// Transient launch over device-resident buffers described by `r`.
+int launch_resolved(emb_engine *e, Resolved &r, emb_index_type itype, hipStream_t s) {
+    if (r.descs.empty()) return EMB_OK;
+    std::lock_guard<std::mutex> lk(e->mu);
+    DescSlot &sl = e->slots[e->next_slot];
+    e->next_slot = (e->next_slot + 1) % kSlots;
+    int rc = ensure_slot(sl, (uint32_t)r.descs.size());
+    if (rc) return rc;
+    memcpy(sl.h, r.descs.data(), sizeof(DevDesc) * r.descs.size());
+    HIP_TRY(hipMemcpyAsync(sl.d, sl.h, sizeof(DevDesc) * r.descs.size(), hipMemcpyHostToDevice, s));
+    DevDesc *cursor = sl.d;
+    for (PlanGroup &g : r.groups) {
+        g.d_descs = cursor;
+        cursor += g.n;
+    }
+    rc = launch_groups(e, r.groups, itype, s);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(sl.done, s));
+    sl.pending = true;
+    return EMB_OK;
+}
+
+int ensure_stage(emb_engine *e, size_t h_bytes, size_t d_bytes) {
+    if (e->h_stage_cap < h_bytes) {
+        if (e->h_stage) (void)hipHostFree(e->h_stage);
+        e->h_stage = nullptr;
+        e->h_stage_cap = 0;
+        size_t cap = h_bytes + h_bytes / 4 + 4096;
+        HIP_TRY(hipHostMalloc((void **)&e->h_stage, cap, hipHostMallocDefault));
+        e->h_stage_cap = cap;
+    }
+    if (e->d_stage_cap < d_bytes) {
+        if (e->d_stage) (void)hipFree(e->d_stage);
+        e->d_stage = nullptr;
+        e->d_stage_cap = 0;
+        size_t cap = d_bytes + d_bytes / 4 + 4096;
+        HIP_TRY(hipMalloc((void **)&e->d_stage, cap));
+        e->d_stage_cap = cap;
+    }
+    return EMB_OK;
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Host-pointer path: pack indices+offsets into pinned staging, one H2D, kernel(s), D2H per table.
+// Synchronous, like the reference's lookup (emb_host.h:350 dpu_sync before return).
+struct HostStage {
+    std::vector<const void *> d_indices, d_offsets;
+    std::vector<float *> d_out;
+    size_t in_bytes = 0, out_bytes = 0;
+};
+
+int stage_host_inputs(emb_engine *e, const emb_lookup_desc *descs, uint32_t n, emb_index_type itype,
+                      hipStream_t s, HostStage *hs, bool with_outputs) {
+    const size_t isz = index_size(itype);
+    size_t in_bytes = 0, out_bytes = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        if (descs[i].table_id >= e->tables.size() || !e->tables[descs[i].table_id].rows)
+            return fail(EMB_ERR_INVALID, "desc %u: table %u is not loaded", i, descs[i].table_id);
+        in_bytes += align_up(descs[i].n_indices * isz, 16);
+        if (descs[i].offsets) in_bytes += align_up(descs[i].n_bags * isz, 16);
+        out_bytes += align_up(descs[i].n_bags * (size_t)e->tables[descs[i].table_id].dim * 4, 16);
+    }
+    if (!with_outputs) out_bytes = 0;
+    int rc = ensure_stage(e, in_bytes, in_bytes + out_bytes);
+    if (rc) return rc;
+    size_t off = 0;
+    hs->d_indices.resize(n);
+    hs->d_offsets.resize(n);
+    hs->d_out.resize(n);
+    for (uint32_t i = 0; i < n; i++) {
+        const emb_lookup_desc &u = descs[i];
+        if (u.n_indices && !u.indices) return fail(EMB_ERR_INVALID, "desc %u: indices is NULL", i);
+        memcpy(e->h_stage + off, u.indices, u.n_indices * isz);
+        hs->d_indices[i] = e->d_stage + off;
+        off += align_up(u.n_indices * isz, 16);
+        if (u.offsets) {
+            memcpy(e->h_stage + off, u.offsets, u.n_bags * isz);
+            hs->d_offsets[i] = e->d_stage + off;
+            off += align_up(u.n_bags * isz, 16);
+        } else {
+            hs->d_offsets[i] = nullptr;
+        }
+    }
+    size_t oo = in_bytes;
+    for (uint32_t i = 0; i < n; i++) {
+        hs->d_out[i] = reinterpret_cast<float *>(e->d_stage + oo);
+        if (with_outputs)
+            oo += align_up(descs[i].n_bags * (size_t)e->tables[descs[i].table_id].dim * 4, 16);
+    }
+    hs->in_bytes = in_bytes;
+    hs->out_bytes = out_bytes;
+    if (in_bytes) HIP_TRY(hipMemcpyAsync(e->d_stage, e->h_stage, in_bytes, hipMemcpyHostToDevice, s));
+    return EMB_OK;
+}
+
+int lookup_host(emb_engine *e, const emb_lookup_desc *descs, uint32_t n, emb_index_type itype,
+                hipStream_t s) {
+    HostStage hs;
+    double t0 = now_us();
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        int rc = stage_host_inputs(e, descs, n, itype, s, &hs, true);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    double t1 = now_us();
+    Resolved r;
+    int rc = resolve(e, descs, n, itype, &hs.d_indices, &hs.d_offsets, &hs.d_out, &r);
+    if (rc) return rc;
+    // descriptor upload ("query copying" in the reference's stage list) + launch
+    rc = launch_resolved(e, r, itype, s);
+    if (rc) return rc;
+    double t2 = now_us();
+    HIP_TRY(hipStreamSynchronize(s));
+    double t3 = now_us();
+    for (uint32_t i = 0; i < n; i++) {
+        size_t bytes = descs[i].n_bags * (size_t)e->tables[descs[i].table_id].dim * 4;
+        if (bytes)
+            HIP_TRY(hipMemcpyAsync(descs[i].pooled, hs.d_out[i], bytes, hipMemcpyDeviceToHost, s));
+    }
+    double t4 = now_us();
+    HIP_TRY(hipStreamSynchronize(s));
+    double t5 = now_us();
+    e->us_copy_in_indices += t1 - t0;
+    e->us_copy_in_lengths += t2 - t1;
+    e->us_launch += t3 - t2;
+    e->us_copy_out += t4 - t3;
+    e->us_sync += t5 - t4;
+    e->n_bags.fetch_add(r.n_bags, std::memory_order_relaxed);
+    e->n_indices.fetch_add(r.n_indices, std::memory_order_relaxed);
+    return EMB_OK;
+}
+
+}  // namespace
+
+int pimemb::fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+// =================================================================================================
+extern "C" {
+
+const char *emb_last_error(void) { return g_last_error.c_str(); }
+
+const char *emb_version(void) { return "pimemb 0.1 gfx950"; }
+
+int emb_create(const emb_config *cfg, emb_engine **out) {
+    if (!out) return fail(EMB_ERR_INVALID, "emb_create: out is NULL");
+    *out = nullptr;
+    int dev = cfg ? cfg->device : -1;
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (count <= 0) return fail(EMB_ERR_DEVICE, "emb_create: no HIP device visible");
+    if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+    if (dev >= count) return fail(EMB_ERR_INVALID, "emb_create: device %d of %d", dev, count);
+    emb_engine *e = new (std::nothrow) emb_engine();
+    if (!e) return fail(EMB_ERR_NOMEM, "emb_create: out of host memory");
+    e->device = dev;
+    uint32_t max_tables = (cfg && cfg->max_tables) ? cfg->max_tables : 1024;
+    e->tables.resize(max_tables);
+    DeviceGuard g(dev);
+    hipError_t err = hipMalloc((void **)&e->d_bad, sizeof(unsigned long long));
+    if (err != hipSuccess) {
+        delete e;
+        return fail(EMB_ERR_DEVICE, "emb_create: hipMalloc failed: %s", hipGetErrorString(err));
+    }
+    *out = e;
+    return EMB_OK;
+}
+
+int emb_destroy(emb_engine *e) {
+    if (!e) return EMB_OK;
+    DeviceGuard g(e->device);
+    (void)hipDeviceSynchronize();
+    for (Table &t : e->tables)
+        if (t.rows) (void)hipFree(t.rows);
+    for (DescSlot &sl : e->slots) {
+        if (sl.h) (void)hipHostFree(sl.h);
+        if (sl.d) (void)hipFree(sl.d);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
+    if (e->h_stage) (void)hipHostFree(e->h_stage);
+    if (e->d_stage) (void)hipFree(e->d_stage);
+    if (e->d_bad) (void)hipFree(e->d_bad);
+    delete e;
+    return EMB_OK;
+}
+
+int emb_alloc_table(emb_engine *e, uint32_t table_id, uint64_t nr_rows, uint32_t dim, emb_dtype dtype) {
+    if (!e) return fail(EMB_ERR_INVALID, "engine is NULL");
+    if (table_id >= e->tables.size())
+        return fail(EMB_ERR_INVALID, "table id %u >= max_tables %zu", table_id, e->tables.size());
+    if (nr_rows == 0) return fail(EMB_ERR_INVALID, "table %u: nr_rows is 0", table_id);
+    LaunchGeom geom;
+    int rc = pimemb::geometry_for(dtype, dim, &geom);
+    if (rc == EMB_ERR_UNSUPPORTED)
+        return fail(rc, "table %u: dim %u of dtype %d: row bytes must be a multiple of 16 and <= 1024",
+                    table_id, dim, (int)dtype);
+    if (rc) return fail(rc, "table %u: bad dtype %d", table_id, (int)dtype);
+    DeviceGuard g(e->device);
+    std::lock_guard<std::mutex> lk(e->mu);
+    Table &t = e->tables[table_id];
+    size_t bytes = (size_t)nr_rows * dim * elem_size(dtype);
+    if (t.rows && t.bytes != bytes) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipFree(t.rows));
+        e->table_bytes -= t.bytes;
+        t = Table{};
+    }
+    if (!t.rows) {
+        HIP_TRY(hipMalloc(&t.rows, bytes));
+        e->table_bytes += bytes;
+    }
+    HIP_TRY(hipMemset(t.rows, 0, bytes));
+    t.nr_rows = nr_rows;
+    t.dim = dim;
+    t.dtype = dtype;
+    t.geom = geom;
+    t.bytes = bytes;
+    return EMB_OK;
+}
+
+int emb_load_table(emb_engine *e, uint32_t table_id, uint64_t nr_rows, uint32_t dim, emb_dtype dtype,
+                   const void *rows, emb_memspace space) {
+    if (!rows) return fail(EMB_ERR_INVALID, "table %u: rows is NULL", table_id);
+    int rc = emb_alloc_table(e, table_id, nr_rows, dim, dtype);
+    if (rc) return rc;
+    DeviceGuard g(e->device);
+    Table &t = e->tables[table_id];
+    HIP_TRY(hipMemcpy(t.rows, rows, t.bytes,
+                      space == EMB_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    return EMB_OK;
+}
+
+int emb_load_table_column(emb_engine *e, uint32_t table_id, uint32_t col, const int32_t *column,
+                          uint64_t nr_rows) {
+    if (!e || !column) return fail(EMB_ERR_INVALID, "engine or column is NULL");
+    if (table_id >= e->tables.size() || !e->tables[table_id].rows)
+        return fail(EMB_ERR_INVALID, "table %u is not allocated", table_id);
+    Table &t = e->tables[table_id];
+    if (t.dtype != EMB_FIXED32) return fail(EMB_ERR_INVALID, "table %u is not EMB_FIXED32", table_id);
+    if (col >= t.dim) return fail(EMB_ERR_INVALID, "table %u: col %u >= dim %u", table_id, col, t.dim);
+    if (nr_rows > t.nr_rows)
+        return fail(EMB_ERR_INVALID, "table %u: %llu rows > allocated %llu", table_id,
+                    (unsigned long long)nr_rows, (unsigned long long)t.nr_rows);
+    DeviceGuard g(e->device);
+    std::lock_guard<std::mutex> lk(e->mu);
+    size_t bytes = nr_rows * sizeof(int32_t);
+    int rc = ensure_stage(e, 0, bytes);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(e->d_stage, column, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(pimemb::launch_scatter_column(static_cast<int32_t *>(t.rows),
+                                          reinterpret_cast<const int32_t *>(e->d_stage), nr_rows,
+                                          t.dim, col, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return EMB_OK;
+}
+
+int emb_table_info(emb_engine *e, uint32_t table_id, void **device_rows, uint64_t *nr_rows,
+                   uint32_t *dim, emb_dtype *dtype) {
+    if (!e) return fail(EMB_ERR_INVALID, "engine is NULL");
+    if (table_id >= e->tables.size() || !e->tables[table_id].rows)
+        return fail(EMB_ERR_INVALID, "table %u is not loaded", table_id);
+    const Table &t = e->tables[table_id];
+    if (device_rows) *device_rows = t.rows;
+    if (nr_rows) *nr_rows = t.nr_rows;
+    if (dim) *dim = t.dim;
+    if (dtype) *dtype = t.dtype;
+    return EMB_OK;
+}
+
+int emb_lookup_batched(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs,
+                       emb_index_type itype, emb_memspace space, void *stream) {
+    if (!e) return fail(EMB_ERR_INVALID, "engine is NULL");
+    if (n_descs == 0) return EMB_OK;
+    if (!descs) return fail(EMB_ERR_INVALID, "descs is NULL");
+    DeviceGuard g(e->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    e->n_lookup_calls.fetch_add(1, std::memory_order_relaxed);
+    if (space == EMB_MEM_HOST) return lookup_host(e, descs, n_descs, itype, s);
+    Resolved r;
+    int rc = resolve(e, descs, n_descs, itype, nullptr, nullptr, nullptr, &r);
+    if (rc) return rc;
+    rc = launch_resolved(e, r, itype, s);
+    if (rc) return rc;
+    e->n_bags.fetch_add(r.n_bags, std::memory_order_relaxed);
+    e->n_indices.fetch_add(r.n_indices, std::memory_order_relaxed);
+    return EMB_OK;
+}
+
+int emb_lookup(emb_engine *e, uint32_t table_id, const void *indices, uint64_t n_indices,
+               const void *offsets, uint64_t n_bags, float *pooled, emb_index_type itype,
+               emb_memspace space, void *stream) {
+    emb_lookup_desc d{};
+    d.table_id = table_id;
+    d.indices = indices;
+    d.offsets = offsets;
+    d.n_indices = n_indices;
+    d.n_bags = n_bags;
+    d.pooled = pooled;
+    if (!offsets && n_bags) {
+        if (n_indices % n_bags) return fail(EMB_ERR_INVALID, "offsets is NULL and n_indices %% n_bags != 0");
+        d.fixed_pooling = (uint32_t)(n_indices / n_bags);
+    }
+    return emb_lookup_batched(e, &d, 1, itype, space, stream);
+}
+
+int emb_plan_create(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs,
+                    emb_index_type itype, emb_plan **out) {
+    if (!e || !out) return fail(EMB_ERR_INVALID, "engine or out is NULL");
+    *out = nullptr;
+    if (!descs || n_descs == 0) return fail(EMB_ERR_INVALID, "plan needs at least one descriptor");
+    DeviceGuard g(e->device);
+    Resolved r;
+    int rc = resolve(e, descs, n_descs, itype, nullptr, nullptr, nullptr, &r);
+    if (rc) return rc;
+    emb_plan *p = new (std::nothrow) emb_plan();
+    if (!p) return fail(EMB_ERR_NOMEM, "out of host memory");
+    p->e = e;
+    p->itype = itype;
+    p->bytes = r.bytes;
+    p->n_bags = r.n_bags;
+    p->n_indices = r.n_indices;
+    DevDesc *d = nullptr;
+    hipError_t err = hipMalloc((void **)&d, sizeof(DevDesc) * r.descs.size());
+    if (err == hipSuccess)
+        err = hipMemcpy(d, r.descs.data(), sizeof(DevDesc) * r.descs.size(), hipMemcpyHostToDevice);
+    if (err != hipSuccess) {
+        if (d) (void)hipFree(d);
+        delete p;
+        return fail(EMB_ERR_DEVICE, "emb_plan_create: %s", hipGetErrorString(err));
+    }
+    DevDesc *cursor = d;
+    for (PlanGroup &gr : r.groups) {
+        gr.d_descs = cursor;
+        cursor += gr.n;
+    }
+    p->groups = r.groups;
+    *out = p;
+    return EMB_OK;
+}
+
+int emb_plan_launch(emb_plan *p, void *stream) {
+    if (!p) return fail(EMB_ERR_INVALID, "plan is NULL");
+    emb_engine *e = p->e;
+    DeviceGuard g(e->device);
+    int rc = launch_groups(e, p->groups, p->itype, static_cast<hipStream_t>(stream));
+    if (rc) return rc;
+    e->n_lookup_calls.fetch_add(1, std::memory_order_relaxed);
+    e->n_bags.fetch_add(p->n_bags, std::memory_order_relaxed);
+    e->n_indices.fetch_add(p->n_indices, std::memory_order_relaxed);
+    return EMB_OK;
+}
+
+int emb_plan_destroy(emb_plan *p) {
+    if (!p) return EMB_OK;
+    DeviceGuard g(p->e->device);
+    (void)hipDeviceSynchronize();
+    if (!p->groups.empty() && p->groups[0].d_descs) (void)hipFree(p->groups[0].d_descs);
+    delete p;
+    return EMB_OK;
+}
+
+int emb_plan_bytes(const emb_plan *p, uint64_t *algorithmic_bytes, uint64_t *n_bags,
+                   uint64_t *n_indices) {
+    if (!p) return fail(EMB_ERR_INVALID, "plan is NULL");
+    if (algorithmic_bytes) *algorithmic_bytes = p->bytes;
+    if (n_bags) *n_bags = p->n_bags;
+    if (n_indices) *n_indices = p->n_indices;
+    return EMB_OK;
+}
+
+int emb_plan_time(emb_plan *p, void *stream, uint32_t warmup, uint32_t iters, float *avg_us) {
+    if (!p || !avg_us || iters == 0) return fail(EMB_ERR_INVALID, "bad argument to emb_plan_time");
+    DeviceGuard g(p->e->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    for (uint32_t i = 0; i < warmup; i++) {
+        int rc = emb_plan_launch(p, stream);
+        if (rc) return rc;
+    }
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    HIP_TRY(hipEventRecord(a, s));
+    for (uint32_t i = 0; i < iters; i++) {
+        int rc = emb_plan_launch(p, stream);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipEventRecord(b, s));
+    HIP_TRY(hipEventSynchronize(b));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    *avg_us = ms * 1000.f / (float)iters;
+    return EMB_OK;
+}
+
+int emb_validate_inputs(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs,
+                        emb_index_type itype, emb_memspace space, uint64_t *n_bad) {
+    if (!e || !descs) return fail(EMB_ERR_INVALID, "engine or descs is NULL");
+    DeviceGuard g(e->device);
+    hipStream_t s = nullptr;
+    HostStage hs;
+    Resolved r;
+    int rc;
+    std::unique_lock<std::mutex> lk(e->mu);
+    if (space == EMB_MEM_HOST) {
+        rc = stage_host_inputs(e, descs, n_descs, itype, s, &hs, false);
+        if (rc) return rc;
+        // pooled pointers are not touched by validation; pass the user's through
+        std::vector<float *> outs(n_descs);
+        for (uint32_t i = 0; i < n_descs; i++) outs[i] = descs[i].pooled ? descs[i].pooled : (float *)16;
+        std::vector<emb_lookup_desc> tmp(descs, descs + n_descs);
+        for (uint32_t i = 0; i < n_descs; i++) tmp[i].pooled = outs[i];
+        rc = resolve(e, tmp.data(), n_descs, itype, &hs.d_indices, &hs.d_offsets, nullptr, &r);
+    } else {
+        std::vector<emb_lookup_desc> tmp(descs, descs + n_descs);
+        for (uint32_t i = 0; i < n_descs; i++)
+            if (!tmp[i].pooled) tmp[i].pooled = (float *)16;
+        rc = resolve(e, tmp.data(), n_descs, itype, nullptr, nullptr, nullptr, &r);
+    }
+    if (rc) return rc;
+    DevDesc *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, sizeof(DevDesc) * r.descs.size()));
+    hipError_t err = hipMemcpy(d, r.descs.data(), sizeof(DevDesc) * r.descs.size(), hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMemsetAsync(e->d_bad, 0, sizeof(unsigned long long), s);
+    if (err == hipSuccess) err = pimemb::launch_validate(d, (uint32_t)r.descs.size(), itype, e->d_bad, s);
+    unsigned long long bad = 0;
+    if (err == hipSuccess) err = hipMemcpy(&bad, e->d_bad, sizeof bad, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (err != hipSuccess) return fail(EMB_ERR_DEVICE, "emb_validate_inputs: %s", hipGetErrorString(err));
+    if (n_bad) *n_bad = bad;
+    if (bad) return fail(EMB_ERR_RANGE, "%llu out-of-range indices / broken offsets", bad);
+    return EMB_OK;
+}
+
+int emb_get_stats(emb_engine *e, emb_stats *out) {
+    if (!e || !out) return fail(EMB_ERR_INVALID, "engine or out is NULL");
+    memset(out, 0, sizeof *out);
+    out->n_lookup_calls = e->n_lookup_calls.load();
+    out->n_kernel_launches = e->n_kernel_launches.load();
+    out->n_bags = e->n_bags.load();
+    out->n_indices = e->n_indices.load();
+    out->table_bytes = e->table_bytes;
+    out->us_copy_in_indices = e->us_copy_in_indices;
+    out->us_copy_in_lengths = e->us_copy_in_lengths;
+    out->us_launch = e->us_launch;
+    out->us_copy_out = e->us_copy_out;
+    out->us_post_process = 0.0;
+    out->us_sync = e->us_sync;
+    return EMB_OK;
+}
+
+int emb_reset_stats(emb_engine *e) {
+    if (!e) return fail(EMB_ERR_INVALID, "engine is NULL");
+    e->n_lookup_calls = 0;
+    e->n_kernel_launches = 0;
+    e->n_bags = 0;
+    e->n_indices = 0;
+    e->us_copy_in_indices = e->us_copy_in_lengths = e->us_launch = e->us_copy_out = e->us_sync = 0;
+    return EMB_OK;
+}
+
+int emb_device_alloc(emb_engine *e, size_t bytes, void **out) {
+    if (!e || !out) return fail(EMB_ERR_INVALID, "engine or out is NULL");
+    DeviceGuard g(e->device);
+    *out = nullptr;
+    HIP_TRY(hipMalloc(out, bytes ? bytes : 16));
+    return EMB_OK;
+}
+
+int emb_device_free(emb_engine *e, void *ptr) {
+    if (!e) return fail(EMB_ERR_INVALID, "engine is NULL");
+    if (!ptr) return EMB_OK;
+    DeviceGuard g(e->device);
+    HIP_TRY(hipFree(ptr));
+    return EMB_OK;
+}
+
+int emb_copy_to_device(emb_engine *e, void *dst_device, const void *src_host, size_t bytes) {
+    if (!e) return fail(EMB_ERR_INVALID, "engine is NULL");
+    if (!bytes) return EMB_OK;
+    DeviceGuard g(e->device);
+    HIP_TRY(hipMemcpy(dst_device, src_host, bytes, hipMemcpyHostToDevice));
+    return EMB_OK;
+}
+
+int emb_copy_to_host(emb_engine *e, void *dst_host, const void *src_device, size_t bytes) {
+    if (!e) return fail(EMB_ERR_INVALID, "engine is NULL");
+    if (!bytes) return EMB_OK;
+    DeviceGuard g(e->device);
+    HIP_TRY(hipMemcpy(dst_host, src_device, bytes, hipMemcpyDeviceToHost));
+    return EMB_OK;
+}
+
+int emb_memset_device(emb_engine *e, void *dst_device, int value, size_t bytes) {
+    if (!e) return fail(EMB_ERR_INVALID, "engine is NULL");
+    if (!bytes) return EMB_OK;
+    DeviceGuard g(e->device);
+    HIP_TRY(hipMemset(dst_device, value, bytes));
+    return EMB_OK;
+}
+
+int emb_synchronize(emb_engine *e, void *stream) {
+    if (!e) return fail(EMB_ERR_INVALID, "engine is NULL");
+    DeviceGuard g(e->device);
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return EMB_OK;
+}
+
+int emb_device_of(emb_engine *e, int32_t *device) {
+    if (!e || !device) return fail(EMB_ERR_INVALID, "engine or device is NULL");
+    *device = e->device;
+    return EMB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,301 @@
+"""Host-side mirror of the reference's operator surface over libpimemb.so.
+
+The reference exposes the hot path as two C calls (upmem/include/emb_host.h:136 `populate_mram`,
+:234 `lookup`) that a PyTorch fork dispatches into from `nn.EmbeddingBag(mode="sum")`; the Python
+here is the equivalent thin layer: it owns no arithmetic, only pointers, shapes and lifetimes.
+Every lookup ends in `emb_lookup_batched` / `emb_plan_launch`, i.e. the fused HIP kernel.
+
+Buffers may be
+  * numpy arrays            -> EMB_MEM_HOST  (the engine copies in/out, like the reference does)
+  * torch CUDA tensors      -> EMB_MEM_DEVICE (zero-copy; enqueued on torch's current stream)
+  * `DeviceBuffer` objects  -> EMB_MEM_DEVICE (HBM owned through the C ABI, no torch involved)
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Sequence
+
+import numpy as np
+
+from . import lib as _l
+
+_NP_TABLE_DTYPES = {np.dtype(np.float32): _l.EMB_F32, np.dtype(np.float16): _l.EMB_F16,
+                    np.dtype(np.int32): _l.EMB_FIXED32}
+_ELEM = {_l.EMB_F32: 4, _l.EMB_F16: 2, _l.EMB_FIXED32: 4}
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch") and hasattr(x, "data_ptr")
+
+
+def _index_type_of(dtype) -> int:
+    name = str(dtype).replace("torch.", "")
+    if name in ("uint32", "int32"):  # int32 bits are read as uint32 (indices are non-negative)
+        return _l.EMB_IDX_U32
+    if name == "int64":
+        return _l.EMB_IDX_I64
+    raise TypeError(f"indices/offsets must be uint32/int32 or int64, got {dtype}")
+
+
+class DeviceBuffer:
+    """A piece of HBM allocated through the C ABI (emb_device_alloc)."""
+
+    def __init__(self, engine: "EmbeddingEngine", nbytes: int, dtype=np.uint8, shape=None):
+        self.engine = engine
+        self.nbytes = int(nbytes)
+        self.dtype = np.dtype(dtype)
+        self.shape = tuple(shape) if shape is not None else (self.nbytes // self.dtype.itemsize,)
+        p = C.c_void_p()
+        _l.check(engine._L.emb_device_alloc(engine._h, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    @classmethod
+    def from_numpy(cls, engine: "EmbeddingEngine", a: np.ndarray) -> "DeviceBuffer":
+        a = np.ascontiguousarray(a)
+        buf = cls(engine, a.nbytes, a.dtype, a.shape)
+        if a.nbytes:
+            _l.check(engine._L.emb_copy_to_device(engine._h, buf.ptr, a.ctypes.data, a.nbytes))
+        return buf
+
+    def numpy(self) -> np.ndarray:
+        out = np.empty(self.shape, dtype=self.dtype)
+        if out.nbytes:
+            _l.check(self.engine._L.emb_copy_to_host(self.engine._h, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def fill(self, byte: int = 0) -> None:
+        _l.check(self.engine._L.emb_memset_device(self.engine._h, self.ptr, byte, self.nbytes))
+
+    def free(self) -> None:
+        if self.ptr and self.engine._h:
+            self.engine._L.emb_device_free(self.engine._h, self.ptr)
+        self.ptr = None
+
+    def __len__(self):
+        return self.shape[0]
+
+
+class _Arg:
+    """Pointer + placement of one caller buffer."""
+    __slots__ = ("ptr", "space", "n", "dtype", "keep")
+
+    def __init__(self, x):
+        if x is None:
+            self.ptr, self.space, self.n, self.dtype, self.keep = None, None, 0, None, None
+        elif isinstance(x, DeviceBuffer):
+            self.ptr, self.space, self.n, self.dtype, self.keep = x.ptr, _l.EMB_MEM_DEVICE, x.shape[0], x.dtype, x
+        elif _is_torch(x):
+            if not x.is_contiguous():
+                raise ValueError("torch tensors passed to the engine must be contiguous")
+            space = _l.EMB_MEM_DEVICE if x.is_cuda else _l.EMB_MEM_HOST
+            self.ptr, self.space, self.n, self.dtype, self.keep = x.data_ptr(), space, x.shape[0], x.dtype, x
+        else:
+            a = np.ascontiguousarray(x)
+            self.ptr, self.space, self.n, self.dtype, self.keep = a.ctypes.data, _l.EMB_MEM_HOST, a.shape[0], a.dtype, a
+
+
+def _current_stream_for(*objs) -> int | None:
+    for o in objs:
+        if _is_torch(o) and o.is_cuda:
+            import torch
+            return torch.cuda.current_stream(o.device).cuda_stream
+    return None
+
+
+class Plan:
+    """A prepared multi-table lookup over device buffers: one kernel enqueue per launch."""
+
+    def __init__(self, engine: "EmbeddingEngine", handle: int, outputs, keep):
+        self.engine, self._p, self.outputs, self._keep = engine, handle, outputs, keep
+
+    def launch(self, stream: int | None = None) -> None:
+        _l.check(self.engine._L.emb_plan_launch(self._p, stream))
+
+    def bytes(self) -> tuple[int, int, int]:
+        b, nb, ni = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _l.check(self.engine._L.emb_plan_bytes(self._p, C.byref(b), C.byref(nb), C.byref(ni)))
+        return b.value, nb.value, ni.value
+
+    def time_us(self, warmup: int = 5, iters: int = 20, stream: int | None = None) -> float:
+        """Mean device time of one launch, HIP events on the launch stream (emb_plan_time)."""
+        us = C.c_float()
+        _l.check(self.engine._L.emb_plan_time(self._p, stream, warmup, iters, C.byref(us)))
+        return us.value
+
+    def destroy(self) -> None:
+        if self._p:
+            self.engine._L.emb_plan_destroy(self._p)
+            self._p = None
+
+
+class EmbeddingEngine:
+    """One engine per GPU: tables resident in HBM, lookups as fused HIP launches."""
+
+    def __init__(self, device: int = -1, max_tables: int = 1024):
+        self._L = _l.load()
+        cfg = _l.EmbConfig(device, max_tables, 0)
+        h = C.c_void_p()
+        _l.check(self._L.emb_create(C.byref(cfg), C.byref(h)))
+        self._h = h.value
+        self._tables: dict[int, tuple[int, int, int]] = {}  # id -> (nr_rows, dim, dtype)
+
+    # ---- tables (populate_mram's job, emb_host.h:136) ------------------------------------------
+    def load_table(self, table_id: int, rows, dtype: int | None = None) -> None:
+        """rows: [nr_rows, dim] numpy float32/float16/int32 (int32 = x1e9 fixed point) or a torch
+        tensor (CPU or CUDA) of those dtypes."""
+        if _is_torch(rows):
+            import torch
+            tmap = {torch.float32: _l.EMB_F32, torch.float16: _l.EMB_F16, torch.int32: _l.EMB_FIXED32}
+            dt = tmap[rows.dtype] if dtype is None else dtype
+            if not rows.is_contiguous():
+                rows = rows.contiguous()
+            space = _l.EMB_MEM_DEVICE if rows.is_cuda else _l.EMB_MEM_HOST
+            if rows.is_cuda:
+                torch.cuda.current_stream(rows.device).synchronize()
+            ptr, shape = rows.data_ptr(), tuple(rows.shape)
+        else:
+            rows = np.ascontiguousarray(rows)
+            dt = _NP_TABLE_DTYPES[rows.dtype] if dtype is None else dtype
+            space, ptr, shape = _l.EMB_MEM_HOST, rows.ctypes.data, rows.shape
+        if len(shape) != 2:
+            raise ValueError("table must be 2-D [nr_rows, dim]")
+        _l.check(self._L.emb_load_table(self._h, table_id, shape[0], shape[1], dt, ptr, space))
+        self._tables[table_id] = (shape[0], shape[1], dt)
+
+    def alloc_table(self, table_id: int, nr_rows: int, dim: int, dtype: int) -> None:
+        _l.check(self._L.emb_alloc_table(self._h, table_id, nr_rows, dim, dtype))
+        self._tables[table_id] = (nr_rows, dim, dtype)
+
+    def load_table_column(self, table_id: int, col: int, column: np.ndarray) -> None:
+        column = np.ascontiguousarray(column, dtype=np.int32)
+        _l.check(self._L.emb_load_table_column(self._h, table_id, col, column.ctypes.data, column.shape[0]))
+
+    def table_info(self, table_id: int):
+        ptr, n, d, dt = C.c_void_p(), C.c_uint64(), C.c_uint32(), C.c_int()
+        _l.check(self._L.emb_table_info(self._h, table_id, C.byref(ptr), C.byref(n), C.byref(d), C.byref(dt)))
+        return ptr.value, n.value, d.value, dt.value
+
+    # ---- lookups (lookup's job, emb_host.h:234) ------------------------------------------------
+    def _alloc_out(self, like, n_bags: int, dim: int):
+        if isinstance(like, DeviceBuffer):
+            return DeviceBuffer(self, n_bags * dim * 4, np.float32, (n_bags, dim))
+        if _is_torch(like):
+            import torch
+            return torch.empty((n_bags, dim), dtype=torch.float32, device=like.device)
+        return np.empty((n_bags, dim), dtype=np.float32)
+
+    def _descs(self, table_ids, indices, offsets, outs, fixed_pooling):
+        n = len(table_ids)
+        if not (len(indices) == n and len(offsets) == n):
+            raise ValueError("table_ids, indices and offsets must have equal length")
+        arr = (_l.EmbLookupDesc * n)()
+        keep, results = [], []
+        itype = space = None
+        for i, t in enumerate(table_ids):
+            if t not in self._tables:
+                raise KeyError(f"table {t} is not loaded")
+            ia, oa = _Arg(indices[i]), _Arg(offsets[i])
+            L = 0
+            if oa.ptr is None:
+                L = int(fixed_pooling[i] if isinstance(fixed_pooling, (list, tuple)) else fixed_pooling or 0)
+                if L <= 0:
+                    raise ValueError("offsets=None needs fixed_pooling > 0")
+                n_bags = ia.n // L
+            else:
+                n_bags = oa.n
+                if _index_type_of(oa.dtype) != _index_type_of(ia.dtype) or oa.space != ia.space:
+                    raise TypeError("indices and offsets must share dtype width and placement")
+            it = _index_type_of(ia.dtype)
+            if itype is None:
+                itype, space = it, ia.space
+            elif it != itype or ia.space != space:
+                raise TypeError("all tables of one batched lookup must share index width and placement")
+            dim = self._tables[t][1]
+            out = outs[i] if outs is not None else self._alloc_out(indices[i], n_bags, dim)
+            ua = _Arg(out)
+            if ua.space != space:
+                raise TypeError("output placement must match the inputs")
+            arr[i] = _l.EmbLookupDesc(t, L, ia.ptr, oa.ptr, ia.n, n_bags, ua.ptr)
+            keep += [ia.keep, oa.keep, ua.keep]
+            results.append(out)
+        return arr, n, itype, space, results, keep
+
+    def lookup_batched(self, table_ids: Sequence[int], indices: Sequence, offsets: Sequence,
+                       outs: Sequence | None = None, fixed_pooling=0, stream: int | None = None):
+        """All tables in one fused launch; returns the list of pooled [B_t, D] outputs
+        (the `apply_emb` contract: one [B, D] per table)."""
+        arr, n, itype, space, results, _keep = self._descs(table_ids, indices, offsets, outs, fixed_pooling)
+        if stream is None and space == _l.EMB_MEM_DEVICE:
+            stream = _current_stream_for(*indices)
+        _l.check(self._L.emb_lookup_batched(self._h, arr, n, itype, space, stream))
+        return results
+
+    def lookup(self, table_id: int, indices, offsets, out=None, fixed_pooling: int = 0,
+               stream: int | None = None):
+        """lookup(table_id, offsets, indices) -> pooled_rows for one table."""
+        return self.lookup_batched([table_id], [indices], [offsets], None if out is None else [out],
+                                   fixed_pooling, stream)[0]
+
+    def plan(self, table_ids, indices, offsets, outs=None, fixed_pooling=0) -> Plan:
+        arr, n, itype, space, results, keep = self._descs(table_ids, indices, offsets, outs, fixed_pooling)
+        if space != _l.EMB_MEM_DEVICE:
+            raise TypeError("plans need device-resident buffers (torch CUDA tensors or DeviceBuffer)")
+        p = C.c_void_p()
+        _l.check(self._L.emb_plan_create(self._h, arr, n, itype, C.byref(p)))
+        return Plan(self, p.value, results, keep)
+
+    def validate(self, table_ids, indices, offsets, fixed_pooling=0) -> int:
+        """Debug check: number of out-of-range indices / broken offsets (0 = clean)."""
+        arr, n, itype, space, _r, _k = self._descs_novalidate(table_ids, indices, offsets, fixed_pooling)
+        bad = C.c_uint64()
+        rc = self._L.emb_validate_inputs(self._h, arr, n, itype, space, C.byref(bad))
+        if rc not in (_l.EMB_OK, _l.EMB_ERR_RANGE):
+            _l.check(rc)
+        return bad.value
+
+    def _descs_novalidate(self, table_ids, indices, offsets, fixed_pooling):
+        n = len(table_ids)
+        arr = (_l.EmbLookupDesc * n)()
+        keep = []
+        itype = space = None
+        for i, t in enumerate(table_ids):
+            ia, oa = _Arg(indices[i]), _Arg(offsets[i])
+            L = 0
+            if oa.ptr is None:
+                L = int(fixed_pooling[i] if isinstance(fixed_pooling, (list, tuple)) else fixed_pooling or 0)
+                n_bags = ia.n // max(L, 1)
+            else:
+                n_bags = oa.n
+            itype, space = _index_type_of(ia.dtype), ia.space
+            arr[i] = _l.EmbLookupDesc(t, L, ia.ptr, oa.ptr, ia.n, n_bags, None)
+            keep += [ia.keep, oa.keep]
+        return arr, n, itype, space, None, keep
+
+    # ---- misc --------------------------------------------------------------------------------------
+    def stats(self) -> dict:
+        s = _l.EmbStats()
+        _l.check(self._L.emb_get_stats(self._h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in s._fields_}
+
+    def reset_stats(self) -> None:
+        _l.check(self._L.emb_reset_stats(self._h))
+
+    def synchronize(self, stream: int | None = None) -> None:
+        _l.check(self._L.emb_synchronize(self._h, stream))
+
+    @property
+    def device(self) -> int:
+        d = C.c_int32()
+        _l.check(self._L.emb_device_of(self._h, C.byref(d)))
+        return d.value
+
+    def close(self) -> None:
+        if self._h:
+            self._L.emb_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

@@ -1,0 +1,56 @@
+"""Synthetic workloads of the shapes BASELINE.json / SURVEY.md section 8(d) name.  Data only:
+nothing here computes a lookup."""
+from __future__ import annotations
+
+import numpy as np
+
+# Criteo-Kaggle categorical cardinalities (the 26 `--arch-embedding-size`
+# values the reference's kaggle runs use, README.md:6,10,14).  Sum = 33 762 577 rows.
+KAGGLE_ROWS = [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 5683, 8351593, 3194,
+               27, 14992, 5461306, 10, 5652, 2173, 4, 7046547, 18, 15, 286181, 105, 142572]
+KAGGLE_DIM = 16       # --arch-sparse-feature-size=16
+KAGGLE_BATCH = 39292  # --mini-batch-size=39292 (README.md:14)
+
+
+def dlrm_table(rng: np.random.Generator, nr_rows: int, dim: int, dtype=np.float32) -> np.ndarray:
+    """DLRM init W ~ U(-sqrt(1/n), sqrt(1/n))."""
+    a = np.sqrt(1.0 / nr_rows)
+    return rng.uniform(-a, a, size=(nr_rows, dim)).astype(dtype)
+
+
+def uniform_indices(rng: np.random.Generator, nr_rows: int, n: int, dtype=np.uint32) -> np.ndarray:
+    """load_generator.c:90: (uint32)((double)rand()/RAND_MAX*nr_rows), i.e. uniform over rows."""
+    return rng.integers(0, nr_rows, size=n, dtype=np.int64).astype(dtype)
+
+
+def zipf_indices(rng: np.random.Generator, nr_rows: int, n: int, alpha: float = 1.2,
+                 dtype=np.uint32, permute: bool = True) -> np.ndarray:
+    """Zipf(alpha) ranks folded into [0, nr_rows) and scattered by a fixed random permutation of the
+    rows (hot rows are not neighbours in memory)."""
+    ranks = (rng.zipf(alpha, size=n) - 1) % nr_rows
+    if permute:
+        # multiplicative hash instead of materialising a 10M-entry permutation per table
+        mult = 2654435761
+        ranks = (ranks * mult + 12345) % nr_rows
+    return ranks.astype(dtype)
+
+
+def fixed_offsets(n_bags: int, pooling: int, dtype=np.uint32) -> np.ndarray:
+    """load_generator.c:88: offsets[i] = i * indices_per_batch."""
+    return (np.arange(n_bags, dtype=np.int64) * pooling).astype(dtype)
+
+
+def ragged_offsets(rng: np.random.Generator, n_bags: int, max_len: int, p_empty: float = 0.1,
+                   dtype=np.uint32):
+    lens = rng.integers(1, max_len + 1, size=n_bags)
+    lens[rng.random(n_bags) < p_empty] = 0
+    off = np.zeros(n_bags, dtype=np.int64)
+    if n_bags > 1:
+        off[1:] = np.cumsum(lens)[:-1]
+    return off.astype(dtype), int(lens.sum())
+
+
+def algorithmic_bytes(n_idx: int, n_bags: int, dim: int, elem: int, idx_bytes: int,
+                      has_offsets: bool = True) -> int:
+    """n_idx*(D*elem + idx) + n_bags*off + n_bags*D*4."""
+    return n_idx * (dim * elem + idx_bytes) + (n_bags * idx_bytes if has_offsets else 0) + n_bags * dim * 4

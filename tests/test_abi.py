@@ -1,0 +1,105 @@
+"""CPU: the C-ABI library loads and exports every symbol include/pimemb.h declares; the ctypes
+binding covers them all; struct layouts match the header.  No compute is called (no GPU here)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "pimemb.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)       # strip comments
+    text = re.sub(r"typedef\s+(struct|enum)\s+\w+\s*\{.*?\}\s*\w+\s*;", "", text, flags=re.S)
+    names = re.findall(r"\b([a-z_][a-z0-9_]*)\s*\([^;{]*\)\s*;", text)
+    return sorted(set(names))
+
+
+def test_header_declares_the_reference_signatures():
+    text = open(HEADER).read()
+    # emb_host.h:136 and :234, token for token
+    assert re.search(r"struct dpu_set_t \*populate_mram\(uint32_t table_id, uint64_t nr_rows, uint32_t col,\s*"
+                     r"int32_t \*table_data, dpu_runtime_totals \*runtime\);", text)
+    assert re.search(r"int32_t \*lookup\(uint32_t \*\*indices, uint32_t \*\*offsets, float \*\*final_results,\s*"
+                     r"void \*dpu_set_ptr_untyped, int64_t latency_print\);", text)
+
+
+def test_library_exports_every_declared_symbol(pel):
+    fns = declared_functions()
+    assert {"populate_mram", "lookup", "emb_create", "emb_lookup", "emb_lookup_batched",
+            "emb_load_table", "emb_get_stats", "emb_destroy", "emb_last_error",
+            "emb_configure"} <= set(fns)
+    assert os.path.exists(pel.LIB_PATH), "libpimemb.so must be built in-tree (__graft_entry__.build())"
+    out = subprocess.check_output(["nm", "-D", "--defined-only", pel.LIB_PATH], text=True)
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    missing = [f for f in fns if f not in exported]
+    assert not missing, f"declared in pimemb.h but not exported: {missing}"
+
+
+def test_ctypes_binding_covers_the_header(pel):
+    assert sorted(pel.lib.SIGNATURES) == declared_functions()
+    L = pel.lib.load()
+    for name in pel.lib.SIGNATURES:
+        assert getattr(L, name) is not None
+    assert L.emb_version().startswith(b"pimemb")
+
+
+def test_struct_layouts(pel):
+    assert C.sizeof(pel.lib.EmbLookupDesc) == 48
+    assert C.sizeof(pel.lib.EmbConfig) == 12
+    assert C.sizeof(pel.lib.EmbStats) == 5 * 8 + 6 * 8
+    assert C.sizeof(pel.lib.DpuRuntimeTotals) == 48      # six doubles, emb_host.h:41-48
+    assert pel.lib.EmbLookupDesc.indices.offset == 8 and pel.lib.EmbLookupDesc.pooled.offset == 40
+
+
+def test_header_compiles_as_c_and_cxx(tmp_path):
+    src = tmp_path / "t.c"
+    src.write_text('#include "pimemb.h"\nint main(void){emb_lookup_desc d; (void)d; return sizeof(emb_stats)==88?0:1;}\n')
+    for cc, std in (("gcc", "-std=c99"), ("g++", "-std=c++11")):
+        exe = tmp_path / ("t_" + cc)
+        subprocess.check_call([cc, std, "-Wall", "-Werror", "-x", "c" if cc == "gcc" else "c++",
+                               "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+        assert subprocess.call([str(exe)]) == 0
+
+
+def test_links_one_hip_runtime_by_unversioned_name(pel):
+    """DT_NEEDED must be the unversioned libamdhip64.so so a torch process shares ONE HIP runtime
+    with the engine (csrc/Makefile note)."""
+    out = subprocess.check_output(["objdump", "-p", pel.LIB_PATH], text=True)
+    needed = re.findall(r"NEEDED\s+(\S+)", out)
+    assert "libamdhip64.so" in needed
+    assert not any(n.startswith("libtorch") or n.startswith("libc10") for n in needed)
+    maps = {line.split()[-1] for line in open("/proc/self/maps") if "libamdhip64" in line}
+    assert len(maps) <= 1, maps
+
+
+def test_no_gpu_fails_loudly_not_silently(pel):
+    """Without a GPU the product must raise; with one (GPU box) creation simply works."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(pel.PimembError) as ei:
+        pel.EmbeddingEngine()
+    assert ei.value.code == pel.lib.EMB_ERR_DEVICE
+    assert pel.lib.load().emb_configure(0, 1, 1, 1) == pel.lib.EMB_ERR_INVALID
+    assert b"non-zero" in pel.lib.load().emb_last_error()
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under the package may import, include, link or
+    dlopen it (comments may mention it)."""
+    pat = re.compile(r"(^\s*(import|from)\s+\S*oracle|#\s*include\s+\S*oracle|libemb_oracle|oracle/|emb_oracle)",
+                     re.M)
+    pkg = os.path.join(ROOT, "pim-embedding-lookup_amd")
+    seen = 0
+    for dirpath, _dirs, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")) or f == "Makefile":
+                seen += 1
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert not pat.search(text), (dirpath, f)
+    assert seen >= 8

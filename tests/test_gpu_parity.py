@@ -1,0 +1,246 @@
+"""GPU: the HIP path, called through the C ABI (libpimemb.so), against the golden fixtures and the
+CPU oracle on the same seeded inputs.  Bar: BIT-EXACT -- indices are integers, the fixed-point mode
+is integer arithmetic, and the fp32 mode accumulates in index order exactly like the oracle
+(tolerance would be 1e-6 abs per load_generator.c:58; we hold 0)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+BAG_FIXTURES = sorted(os.path.basename(p) for p in glob.glob(
+    os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
+    if not os.path.basename(p).startswith(("toy_", "kaggle26")))
+
+
+@pytest.fixture(scope="module")
+def eng(pel):
+    e = pel.EmbeddingEngine(device=0, max_tables=64)
+    yield e
+    e.close()
+
+
+def _dev(pel, eng, a):
+    return pel.DeviceBuffer.from_numpy(eng, a)
+
+
+@pytest.mark.parametrize("name", BAG_FIXTURES)
+@pytest.mark.parametrize("itype", [np.uint32, np.int64])
+def test_golden_fixture_host_and_device_paths(pel, eng, oracle, golden_dir, name, itype):
+    z = np.load(os.path.join(golden_dir, name))
+    tab, exp = z["table"], z["expect"]
+    idx, off = z["indices"].astype(itype), z["offsets"].astype(itype)
+    eng.load_table(0, tab)
+    # (1) host pointers: copy in, kernel, copy out -- the reference's calling convention
+    got = eng.lookup(0, idx, off)
+    assert got.dtype == np.float32 and got.shape == exp.shape
+    assert np.array_equal(got, exp), f"{name}: host path differs, max |d| = {np.abs(got - exp).max(initial=0)}"
+    # (2) device-resident buffers: zero-copy launch
+    d_idx, d_off = _dev(pel, eng, idx), _dev(pel, eng, off)
+    d_out = eng.lookup(0, d_idx, d_off)
+    eng.synchronize()
+    assert np.array_equal(d_out.numpy(), exp)
+    # (3) prepared plan, launched twice (idempotent: output is overwritten, not accumulated)
+    plan = eng.plan([0], [d_idx], [d_off])
+    plan.launch(); plan.launch()
+    eng.synchronize()
+    assert np.array_equal(plan.outputs[0].numpy(), exp)
+    assert np.array_equal(plan.outputs[0].numpy(), oracle.c_bag_sum(tab, idx, off))
+    nbytes, nb, ni = plan.bytes()
+    assert (nb, ni) == (off.shape[0], idx.shape[0])
+    elem = tab.dtype.itemsize
+    isz = np.dtype(itype).itemsize
+    assert nbytes == ni * (tab.shape[1] * elem + isz) + nb * isz + nb * tab.shape[1] * 4
+    plan.destroy()
+    for b in (d_idx, d_off, d_out):
+        b.free()
+
+
+def test_toy_ctest_known_answer_through_reference_entry_points(pel, oracle, golden_dir):
+    """populate_mram / lookup with the reference's own toy data (c_test.py:40,55-57):
+    every bag must come out as [10,20,...,80] / 1e9."""
+    from importlib import import_module
+    compat = import_module("pim-embedding-lookup_amd.compat")
+    z = np.load(os.path.join(golden_dir, "toy_ctest.npz"))
+    tab, idx, off = z["table_i32"], z["indices"], z["offsets"]
+    T = 3
+    compat.reset()
+    compat.configure(nr_tables=T, nr_cols=8, max_nr_batches=32, max_indices_per_batch=4)
+    rt = pel.lib.DpuRuntimeTotals()
+    h = compat.populate([tab] * T, rt)
+    assert h and rt.execution_time_populate_copy_in > 0
+    res = compat.lookup(h, [idx] * T, [off] * T, nr_cols=8, latency_print=1)
+    want = oracle.c_lookup_fixed32(tab, idx, off)
+    assert np.array_equal(want * np.float32(1e9), np.tile(np.arange(10, 90, 10, dtype=np.float32), (32, 1)))
+    for t in range(T):
+        assert np.array_equal(res[t], want)
+        assert oracle.c_validate_result(tab, idx, off, res[t]) == 0      # load_generator.c:58
+    compat.reset()
+
+
+def test_reference_lookup_semantics_random(pel, oracle):
+    """Reference shapes (toy preset run.sh:93-101 scaled): T tables x C cols, Bmax bags, L idx/bag,
+    int32 tables from rand() like load_generator.c:33, including wrap-around sums."""
+    from importlib import import_module
+    compat = import_module("pim-embedding-lookup_amd.compat")
+    rng = np.random.default_rng(7)
+    T, Cc, Bmax, Lmax, rows = 5, 64, 65, 32, 5000      # odd Bmax: the DPU writeback bug case (A3)
+    tabs = [rng.integers(-2**31, 2**31 - 1, size=(rows, Cc), dtype=np.int64).astype(np.int32) for _ in range(T)]
+    compat.reset()
+    compat.configure(T, Cc, Bmax, Lmax)
+    h = compat.populate(tabs)
+    idx = [rng.integers(0, rows, size=Bmax * Lmax).astype(np.uint32) for _ in range(T)]
+    # ragged bag starts inside the fixed-size index buffer; last bag runs to INDICES_LEN
+    off = [np.sort(rng.integers(0, Bmax * Lmax, size=Bmax)).astype(np.uint32) for _ in range(T)]
+    for o in off:
+        o[0] = 0
+    res = compat.lookup(h, idx, off, nr_cols=Cc)
+    for t in range(T):
+        want = oracle.c_lookup_fixed32(tabs[t], idx[t], off[t])
+        assert np.array_equal(res[t], want)
+        assert np.array_equal(res[t][-1], want[-1])      # odd nr_batches: last bag is NOT dropped
+    compat.reset()
+
+
+def test_kaggle26_fixture_one_fused_launch(pel, eng, golden_dir):
+    """C1-shaped plumbing: 26 tables, D=16, all tables in ONE batched call."""
+    z = np.load(os.path.join(golden_dir, "kaggle26_capped_b4.npz"))
+    ids = list(range(26))
+    for t in ids:
+        eng.load_table(t, z[f"table_{t}"])
+    before = eng.stats()["n_kernel_launches"]
+    outs = eng.lookup_batched(ids, [z[f"indices_{t}"] for t in ids], [z[f"offsets_{t}"] for t in ids])
+    assert eng.stats()["n_kernel_launches"] == before + 1
+    for t in ids:
+        assert np.array_equal(outs[t], z[f"expect_{t}"])
+
+
+@pytest.mark.parametrize("dim,dtype", [(4, np.float32), (8, np.float32), (16, np.float32), (32, np.float32),
+                                       (48, np.float32), (64, np.float32), (128, np.float32),
+                                       (256, np.float32), (8, np.float16), (64, np.float16),
+                                       (200, np.float16), (512, np.float16), (16, np.int32), (64, np.int32)])
+def test_every_row_width_against_oracle(pel, eng, oracle, dim, dtype):
+    rng = np.random.default_rng(dim * 7 + np.dtype(dtype).itemsize)
+    rows, bags = 3001, 777          # not multiples of any tile size
+    if dtype == np.int32:
+        tab = rng.integers(-2**31, 2**31 - 1, size=(rows, dim), dtype=np.int64).astype(np.int32)
+    else:
+        tab = rng.standard_normal((rows, dim)).astype(dtype)
+    off, n_idx = pel.workloads.ragged_offsets(rng, bags, 70, p_empty=0.2, dtype=np.int64)
+    idx = rng.integers(0, rows, size=n_idx).astype(np.int64)
+    eng.load_table(1, tab)
+    got = eng.lookup(1, idx, off)
+    want = (oracle.c_lookup_fixed32(tab, idx.astype(np.uint32), off.astype(np.uint32)) if dtype == np.int32
+            else oracle.c_bag_sum(tab, idx, off))
+    assert np.array_equal(got, want)
+
+
+def test_mixed_shapes_in_one_batched_call(pel, eng, oracle):
+    rng = np.random.default_rng(11)
+    specs = [(10, 16, np.float32), (11, 64, np.float32), (12, 16, np.float32), (13, 64, np.float16)]
+    tabs, idxs, offs = {}, [], []
+    for tid, dim, dt in specs:
+        tabs[tid] = rng.standard_normal((500 + tid, dim)).astype(dt)
+        eng.load_table(tid, tabs[tid])
+        off, n = pel.workloads.ragged_offsets(rng, 100 + tid, 9, dtype=np.uint32)
+        offs.append(off)
+        idxs.append(rng.integers(0, 500 + tid, size=n).astype(np.uint32))
+    outs = eng.lookup_batched([s[0] for s in specs], idxs, offs)
+    for (tid, _d, _t), i, o, got in zip(specs, idxs, offs, outs):
+        assert np.array_equal(got, oracle.c_bag_sum(tabs[tid], i, o))
+
+
+def test_fixed_pooling_without_offsets(pel, eng, oracle):
+    """offsets=NULL + fixed_pooling=L == offsets[i]=i*L (load_generator.c:88)."""
+    rng = np.random.default_rng(5)
+    tab = rng.standard_normal((10000, 128)).astype(np.float32)
+    eng.load_table(2, tab)
+    for L in (1, 3, 32, 120):       # 120 = r.sh:9
+        idx = rng.integers(0, 10000, size=257 * L).astype(np.uint32)
+        got = eng.lookup(2, idx, None, fixed_pooling=L)
+        want = oracle.c_bag_sum(tab, idx, pel.workloads.fixed_offsets(257, L))
+        assert np.array_equal(got, want)
+
+
+def test_edge_cases(pel, eng, oracle):
+    rng = np.random.default_rng(3)
+    tab = rng.standard_normal((9, 16)).astype(np.float32)
+    eng.load_table(3, tab)
+    # zero bags, zero indices
+    out = eng.lookup(3, np.zeros(0, np.uint32), np.zeros(0, np.uint32))
+    assert out.shape == (0, 16)
+    # all bags empty -> zeros (emb_dpu_lookup.c:108)
+    out = eng.lookup(3, np.zeros(0, np.int64), np.zeros(13, np.int64))
+    assert np.array_equal(out, np.zeros((13, 16), np.float32))
+    # one giant bag of duplicates
+    idx = np.full(100000, 4, dtype=np.uint32)
+    out = eng.lookup(3, idx, np.zeros(1, np.uint32))
+    assert np.array_equal(out, oracle.c_bag_sum(tab, idx, np.zeros(1, np.uint32)))
+    # first / last row of the table, single-row table
+    idx = np.array([0, 8, 8, 0], dtype=np.uint32)
+    assert np.array_equal(eng.lookup(3, idx, np.array([0, 1, 2, 3], np.uint32)), tab[idx])
+    one = rng.standard_normal((1, 64)).astype(np.float32)
+    eng.load_table(4, one)
+    assert np.array_equal(eng.lookup(4, np.zeros(5, np.int64), np.arange(5, dtype=np.int64)), np.tile(one, (5, 1)))
+
+
+def test_errors_are_codes_not_exits(pel, eng):
+    with pytest.raises(KeyError):
+        eng.lookup(63, np.zeros(1, np.uint32), np.zeros(1, np.uint32))
+    L = pel.lib.load()
+    import ctypes as C
+    d = pel.lib.EmbLookupDesc(62, 0, None, None, 0, 1, None)
+    assert L.emb_lookup_batched(eng._h, C.byref(d), 1, 0, 0, None) == pel.lib.EMB_ERR_INVALID
+    assert b"not loaded" in L.emb_last_error()
+    with pytest.raises(pel.PimembError) as ei:
+        eng.alloc_table(5, 10, 3, pel.EMB_F32)          # 12-byte rows
+    assert ei.value.code == pel.lib.EMB_ERR_UNSUPPORTED
+    with pytest.raises(pel.PimembError):
+        eng.alloc_table(999, 10, 16, pel.EMB_F32)       # beyond max_tables
+
+
+def test_validate_inputs_counts_bad_indices(pel, eng):
+    tab = np.zeros((50, 16), np.float32)
+    eng.load_table(6, tab)
+    idx = np.array([0, 49, 50, 7, 2**31], dtype=np.uint32)
+    off = np.array([0, 2, 1], dtype=np.uint32)          # 2 -> 1 is non-monotone
+    assert eng.validate([6], [idx], [off]) == 3
+    assert eng.validate([6], [idx[:2]], [np.array([0, 1], np.uint32)]) == 0
+
+
+def test_torch_tensors_zero_copy_on_current_stream(pel, eng, oracle):
+    import torch
+    rng = np.random.default_rng(21)
+    tab = rng.standard_normal((4096, 16)).astype(np.float32)
+    w = torch.from_numpy(tab).cuda()
+    eng.load_table(7, w)                                 # device-to-device upload
+    idx = rng.integers(0, 4096, size=3000).astype(np.int64)
+    off = np.arange(0, 3000, 3, dtype=np.int64)
+    ti, to = torch.from_numpy(idx).cuda(), torch.from_numpy(off).cuda()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        out = eng.lookup(7, ti, to)
+    s.synchronize()
+    assert out.is_cuda and out.shape == (1000, 16)
+    want = oracle.c_bag_sum(tab, idx, off)
+    assert np.array_equal(out.cpu().numpy(), want)
+    # and torch's own GPU EmbeddingBag agrees to fp32 tolerance (different summation order allowed)
+    ref = torch.nn.functional.embedding_bag(ti, w, to, mode="sum")
+    assert torch.allclose(out, ref, atol=1e-6, rtol=0)
+
+
+def test_moderate_size_all_index_distributions(pel, eng, oracle):
+    """Sizes the oracle finishes in seconds: 200k bags, uniform and Zipf(1.2) indices, pooling 1/32."""
+    rng = np.random.default_rng(1)
+    rows = 1_000_000
+    tab = pel.workloads.dlrm_table(rng, rows, 16)
+    eng.load_table(8, tab)
+    for L, gen in ((1, pel.workloads.uniform_indices), (1, pel.workloads.zipf_indices),
+                   (32, pel.workloads.zipf_indices)):
+        B = 200_000 if L == 1 else 20_000
+        idx = gen(rng, rows, B * L)
+        off = pel.workloads.fixed_offsets(B, L)
+        got = eng.lookup(8, idx, off)
+        assert np.array_equal(got, oracle.c_bag_sum(tab, idx, off))
