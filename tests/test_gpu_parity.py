@@ -73,7 +73,7 @@ def test_toy_ctest_known_answer_through_reference_entry_points(pel, oracle, gold
     assert h and rt.execution_time_populate_copy_in > 0
     res = compat.lookup(h, [idx] * T, [off] * T, nr_cols=8, latency_print=1)
     want = oracle.c_lookup_fixed32(tab, idx, off)
-    assert np.array_equal(want * np.float32(1e9), np.tile(np.arange(10, 90, 10, dtype=np.float32), (32, 1)))
+    assert np.array_equal(np.rint(want.astype(np.float64) * 1e9), np.tile(np.arange(10.0, 90.0, 10.0), (32, 1)))
     for t in range(T):
         assert np.array_equal(res[t], want)
         assert oracle.c_validate_result(tab, idx, off, res[t]) == 0      # load_generator.c:58
