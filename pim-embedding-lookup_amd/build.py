@@ -7,7 +7,7 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "lib", "libpimemb.so")
-SOURCES = ["pimemb_kernels.hip", "pimemb_engine.cpp", "pimemb_compat.cpp", "pimemb_internal.h",
+SOURCES = ["pimemb_kernels.hip", "pimemb_engine.cpp", "pimemb_compat.cpp", "pimemb_internal.h", "pimemb_bag_kernels.h",
            "Makefile", os.path.join("..", "..", "include", "pimemb.h")]
 
 

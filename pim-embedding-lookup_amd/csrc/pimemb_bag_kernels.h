@@ -1,0 +1,384 @@
+// pimemb_bag_kernels.h -- device code of the hot path (gfx950 / MI355X, CDNA4), as templates so the
+// library (pimemb_kernels.hip) and the tuning tool (tools/tune_bag_kernels.hip) compile the very
+// same source with different compile-time knobs.
+//
+// Replaces the UPMEM DPU program upmem/src/dpu/emb_dpu_lookup.c:36-138 (one DPU per (table,
+// column), 14 tasklets striding over bags, one 8-byte MRAM read per (index, column)) and the host
+// post-process upmem/include/emb_host.h:186-222 with ONE fused launch over all tables:
+//
+//   out[t][b][:] = sum_{p = off_t[b]}^{end-1} W_t[idx_t[p]][:]      end = off_t[b+1] | n_idx_t
+//
+// Mapping to the machine (bandwidth/latency-bound indexing; no MFMA -- there is no contraction):
+//   * rows stay row-major [nr_rows][dim] in HBM; a row is read as 16-byte pieces, one per lane,
+//     so the LPR = row_bytes/16 lanes of a "lane group" fetch a whole row with one coalesced
+//     global_load_dwordx4 (64 B for dim 16 fp32, 512 B for dim 128 fp32);
+//   * a 64-lane wavefront owns 64 consecutive bags per step ("wave batch"): lane l first loads the
+//     bounds of bag l (two coalesced 256-B loads instead of 64/LPR scattered ones), then the
+//     wavefront walks the batch in LPR rounds of 64/LPR bags, lane groups picking their bag's
+//     bounds / index out of the owning lane with a wavefront shuffle (ds_bpermute);
+//   * one-hot batches (every bag <= 1 index: the Criteo-Kaggle shape) take a fast path that
+//     issues all rounds' row gathers before the first store, so a lane keeps up to 8 independent
+//     16-byte gathers in flight; longer bags keep kUnroll gathers in flight inside the bag;
+//   * every output element is accumulated by ONE lane in index order starting from +0, the order
+//     of a sequential CPU EmbeddingBag: fp32 results are bit-identical to the oracle for any
+//     pooling factor (no cross-lane reduction tree whose rounding would differ);
+//   * the fixed-point mode keeps the reference arithmetic: int32 wrap-around accumulate
+//     (emb_dpu_lookup.c:114) and out = (float)acc / 1e9 through double (emb_host.h:210).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pimemb.h"
+
+namespace pimemb {
+
+// One table's share of a fused launch as the kernel sees it (HBM-resident array, 64 B each so a
+// workgroup fetches its descriptor with one scalar load burst).
+struct alignas(64) DevDesc {
+    const void *weights;    // row-major [nr_rows][dim] of the table dtype
+    const void *indices;    // IdxT[n_idx]
+    const void *offsets;    // IdxT[n_bags] bag starts, or nullptr when fixed_pooling > 0
+    float *out;             // float[n_bags][dim]
+    uint64_t n_idx;
+    uint64_t n_bags;
+    uint64_t nr_rows;       // only read by the validation kernel
+    uint32_t fixed_pooling; // L > 0: offsets[b] = b*L (load_generator.c:88)
+    uint32_t n_tiles;       // ceil(n_bags / bags_per_tile) for this launch geometry
+};
+static_assert(sizeof(DevDesc) == 64, "DevDesc must stay one 64-byte line");
+
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f32x8 = __attribute__((ext_vector_type(8))) float;
+
+// Compile-time knobs of the bag kernels.
+template <int BLOCK = 256, int UNROLL = 8, bool NT_STORE = false, bool NT_META = false,
+          int ONEHOT_INFLIGHT = 8, int MIN_WAVES = 1, int BATCHES = 1, bool NT_ROW = false,
+          bool SPECULATE = false>
+struct BagCfg {
+    static constexpr bool kSpeculate = SPECULATE; // prefetch indices[bag] before the bounds arrive
+    static constexpr int kMinWaves = MIN_WAVES;   // __launch_bounds__ 2nd arg: waves per SIMD wanted
+    static constexpr int kBatches = BATCHES;      // 64-bag batches a wavefront takes per step
+    static constexpr bool kNtRow = NT_ROW;        // non-temporal row gathers
+    static constexpr int kBlock = BLOCK;          // threads per workgroup (multiple of 64)
+    static constexpr int kUnroll = UNROLL;        // row gathers in flight per lane inside a bag
+    static constexpr bool kNtStore = NT_STORE;    // non-temporal pooled-row stores
+    static constexpr bool kNtMeta = NT_META;      // non-temporal index / offset loads
+    static constexpr int kOneHot = ONEHOT_INFLIGHT;  // rounds batched on the one-hot fast path
+};
+
+// ---- per-dtype accumulate / store -----------------------------------------------------------
+template <int DT>
+struct RowOps;
+
+template <bool NT>
+__device__ __forceinline__ void store_f32x4(float *dst, f32x4 v) {
+    if constexpr (NT)
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(dst));
+    else
+        *reinterpret_cast<f32x4 *>(dst) = v;
+}
+
+template <>
+struct RowOps<EMB_F32> {
+    using Acc = f32x4;
+    static constexpr uint32_t kFloatsPerLane = 4;
+    static __device__ __forceinline__ Acc zero() { return Acc{0.f, 0.f, 0.f, 0.f}; }
+    static __device__ __forceinline__ void add(Acc &a, u32x4 raw) { a += __builtin_bit_cast(f32x4, raw); }
+    template <bool NT>
+    static __device__ __forceinline__ void store(const Acc &a, float *dst) {
+        store_f32x4<NT>(dst, a);
+    }
+};
+
+template <>
+struct RowOps<EMB_F16> {
+    using Acc = f32x8;
+    static constexpr uint32_t kFloatsPerLane = 8;
+    static __device__ __forceinline__ Acc zero() { return Acc{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; }
+    static __device__ __forceinline__ void add(Acc &a, u32x4 raw) {
+        a += __builtin_convertvector(__builtin_bit_cast(f16x8, raw), f32x8);
+    }
+    template <bool NT>
+    static __device__ __forceinline__ void store(const Acc &a, float *dst) {
+        store_f32x4<NT>(dst, f32x4{a[0], a[1], a[2], a[3]});
+        store_f32x4<NT>(dst + 4, f32x4{a[4], a[5], a[6], a[7]});
+    }
+};
+
+template <>
+struct RowOps<EMB_FIXED32> {
+    using Acc = u32x4;  // unsigned add == int32 two's-complement wrap (emb_dpu_lookup.c:114)
+    static constexpr uint32_t kFloatsPerLane = 4;
+    static __device__ __forceinline__ Acc zero() { return Acc{0u, 0u, 0u, 0u}; }
+    static __device__ __forceinline__ void add(Acc &a, u32x4 raw) { a += raw; }
+    static __device__ __forceinline__ float conv(uint32_t acc) {
+        // emb_host.h:210: (float)tmp / pow(10,9): int32 -> float, divide in double, round to float
+        return (float)((double)(float)(int32_t)acc / 1.0e9);
+    }
+    template <bool NT>
+    static __device__ __forceinline__ void store(const Acc &a, float *dst) {
+        store_f32x4<NT>(dst, f32x4{conv(a[0]), conv(a[1]), conv(a[2]), conv(a[3])});
+    }
+};
+
+template <bool NT, typename T>
+__device__ __forceinline__ T load_meta(const T *p) {
+    if constexpr (NT)
+        return __builtin_nontemporal_load(p);
+    else
+        return *p;
+}
+
+template <bool NT>
+__device__ __forceinline__ u32x4 load_row(const char *p) {
+    if constexpr (NT)
+        return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    else
+        return *reinterpret_cast<const u32x4 *>(p);
+}
+
+__device__ __forceinline__ uint32_t shfl_u32(uint32_t v, uint32_t src) {
+    return (uint32_t)__shfl((int)v, (int)src, 64);
+}
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, uint32_t src) {
+    uint32_t lo = shfl_u32((uint32_t)v, src), hi = shfl_u32((uint32_t)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+}
+template <typename IdxT>
+__device__ __forceinline__ uint64_t shfl_index(IdxT v, uint32_t src) {
+    if constexpr (sizeof(IdxT) == 8)
+        return shfl_u64((uint64_t)v, src);
+    else
+        return (uint64_t)shfl_u32((uint32_t)v, src);
+}
+
+// Workgroup -> (descriptor, tile).  xmap == nullptr: 2-D grid (x = tile, y = descriptor).
+// Otherwise the 1-D XCD-aware map built by pimemb_xcd_map.h: residue class blockIdx.x % 8 owns a
+// contiguous share of the (table, tile) list, so a table's rows stay in ONE XCD's L2.
+struct XcdSegDev {
+    uint32_t desc, tile0, slot_begin, slot_end;
+};
+__device__ __forceinline__ bool decode_block(const uint32_t *__restrict__ xmap, uint32_t *desc_i,
+                                             uint32_t *tile) {
+    if (xmap == nullptr) {
+        *desc_i = blockIdx.y;
+        *tile = blockIdx.x;
+        return true;
+    }
+    const uint32_t cls = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const uint32_t ns = xmap[cls];
+    const XcdSegDev *segs = reinterpret_cast<const XcdSegDev *>(xmap + 16) + xmap[8 + cls];
+    for (uint32_t i = 0; i < ns; i++) {
+        const XcdSegDev sg = segs[i];
+        if (slot < sg.slot_end) {
+            *desc_i = sg.desc;
+            *tile = sg.tile0 + (slot - sg.slot_begin);
+            return true;
+        }
+    }
+    return false;
+}
+
+// ---- v1: one lane group per bag, no cross-lane traffic (kept as the A/B baseline) -------------
+template <typename IdxT, int DT, int LPR, class Cfg>
+__global__ void __launch_bounds__(Cfg::kBlock)
+bag_sum_group_kernel(const DevDesc *__restrict__ descs, uint32_t chunks,
+                     const uint32_t *__restrict__ xmap) {
+    using Ops = RowOps<DT>;
+    constexpr uint32_t kWaves = Cfg::kBlock / 64;
+    constexpr uint32_t BPW = 64 / LPR;
+    constexpr uint32_t BAGS_PER_TILE = BPW * kWaves;
+    constexpr int U = Cfg::kUnroll;
+
+    uint32_t desc_i, tile;
+    if (!decode_block(xmap, &desc_i, &tile)) return;
+    const DevDesc *dp = descs + desc_i;
+    const char *__restrict__ weights = static_cast<const char *>(dp->weights);
+    const IdxT *__restrict__ indices = static_cast<const IdxT *>(dp->indices);
+    const IdxT *__restrict__ offsets = static_cast<const IdxT *>(dp->offsets);
+    float *__restrict__ out = dp->out;
+    const uint64_t n_idx = dp->n_idx, n_bags = dp->n_bags;
+    const uint32_t fixed_pooling = dp->fixed_pooling, n_tiles = dp->n_tiles;
+
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t sub = lane & (LPR - 1), grp = lane / LPR;
+    const uint32_t row_bytes = chunks * 16u;
+    const uint32_t out_stride = chunks * Ops::kFloatsPerLane;
+    const char *__restrict__ wsub = weights + sub * 16u;
+
+    if (tile < n_tiles) {
+        const uint64_t bag = (uint64_t)tile * BAGS_PER_TILE + wave * BPW + grp;
+        if (bag >= n_bags || sub >= chunks) return;
+        uint64_t p, e;
+        if (offsets != nullptr) {
+            p = (uint64_t)load_meta<Cfg::kNtMeta>(offsets + bag);
+            e = (bag + 1 < n_bags) ? (uint64_t)load_meta<Cfg::kNtMeta>(offsets + bag + 1) : n_idx;
+        } else {
+            p = bag * fixed_pooling;
+            e = p + fixed_pooling;
+        }
+        typename Ops::Acc acc = Ops::zero();
+        for (; p + U <= e; p += U) {
+            uint64_t r[U];
+#pragma unroll
+            for (int k = 0; k < U; k++) r[k] = (uint64_t)load_meta<Cfg::kNtMeta>(indices + p + k);
+            u32x4 v[U];
+#pragma unroll
+            for (int k = 0; k < U; k++) v[k] = *reinterpret_cast<const u32x4 *>(wsub + r[k] * row_bytes);
+#pragma unroll
+            for (int k = 0; k < U; k++) Ops::add(acc, v[k]);
+        }
+        for (; p < e; p++) {
+            const uint64_t r = (uint64_t)load_meta<Cfg::kNtMeta>(indices + p);
+            Ops::add(acc, *reinterpret_cast<const u32x4 *>(wsub + r * row_bytes));
+        }
+        Ops::template store<Cfg::kNtStore>(acc, out + bag * out_stride + sub * Ops::kFloatsPerLane);
+    }
+}
+
+// ---- v2: wave batches of 64 bags, coalesced bounds, shuffle-distributed, one-hot fast path -------
+template <typename IdxT, int DT, int LPR, class Cfg>
+__global__ void __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves)
+bag_sum_wavebatch_kernel(const DevDesc *__restrict__ descs, uint32_t chunks,
+                         const uint32_t *__restrict__ xmap) {
+    using Ops = RowOps<DT>;
+    constexpr uint32_t kWaves = Cfg::kBlock / 64;
+    constexpr uint32_t BPR = 64 / LPR;      // bags per round
+    constexpr uint32_t ROUNDS = LPR;        // rounds per 64-bag wave batch
+    constexpr uint32_t NB = Cfg::kBatches;  // wave batches per step
+    constexpr int U = Cfg::kUnroll;
+    constexpr uint32_t RU = (ROUNDS < (uint32_t)Cfg::kOneHot) ? ROUNDS : (uint32_t)Cfg::kOneHot;
+
+    uint32_t desc_i, tile;
+    if (!decode_block(xmap, &desc_i, &tile)) return;
+    const DevDesc *dp = descs + desc_i;
+    const char *__restrict__ weights = static_cast<const char *>(dp->weights);
+    const IdxT *__restrict__ indices = static_cast<const IdxT *>(dp->indices);
+    const IdxT *__restrict__ offsets = static_cast<const IdxT *>(dp->offsets);
+    float *__restrict__ out = dp->out;
+    const uint64_t n_idx = dp->n_idx, n_bags = dp->n_bags;
+    const uint32_t fixed_pooling = dp->fixed_pooling, n_tiles = dp->n_tiles;
+
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t sub = lane & (LPR - 1), grp = lane / LPR;
+    const uint32_t row_bytes = chunks * 16u;
+    const uint32_t out_stride = chunks * Ops::kFloatsPerLane;
+    const char *__restrict__ wsub = weights + sub * 16u;
+    const bool lane_live = sub < chunks;
+
+    if (tile < n_tiles) {
+        const uint64_t step_base = ((uint64_t)tile * kWaves + wave) * (64u * NB);
+        if (step_base >= n_bags) return;  // wave-uniform
+
+        // lane l of batch q holds the bounds of bag step_base + 64q + l (past-the-end = empty)
+        uint64_t st[NB];
+        uint32_t len[NB];
+        bool small = true;
+        // Speculation: in a one-hot batch with contiguous bags offsets[b] == b, so bag b's only index
+        // sits at indices[b].  Fetch it NOW, in the shadow of the bounds loads, and keep it only if
+        // the bounds agree -- one memory round trip less on the critical path of the Kaggle shape.
+        IdxT spec[NB];
+        if constexpr (Cfg::kSpeculate) {
+#pragma unroll
+            for (uint32_t q = 0; q < NB; q++) {
+                const uint64_t mb = step_base + 64u * q + lane;
+                spec[q] = 0;
+                if (mb < n_idx) spec[q] = load_meta<Cfg::kNtMeta>(indices + mb);
+            }
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < NB; q++) {
+            const uint64_t mb = step_base + 64u * q + lane;
+            uint64_t en;
+            if (offsets != nullptr) {
+                st[q] = (mb < n_bags) ? (uint64_t)load_meta<Cfg::kNtMeta>(offsets + mb) : n_idx;
+                en = (mb + 1 < n_bags) ? (uint64_t)load_meta<Cfg::kNtMeta>(offsets + mb + 1) : n_idx;
+            } else {
+                st[q] = (mb < n_bags ? mb : n_bags) * fixed_pooling;
+                en = (mb + 1 < n_bags ? mb + 1 : n_bags) * fixed_pooling;
+            }
+            len[q] = (uint32_t)(en - st[q]);
+            small = small && (len[q] <= 1u);
+        }
+
+        if (__all(small)) {
+            // one-hot step: lane l fetches its bag's only index (coalesced), groups pull theirs and
+            // every gather of the step is issued before the first store.
+            IdxT my[NB];
+#pragma unroll
+            for (uint32_t q = 0; q < NB; q++) {
+                my[q] = 0;
+                if constexpr (Cfg::kSpeculate) {
+                    const uint64_t mb = step_base + 64u * q + lane;
+                    if (len[q]) my[q] = (st[q] == mb) ? spec[q] : load_meta<Cfg::kNtMeta>(indices + st[q]);
+                } else {
+                    if (len[q]) my[q] = load_meta<Cfg::kNtMeta>(indices + st[q]);
+                }
+            }
+#pragma unroll
+            for (uint32_t j0 = 0; j0 < ROUNDS; j0 += RU) {
+                u32x4 v[NB][RU];
+                bool has[NB][RU];
+#pragma unroll
+                for (uint32_t q = 0; q < NB; q++)
+#pragma unroll
+                    for (uint32_t jj = 0; jj < RU; jj++) {
+                        const uint32_t src = (j0 + jj) * BPR + grp;
+                        const uint64_t r = shfl_index<IdxT>(my[q], src);
+                        has[q][jj] = shfl_u32(len[q], src) != 0u;
+                        v[q][jj] = u32x4{0u, 0u, 0u, 0u};
+                        if (has[q][jj] && lane_live) v[q][jj] = load_row<Cfg::kNtRow>(wsub + r * row_bytes);
+                    }
+#pragma unroll
+                for (uint32_t q = 0; q < NB; q++)
+#pragma unroll
+                    for (uint32_t jj = 0; jj < RU; jj++) {
+                        const uint64_t bag = step_base + 64u * q + (j0 + jj) * BPR + grp;
+                        if (bag < n_bags && lane_live) {
+                            typename Ops::Acc acc = Ops::zero();
+                            if (has[q][jj]) Ops::add(acc, v[q][jj]);
+                            Ops::template store<Cfg::kNtStore>(
+                                acc, out + bag * out_stride + sub * Ops::kFloatsPerLane);
+                        }
+                    }
+            }
+            return;
+        }
+
+        // general step: each round, a lane group walks its bag in index order
+#pragma unroll 1
+        for (uint32_t q = 0; q < NB; q++) {
+#pragma unroll 1
+            for (uint32_t j = 0; j < ROUNDS; j++) {
+                const uint32_t src = j * BPR + grp;
+                uint64_t p = shfl_u64(st[q], src);
+                const uint64_t e = p + shfl_u32(len[q], src);
+                const uint64_t bag = step_base + 64u * q + src;
+                // (no early `continue`: every lane must reach the next round's shuffles)
+                if (bag < n_bags && lane_live) {
+                    typename Ops::Acc acc = Ops::zero();
+                    for (; p + U <= e; p += U) {
+                        uint64_t r[U];
+#pragma unroll
+                        for (int k = 0; k < U; k++) r[k] = (uint64_t)load_meta<Cfg::kNtMeta>(indices + p + k);
+                        u32x4 v[U];
+#pragma unroll
+                        for (int k = 0; k < U; k++) v[k] = load_row<Cfg::kNtRow>(wsub + r[k] * row_bytes);
+#pragma unroll
+                        for (int k = 0; k < U; k++) Ops::add(acc, v[k]);
+                    }
+                    for (; p < e; p++) {
+                        const uint64_t r = (uint64_t)load_meta<Cfg::kNtMeta>(indices + p);
+                        Ops::add(acc, load_row<Cfg::kNtRow>(wsub + r * row_bytes));
+                    }
+                    Ops::template store<Cfg::kNtStore>(acc, out + bag * out_stride + sub * Ops::kFloatsPerLane);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace pimemb

@@ -19,8 +19,10 @@
 #include <vector>
 
 #include "pimemb_internal.h"
+#include "pimemb_xcd_map.h"
 
 using pimemb::DevDesc;
+using pimemb::KernelKind;
 using pimemb::LaunchGeom;
 
 namespace {
@@ -58,9 +60,9 @@ struct Table {
 // the HBM copy must both outlive the asynchronous upload + kernel, so a slot is reused only after
 // its event has completed.
 struct DescSlot {
-    DevDesc *h = nullptr;
-    DevDesc *d = nullptr;
-    uint32_t cap = 0;
+    char *h = nullptr;
+    char *d = nullptr;
+    size_t cap = 0;  // bytes
     hipEvent_t done = nullptr;
     bool pending = false;
 };
@@ -93,12 +95,18 @@ struct PlanGroup {
     uint32_t max_tiles = 0;
     emb_dtype dtype = EMB_F32;
     LaunchGeom geom{};
+    KernelKind kind = pimemb::KERNEL_WAVEBATCH;
+    uint32_t *d_xmap = nullptr;      // XCD-aware workgroup map, or null (2-D grid)
+    uint32_t xgrid = 0;
+    size_t desc_off = 0, xmap_off = 0;  // byte offsets of this group's pieces in the launch image
+    std::vector<uint32_t> xmap_words;
 };
 
 struct emb_plan {
     emb_engine *e = nullptr;
     emb_index_type itype = EMB_IDX_U32;
     std::vector<PlanGroup> groups;
+    char *d_image = nullptr;  // descriptors + XCD maps in HBM
     uint64_t bytes = 0, n_bags = 0, n_indices = 0;
 };
 
@@ -125,6 +133,33 @@ struct Resolved {
     std::vector<PlanGroup> groups;    // d_descs left null; n / max_tiles / dtype / geom filled
     std::vector<uint32_t> order;      // descs[i] came from user desc order[i]
     uint64_t bytes = 0, n_bags = 0, n_indices = 0;
+    std::vector<char> image;          // descriptors of every group, then each group's XCD map
+
+    // Lay descriptors and maps out in one host image; offsets go into the groups.
+    void build_image() {
+        size_t off = 0, di = 0;
+        for (PlanGroup &g : groups) {
+            g.desc_off = off;
+            off += sizeof(DevDesc) * g.n;
+        }
+        for (PlanGroup &g : groups) {
+            g.xmap_off = off;
+            off += (g.xmap_words.size() * 4 + 63) / 64 * 64;
+        }
+        image.assign(off ? off : 64, 0);
+        for (PlanGroup &g : groups) {
+            memcpy(image.data() + g.desc_off, descs.data() + di, sizeof(DevDesc) * g.n);
+            di += g.n;
+            if (!g.xmap_words.empty())
+                memcpy(image.data() + g.xmap_off, g.xmap_words.data(), g.xmap_words.size() * 4);
+        }
+    }
+    void bind(char *d_base) {
+        for (PlanGroup &g : groups) {
+            g.d_descs = reinterpret_cast<DevDesc *>(d_base + g.desc_off);
+            g.d_xmap = g.xmap_words.empty() ? nullptr : reinterpret_cast<uint32_t *>(d_base + g.xmap_off);
+        }
+    }
 };
 
 int resolve(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs, emb_index_type itype,
@@ -155,11 +190,17 @@ int resolve(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs, emb_i
         g.n = (uint32_t)kv.second.size();
         const Table &t0 = e->tables[descs[kv.second[0]].table_id];
         g.geom = t0.geom;
+        uint64_t group_bags = 0;
+        for (uint32_t i : kv.second) group_bags += descs[i].n_bags;
+        g.kind = pimemb::choose_kernel(group_bags, g.geom);
+        const uint32_t bpt = pimemb::bags_per_tile(g.kind, g.geom);
+        std::vector<uint32_t> tiles_of;
+        std::vector<uint64_t> bytes_of;
         for (uint32_t i : kv.second) {
             const emb_lookup_desc &u = descs[i];
             const Table &t = e->tables[u.table_id];
-            uint64_t tiles = (u.n_bags + g.geom.bags_per_tile - 1) / g.geom.bags_per_tile;
-            if (tiles > 0x7fffffffull) return fail(EMB_ERR_UNSUPPORTED, "desc %u: too many bags", i);
+            uint64_t tiles = (u.n_bags + bpt - 1) / bpt;
+            if (tiles > 0x0fffffffull) return fail(EMB_ERR_UNSUPPORTED, "desc %u: too many bags", i);
             DevDesc d{};
             d.weights = t.rows;
             d.indices = st_indices ? (*st_indices)[i] : u.indices;
@@ -171,6 +212,8 @@ int resolve(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs, emb_i
             d.fixed_pooling = u.offsets ? 0u : u.fixed_pooling;
             d.n_tiles = (uint32_t)tiles;
             if (d.n_tiles > g.max_tiles) g.max_tiles = d.n_tiles;
+            tiles_of.push_back(d.n_tiles);
+            bytes_of.push_back(t.bytes);
             r->descs.push_back(d);
             r->order.push_back(i);
             r->n_bags += u.n_bags;
@@ -179,21 +222,33 @@ int resolve(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs, emb_i
             r->bytes += u.n_indices * ((uint64_t)t.dim * elem_size(t.dtype) + isz) +
                         (u.offsets ? u.n_bags * isz : 0) + u.n_bags * (uint64_t)t.dim * 4;
         }
-        r->groups.push_back(g);
+        // several tables in one launch: XCD-aware workgroup map (one table <-> one XCD's L2)
+        if (g.n > 1 && g.max_tiles > 0) {
+            uint64_t total_tiles = 0;
+            for (uint32_t t : tiles_of) total_tiles += t;
+            if (total_tiles + 8 * (uint64_t)g.n > 0x7fffffffull)
+                return fail(EMB_ERR_UNSUPPORTED, "launch too large for one grid");
+            g.xgrid = pimemb::build_xcd_map(tiles_of, bytes_of, &g.xmap_words, 1);
+        } else if (g.n > 65535u) {
+            return fail(EMB_ERR_UNSUPPORTED, "more than 65535 descriptors of one shape");
+        }
+        r->groups.push_back(std::move(g));
     }
+    r->build_image();
     return EMB_OK;
 }
 
 int launch_groups(emb_engine *e, const std::vector<PlanGroup> &groups, emb_index_type itype,
                   hipStream_t s) {
     for (const PlanGroup &g : groups) {
-        HIP_TRY(pimemb::launch_bag_sum(g.d_descs, g.n, g.max_tiles, g.dtype, itype, g.geom, s));
+        HIP_TRY(pimemb::launch_bag_sum(g.d_descs, g.n, g.max_tiles, g.dtype, itype, g.geom, g.kind, g.d_xmap,
+                                       g.xgrid, s));
         e->n_kernel_launches.fetch_add(1, std::memory_order_relaxed);
     }
     return EMB_OK;
 }
 
-int ensure_slot(DescSlot &sl, uint32_t n) {
+int ensure_slot(DescSlot &sl, size_t n) {
     if (sl.pending) {
         HIP_TRY(hipEventSynchronize(sl.done));
         sl.pending = false;
@@ -204,9 +259,9 @@ int ensure_slot(DescSlot &sl, uint32_t n) {
         sl.h = nullptr;
         sl.d = nullptr;
         sl.cap = 0;
-        uint32_t cap = n < 64 ? 64 : n;
-        HIP_TRY(hipHostMalloc((void **)&sl.h, sizeof(DevDesc) * cap, hipHostMallocDefault));
-        HIP_TRY(hipMalloc((void **)&sl.d, sizeof(DevDesc) * cap));
+        size_t cap = n < 8192 ? 8192 : n + n / 4;
+        HIP_TRY(hipHostMalloc((void **)&sl.h, cap, hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void **)&sl.d, cap));
         sl.cap = cap;
     }
     if (!sl.done) HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
@@ -219,15 +274,11 @@ int launch_resolved(emb_engine *e, Resolved &r, emb_index_type itype, hipStream_
     std::lock_guard<std::mutex> lk(e->mu);
     DescSlot &sl = e->slots[e->next_slot];
     e->next_slot = (e->next_slot + 1) % kSlots;
-    int rc = ensure_slot(sl, (uint32_t)r.descs.size());
+    int rc = ensure_slot(sl, r.image.size());
     if (rc) return rc;
-    memcpy(sl.h, r.descs.data(), sizeof(DevDesc) * r.descs.size());
-    HIP_TRY(hipMemcpyAsync(sl.d, sl.h, sizeof(DevDesc) * r.descs.size(), hipMemcpyHostToDevice, s));
-    DevDesc *cursor = sl.d;
-    for (PlanGroup &g : r.groups) {
-        g.d_descs = cursor;
-        cursor += g.n;
-    }
+    memcpy(sl.h, r.image.data(), r.image.size());
+    HIP_TRY(hipMemcpyAsync(sl.d, sl.h, r.image.size(), hipMemcpyHostToDevice, s));
+    r.bind(sl.d);
     rc = launch_groups(e, r.groups, itype, s);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(sl.done, s));
@@ -543,20 +594,16 @@ int emb_plan_create(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_desc
     p->bytes = r.bytes;
     p->n_bags = r.n_bags;
     p->n_indices = r.n_indices;
-    DevDesc *d = nullptr;
-    hipError_t err = hipMalloc((void **)&d, sizeof(DevDesc) * r.descs.size());
-    if (err == hipSuccess)
-        err = hipMemcpy(d, r.descs.data(), sizeof(DevDesc) * r.descs.size(), hipMemcpyHostToDevice);
+    char *d = nullptr;
+    hipError_t err = hipMalloc((void **)&d, r.image.size());
+    if (err == hipSuccess) err = hipMemcpy(d, r.image.data(), r.image.size(), hipMemcpyHostToDevice);
     if (err != hipSuccess) {
         if (d) (void)hipFree(d);
         delete p;
         return fail(EMB_ERR_DEVICE, "emb_plan_create: %s", hipGetErrorString(err));
     }
-    DevDesc *cursor = d;
-    for (PlanGroup &gr : r.groups) {
-        gr.d_descs = cursor;
-        cursor += gr.n;
-    }
+    r.bind(d);
+    p->d_image = d;
     p->groups = r.groups;
     *out = p;
     return EMB_OK;
@@ -578,7 +625,7 @@ int emb_plan_destroy(emb_plan *p) {
     if (!p) return EMB_OK;
     DeviceGuard g(p->e->device);
     (void)hipDeviceSynchronize();
-    if (!p->groups.empty() && p->groups[0].d_descs) (void)hipFree(p->groups[0].d_descs);
+    if (p->d_image) (void)hipFree(p->d_image);
     delete p;
     return EMB_OK;
 }

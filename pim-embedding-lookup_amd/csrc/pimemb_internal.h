@@ -5,38 +5,37 @@
 #include <stdint.h>
 
 #include "pimemb.h"
+#include "pimemb_bag_kernels.h"
 
 namespace pimemb {
 
-// One table's share of a fused launch as the kernel sees it (HBM-resident array, 64 B each so a
-// workgroup fetches its descriptor with one scalar load burst).
-struct alignas(64) DevDesc {
-    const void *weights;    // row-major [nr_rows][dim] of the table dtype
-    const void *indices;    // IdxT[n_idx]
-    const void *offsets;    // IdxT[n_bags] bag starts, or nullptr when fixed_pooling > 0
-    float *out;             // float[n_bags][dim]
-    uint64_t n_idx;
-    uint64_t n_bags;
-    uint64_t nr_rows;       // only read by the validation kernel
-    uint32_t fixed_pooling; // L > 0: offsets[b] = b*L (load_generator.c:88)
-    uint32_t n_tiles;       // ceil(n_bags / bags_per_tile) for this launch geometry
-};
-static_assert(sizeof(DevDesc) == 64, "DevDesc must stay one 64-byte line");
-
-// Launch geometry for one (dtype, dim) group.
+// Row shape of one (dtype, dim) group.
 struct LaunchGeom {
     uint32_t lanes_per_row;   // power of two, 1..64: lanes that cooperate on one bag
     uint32_t chunks;          // 16-byte pieces per row actually used (<= lanes_per_row)
-    uint32_t bags_per_tile;   // bags one 256-thread workgroup finishes per tile
+};
+
+// Which bag kernel a launch uses.
+enum KernelKind : uint32_t {
+    KERNEL_WAVEBATCH = 0,  // 64 bags per wavefront, coalesced bounds, one-hot fast path: big batches
+    KERNEL_GROUP = 1       // one lane group per bag, finest granularity: small batches (latency)
 };
 
 // Returns EMB_OK / EMB_ERR_UNSUPPORTED and fills `g` for a table shape.
 int geometry_for(emb_dtype dtype, uint32_t dim, LaunchGeom *g);
 
+// Bags one workgroup finishes per tile for this kernel kind and row shape.
+uint32_t bags_per_tile(KernelKind kind, const LaunchGeom &g);
+
+// Picks the kernel for a launch group from its total bag count.
+KernelKind choose_kernel(uint64_t total_bags, const LaunchGeom &g);
+
 // Enqueue the fused gather + segment-sum over `n_descs` descriptors (all of one dtype/dim).
-// max_tiles = max over descs of n_tiles.  Pure enqueue: no allocation, copy or sync.
+// d_xmap == nullptr: 2-D grid (max_tiles x n_descs).  Otherwise the XCD-aware 1-D map built by
+// pimemb_xcd_map.h with `xgrid` workgroups.  Pure enqueue: no allocation, copy or sync.
 hipError_t launch_bag_sum(const DevDesc *d_descs, uint32_t n_descs, uint32_t max_tiles,
                           emb_dtype dtype, emb_index_type itype, const LaunchGeom &g,
+                          KernelKind kind, const uint32_t *d_xmap, uint32_t xgrid,
                           hipStream_t stream);
 
 // Scatter an int32 column (device buffer, nr_rows entries) into column `col` of a row-major

@@ -1,154 +1,39 @@
-// pimemb_kernels.hip -- the device side of the hot path, written for gfx950 (MI355X, CDNA4).
-//
-// Replaces the UPMEM DPU program upmem/src/dpu/emb_dpu_lookup.c:36-138 (one DPU per (table,
-// column), 14 tasklets striding over bags, one 8-byte MRAM read per (index, column)) and the host
-// post-process upmem/include/emb_host.h:186-222 with ONE fused launch over all tables:
-//
-//   out[t][b][:] = sum_{p = off_t[b]}^{end-1} W_t[idx_t[p]][:]      end = off_t[b+1] | n_idx_t
-//
-// Mapping to the machine (bandwidth-bound indexing; no MFMA, there is no contraction here):
-//   * rows stay row-major [nr_rows][dim] in HBM; a row is read as 16-byte pieces, one piece per
-//     lane, so the LPR = row_bytes/16 lanes of a "lane group" fetch one whole row with a single
-//     coalesced global_load_dwordx4 (64 B for dim 16 fp32, 512 B for dim 128 fp32);
-//   * a 64-lane wavefront therefore works on 64/LPR bags at once, a 256-thread workgroup on
-//     4 * 64/LPR bags per tile; blockIdx.y picks the table descriptor (scalar loads), blockIdx.x
-//     strides over that table's tiles;
-//   * every output element is accumulated by ONE lane in index order, starting from +0 -- the
-//     same order as a sequential CPU EmbeddingBag, so fp32 results are bit-identical to the
-//     oracle for any pooling factor (no cross-lane tree whose rounding would differ);
-//   * UNROLL independent row loads are kept in flight per lane before the ordered adds, which is
-//     what hides HBM latency for long bags; one-hot bags (Kaggle, L=1) rely on occupancy.
-//   * the fixed-point mode keeps the reference arithmetic: int32 wrap-around accumulate
-//     (emb_dpu_lookup.c:114) and out = (float)acc / 1e9 via double (emb_host.h:210).
+// pimemb_kernels.hip -- instantiates the bag kernels of pimemb_bag_kernels.h for the library and
+// holds the two small helper kernels (column scatter, input validation).  gfx950 only.
 #include "pimemb_internal.h"
 
 namespace pimemb {
 namespace {
 
-using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
-using f32x8 = __attribute__((ext_vector_type(8))) float;
+// Shipped configurations, chosen with tools/tune_bag_kernels.hip on MI355X (DESIGN.md "Tuning"):
+//   big batches : wave-batch kernel, 64-thread workgroups (finest interleave under the XCD map),
+//                 <= 64 VGPRs (8 waves/SIMD), non-temporal pooled-row stores, speculative one-hot
+//                 index prefetch;
+//   small batches: lane-group kernel, 256-thread workgroups (most wavefronts for few bags).
+//                        BLOCK U  ntS   ntM   inflight minW batches ntRow  spec
+using WaveCfg = BagCfg<64, 8, true, false, 8, 8, 1, false, true>;
+using GroupCfg = BagCfg<256, 8, true, false, 8, 1, 1, false, false>;
+constexpr int kBlock = 256;  // helper kernels below
 
-constexpr int kBlock = 256;  // 4 wavefronts
-constexpr int kWaves = kBlock / 64;
-constexpr int kUnroll = 8;   // row loads in flight per lane inside a bag
-
-// ---- per-dtype accumulate / store -----------------------------------------------------------
-template <int DT>
-struct RowOps;
-
-template <>
-struct RowOps<EMB_F32> {
-    using Acc = f32x4;
-    static constexpr uint32_t kFloatsPerLane = 4;
-    static __device__ __forceinline__ Acc zero() { return Acc{0.f, 0.f, 0.f, 0.f}; }
-    static __device__ __forceinline__ void add(Acc &a, u32x4 raw) {
-        a += __builtin_bit_cast(f32x4, raw);
-    }
-    static __device__ __forceinline__ void store(const Acc &a, float *dst) {
-        *reinterpret_cast<f32x4 *>(dst) = a;
-    }
-};
-
-template <>
-struct RowOps<EMB_F16> {
-    using Acc = f32x8;
-    static constexpr uint32_t kFloatsPerLane = 8;
-    static __device__ __forceinline__ Acc zero() { return Acc{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; }
-    static __device__ __forceinline__ void add(Acc &a, u32x4 raw) {
-        a += __builtin_convertvector(__builtin_bit_cast(f16x8, raw), f32x8);
-    }
-    static __device__ __forceinline__ void store(const Acc &a, float *dst) {
-        f32x4 lo = {a[0], a[1], a[2], a[3]}, hi = {a[4], a[5], a[6], a[7]};
-        reinterpret_cast<f32x4 *>(dst)[0] = lo;
-        reinterpret_cast<f32x4 *>(dst)[1] = hi;
-    }
-};
-
-template <>
-struct RowOps<EMB_FIXED32> {
-    using Acc = u32x4;  // unsigned add == int32 two's-complement wrap (emb_dpu_lookup.c:114)
-    static constexpr uint32_t kFloatsPerLane = 4;
-    static __device__ __forceinline__ Acc zero() { return Acc{0u, 0u, 0u, 0u}; }
-    static __device__ __forceinline__ void add(Acc &a, u32x4 raw) { a += raw; }
-    static __device__ __forceinline__ float conv(uint32_t acc) {
-        // emb_host.h:210: (float)tmp / pow(10,9): int32 -> float, divide in double, round to float
-        return (float)((double)(float)(int32_t)acc / 1.0e9);
-    }
-    static __device__ __forceinline__ void store(const Acc &a, float *dst) {
-        f32x4 o = {conv(a[0]), conv(a[1]), conv(a[2]), conv(a[3])};
-        *reinterpret_cast<f32x4 *>(dst) = o;
-    }
-};
-
-// ---- fused multi-table gather + segment-sum -------------------------------------------------
-template <typename IdxT, int DT, int LPR>
-__global__ void __launch_bounds__(kBlock)
-bag_sum_kernel(const DevDesc *__restrict__ descs, uint32_t chunks) {
-    using Ops = RowOps<DT>;
-    constexpr uint32_t BPW = 64 / LPR;           // bags per wavefront
-    constexpr uint32_t BAGS_PER_TILE = BPW * kWaves;
-
-    const DevDesc *dp = descs + blockIdx.y;      // wave-uniform: scalar loads
-    const char *__restrict__ weights = static_cast<const char *>(dp->weights);
-    const IdxT *__restrict__ indices = static_cast<const IdxT *>(dp->indices);
-    const IdxT *__restrict__ offsets = static_cast<const IdxT *>(dp->offsets);
-    float *__restrict__ out = dp->out;
-    const uint64_t n_idx = dp->n_idx;
-    const uint64_t n_bags = dp->n_bags;
-    const uint32_t fixed_pooling = dp->fixed_pooling;
-    const uint32_t n_tiles = dp->n_tiles;
-
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t sub = lane & (LPR - 1);       // which 16-byte piece of the row
-    const uint32_t grp = lane / LPR;             // which bag of this wavefront
-    const uint32_t row_bytes = chunks * 16u;
-    const uint32_t out_stride = chunks * Ops::kFloatsPerLane;  // = dim
-    const char *__restrict__ wsub = weights + sub * 16u;
-
-    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const uint64_t bag = (uint64_t)tile * BAGS_PER_TILE + wave * BPW + grp;
-        if (bag >= n_bags || sub >= chunks) continue;
-
-        uint64_t p, e;
-        if (offsets != nullptr) {
-            p = (uint64_t)offsets[bag];
-            e = (bag + 1 < n_bags) ? (uint64_t)offsets[bag + 1] : n_idx;  // emb_dpu_lookup.c:109-110
-        } else {
-            p = bag * fixed_pooling;
-            e = p + fixed_pooling;
-        }
-
-        typename Ops::Acc acc = Ops::zero();     // empty bag -> 0 (emb_dpu_lookup.c:108)
-        for (; p + kUnroll <= e; p += kUnroll) {
-            uint64_t r[kUnroll];
-#pragma unroll
-            for (int k = 0; k < kUnroll; k++) r[k] = (uint64_t)indices[p + k];
-            u32x4 v[kUnroll];
-#pragma unroll
-            for (int k = 0; k < kUnroll; k++)
-                v[k] = *reinterpret_cast<const u32x4 *>(wsub + r[k] * row_bytes);
-#pragma unroll
-            for (int k = 0; k < kUnroll; k++) Ops::add(acc, v[k]);  // index order
-        }
-        for (; p < e; p++) {
-            const uint64_t r = (uint64_t)indices[p];
-            Ops::add(acc, *reinterpret_cast<const u32x4 *>(wsub + r * row_bytes));
-        }
-        Ops::store(acc, out + bag * out_stride + sub * Ops::kFloatsPerLane);
-    }
+template <typename IdxT, int DT, int L>
+void launch_one(const DevDesc *d, uint32_t n, uint32_t max_tiles, const LaunchGeom &g, KernelKind kind,
+                const uint32_t *xmap, uint32_t xgrid, hipStream_t s) {
+    const dim3 grid = xmap ? dim3(xgrid, 1, 1) : dim3(max_tiles, n, 1);
+    if (kind == KERNEL_WAVEBATCH)
+        hipLaunchKernelGGL((bag_sum_wavebatch_kernel<IdxT, DT, L, WaveCfg>), grid, dim3(WaveCfg::kBlock), 0,
+                           s, d, g.chunks, xmap);
+    else
+        hipLaunchKernelGGL((bag_sum_group_kernel<IdxT, DT, L, GroupCfg>), grid, dim3(GroupCfg::kBlock), 0,
+                           s, d, g.chunks, xmap);
 }
 
 template <typename IdxT, int DT>
 hipError_t launch_lpr(const DevDesc *d, uint32_t n, uint32_t max_tiles, const LaunchGeom &g,
-                      hipStream_t s) {
-    dim3 grid(max_tiles, n, 1), block(kBlock, 1, 1);
+                      KernelKind kind, const uint32_t *xmap, uint32_t xgrid, hipStream_t s) {
     switch (g.lanes_per_row) {
-#define PIMEMB_CASE(L)                                                                        \
-    case L:                                                                                   \
-        hipLaunchKernelGGL((bag_sum_kernel<IdxT, DT, L>), grid, block, 0, s, d, g.chunks);    \
+#define PIMEMB_CASE(L)                                                          \
+    case L:                                                                     \
+        launch_one<IdxT, DT, L>(d, n, max_tiles, g, kind, xmap, xgrid, s);      \
         break;
         PIMEMB_CASE(1)
         PIMEMB_CASE(2)
@@ -166,14 +51,15 @@ hipError_t launch_lpr(const DevDesc *d, uint32_t n, uint32_t max_tiles, const La
 
 template <typename IdxT>
 hipError_t launch_dtype(const DevDesc *d, uint32_t n, uint32_t max_tiles, emb_dtype dtype,
-                        const LaunchGeom &g, hipStream_t s) {
+                        const LaunchGeom &g, KernelKind kind, const uint32_t *xmap, uint32_t xgrid,
+                        hipStream_t s) {
     switch (dtype) {
         case EMB_F32:
-            return launch_lpr<IdxT, EMB_F32>(d, n, max_tiles, g, s);
+            return launch_lpr<IdxT, EMB_F32>(d, n, max_tiles, g, kind, xmap, xgrid, s);
         case EMB_F16:
-            return launch_lpr<IdxT, EMB_F16>(d, n, max_tiles, g, s);
+            return launch_lpr<IdxT, EMB_F16>(d, n, max_tiles, g, kind, xmap, xgrid, s);
         case EMB_FIXED32:
-            return launch_lpr<IdxT, EMB_FIXED32>(d, n, max_tiles, g, s);
+            return launch_lpr<IdxT, EMB_FIXED32>(d, n, max_tiles, g, kind, xmap, xgrid, s);
     }
     return hipErrorInvalidValue;
 }
@@ -225,18 +111,30 @@ int geometry_for(emb_dtype dtype, uint32_t dim, LaunchGeom *g) {
     while (lpr < chunks) lpr <<= 1;
     g->lanes_per_row = lpr;
     g->chunks = chunks;
-    g->bags_per_tile = (64 / lpr) * kWaves;
     return EMB_OK;
+}
+
+uint32_t bags_per_tile(KernelKind kind, const LaunchGeom &g) {
+    if (kind == KERNEL_WAVEBATCH) return 64u * WaveCfg::kBatches * (WaveCfg::kBlock / 64);
+    return (64u / g.lanes_per_row) * (GroupCfg::kBlock / 64);
+}
+
+KernelKind choose_kernel(uint64_t total_bags, const LaunchGeom &g) {
+    // The wave-batch kernel gives one wavefront 64 bags; below ~2 wavefronts per SIMD on the chip
+    // (256 CUs x 4 SIMDs) the finer lane-group kernel fills the machine better.
+    (void)g;
+    return (total_bags / 64u >= 2048u) ? KERNEL_WAVEBATCH : KERNEL_GROUP;
 }
 
 hipError_t launch_bag_sum(const DevDesc *d_descs, uint32_t n_descs, uint32_t max_tiles,
                           emb_dtype dtype, emb_index_type itype, const LaunchGeom &g,
+                          KernelKind kind, const uint32_t *d_xmap, uint32_t xgrid,
                           hipStream_t stream) {
     if (n_descs == 0 || max_tiles == 0) return hipSuccess;
-    if (n_descs > 65535u) return hipErrorInvalidValue;
+    if (d_xmap == nullptr && n_descs > 65535u) return hipErrorInvalidValue;
     if (itype == EMB_IDX_U32)
-        return launch_dtype<uint32_t>(d_descs, n_descs, max_tiles, dtype, g, stream);
-    return launch_dtype<int64_t>(d_descs, n_descs, max_tiles, dtype, g, stream);
+        return launch_dtype<uint32_t>(d_descs, n_descs, max_tiles, dtype, g, kind, d_xmap, xgrid, stream);
+    return launch_dtype<int64_t>(d_descs, n_descs, max_tiles, dtype, g, kind, d_xmap, xgrid, stream);
 }
 
 hipError_t launch_scatter_column(int32_t *table, const int32_t *column, uint64_t nr_rows,

@@ -244,3 +244,37 @@ def test_moderate_size_all_index_distributions(pel, eng, oracle):
         off = pel.workloads.fixed_offsets(B, L)
         got = eng.lookup(8, idx, off)
         assert np.array_equal(got, oracle.c_bag_sum(tab, idx, off))
+
+
+def test_big_multi_table_launch_wavebatch_xcd_map(pel, eng, oracle):
+    """Big enough for the wave-batch kernel + XCD-aware workgroup map (several tables, > 131072 bags):
+    (a) one-hot bags, (b) bags of 0/1 indices (speculative index prefetch must fall back),
+    (c) ragged bags 0..5, (d) fixed pooling 4 -- every table bit-exact against the oracle."""
+    rng = np.random.default_rng(99)
+    sizes = [3, 1000, 70_000, 1_500_000, 40_000, 17]
+    tabs = [pel.workloads.dlrm_table(rng, n, 16) for n in sizes]
+    ids = list(range(20, 20 + len(sizes)))
+    for t, tab in zip(ids, tabs):
+        eng.load_table(t, tab)
+    B = 40_000
+
+    def run(make_bags):
+        idxs, offs = [], []
+        for n in sizes:
+            off, n_idx = make_bags()
+            offs.append(off)
+            idxs.append(rng.integers(0, n, size=n_idx).astype(np.uint32))
+        before = eng.stats()["n_kernel_launches"]
+        outs = eng.lookup_batched(ids, idxs, offs)
+        assert eng.stats()["n_kernel_launches"] == before + 1      # still ONE fused launch
+        for tab, i, o, got in zip(tabs, idxs, offs, outs):
+            assert np.array_equal(got, oracle.c_bag_sum(tab, i, o))
+
+    run(lambda: (pel.workloads.fixed_offsets(B, 1), B))
+    def zero_one():
+        lens = rng.integers(0, 2, size=B)
+        off = np.zeros(B, np.int64); off[1:] = np.cumsum(lens)[:-1]
+        return off.astype(np.uint32), int(lens.sum())
+    run(zero_one)
+    run(lambda: pel.workloads.ragged_offsets(rng, B, 5, p_empty=0.2, dtype=np.uint32))
+    run(lambda: (pel.workloads.fixed_offsets(B, 4), 4 * B))
