@@ -40,6 +40,8 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=None, help="bags per table per rank (default 39292)")
     ap.add_argument("--nbatch", type=int, default=8, help="distinct index batches rotated through")
     ap.add_argument("--index-dist", choices=["uniform", "zipf"], default="uniform")
+    ap.add_argument("--replicate-mb", type=int, default=64,
+                    help="N>1: tables up to this size are replicated on every rank, larger ones are sharded")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     return ap.parse_args()

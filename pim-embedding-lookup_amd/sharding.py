@@ -1,0 +1,255 @@
+"""Multi-GPU embedding lookup: one process per GPU, tables sharded over the ranks of one node, indices
+in / pooled rows out exchanged with all-to-all (RCCL over xGMI on GPUs; gloo in the CPU tests).
+
+Counterpart of the reference's only "distribution" mechanism -- one DPU per (table, column) with the
+indices broadcast to a table's DPUs and the per-DPU results gathered back by the host
+(upmem/include/emb_host.h:167 DPU id = table*NR_COLS + col; :258-270 index/offset push; :312-321
+result pull) -- re-thought for 8 GPUs with 288 GB each:
+
+  * inputs are data-parallel: rank r holds its own B bags for every table;
+  * tables are model-parallel.  The planner places each table as
+      - REPLICATED  (<= replicate_bytes): every rank holds it, no exchange at all;
+      - WHOLE       : one owner rank (greedy bin-packing on bytes);
+      - ROW-SPLIT   (> split_bytes): contiguous row ranges over all ranks; each rank returns a
+                      partial pooled sum, the sample owner adds the partials in shard order
+                      (deterministic).  Column (D) splitting as in the reference is NOT carried over:
+                      rows of <= 1 KiB are already smaller than an efficient transfer unit.
+  * one step = all_to_all(bag lengths + indices) -> ONE fused local lookup (HIP engine) over all
+    units this rank serves -> all_to_all(pooled rows) -> per-table [B, D] outputs.
+
+Nothing here computes a lookup: the local step is delegated to a backend (`EngineBackend` = the HIP
+engine).  Tests inject their own backend to check the routing on CPU."""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, Sequence
+
+import numpy as np
+
+REPLICATED, WHOLE, ROW_SPLIT = "replicated", "whole", "row_split"
+
+
+@dataclass(frozen=True)
+class Unit:
+    """A contiguous row range of one table served by one rank."""
+    table: int
+    owner: int          # -1: every rank (replicated)
+    row_lo: int
+    row_hi: int
+    uid: int            # dense id, also the local engine table id on the owner
+
+
+@dataclass
+class ShardPlan:
+    world: int
+    rows: list[int]
+    dim: int
+    elem_bytes: int
+    kinds: list[str]
+    units: list[Unit]
+    units_of_table: list[list[int]] = field(default_factory=list)
+
+    def owned_units(self, rank: int) -> list[Unit]:
+        return [u for u in self.units if u.owner == rank]
+
+    def replicated_units(self) -> list[Unit]:
+        return [u for u in self.units if u.owner < 0]
+
+    def bytes_on(self, rank: int) -> int:
+        return sum((u.row_hi - u.row_lo) * self.dim * self.elem_bytes
+                   for u in self.units if u.owner in (rank, -1))
+
+    def describe(self) -> str:
+        n = {k: self.kinds.count(k) for k in (REPLICATED, WHOLE, ROW_SPLIT)}
+        return (f"{len(self.rows)} tables over {self.world} ranks: {n[REPLICATED]} replicated, "
+                f"{n[WHOLE]} whole, {n[ROW_SPLIT]} row-split; bytes/rank "
+                f"{[self.bytes_on(r) for r in range(self.world)]}")
+
+
+def plan_shards(rows: Sequence[int], dim: int, elem_bytes: int, world: int,
+                replicate_bytes: int = 64 << 20, split_bytes: int | None = None) -> ShardPlan:
+    """Greedy placement.  split_bytes=None: split tables larger than 1/world of all sharded bytes."""
+    rows = [int(r) for r in rows]
+    size = [r * dim * elem_bytes for r in rows]
+    kinds = [REPLICATED if (world == 1 or s <= replicate_bytes) else WHOLE for s in size]
+    sharded = [t for t, k in enumerate(kinds) if k == WHOLE]
+    if split_bytes is None:
+        split_bytes = max(1, sum(size[t] for t in sharded) // max(world, 1))
+    for t in sharded:
+        if size[t] > split_bytes and rows[t] >= world:
+            kinds[t] = ROW_SPLIT
+    load = [0] * world
+    for t in sharded:                       # row-split tables load every rank equally
+        if kinds[t] == ROW_SPLIT:
+            for r in range(world):
+                load[r] += size[t] // world
+    owner = {}
+    for t in sorted((t for t in sharded if kinds[t] == WHOLE), key=lambda t: -size[t]):
+        r = min(range(world), key=lambda r: (load[r], r))
+        owner[t] = r
+        load[r] += size[t]
+    units, units_of_table = [], []
+    for t, k in enumerate(kinds):
+        ids = []
+        if k == REPLICATED:
+            ids.append(len(units)); units.append(Unit(t, -1, 0, rows[t], len(units)))
+        elif k == WHOLE:
+            ids.append(len(units)); units.append(Unit(t, owner[t], 0, rows[t], len(units)))
+        else:
+            per = -(-rows[t] // world)
+            for r in range(world):
+                lo, hi = min(r * per, rows[t]), min((r + 1) * per, rows[t])
+                ids.append(len(units)); units.append(Unit(t, r, lo, hi, len(units)))
+        units_of_table.append(ids)
+    return ShardPlan(world, rows, dim, elem_bytes, kinds, units, units_of_table)
+
+
+# ------------------------------------------------------------------------------------------------
+class EngineBackend:
+    """Local step on the HIP engine: unit uid -> engine table uid; torch CUDA tensors, zero-copy."""
+
+    def __init__(self, engine):
+        self.engine = engine
+
+    def load(self, uid: int, rows) -> None:
+        self.engine.load_table(uid, rows)
+
+    def lookup(self, uids, indices, offsets, outs):
+        """One fused launch over every unit this rank serves."""
+        return self.engine.lookup_batched(uids, indices, offsets, outs)
+
+
+class ShardedLookup:
+    """Data-parallel in, model-parallel tables, all-to-all both ways.  `torch.distributed` must be
+    initialised (backend nccl = RCCL on GPUs; gloo for CPU tests).  comm_device: where collective
+    buffers live ('cuda:N' for RCCL; 'cpu' stages through host for gloo)."""
+
+    def __init__(self, plan: ShardPlan, rank: int, backend, device, comm_device=None, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.plan, self.rank, self.world = plan, rank, plan.world
+        self.backend, self.device, self.group = backend, torch.device(device), group
+        self.comm_device = torch.device(comm_device) if comm_device is not None else self.device
+        self.served = plan.owned_units(rank)              # units whose rows live here (sharded)
+        self.local = plan.replicated_units()              # units every rank holds
+        # units I must send requests for, grouped by destination rank, in a fixed global order
+        self.send_units = [[u for u in plan.units if u.owner == d] for d in range(self.world)]
+
+    # ---- tables -------------------------------------------------------------------------------
+    def load_tables(self, table_rows: Callable[[int, int, int], object]) -> None:
+        """table_rows(table, row_lo, row_hi) -> [row_hi-row_lo, dim] rows (torch tensor or numpy);
+        only the shards this rank serves are requested."""
+        for u in self.served + self.local:
+            self.backend.load(u.uid, table_rows(u.table, u.row_lo, u.row_hi))
+
+    # ---- one step -----------------------------------------------------------------------------
+    def _lens(self, offsets, n_idx: int):
+        t = self.torch
+        end = t.cat([offsets[1:], offsets.new_tensor([n_idx])]) if offsets.numel() else offsets
+        return end - offsets
+
+    def _route(self, u: Unit, idx, lens):
+        """Indices of my bags that fall into unit u (rebased to the unit's first row) + per-bag
+        counts.  Whole tables pass through untouched."""
+        t = self.torch
+        if u.row_lo == 0 and u.row_hi == self.plan.rows[u.table]:
+            return idx, lens
+        keep = (idx >= u.row_lo) & (idx < u.row_hi)
+        bag_of = t.repeat_interleave(t.arange(lens.numel(), device=idx.device), lens)
+        new_lens = t.bincount(bag_of[keep], minlength=lens.numel()).to(lens.dtype)
+        return idx[keep] - u.row_lo, new_lens
+
+    def _a2a(self, send_parts, dtype, recv_counts=None):
+        """all_to_all of one 1-D tensor per destination.  recv_counts=None: element counts are
+        exchanged first (alltoallv); otherwise they are known from the plan.  Returns the list of
+        received pieces, one per source rank."""
+        t, dist = self.torch, self.dist
+        counts = [int(p.numel()) for p in send_parts]
+        if recv_counts is None:
+            c = t.tensor(counts, dtype=t.int64, device=self.comm_device)
+            r = t.empty(self.world, dtype=t.int64, device=self.comm_device)
+            dist.all_to_all_single(r, c, group=self.group)
+            recv_counts = [int(x) for x in r.cpu().tolist()]
+        send = t.cat([p.reshape(-1).to(dtype) for p in send_parts]).to(self.comm_device)
+        recv = t.empty(int(sum(recv_counts)), dtype=dtype, device=self.comm_device)
+        dist.all_to_all_single(recv, send, output_split_sizes=list(recv_counts),
+                               input_split_sizes=counts, group=self.group)
+        return list(recv.split(list(recv_counts))), recv_counts
+
+    def forward(self, indices: Sequence, offsets: Sequence):
+        """indices[t], offsets[t]: this rank's bags for table t (torch int64/int32 tensors on
+        `device`).  Returns [B_t, dim] fp32 per table -- the `apply_emb` contract."""
+        t = self.torch
+        T = len(self.plan.rows)
+        assert len(indices) == T and len(offsets) == T
+        idx_dtype = indices[0].dtype
+        lens = [self._lens(offsets[i], indices[i].numel()) for i in range(T)]
+        n_bags = [int(l.numel()) for l in lens]
+
+        # 1. requests per destination: for every unit it owns -> (n_bags header, lens, indices)
+        send_meta, send_lens, send_idx = [], [], []
+        for d in range(self.world):
+            meta, ls, ix = [], [], []
+            for u in self.send_units[d]:
+                i_u, l_u = self._route(u, indices[u.table], lens[u.table])
+                meta.append(t.tensor([l_u.numel(), i_u.numel()], dtype=t.int64))
+                ls.append(l_u.to(t.int64))
+                ix.append(i_u)
+            send_meta.append(t.cat(meta) if meta else t.empty(0, dtype=t.int64))
+            send_lens.append(t.cat(ls) if ls else t.empty(0, dtype=t.int64))
+            send_idx.append(t.cat(ix) if ix else t.empty(0, dtype=idx_dtype))
+        meta_in, _ = self._a2a(send_meta, t.int64, recv_counts=[2 * len(self.served)] * self.world)
+        lens_in, _ = self._a2a(send_lens, t.int64)
+        idx_in, _ = self._a2a(send_idx, idx_dtype)
+
+        # 2. ONE fused local lookup: served units over the bags of every source rank (in rank order)
+        #    + replicated units over my own bags
+        uids, l_idx, l_off, src_bags = [], [], [], []
+        cursor_l = [0] * self.world
+        cursor_i = [0] * self.world
+        for k, u in enumerate(self.served):
+            parts_l, parts_i, bags_per_src = [], [], []
+            for s in range(self.world):
+                nb, ni = int(meta_in[s][2 * k]), int(meta_in[s][2 * k + 1])
+                parts_l.append(lens_in[s][cursor_l[s]:cursor_l[s] + nb])
+                parts_i.append(idx_in[s][cursor_i[s]:cursor_i[s] + ni])
+                cursor_l[s] += nb
+                cursor_i[s] += ni
+                bags_per_src.append(nb)
+            all_l = t.cat(parts_l).to(self.device)
+            off = (t.cumsum(all_l, 0) - all_l).to(idx_dtype)
+            uids.append(u.uid)
+            l_idx.append(t.cat(parts_i).to(self.device).contiguous())
+            l_off.append(off.contiguous())
+            src_bags.append(bags_per_src)
+        for u in self.local:
+            uids.append(u.uid)
+            l_idx.append(indices[u.table].contiguous())
+            l_off.append(offsets[u.table].contiguous())
+        outs = self.backend.lookup(uids, l_idx, l_off, None) if uids else []
+
+        # 3. pooled rows back to the ranks that own the bags
+        D = self.plan.dim
+        send_out = []
+        for s in range(self.world):
+            parts = []
+            for k in range(len(self.served)):
+                lo = sum(src_bags[k][:s])
+                parts.append(outs[k][lo:lo + src_bags[k][s]].reshape(-1))
+            send_out.append(t.cat(parts) if parts else t.empty(0, dtype=t.float32))
+        recv_counts = [sum(n_bags[u.table] for u in self.send_units[d]) * D for d in range(self.world)]
+        out_in, _ = self._a2a(send_out, t.float32, recv_counts=recv_counts)
+
+        # 4. assemble per table; row-split partials are added in shard (rank) order
+        result = [None] * T
+        for j, u in enumerate(self.local):
+            result[u.table] = outs[len(self.served) + j]
+        for d in range(self.world):
+            cur = 0
+            for u in self.send_units[d]:
+                nb = n_bags[u.table]
+                part = out_in[d][cur:cur + nb * D].reshape(nb, D).to(self.device)
+                cur += nb * D
+                result[u.table] = part if result[u.table] is None else result[u.table] + part
+        return result
