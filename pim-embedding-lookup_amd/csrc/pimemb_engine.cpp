@@ -314,6 +314,7 @@ struct HostStage {
     std::vector<const void *> d_indices, d_offsets;
     std::vector<float *> d_out;
     size_t in_bytes = 0, out_bytes = 0;
+    char *h_out = nullptr;  // pinned landing zone for small results (null if not reserved)
 };
 
 int stage_host_inputs(emb_engine *e, const emb_lookup_desc *descs, uint32_t n, emb_index_type itype,
@@ -328,8 +329,10 @@ int stage_host_inputs(emb_engine *e, const emb_lookup_desc *descs, uint32_t n, e
         out_bytes += align_up(descs[i].n_bags * (size_t)e->tables[descs[i].table_id].dim * 4, 16);
     }
     if (!with_outputs) out_bytes = 0;
-    int rc = ensure_stage(e, in_bytes, in_bytes + out_bytes);
+    const size_t h_out_bytes = (out_bytes <= (1u << 20)) ? out_bytes : 0;
+    int rc = ensure_stage(e, in_bytes + h_out_bytes, in_bytes + out_bytes);
     if (rc) return rc;
+    hs->h_out = h_out_bytes ? e->h_stage + in_bytes : nullptr;
     size_t off = 0;
     hs->d_indices.resize(n);
     hs->d_offsets.resize(n);
@@ -380,13 +383,30 @@ int lookup_host(emb_engine *e, const emb_lookup_desc *descs, uint32_t n, emb_ind
     double t2 = now_us();
     HIP_TRY(hipStreamSynchronize(s));
     double t3 = now_us();
-    for (uint32_t i = 0; i < n; i++) {
-        size_t bytes = descs[i].n_bags * (size_t)e->tables[descs[i].table_id].dim * 4;
-        if (bytes)
-            HIP_TRY(hipMemcpyAsync(descs[i].pooled, hs.d_out[i], bytes, hipMemcpyDeviceToHost, s));
+    // Small results (the reference's presets: tens of KB per table): ONE device-to-host copy of the
+    // whole output region into pinned staging, then host memcpys -- a per-table hipMemcpy costs
+    // ~12 us each.  Large results go straight to the caller's buffers, table by table.
+    const bool staged_out = hs.out_bytes > 0 && hs.out_bytes <= (1u << 20) && hs.h_out != nullptr;
+    double t4;
+    if (staged_out) {
+        HIP_TRY(hipMemcpyAsync(hs.h_out, hs.d_out[0], hs.out_bytes, hipMemcpyDeviceToHost, s));
+        t4 = now_us();
+        HIP_TRY(hipStreamSynchronize(s));
+        for (uint32_t i = 0; i < n; i++) {
+            size_t bytes = descs[i].n_bags * (size_t)e->tables[descs[i].table_id].dim * 4;
+            if (bytes)
+                memcpy(descs[i].pooled, hs.h_out + (reinterpret_cast<char *>(hs.d_out[i]) -
+                                                    reinterpret_cast<char *>(hs.d_out[0])), bytes);
+        }
+    } else {
+        for (uint32_t i = 0; i < n; i++) {
+            size_t bytes = descs[i].n_bags * (size_t)e->tables[descs[i].table_id].dim * 4;
+            if (bytes)
+                HIP_TRY(hipMemcpyAsync(descs[i].pooled, hs.d_out[i], bytes, hipMemcpyDeviceToHost, s));
+        }
+        t4 = now_us();
+        HIP_TRY(hipStreamSynchronize(s));
     }
-    double t4 = now_us();
-    HIP_TRY(hipStreamSynchronize(s));
     double t5 = now_us();
     e->us_copy_in_indices += t1 - t0;
     e->us_copy_in_lengths += t2 - t1;
