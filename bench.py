@@ -39,7 +39,12 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--batch", type=int, default=None, help="bags per table per rank (default 39292)")
     ap.add_argument("--nbatch", type=int, default=8, help="distinct index batches rotated through")
-    ap.add_argument("--index-dist", choices=["uniform", "zipf"], default="uniform")
+    ap.add_argument("--index-dist", choices=["uniform", "zipf"], default=None,
+                    help="default: uniform for c2, zipf(1.2) for c3")
+    ap.add_argument("--workload", choices=["c2", "c3"], default="c2",
+                    help="c2 = BASELINE configs[1] (the metric's config, default); c3 = configs[2] scaled "
+                         "to fit one GPU: 48 tables x 10M rows x dim 128 fp32, B=16384, pooling 32")
+    ap.add_argument("--tables", type=int, default=None, help="c3: number of tables (default 48)")
     ap.add_argument("--replicate-mb", type=int, default=64,
                     help="N>1: tables up to this size are replicated on every rank, larger ones are sharded")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -58,20 +63,36 @@ def make_tables_on_gpu(torch, eng, rows_list, dim, device, seed=0, keep_host=Fal
         w = torch.empty((n, dim), dtype=torch.float32, device=device)
         w.uniform_(-a, a, generator=g)
         eng.load_table(t, w)
-        if keep_host:
+        if t < int(keep_host):
             host.append(w.cpu().numpy())
         del w
     torch.cuda.empty_cache()
     return host
 
 
-def make_batches(pel, rows_list, B, nbatch, dist, seed=1):
+def workload_spec(pel, args):
+    """rows per table, dim, bags per table, pooling, index distribution, description."""
+    if args.workload == "c2":
+        B = args.batch or pel.workloads.KAGGLE_BATCH
+        dist = args.index_dist or "uniform"
+        return dict(rows=pel.workloads.KAGGLE_ROWS, dim=pel.workloads.KAGGLE_DIM, B=B, L=1, dist=dist,
+                    name="C2: 26 Criteo-Kaggle tables, dim 16 fp32, B=%d bags/table, L=1, u32 indices+offsets, "
+                         "%s indices" % (B, dist))
+    T = args.tables or 48
+    B = args.batch or 16384
+    dist = args.index_dist or "zipf"
+    return dict(rows=[10_000_000] * T, dim=128, B=B, L=32, dist=dist,
+                name="C3 scaled to fit 288 GB (as written it needs 327.7 GB): %d tables x 10M rows, dim 128 fp32, "
+                     "B=%d bags/table, L=32, u32 indices+offsets, %s indices" % (T, B, dist))
+
+
+def make_batches(pel, spec, nbatch, seed=1):
     rng = np.random.default_rng(seed)
-    gen = pel.workloads.uniform_indices if dist == "uniform" else pel.workloads.zipf_indices
+    gen = pel.workloads.uniform_indices if spec["dist"] == "uniform" else pel.workloads.zipf_indices
     batches = []
-    off = pel.workloads.fixed_offsets(B, 1)
+    off = pel.workloads.fixed_offsets(spec["B"], spec["L"])
     for _ in range(nbatch):
-        batches.append(([gen(rng, n, B) for n in rows_list], [off] * len(rows_list)))
+        batches.append(([gen(rng, n, spec["B"] * spec["L"]) for n in spec["rows"]], [off] * len(spec["rows"])))
     return batches
 
 
@@ -80,6 +101,7 @@ def cpu_baseline(pel, host_tables, batch, seconds):
     sample of the same workload: whole batches of the C2 shape until ~`seconds` have elapsed."""
     from oracle import oracle
     idx, off = batch
+    idx, off = idx[:len(host_tables)], off[:len(host_tables)]
     oracle.c_lookup_tables(host_tables, idx, off)      # warm
     n, t0 = 0, time.perf_counter()
     while True:
@@ -90,7 +112,8 @@ def cpu_baseline(pel, host_tables, batch, seconds):
             break
     lookups = n * sum(o.shape[0] for o in off)
     return {"value": lookups / el, "unit": "pooled-lookups/s", "cores": 1, "kind": "port",
-            "sample": f"{n} batches of the bench workload (26 tables x {off[0].shape[0]} bags, L=1) "
+            "sample": f"{n} batches of the bench workload restricted to its first {len(host_tables)} tables "
+                      f"({off[0].shape[0]} bags/table, {idx[0].shape[0] // max(off[0].shape[0], 1)} indices/bag) "
                       f"through oracle/emb_oracle.c in {el:.1f} s, host has {os.cpu_count()} cpus"}
 
 
@@ -100,14 +123,14 @@ def run_single(args):
 
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    rows_list = pel.workloads.KAGGLE_ROWS
-    dim = pel.workloads.KAGGLE_DIM
-    B = args.batch or pel.workloads.KAGGLE_BATCH
+    spec = workload_spec(pel, args)
+    rows_list, dim, B = spec["rows"], spec["dim"], spec["B"]
     T = len(rows_list)
     eng = pel.EmbeddingEngine(device=0, max_tables=T)
     want_cpu = not args.no_cpu_baseline
-    host_tables = make_tables_on_gpu(torch, eng, rows_list, dim, dev, keep_host=want_cpu)
-    batches = make_batches(pel, rows_list, B, args.nbatch, args.index_dist)
+    n_host = T if args.workload == "c2" else 2        # c3: 5 GB per table, sample two on the host
+    host_tables = make_tables_on_gpu(torch, eng, rows_list, dim, dev, keep_host=n_host if want_cpu else 0)
+    batches = make_batches(pel, spec, args.nbatch)
 
     plans = []
     for idx, off in batches:
@@ -142,10 +165,8 @@ def run_single(args):
         "ms_per_step": wall * 1000.0 / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "C2: 26 Criteo-Kaggle tables, dim 16 fp32, B=%d bags/table, L=1, "
-                               "u32 indices+offsets, %s indices, %d rotating batches" %
-                               (B, args.index_dist, len(plans)),
-                   "tables": T, "dim": dim, "bags_per_table": B, "pooling": 1,
+        "config": {"workload": "%s, %d rotating batches" % (spec["name"], len(plans)),
+                   "tables": T, "dim": dim, "bags_per_table": B, "pooling": spec["L"],
                    "table_bytes": eng.stats()["table_bytes"], "parallelism": "single"},
         "roofline": {"bound": "hbm", "achieved": alg_bytes / (kernel_us * 1e-6) / 1e9,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -190,9 +190,12 @@ int resolve(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs, emb_i
         g.n = (uint32_t)kv.second.size();
         const Table &t0 = e->tables[descs[kv.second[0]].table_id];
         g.geom = t0.geom;
-        uint64_t group_bags = 0;
-        for (uint32_t i : kv.second) group_bags += descs[i].n_bags;
-        g.kind = pimemb::choose_kernel(group_bags, g.geom);
+        uint64_t group_bags = 0, group_idx = 0;
+        for (uint32_t i : kv.second) {
+            group_bags += descs[i].n_bags;
+            group_idx += descs[i].n_indices;
+        }
+        g.kind = pimemb::choose_kernel(group_bags, group_idx, g.geom);
         const uint32_t bpt = pimemb::bags_per_tile(g.kind, g.geom);
         std::vector<uint32_t> tiles_of;
         std::vector<uint64_t> bytes_of;

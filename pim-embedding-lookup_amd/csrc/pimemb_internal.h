@@ -27,8 +27,8 @@ int geometry_for(emb_dtype dtype, uint32_t dim, LaunchGeom *g);
 // Bags one workgroup finishes per tile for this kernel kind and row shape.
 uint32_t bags_per_tile(KernelKind kind, const LaunchGeom &g);
 
-// Picks the kernel for a launch group from its total bag count.
-KernelKind choose_kernel(uint64_t total_bags, const LaunchGeom &g);
+// Picks the kernel for a launch group from its bag and index counts.
+KernelKind choose_kernel(uint64_t total_bags, uint64_t total_indices, const LaunchGeom &g);
 
 // Enqueue the fused gather + segment-sum over `n_descs` descriptors (all of one dtype/dim).
 // d_xmap == nullptr: 2-D grid (max_tiles x n_descs).  Otherwise the XCD-aware 1-D map built by

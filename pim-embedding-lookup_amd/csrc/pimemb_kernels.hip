@@ -119,11 +119,17 @@ uint32_t bags_per_tile(KernelKind kind, const LaunchGeom &g) {
     return (64u / g.lanes_per_row) * (GroupCfg::kBlock / 64);
 }
 
-KernelKind choose_kernel(uint64_t total_bags, const LaunchGeom &g) {
-    // The wave-batch kernel gives one wavefront 64 bags; below ~2 wavefronts per SIMD on the chip
-    // (256 CUs x 4 SIMDs) the finer lane-group kernel fills the machine better.
+KernelKind choose_kernel(uint64_t total_bags, uint64_t total_indices, const LaunchGeom &g) {
+    // Measured on MI355X (tools/tune_bag_kernels.hip, tools/tune_pooled.hip):
+    //   * one-hot-ish launches (<= 2 indices per bag on average) that fill the chip with 64-bag
+    //     wave batches (>= 2 wavefronts per SIMD) run 1.5x faster on the wave-batch kernel
+    //     (coalesced bounds, all gathers of a batch in flight, speculative index prefetch);
+    //   * pooled launches (dim 128, 32 indices per bag) run 1.3x faster on the lane-group kernel:
+    //     a bag is already a long stream of gathers, and 64 bags per wavefront leave too few
+    //     wavefronts to balance the machine.
     (void)g;
-    return (total_bags / 64u >= 2048u) ? KERNEL_WAVEBATCH : KERNEL_GROUP;
+    const bool one_hot_ish = total_indices <= 2 * total_bags;
+    return (one_hot_ish && total_bags / 64u >= 2048u) ? KERNEL_WAVEBATCH : KERNEL_GROUP;
 }
 
 hipError_t launch_bag_sum(const DevDesc *d_descs, uint32_t n_descs, uint32_t max_tiles,

@@ -43,7 +43,8 @@ constexpr uint64_t kXcdCacheableBytes = 32ull << 20;
 //     that still has tile room; a table that fits nowhere whole is split over two classes;
 //   * within a class the two kinds are interleaved in `rounds` rounds so misses and hits overlap.
 inline uint32_t build_xcd_map(const std::vector<uint32_t> &n_tiles, const std::vector<uint64_t> &table_bytes,
-                              std::vector<uint32_t> *words, uint32_t rounds = 4) {
+                              std::vector<uint32_t> *words, uint32_t rounds = 1,
+                              uint64_t cacheable_bytes = kXcdCacheableBytes) {
     const uint32_t n = (uint32_t)n_tiles.size();
     struct Run { uint32_t desc, tile0, count; };
     std::vector<std::vector<Run>> cache_runs(kXcdGroups), stream_runs(kXcdGroups);
@@ -52,7 +53,7 @@ inline uint32_t build_xcd_map(const std::vector<uint32_t> &n_tiles, const std::v
     std::vector<uint32_t> cacheable;
     uint64_t cache_tiles = 0;
     for (uint32_t d = 0; d < n; d++) {
-        if (table_bytes[d] <= kXcdCacheableBytes) {
+        if (table_bytes[d] <= cacheable_bytes) {
             cacheable.push_back(d);
             cache_tiles += n_tiles[d];
             continue;

@@ -1,0 +1,199 @@
+// tune_pooled.hip -- developer tool: interleaved A/B timing of bag-kernel variants on POOLED
+// workloads (BASELINE config C3 shape: T tables x N rows x dim 128 fp32, B bags x L indices per bag,
+// Zipf(alpha) ranks scattered by a multiplicative hash).  Same rules as tune_bag_kernels.hip: one
+// process, rounds interleaved, every variant cross-checked bit for bit against the first.
+//   tune_pooled [T rows B L alpha NB rounds iters]      defaults 16 4000000 16384 32 1.2 2 5 6
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../pimemb_bag_kernels.h"
+#include "../pimemb_xcd_map.h"
+
+using namespace pimemb;
+
+#define CK(x)                                                                              \
+    do {                                                                                   \
+        hipError_t e_ = (x);                                                               \
+        if (e_ != hipSuccess) {                                                            \
+            fprintf(stderr, "%s: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+            exit(1);                                                                       \
+        }                                                                                  \
+    } while (0)
+
+constexpr int D = 128, LPR = 32;
+
+__global__ void fill_table(float *w, uint64_t n, uint32_t seed) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t h = (uint32_t)i * 2654435761u ^ seed;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        w[i] = (float)(int32_t)h * (1.0f / 2147483648.0f);
+    }
+}
+
+static uint64_t rng_state = 88172645463325252ull;
+static inline uint64_t xorshift() {
+    rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17;
+    return rng_state;
+}
+static inline double urand() { return (double)(xorshift() >> 11) * (1.0 / 9007199254740992.0); }
+
+using LaunchFn = void (*)(const DevDesc *, uint32_t, uint32_t, const uint32_t *, uint32_t, hipStream_t);
+struct Variant {
+    std::string name;
+    uint32_t bags_per_tile = 256;
+    LaunchFn fn = nullptr;
+    bool xcd = false;
+    uint64_t cacheable = kXcdCacheableBytes;
+    uint32_t *d_xmap = nullptr;
+    uint32_t xgrid = 0;
+    std::vector<float> us;
+};
+
+template <class Cfg, bool WAVEBATCH>
+void do_launch(const DevDesc *d, uint32_t n, uint32_t tiles, const uint32_t *xmap, uint32_t xgrid, hipStream_t s) {
+    dim3 grid = xmap ? dim3(xgrid, 1, 1) : dim3(tiles, n, 1), block(Cfg::kBlock, 1, 1);
+    if (WAVEBATCH)
+        hipLaunchKernelGGL((bag_sum_wavebatch_kernel<uint32_t, EMB_F32, LPR, Cfg>), grid, block, 0, s, d, (uint32_t)LPR, xmap);
+    else
+        hipLaunchKernelGGL((bag_sum_group_kernel<uint32_t, EMB_F32, LPR, Cfg>), grid, block, 0, s, d, (uint32_t)LPR, xmap);
+}
+template <class Cfg, bool WAVEBATCH>
+Variant make_variant(const char *name, bool xcd = false) {
+    Variant v;
+    v.name = name;
+    v.xcd = xcd;
+    v.bags_per_tile = WAVEBATCH ? 64u * Cfg::kBatches * (Cfg::kBlock / 64) : (64u / LPR) * (Cfg::kBlock / 64);
+    v.fn = &do_launch<Cfg, WAVEBATCH>;
+    return v;
+}
+
+int main(int argc, char **argv) {
+    uint32_t T = argc > 1 ? atoi(argv[1]) : 16;
+    uint64_t rows = argc > 2 ? strtoull(argv[2], 0, 10) : 4000000ull;
+    uint32_t B = argc > 3 ? atoi(argv[3]) : 16384;
+    uint32_t L = argc > 4 ? atoi(argv[4]) : 32;
+    double alpha = argc > 5 ? atof(argv[5]) : 1.2;
+    int NB = argc > 6 ? atoi(argv[6]) : 2;
+    int rounds = argc > 7 ? atoi(argv[7]) : 5;
+    int iters = argc > 8 ? atoi(argv[8]) : 6;
+    CK(hipSetDevice(0));
+    hipStream_t s;
+    CK(hipStreamCreate(&s));
+    printf("pooled workload: %u tables x %llu rows x dim %d fp32 (%.1f GB), B=%u, L=%u, zipf %.2f, %d batches\n", T,
+           (unsigned long long)rows, D, T * rows * D * 4 / 1e9, B, L, alpha, NB);
+
+    std::vector<float *> tables(T);
+    for (uint32_t t = 0; t < T; t++) {
+        CK(hipMalloc((void **)&tables[t], rows * D * 4));
+        hipLaunchKernelGGL(fill_table, dim3(4096), dim3(256), 0, s, tables[t], rows * D, t + 1);
+    }
+    const uint64_t n_idx = (uint64_t)B * L;
+    std::vector<std::vector<uint32_t *>> d_idx(NB, std::vector<uint32_t *>(T)), d_off(NB, std::vector<uint32_t *>(T));
+    std::vector<std::vector<float *>> d_out(NB, std::vector<float *>(T));
+    std::vector<uint32_t> off(B), h(n_idx);
+    for (uint32_t i = 0; i < B; i++) off[i] = i * L;
+    const double oma = 1.0 - alpha, nn = std::pow((double)rows, oma) - 1.0;
+    for (int b = 0; b < NB; b++)
+        for (uint32_t t = 0; t < T; t++) {
+            for (uint64_t i = 0; i < n_idx; i++) {
+                uint64_t rank;
+                if (alpha <= 0.0) rank = xorshift() % rows;          // uniform
+                else rank = (uint64_t)std::pow(nn * urand() + 1.0, 1.0 / oma) - 1;  // bounded Pareto ~ Zipf
+                if (rank >= rows) rank = rows - 1;
+                h[i] = (uint32_t)((rank * 2654435761ull + 12345ull + t) % rows);     // scatter hot rows
+            }
+            CK(hipMalloc((void **)&d_idx[b][t], n_idx * 4));
+            CK(hipMemcpy(d_idx[b][t], h.data(), n_idx * 4, hipMemcpyHostToDevice));
+            CK(hipMalloc((void **)&d_off[b][t], B * 4));
+            CK(hipMemcpy(d_off[b][t], off.data(), B * 4, hipMemcpyHostToDevice));
+            CK(hipMalloc((void **)&d_out[b][t], (size_t)B * D * 4));
+        }
+
+    std::vector<Variant> vars;
+    //                        BLOCK U  ntS   ntM  inflight minW batches ntRow spec
+    vars.push_back(make_variant<BagCfg<256, 8, false, false, 8>, false>("v1 group blk256 U8"));
+    vars.push_back(make_variant<BagCfg<256, 8, true, false, 8>, false>("v1 blk256 U8 ntS XCD-stream", true));
+    { Variant v = make_variant<BagCfg<256, 8, true, false, 8>, false>("v1 blk256 U8 ntS XCD-pin", true); v.cacheable = ~0ull; vars.push_back(v); }
+    { Variant v = make_variant<BagCfg<256, 16, true, false, 8>, false>("v1 blk256 U16 ntS XCD-pin", true); v.cacheable = ~0ull; vars.push_back(v); }
+    { Variant v = make_variant<BagCfg<256, 4, true, false, 8>, false>("v1 blk256 U4 ntS XCD-pin", true); v.cacheable = ~0ull; vars.push_back(v); }
+    { Variant v = make_variant<BagCfg<128, 8, true, false, 8>, false>("v1 blk128 U8 ntS XCD-pin", true); v.cacheable = ~0ull; vars.push_back(v); }
+    { Variant v = make_variant<BagCfg<512, 8, true, false, 8>, false>("v1 blk512 U8 ntS XCD-pin", true); v.cacheable = ~0ull; vars.push_back(v); }
+    { Variant v = make_variant<BagCfg<64, 8, true, false, 8>, false>("v1 blk64 U8 ntS XCD-pin", true); v.cacheable = ~0ull; vars.push_back(v); }
+    { Variant v = make_variant<BagCfg<256, 8, true, false, 8, 8>, false>("v1 blk256 U8 ntS minw8 XCD-pin", true); v.cacheable = ~0ull; vars.push_back(v); }
+    vars.push_back(make_variant<BagCfg<64, 8, true, false, 8, 8, 1, false, true>, true>("v2 SHIP (blk64 U8 minw8)"));
+
+    std::vector<std::vector<DevDesc *>> d_desc(vars.size(), std::vector<DevDesc *>(NB));
+    std::vector<uint32_t> tiles(vars.size());
+    for (size_t v = 0; v < vars.size(); v++) {
+        tiles[v] = (B + vars[v].bags_per_tile - 1) / vars[v].bags_per_tile;
+        for (int b = 0; b < NB; b++) {
+            std::vector<DevDesc> hd(T);
+            for (uint32_t t = 0; t < T; t++) {
+                hd[t] = DevDesc{};
+                hd[t].weights = tables[t];
+                hd[t].indices = d_idx[b][t];
+                hd[t].offsets = d_off[b][t];
+                hd[t].out = d_out[b][t];
+                hd[t].n_idx = n_idx;
+                hd[t].n_bags = B;
+                hd[t].nr_rows = rows;
+                hd[t].n_tiles = tiles[v];
+            }
+            CK(hipMalloc((void **)&d_desc[v][b], sizeof(DevDesc) * T));
+            CK(hipMemcpy(d_desc[v][b], hd.data(), sizeof(DevDesc) * T, hipMemcpyHostToDevice));
+        }
+        if (vars[v].xcd) {
+            std::vector<uint32_t> nt(T, tiles[v]), words;
+            std::vector<uint64_t> bytes(T, rows * D * 4);
+            vars[v].xgrid = build_xcd_map(nt, bytes, &words, 1, vars[v].cacheable);
+            CK(hipMalloc((void **)&vars[v].d_xmap, words.size() * 4));
+            CK(hipMemcpy(vars[v].d_xmap, words.data(), words.size() * 4, hipMemcpyHostToDevice));
+        }
+    }
+    CK(hipDeviceSynchronize());
+
+    size_t out_bytes = (size_t)B * D * 4;
+    std::vector<char> ref(out_bytes * T), got(out_bytes * T);
+    for (size_t v = 0; v < vars.size(); v++) {
+        for (uint32_t t = 0; t < T; t++) CK(hipMemsetAsync(d_out[0][t], 0xff, out_bytes, s));
+        vars[v].fn(d_desc[v][0], T, tiles[v], vars[v].d_xmap, vars[v].xgrid, s);
+        CK(hipGetLastError());
+        CK(hipStreamSynchronize(s));
+        for (uint32_t t = 0; t < T; t++)
+            CK(hipMemcpy((v == 0 ? ref : got).data() + t * out_bytes, d_out[0][t], out_bytes, hipMemcpyDeviceToHost));
+        if (v && memcmp(ref.data(), got.data(), out_bytes * T)) {
+            fprintf(stderr, "MISMATCH variant %s\n", vars[v].name.c_str());
+            return 2;
+        }
+    }
+    printf("all variants bit-identical on batch 0\n");
+
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    for (int r = -1; r < rounds; r++)
+        for (size_t v = 0; v < vars.size(); v++) {
+            CK(hipEventRecord(e0, s));
+            for (int i = 0; i < iters; i++) vars[v].fn(d_desc[v][i % NB], T, tiles[v], vars[v].d_xmap, vars[v].xgrid, s);
+            CK(hipEventRecord(e1, s));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            if (r >= 0) vars[v].us.push_back(ms * 1000.f / iters);
+        }
+    const double alg = (double)T * ((double)n_idx * (D * 4 + 4) + (double)B * 4 + (double)B * D * 4);
+    printf("%-34s %10s %10s %9s %12s\n", "variant", "min us", "med us", "TB/s@med", "Gbags/s@med");
+    for (auto &v : vars) {
+        std::sort(v.us.begin(), v.us.end());
+        float med = v.us[v.us.size() / 2];
+        printf("%-34s %10.1f %10.1f %9.2f %12.3f\n", v.name.c_str(), v.us[0], med, alg / (med * 1e-6) / 1e12,
+               (double)T * B / (med * 1e-6) / 1e9);
+    }
+    return 0;
+}
