@@ -169,6 +169,26 @@ int emb_validate_inputs(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_
 int emb_get_stats(emb_engine *e, emb_stats *out);
 int emb_reset_stats(emb_engine *e);
 
+/* Per-call stage intervals of the host-pointer path, for the reference's profiling workflow: the
+ * interval CSV "DPU, Start, Stop" written by upmem/dputypes.py:87-98 and plotted by
+ * graph/runtime_intervals/main.py, and the Chrome trace of upmem/test.json.  Clock: CLOCK_MONOTONIC
+ * in microseconds (the reference's TIME_NOW, emb_host.h:35). */
+#define EMB_STAGE_COPY_IN 0      /* indices + offsets host -> HBM        (emb_host.h:258-270) */
+#define EMB_STAGE_DESCRIPTORS 1  /* descriptor / lengths upload          (emb_host.h:280-287) */
+#define EMB_STAGE_LAUNCH 2       /* kernel enqueue .. completion         (emb_host.h:297)     */
+#define EMB_STAGE_COPY_OUT 3     /* pooled rows HBM -> host              (emb_host.h:312-321) */
+#define EMB_STAGE_SYNC 4         /* final wait                           (emb_host.h:350)     */
+typedef struct emb_trace_event {
+    uint32_t stage;   /* EMB_STAGE_* */
+    uint32_t call_id; /* running number of the host-path lookup call */
+    double start_us;
+    double stop_us;
+} emb_trace_event;
+/* Keep the last `capacity` events (0 switches tracing off and drops what was recorded). */
+int emb_trace_enable(emb_engine *e, uint32_t capacity);
+/* Copy out up to max_events recorded events, oldest first, and remove them from the buffer. */
+int emb_trace_read(emb_engine *e, emb_trace_event *out, uint32_t max_events, uint32_t *n_events);
+
 /* Device-memory helpers so callers without a HIP binding (ctypes, cgo, JNI) can keep inputs and
  * outputs resident in HBM. */
 int emb_device_alloc(emb_engine *e, size_t bytes, void **out);

@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <new>
@@ -87,6 +88,15 @@ struct emb_engine {
     uint64_t table_bytes = 0;
     double us_copy_in_indices = 0, us_copy_in_lengths = 0, us_launch = 0, us_copy_out = 0,
            us_sync = 0;
+    // stage trace (host-pointer path)
+    std::deque<emb_trace_event> trace;
+    uint32_t trace_cap = 0;
+    uint32_t host_call_id = 0;
+    void record(uint32_t stage, double a, double b) {
+        if (!trace_cap) return;
+        if (trace.size() >= trace_cap) trace.pop_front();
+        trace.push_back(emb_trace_event{stage, host_call_id, a, b});
+    }
 };
 
 struct PlanGroup {
@@ -416,6 +426,15 @@ int lookup_host(emb_engine *e, const emb_lookup_desc *descs, uint32_t n, emb_ind
     e->us_launch += t3 - t2;
     e->us_copy_out += t4 - t3;
     e->us_sync += t5 - t4;
+    if (e->trace_cap) {
+        std::lock_guard<std::mutex> lk(e->mu);
+        e->record(EMB_STAGE_COPY_IN, t0, t1);
+        e->record(EMB_STAGE_DESCRIPTORS, t1, t2);
+        e->record(EMB_STAGE_LAUNCH, t2, t3);
+        e->record(EMB_STAGE_COPY_OUT, t3, t4);
+        e->record(EMB_STAGE_SYNC, t4, t5);
+        e->host_call_id++;
+    }
     e->n_bags.fetch_add(r.n_bags, std::memory_order_relaxed);
     e->n_indices.fetch_add(r.n_indices, std::memory_order_relaxed);
     return EMB_OK;
@@ -751,6 +770,27 @@ int emb_reset_stats(emb_engine *e) {
     e->n_bags = 0;
     e->n_indices = 0;
     e->us_copy_in_indices = e->us_copy_in_lengths = e->us_launch = e->us_copy_out = e->us_sync = 0;
+    return EMB_OK;
+}
+
+int emb_trace_enable(emb_engine *e, uint32_t capacity) {
+    if (!e) return fail(EMB_ERR_INVALID, "engine is NULL");
+    std::lock_guard<std::mutex> lk(e->mu);
+    e->trace_cap = capacity;
+    e->trace.clear();
+    e->host_call_id = 0;
+    return EMB_OK;
+}
+
+int emb_trace_read(emb_engine *e, emb_trace_event *out, uint32_t max_events, uint32_t *n_events) {
+    if (!e || !n_events || (max_events && !out)) return fail(EMB_ERR_INVALID, "bad argument to emb_trace_read");
+    std::lock_guard<std::mutex> lk(e->mu);
+    uint32_t n = 0;
+    while (n < max_events && !e->trace.empty()) {
+        out[n++] = e->trace.front();
+        e->trace.pop_front();
+    }
+    *n_events = n;
     return EMB_OK;
 }
 

@@ -1,0 +1,159 @@
+"""`apply_emb`-shaped harness over the engine.
+
+Stands where `dlrm_s_pytorch.py::apply_emb` stands in the reference's stack [EXT: that file is an
+empty submodule here; flags from README.md:6,10,14 and upmem/run.sh:72-82,111-121]: a list of
+`nn.EmbeddingBag(n_k, m, mode="sum")` called per table with (indices_k, offsets_k), each returning
+[B, m].  Here all tables are served by ONE fused HIP launch.  No autograd (inference only, as the
+reference's `--inference-only` runs), no MLPs -- the rest of the model is out of scope.
+
+    python -m pim_embedding_lookup_amd.dlrm_harness --arch-sparse-feature-size=16 \
+        --arch-embedding-size=1460-583-10131227-… --mini-batch-size=39292 --inference-only
+"""
+from __future__ import annotations
+
+import argparse
+import sys
+import time
+
+import numpy as np
+
+from . import workloads
+from .engine import EmbeddingEngine
+
+
+class EmbeddingBagCollection:
+    """emb_l of a DLRM: T tables of dim m in HBM; forward(lS_o, lS_i) -> list of [B, m]."""
+
+    def __init__(self, ln_emb, m_spa: int, device: int = 0, weights=None, seed: int = 0, dtype="f32"):
+        import torch
+        self.torch = torch
+        self.device = torch.device("cuda", device)
+        self.ln_emb, self.m = [int(n) for n in ln_emb], int(m_spa)
+        self.engine = EmbeddingEngine(device=device, max_tables=len(self.ln_emb))
+        g = torch.Generator(device=self.device)
+        g.manual_seed(seed)
+        for k, n in enumerate(self.ln_emb):
+            if weights is not None:
+                w = torch.as_tensor(np.asarray(weights[k]), dtype=torch.float32)
+                if tuple(w.shape) != (n, self.m):
+                    raise ValueError(f"table {k}: weight shape {tuple(w.shape)} != ({n}, {self.m})")
+            else:  # DLRM init: U(-sqrt(1/n), sqrt(1/n))
+                a = float(np.sqrt(1.0 / n))
+                w = torch.empty((n, self.m), dtype=torch.float32, device=self.device).uniform_(-a, a, generator=g)
+            if dtype == "f16":
+                w = w.to(torch.float16)
+            self.engine.load_table(k, w)
+        self._plans = {}
+
+    @classmethod
+    def from_checkpoint(cls, path: str, device: int = 0):
+        from .formats import load_dlrm_embedding_weights
+        ws = load_dlrm_embedding_weights(path)
+        return cls([w.shape[0] for w in ws], ws[0].shape[1], device=device, weights=ws)
+
+    def apply_emb(self, lS_o, lS_i):
+        """lS_o[k], lS_i[k]: offsets / indices of table k (torch CUDA tensors, int64 or int32, or
+        numpy arrays -> host path).  Returns ly: list of [B_k, m] fp32."""
+        if len(lS_o) != len(self.ln_emb) or len(lS_i) != len(self.ln_emb):
+            raise ValueError("need one (offsets, indices) pair per table")
+        if hasattr(lS_i[0], "is_cuda") and lS_i[0].is_cuda:
+            key = tuple((o.data_ptr(), i.data_ptr(), o.numel(), i.numel()) for o, i in zip(lS_o, lS_i))
+            plan = self._plans.get(key)
+            if plan is None:
+                if len(self._plans) > 64:
+                    for p in self._plans.values():
+                        p.destroy()
+                    self._plans.clear()
+                plan = self.engine.plan(list(range(len(self.ln_emb))), list(lS_i), list(lS_o))
+                self._plans[key] = plan
+            plan.launch(self.torch.cuda.current_stream(self.device).cuda_stream)
+            return plan.outputs
+        return self.engine.lookup_batched(list(range(len(self.ln_emb))), list(lS_i), list(lS_o))
+
+    forward = __call__ = apply_emb
+
+    def close(self):
+        for p in self._plans.values():
+            p.destroy()
+        self._plans.clear()
+        self.engine.close()
+
+
+def random_batch(rng, ln_emb, batch: int, num_indices_per_lookup: int, fixed: bool, device=None):
+    """DLRM's synthetic generator [EXT]: per sample and table, `num_indices_per_lookup` indices
+    (fixed) or 1..num_indices_per_lookup (random), uniform over the table."""
+    lS_o, lS_i = [], []
+    for n in ln_emb:
+        if fixed:
+            lens = np.full(batch, num_indices_per_lookup, dtype=np.int64)
+        else:
+            lens = rng.integers(1, num_indices_per_lookup + 1, size=batch)
+        off = np.zeros(batch, dtype=np.int64)
+        off[1:] = np.cumsum(lens)[:-1]
+        idx = rng.integers(0, n, size=int(lens.sum()), dtype=np.int64)
+        lS_o.append(off)
+        lS_i.append(idx)
+    if device is not None:
+        import torch
+        lS_o = [torch.from_numpy(o).to(device) for o in lS_o]
+        lS_i = [torch.from_numpy(i).to(device) for i in lS_i]
+    return lS_o, lS_i
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="embedding path of DLRM on the MI355X engine")
+    ap.add_argument("--arch-sparse-feature-size", type=int, default=16)
+    ap.add_argument("--arch-embedding-size", type=str, default="-".join(map(str, workloads.KAGGLE_ROWS)))
+    ap.add_argument("--mini-batch-size", type=int, default=1)
+    ap.add_argument("--num-indices-per-lookup", type=int, default=1)
+    ap.add_argument("--num-indices-per-lookup-fixed", action="store_true")
+    ap.add_argument("--num-batches", type=int, default=100)
+    ap.add_argument("--inference-only", action="store_true")
+    ap.add_argument("--data-set", type=str, default="random", choices=["random", "kaggle"])
+    ap.add_argument("--processed-data-file", type=str, default="")
+    ap.add_argument("--load-model", type=str, default="")
+    ap.add_argument("--numpy-rand-seed", type=int, default=123)
+    args = ap.parse_args(argv)
+    if not args.inference_only:
+        print("note: only the inference embedding path exists here; running it (--inference-only implied)")
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(args.numpy_rand_seed)
+    data = None
+    if args.data_set == "kaggle":
+        from .formats import CriteoKaggleNpz
+        data = CriteoKaggleNpz(args.processed_data_file)
+        ln_emb = data.table_rows
+    else:
+        ln_emb = [int(x) for x in args.arch_embedding_size.split("-")]
+    if args.load_model:
+        ebc = EmbeddingBagCollection.from_checkpoint(args.load_model)
+    else:
+        ebc = EmbeddingBagCollection(ln_emb, args.arch_sparse_feature_size)
+    B = args.mini_batch_size
+    batches = []
+    for b in range(min(args.num_batches, 16)):
+        if data is not None:
+            o, i = data.batch((b * B) % max(data.n_samples - B, 1), B)
+            batches.append(([torch.from_numpy(x).to(dev) for x in o], [torch.from_numpy(x).to(dev) for x in i]))
+        else:
+            batches.append(random_batch(rng, ebc.ln_emb, B, args.num_indices_per_lookup,
+                                        args.num_indices_per_lookup_fixed, dev))
+    for o, i in batches:
+        ebc.apply_emb(o, i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for b in range(args.num_batches):
+        o, i = batches[b % len(batches)]
+        ly = ebc.apply_emb(o, i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.num_batches
+    n_bags = sum(int(x.shape[0]) for x in ly)
+    print(f"apply_emb: {len(ebc.ln_emb)} tables, m={ebc.m}, batch {B}: {dt * 1e3:.4f} ms/batch, "
+          f"{n_bags / dt:.3e} pooled lookups/s")
+    ebc.close()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -33,6 +33,10 @@ class EmbStats(C.Structure):
                 ("us_post_process", C.c_double), ("us_sync", C.c_double)]
 
 
+class EmbTraceEvent(C.Structure):
+    _fields_ = [("stage", C.c_uint32), ("call_id", C.c_uint32), ("start_us", C.c_double), ("stop_us", C.c_double)]
+
+
 class DpuRuntimeTotals(C.Structure):
     """emb_host.h:41-48 / upmem/dputypes.py:67-79"""
     _fields_ = [("execution_time_prepare", C.c_double),
@@ -65,6 +69,8 @@ SIGNATURES = {
                                       C.POINTER(_u64)]),
     "emb_get_stats": (C.c_int, [_vp, C.POINTER(EmbStats)]),
     "emb_reset_stats": (C.c_int, [_vp]),
+    "emb_trace_enable": (C.c_int, [_vp, _u32]),
+    "emb_trace_read": (C.c_int, [_vp, C.POINTER(EmbTraceEvent), _u32, C.POINTER(_u32)]),
     "emb_device_alloc": (C.c_int, [_vp, _sz, _pp]),
     "emb_device_free": (C.c_int, [_vp, _vp]),
     "emb_copy_to_device": (C.c_int, [_vp, _vp, _vp, _sz]),

@@ -278,3 +278,156 @@ def test_big_multi_table_launch_wavebatch_xcd_map(pel, eng, oracle):
     run(zero_one)
     run(lambda: pel.workloads.ragged_offsets(rng, B, 5, p_empty=0.2, dtype=np.uint32))
     run(lambda: (pel.workloads.fixed_offsets(B, 4), 4 * B))
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE.json full sizes: size-independent properties (the oracle is only sampled here)
+# ---------------------------------------------------------------------------------------------------
+def test_full_size_c2_properties(pel, oracle):
+    """configs[1]: the 26 Criteo-Kaggle tables (33.8 M rows, dim 16 fp32), B = 39292, L = 1.
+    (1) one-hot => pooled row IS the table row, bit for bit, for every one of the 1 021 592 bags
+        (checked against an independent torch gather on the GPU);
+    (2) linearity: a table scaled by 2 gives exactly 2x the pooled rows (x2 is exact in fp32);
+    (3) idempotence: a second launch of the same plan leaves the output unchanged;
+    (4) the oracle agrees on a sample of bags of every table (rows fetched from the GPU)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rows = pel.workloads.KAGGLE_ROWS
+    B = pel.workloads.KAGGLE_BATCH
+    T = len(rows)
+    e = pel.EmbeddingEngine(device=0, max_tables=2 * T)
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    rng = np.random.default_rng(1)
+    ws, idxs = [], []
+    for t, n in enumerate(rows):
+        a = float(np.sqrt(1.0 / n))
+        w = torch.empty((n, 16), dtype=torch.float32, device=dev).uniform_(-a, a, generator=g)
+        e.load_table(t, w)
+        e.load_table(T + t, w * 2.0)
+        ws.append(w)
+        idxs.append(torch.from_numpy(pel.workloads.uniform_indices(rng, n, B).view(np.int32)).to(dev))
+    off = torch.arange(B, dtype=torch.int32, device=dev)
+    plan1 = e.plan(list(range(T)), idxs, [off] * T)
+    plan2 = e.plan(list(range(T, 2 * T)), idxs, [off] * T)
+    plan1.launch(); plan2.launch()
+    torch.cuda.synchronize()
+    first = [o.clone() for o in plan1.outputs]
+    plan1.launch()
+    torch.cuda.synchronize()
+    checksum = 0.0
+    for t in range(T):
+        want = ws[t][idxs[t].long()]
+        assert torch.equal(plan1.outputs[t], want), f"table {t}: pooled row != table row"
+        assert torch.equal(plan1.outputs[t], first[t])                      # idempotent
+        assert torch.equal(plan2.outputs[t], plan1.outputs[t] * 2.0)        # linear
+        checksum += float(plan1.outputs[t].double().sum())
+        # oracle on a sample: 64 bags, rows copied back from HBM
+        sel = rng.integers(0, B, size=64)
+        idx_s = idxs[t][sel].cpu().numpy().astype(np.int64)
+        uniq, inv = np.unique(idx_s, return_inverse=True)
+        small = ws[t][torch.from_numpy(uniq).to(dev)].cpu().numpy()
+        want_s = oracle.c_bag_sum(small, inv.astype(np.int64), np.arange(64, dtype=np.int64))
+        assert np.array_equal(plan1.outputs[t][torch.from_numpy(sel).to(dev)].cpu().numpy(), want_s)
+    # checksum of checksums: sum of all pooled values == sum over gathered rows (float64)
+    ref = sum(float(ws[t][idxs[t].long()].double().sum()) for t in range(T))
+    assert abs(checksum - ref) <= 1e-9 * max(1.0, abs(ref))
+    nb, ni = plan1.bytes()[1:]
+    assert (nb, ni) == (T * B, T * B)
+    plan1.destroy(); plan2.destroy(); e.close()
+
+
+def test_full_width_pooled_properties(pel, oracle):
+    """configs[2] shape at reduced table count (dim 128 fp32, 10 M rows, B = 16384, pooling 32,
+    Zipf(1.2)): linearity (exact), bag-concatenation additivity within 1e-6, and the oracle on a
+    sample of bags."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(2)
+    n, D, B, L = 10_000_000, 128, 16384, 32
+    e = pel.EmbeddingEngine(device=0, max_tables=4)
+    a = float(np.sqrt(1.0 / n))
+    w = torch.empty((n, D), dtype=torch.float32, device=dev).uniform_(-a, a)
+    e.load_table(0, w)
+    e.load_table(1, w * 2.0)
+    idx = torch.from_numpy(pel.workloads.zipf_indices(rng, n, B * L).view(np.int32)).to(dev)
+    off = torch.from_numpy(pel.workloads.fixed_offsets(B, L).view(np.int32)).to(dev)
+    out1 = e.lookup(0, idx, off)
+    out2 = e.lookup(1, idx, off)
+    # additivity: bags of 32 == (first 16) + (last 16) up to fp32 reassociation
+    off16 = torch.from_numpy(pel.workloads.fixed_offsets(2 * B, L // 2).view(np.int32)).to(dev)
+    halves = e.lookup(0, idx, off16)
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out1 * 2.0)
+    assert float((halves[0::2] + halves[1::2] - out1).abs().max()) <= 1e-6
+    sel = rng.integers(0, B, size=48)
+    pos = (sel[:, None] * L + np.arange(L)[None, :]).reshape(-1)
+    idx_s = idx[torch.from_numpy(pos).to(dev)].cpu().numpy().astype(np.int64)
+    uniq, inv = np.unique(idx_s, return_inverse=True)
+    small = w[torch.from_numpy(uniq).to(dev)].cpu().numpy()
+    want = oracle.c_bag_sum(small, inv.astype(np.int64), np.arange(48, dtype=np.int64) * L)
+    assert np.array_equal(out1[torch.from_numpy(sel).to(dev)].cpu().numpy(), want)
+    e.close()
+
+
+def test_apply_emb_harness_matches_torch_embeddingbag(pel, oracle, tmp_path):
+    """F1: the apply_emb contract -- list of (offsets_k, indices_k) in, list of [B, m] out -- against
+    torch CPU nn.EmbeddingBag(mode="sum") built from the same checkpoint (F2 format)."""
+    import torch
+    from importlib import import_module
+    hz = import_module("pim-embedding-lookup_amd.dlrm_harness")
+    fm = import_module("pim-embedding-lookup_amd.formats")
+    rng = np.random.default_rng(4)
+    ln_emb, m = [1460, 583, 50000, 3, 27], 16
+    tabs = [pel.workloads.dlrm_table(rng, n, m) for n in ln_emb]
+    ckpt = tmp_path / "dlrm.pt"
+    fm.save_dlrm_embedding_weights(str(ckpt), tabs)
+    ebc = hz.EmbeddingBagCollection.from_checkpoint(str(ckpt))
+    dev = torch.device("cuda", 0)
+    for B, L, fixed in ((1, 1, True), (188, 1, True), (77, 6, False)):
+        lS_o, lS_i = hz.random_batch(rng, ln_emb, B, L, fixed, dev)
+        ly = ebc.apply_emb(lS_o, lS_i)
+        ly2 = ebc.apply_emb(lS_o, lS_i)                 # cached plan
+        torch.cuda.synchronize()
+        for k in range(len(ln_emb)):
+            bag = torch.nn.EmbeddingBag.from_pretrained(torch.from_numpy(tabs[k]), mode="sum")
+            want = bag(lS_i[k].cpu(), lS_o[k].cpu())
+            assert torch.equal(ly[k].cpu(), want) and ly[k].shape == (B, m)
+            assert ly2[k].data_ptr() == ly[k].data_ptr()
+    # host (numpy) inputs go through the copy-in/copy-out path and agree too
+    lS_o, lS_i = hz.random_batch(rng, ln_emb, 9, 3, False, None)
+    ly = ebc.apply_emb(lS_o, lS_i)
+    for k in range(len(ln_emb)):
+        assert np.array_equal(ly[k], oracle.c_bag_sum(tabs[k], lS_i[k], lS_o[k]))
+    ebc.close()
+    assert hz.main(["--arch-embedding-size=100-200-300", "--mini-batch-size=32", "--num-batches=3",
+                    "--num-indices-per-lookup=4", "--inference-only"]) == 0
+
+
+def test_stage_trace_export(pel, eng, tmp_path):
+    """F4: per-call stage intervals -> the reference's interval CSV and a Chrome trace."""
+    import csv
+    import json
+    from importlib import import_module
+    tr = import_module("pim-embedding-lookup_amd.trace")
+    tab = np.ones((100, 16), np.float32)
+    eng.load_table(9, tab)
+    tr.enable(eng, 1000)
+    for _ in range(3):
+        eng.lookup(9, np.arange(50, dtype=np.uint32), np.arange(0, 50, 5, dtype=np.uint32))
+    ev = tr.read(eng)
+    assert len(ev) == 15 and [e["stage"] for e in ev[:5]] == [0, 1, 2, 3, 4]
+    assert [e["call_id"] for e in ev[::5]] == [0, 1, 2]
+    assert all(e["stop_us"] >= e["start_us"] for e in ev)
+    assert all(a["stop_us"] <= b["start_us"] + 1e-3 for a, b in zip(ev, ev[1:]))   # stages do not overlap
+    assert tr.read(eng) == []                                                     # drained
+    tr.write_interval_csv(ev, tmp_path / "runtimes.csv")
+    rows = list(csv.reader(open(tmp_path / "runtimes.csv")))
+    assert rows[0] == ["DPU", "Start", "Stop"] and len(rows) == 16
+    assert float(rows[1][2]) >= float(rows[1][1])
+    tr.write_chrome_trace(ev, tmp_path / "trace.json")
+    t = json.load(open(tmp_path / "trace.json"))["traceEvents"]
+    assert len(t) == 30 and {x["ph"] for x in t} == {"B", "E"} and t[4]["name"] == "launch"
+    tr.enable(eng, 0)
+    eng.lookup(9, np.arange(5, dtype=np.uint32), np.arange(5, dtype=np.uint32))
+    assert tr.read(eng) == []
