@@ -70,6 +70,16 @@ def make_tables_on_gpu(torch, eng, rows_list, dim, device, seed=0, keep_host=Fal
     return host
 
 
+def measured_traffic(workload: str):
+    """HBM bytes per launch from the committed PMC profile of this very command (profiles/traffic.json),
+    or None when no profile exists for the workload / batch shape being run."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f).get(workload, {}).get("traffic_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
 def workload_spec(pel, args):
     """rows per table, dim, bags per table, pooling, index distribution, description."""
     if args.workload == "c2":
@@ -171,7 +181,9 @@ def run_single(args):
         "roofline": {"bound": "hbm", "achieved": alg_bytes / (kernel_us * 1e-6) / 1e9,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": alg_bytes / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                     "traffic": None, "kernel_us": kernel_us, "algorithmic_bytes": alg_bytes},
+                     "traffic": measured_traffic(args.workload) if (args.batch is None and args.index_dist is None
+                                                                    and args.tables is None) else None,
+                     "kernel_us": kernel_us, "algorithmic_bytes": alg_bytes},
     }
     if want_cpu:
         result["cpu_baseline"] = cpu_baseline(pel, host_tables, batches[0], args.cpu_seconds)
@@ -184,7 +196,7 @@ def run_single(args):
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or os.environ.get("PIMEMB_FORCE_DIST") == "1":   # last: 1-rank RCCL rehearsal
         from importlib import import_module
         import_module("pim-embedding-lookup_amd.dist_bench").run(args, HBM_PEAK_GBS)
     else:

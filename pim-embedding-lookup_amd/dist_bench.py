@@ -3,17 +3,20 @@ weak scaling -- every rank owns B bags per table, so the global batch is N * B.
 
 Static-shape fast path of sharding.py for the bench workload (one index per bag, equal B on every
 rank): tables <= --replicate-mb are replicated (no exchange), the rest are placed whole on owner
-ranks by the shard planner.  One step on every rank:
+ranks by the shard planner.  The two exchanges of a lookup -- indices in, pooled rows out -- are
+software-pipelined over consecutive batches so that ONE all_to_all per step carries both the
+pooled rows of batch i and the indices of batch i+1 (byte payloads with static splits):
 
-    all_to_all(indices of the sharded tables)          RCCL, overlaps with launch A
-    launch A: fused lookup of the replicated tables    HIP engine plan (local bags)
-    launch B: fused lookup of the tables served here   HIP engine plan (bags of ALL ranks), pooled
-              rows are written straight into the outgoing all_to_all buffer
-    all_to_all(pooled rows)                            RCCL
-    outputs: replicated tables -> own buffers; sharded tables -> views of the receive buffer
+    launch A(i): fused lookup of the replicated tables        HIP engine plan, local bags, no dependency
+    wait collective(i-1)                                      stream-level, the CPU never blocks
+    launch B(i): fused lookup of the tables served here       HIP engine plan over the bags of ALL ranks;
+                 indices are read from collective(i-1)'s receive buffer, pooled rows are written
+                 straight into collective(i)'s send buffer
+    collective(i) = all_to_all([pooled rows of batch i | indices of batch i+1])   RCCL over xGMI
+    outputs(i): replicated tables -> own buffers; sharded tables -> views of the receive buffer
 
-All buffers and both engine plans are created once per rotating batch slot; a step enqueues two
-collectives and two kernels, nothing else."""
+All buffers and both engine plans are created once per rotating batch slot; a step enqueues one
+collective and two kernels, nothing else."""
 from __future__ import annotations
 
 import json
@@ -66,7 +69,9 @@ def run(args, hbm_peak_gbs: float) -> None:
     rows_list = pel.workloads.KAGGLE_ROWS
     dim = pel.workloads.KAGGLE_DIM
     B = args.batch or pel.workloads.KAGGLE_BATCH
+    Bp = (B + 3) // 4 * 4                   # index slots per (table, rank): keeps every piece 16-B aligned
     T = len(rows_list)
+    NBATCH = max(2, args.nbatch)
     rep_bytes = int(getattr(args, "replicate_mb", 64)) << 20
     plan = sh.plan_shards(rows_list, dim, 4, world, replicate_bytes=rep_bytes, split_bytes=1 << 62)
     served = plan.owned_units(rank)
@@ -83,109 +88,143 @@ def run(args, hbm_peak_gbs: float) -> None:
         del w
     torch.cuda.empty_cache()
 
-    # ---- rotating batch slots: indices, exchange buffers, outputs, two engine plans each ----------
+    # ---- byte layout of the fused collective ----------------------------------------------------
+    # to destination d  : [ K tables x B x dim fp32 pooled rows of d's bags | n_send[d] tables x Bp u32 indices ]
+    # from source s     : [ n_send[s] tables x B x dim fp32 pooled rows of MY bags | K tables x Bp u32 indices of s's bags ]
+    row_b = dim * 4
+    in_split = [K * B * row_b + n_send[d] * Bp * 4 for d in range(world)]
+    out_split = [n_send[s] * B * row_b + K * Bp * 4 for s in range(world)]
+    in_off = np.concatenate([[0], np.cumsum(in_split)]).astype(np.int64)
+    out_off = np.concatenate([[0], np.cumsum(out_split)]).astype(np.int64)
+
+    def f32_view(buf, byte_off, n_rows):
+        return buf[byte_off:byte_off + n_rows * row_b].view(torch.float32).view(n_rows, dim)
+
+    def i32_view(buf, byte_off, n):
+        return buf[byte_off:byte_off + n * 4].view(torch.int32)
+
     rng = np.random.default_rng(1 + rank)
     off_dev = torch.arange(B, dtype=torch.int32, device=dev)
+    idx_host = [[pel.workloads.uniform_indices(rng, n, B).view(np.int32) for n in rows_list]
+                for _ in range(NBATCH)]
     slots = []
-    for _ in range(args.nbatch):
-        idx_host = [pel.workloads.uniform_indices(rng, n, B).view(np.int32) for n in rows_list]
-        idx_local = {u.table: torch.from_numpy(idx_host[u.table]).to(dev) for u in local}
-        # outgoing index buffer, ordered (destination, its tables)
-        send_idx = torch.empty(max(n_sharded, 1) * B, dtype=torch.int32, device=dev)
-        pos = 0
+    for j in range(NBATCH):
+        send = torch.zeros(max(int(in_off[-1]), 16), dtype=torch.uint8, device=dev)
+        recv = torch.zeros(max(int(out_off[-1]), 16), dtype=torch.uint8, device=dev)   # zeros: index 0 is valid
+        slots.append(dict(send=send, recv=recv))
+    for j in range(NBATCH):
+        sl, nxt = slots[j], (j + 1) % NBATCH
+        # indices of the NEXT batch ride in this slot's send buffer (static, written once)
         for d in range(world):
-            for u in send_units[d]:
-                send_idx[pos:pos + B] = torch.from_numpy(idx_host[u.table]).to(dev)
-                pos += B
-        recv_idx = torch.empty(max(world * K, 1) * B, dtype=torch.int32, device=dev)   # [src][k][B]
-        send_out = torch.empty(max(world * K, 1) * B * dim, dtype=torch.float32, device=dev)  # [src][k][B][D]
-        recv_out = torch.empty(max(n_sharded, 1) * B * dim, dtype=torch.float32, device=dev)  # [owner][table][B][D]
-        out_local = {u.table: torch.empty((B, dim), dtype=torch.float32, device=dev) for u in local}
-        plan_a = None
+            base = int(in_off[d]) + K * B * row_b
+            for q, u in enumerate(send_units[d]):
+                i32_view(sl["send"], base + q * Bp * 4, B).copy_(torch.from_numpy(idx_host[nxt][u.table]))
+        sl["idx_local"] = {u.table: torch.from_numpy(idx_host[j][u.table]).to(dev) for u in local}
+        sl["out_local"] = {u.table: torch.empty((B, dim), dtype=torch.float32, device=dev) for u in local}
+        sl["plan_a"] = None
         if local:
-            plan_a = eng.plan([u.uid for u in local], [idx_local[u.table] for u in local],
-                              [off_dev] * len(local), [out_local[u.table] for u in local])
-        plan_b = None
-        if K:
+            sl["plan_a"] = eng.plan([u.uid for u in local], [sl["idx_local"][u.table] for u in local],
+                                    [off_dev] * len(local), [sl["out_local"][u.table] for u in local])
+    for j in range(NBATCH):
+        sl, prev = slots[j], slots[(j - 1) % NBATCH]
+        sl["plan_b"] = None
+        if K:   # indices of batch j arrived with collective(j-1); pooled rows go into collective(j)
             ids, ii, oo, uu = [], [], [], []
             for s in range(world):
                 for k, u in enumerate(served):
-                    base = (s * K + k) * B
                     ids.append(u.uid)
-                    ii.append(recv_idx[base:base + B])
+                    ii.append(i32_view(prev["recv"], int(out_off[s]) + n_send[s] * B * row_b + k * Bp * 4, B))
                     oo.append(off_dev)
-                    uu.append(send_out[base * dim:(base + B) * dim].view(B, dim))
-            plan_b = eng.plan(ids, ii, oo, uu)
-        slots.append(dict(idx_host=idx_host, send_idx=send_idx, recv_idx=recv_idx, send_out=send_out,
-                          recv_out=recv_out, out_local=out_local, plan_a=plan_a, plan_b=plan_b))
+                    uu.append(f32_view(sl["send"], int(in_off[s]) + k * B * row_b, B))
+            sl["plan_b"] = eng.plan(ids, ii, oo, uu)
 
-    in_splits_idx = [n * B for n in n_send]
-    out_splits_idx = [K * B] * world
-    in_splits_out = [K * B * dim] * world
-    out_splits_out = [n * B * dim for n in n_send]
     stream = torch.cuda.current_stream(dev)
     sh_handle = stream.cuda_stream
+    pending = [None]
 
-    def a2a(recv, send, out_splits, in_splits, async_op):
+    def collective(sl):
         if n_sharded == 0:
             return None
         if stage_cpu:
-            r, s_ = torch.empty(recv.shape, dtype=recv.dtype), send.cpu()
-            dist.all_to_all_single(r, s_, output_split_sizes=out_splits, input_split_sizes=in_splits)
-            recv.copy_(r)
+            r, s_ = torch.empty(sl["recv"].shape, dtype=torch.uint8), sl["send"].cpu()
+            dist.all_to_all_single(r, s_, output_split_sizes=out_split, input_split_sizes=in_split)
+            sl["recv"].copy_(r)
             return None
-        return dist.all_to_all_single(recv, send, output_split_sizes=out_splits,
-                                      input_split_sizes=in_splits, async_op=async_op)
+        return dist.all_to_all_single(sl["recv"], sl["send"], output_split_sizes=out_split,
+                                      input_split_sizes=in_split, async_op=True)
 
-    def step(sl):
-        w = a2a(sl["recv_idx"], sl["send_idx"], out_splits_idx, in_splits_idx, True)
+    def step(i):
+        sl = slots[i % NBATCH]
         if sl["plan_a"] is not None:
-            sl["plan_a"].launch(sh_handle)          # overlaps with the index exchange
-        if w is not None:
-            w.wait()
+            sl["plan_a"].launch(sh_handle)          # independent of the exchange
+        if pending[0] is not None:
+            pending[0].wait()                       # compute stream waits for collective(i-1)
         if sl["plan_b"] is not None:
             sl["plan_b"].launch(sh_handle)
-        w2 = a2a(sl["recv_out"], sl["send_out"], out_splits_out, in_splits_out, True)
-        if w2 is not None:
-            w2.wait()
+        pending[0] = collective(sl)
+
+    def drain():
+        if pending[0] is not None:
+            pending[0].wait()
+            pending[0] = None
+        torch.cuda.synchronize()
 
     def outputs(sl):
         res = [None] * T
         for u in local:
             res[u.table] = sl["out_local"][u.table]
-        pos = 0
-        for d in range(world):
-            for u in send_units[d]:
-                res[u.table] = sl["recv_out"][pos * dim:(pos + B) * dim].view(B, dim)
-                pos += B
+        for s in range(world):
+            for q, u in enumerate(send_units[s]):
+                res[u.table] = f32_view(sl["recv"], int(out_off[s]) + q * B * row_b, B)
         return res
 
-    # ---- parity of the distributed path: every table, every rank, bit-exact (one-hot = row copy) --
-    step(slots[0])
-    torch.cuda.synchronize()
-    res = outputs(slots[0])
-    for t in range(T):
-        idx = torch.from_numpy(slots[0]["idx_host"][t]).to(dev)
-        want = expected_rows(torch, t, idx, dim)
-        if not torch.equal(res[t], want + 0.0):
-            raise AssertionError(f"rank {rank}: table {t} ({plan.kinds[t]}) differs from the expected rows")
+    # ---- prime the pipeline (one full rotation), then check two consecutive steps bit-exactly:
+    #      every table on every rank (one-hot => pooled row == table row) ---------------------------
+    for i in range(NBATCH):
+        step(i)
+    for i in (NBATCH, NBATCH + 1):
+        step(i)
+        drain()
+        res = outputs(slots[i % NBATCH])
+        for t in range(T):
+            idx = torch.from_numpy(idx_host[i % NBATCH][t]).to(dev)
+            if not torch.equal(res[t], expected_rows(torch, t, idx, dim) + 0.0):
+                raise AssertionError(f"rank {rank}: step {i} table {t} ({plan.kinds[t]}) differs from the expected rows")
+    n_primed = NBATCH + 2
 
-    # ---- kernel-only time of this rank's two launches (roofline object) ---------------------------
+    # ---- kernel-only time of this rank's two launches, rotating over the batch slots (roofline) ----
     kernel_us, alg_bytes = 0.0, 0
-    for p in (slots[0]["plan_a"], slots[0]["plan_b"]):
-        if p is not None:
-            kernel_us += p.time_us(warmup=5, iters=50, stream=sh_handle)
-            alg_bytes += p.bytes()[0]
+    for key in ("plan_a", "plan_b"):
+        if slots[0][key] is None:
+            continue
+        alg_bytes += slots[0][key].bytes()[0]
+        for i in range(8):
+            slots[i % NBATCH][key].launch(sh_handle)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n_rep = 64
+        e0.record(stream)
+        for i in range(n_rep):
+            slots[i % NBATCH][key].launch(sh_handle)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        kernel_us += e0.elapsed_time(e1) * 1000.0 / n_rep
 
-    for i in range(args.warmup):
-        step(slots[i % len(slots)])
-    torch.cuda.synchronize()
+    # NOTE: steps are enqueued eagerly.  The engine's launches are hipGraph-capturable (tests/
+    # test_gpu_parity.py::test_plan_launch_is_graph_capturable), but capturing RCCL's all_to_all with
+    # this torch 2.10 / RCCL 2.26 build segfaults in capture_end (csrc/tools/graph_probe.py), so the
+    # collective keeps the step out of a graph.
+    it = n_primed
+    for _ in range(args.warmup):
+        step(it)
+        it += 1
+    drain()
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(slots[i % len(slots)])
-    torch.cuda.synchronize()
+    for _ in range(args.steps):
+        step(it)
+        it += 1
+    drain()
     dist.barrier()
     torch.cuda.synchronize()
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if stage_cpu else dev)
@@ -202,10 +241,12 @@ def run(args, hbm_peak_gbs: float) -> None:
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C2 sharded: 26 Criteo-Kaggle tables, dim 16 fp32, B=%d bags/table PER RANK, "
-                                   "L=1, %d rotating batches; %s" % (B, len(slots), plan.describe()),
+                                   "L=1, %d rotating batches; %s" % (B, NBATCH, plan.describe()),
                        "tables": T, "dim": dim, "bags_per_table_per_rank": B, "global_bags_per_table": world * B,
-                       "parallelism": "tables sharded by id (replicate <= %d MiB), all_to_all indices in / "
-                                      "pooled rows out, backend %s" % (rep_bytes >> 20, backend)},
+                       "parallelism": "tables sharded by id (replicate <= %d MiB); one all_to_all per step carries "
+                                      "pooled rows of batch i + indices of batch i+1 (%d B out / %d B in per rank); "
+                                      "backend %s, eager steps" %
+                                      (rep_bytes >> 20, int(in_off[-1]), int(out_off[-1]), backend)},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": hbm_peak_gbs, "unit": "GB/s",
                          "frac": ach / hbm_peak_gbs, "traffic": None, "kernel_us": kernel_us,
                          "algorithmic_bytes": alg_bytes,

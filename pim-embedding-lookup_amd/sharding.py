@@ -71,12 +71,12 @@ def plan_shards(rows: Sequence[int], dim: int, elem_bytes: int, world: int,
     """Greedy placement.  split_bytes=None: split tables larger than 1/world of all sharded bytes."""
     rows = [int(r) for r in rows]
     size = [r * dim * elem_bytes for r in rows]
-    kinds = [REPLICATED if (world == 1 or s <= replicate_bytes) else WHOLE for s in size]
+    kinds = [REPLICATED if s <= replicate_bytes else WHOLE for s in size]
     sharded = [t for t, k in enumerate(kinds) if k == WHOLE]
     if split_bytes is None:
         split_bytes = max(1, sum(size[t] for t in sharded) // max(world, 1))
     for t in sharded:
-        if size[t] > split_bytes and rows[t] >= world:
+        if world > 1 and size[t] > split_bytes and rows[t] >= world:
             kinds[t] = ROW_SPLIT
     load = [0] * world
     for t in sharded:                       # row-split tables load every rank equally

@@ -431,3 +431,34 @@ def test_stage_trace_export(pel, eng, tmp_path):
     tr.enable(eng, 0)
     eng.lookup(9, np.arange(5, dtype=np.uint32), np.arange(5, dtype=np.uint32))
     assert tr.read(eng) == []
+
+
+def test_plan_launch_is_graph_capturable(pel, eng):
+    """emb_plan_launch is a pure enqueue (no allocation, copy or sync): it can be captured into a
+    hipGraph and replayed -- the launch-bound small-batch loop (reference presets: 64-512 bags)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    w = torch.randn(5000, 16, device=dev)
+    eng.load_table(30, w)
+    eng.load_table(31, w * 3.0)
+    idx = torch.randint(0, 5000, (512,), dtype=torch.int64, device=dev)
+    off = torch.arange(0, 512, 2, dtype=torch.int64, device=dev)
+    plan = eng.plan([30, 31], [idx, idx], [off, off])
+    s = torch.cuda.Stream(dev)
+    g = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g, stream=s):
+        plan.launch(torch.cuda.current_stream().cuda_stream)
+    for o in plan.outputs:
+        o.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    want = w[idx[0::2]] + w[idx[1::2]]
+    assert torch.equal(plan.outputs[0], want)
+    assert torch.equal(plan.outputs[1], w[idx[0::2]] * 3.0 + w[idx[1::2]] * 3.0)
+    # new indices in the same buffers: replay picks them up (descriptors hold pointers, not values)
+    idx.copy_(torch.randint(0, 5000, (512,), dtype=torch.int64, device=dev))
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(plan.outputs[0], w[idx[0::2]] + w[idx[1::2]])
+    plan.destroy()

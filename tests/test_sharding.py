@@ -42,9 +42,9 @@ def test_planner_kaggle_8_ranks(pel):
 
 def test_planner_policies():
     sh = _sharding()
-    # world 1: everything local
-    p1 = sh.plan_shards([10, 1000], 16, 4, world=1)
-    assert p1.kinds == [sh.REPLICATED] * 2
+    # world 1: small tables local; a big one is "owned" by rank 0 (self exchange, used to rehearse RCCL)
+    p1 = sh.plan_shards([10, 1000, 2_000_000], 16, 4, world=1)
+    assert p1.kinds == [sh.REPLICATED, sh.REPLICATED, sh.WHOLE] and p1.units[2].owner == 0
     # nothing replicated, giant table row-split, others whole and balanced
     rows = [200_000_000, 40_000_000, 30_000_000, 20_000_000, 10_000_000, 5]
     p = sh.plan_shards(rows, 128, 4, world=8, replicate_bytes=0)
