@@ -110,17 +110,20 @@ def main(argv=None):
     ap.add_argument("--num-batches", type=int, default=100)
     ap.add_argument("--inference-only", action="store_true")
     ap.add_argument("--data-set", type=str, default="random", choices=["random", "kaggle"])
+    ap.add_argument("--data-generation", type=str, default="random", choices=["random", "dataset"])
     ap.add_argument("--processed-data-file", type=str, default="")
     ap.add_argument("--load-model", type=str, default="")
     ap.add_argument("--numpy-rand-seed", type=int, default=123)
-    args = ap.parse_args(argv)
+    args, ignored = ap.parse_known_args(argv)
+    if ignored:   # MLP / training / logging flags of the reference command lines (README.md:6,10,14)
+        print("ignored (outside the embedding path):", " ".join(ignored))
     if not args.inference_only:
         print("note: only the inference embedding path exists here; running it (--inference-only implied)")
     import torch
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(args.numpy_rand_seed)
     data = None
-    if args.data_set == "kaggle":
+    if args.data_set == "kaggle" and args.processed_data_file:
         from .formats import CriteoKaggleNpz
         data = CriteoKaggleNpz(args.processed_data_file)
         ln_emb = data.table_rows
