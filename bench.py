@@ -41,9 +41,10 @@ def parse_args():
     ap.add_argument("--nbatch", type=int, default=8, help="distinct index batches rotated through")
     ap.add_argument("--index-dist", choices=["uniform", "zipf"], default=None,
                     help="default: uniform for c2, zipf(1.2) for c3")
-    ap.add_argument("--workload", choices=["c2", "c3"], default="c2",
+    ap.add_argument("--workload", choices=["c2", "c3", "c5"], default="c2",
                     help="c2 = BASELINE configs[1] (the metric's config, default); c3 = configs[2] scaled "
-                         "to fit one GPU: 48 tables x 10M rows x dim 128 fp32, B=16384, pooling 32")
+                         "to fit one GPU: 48 tables x 10M rows x dim 128 fp32, B=16384, pooling 32; c5 = one GPU's "
+                         "share of configs[4]: 64 tables x 30M rows x dim 64 fp16, mixed Zipf/uniform, pooling 32")
     ap.add_argument("--tables", type=int, default=None, help="c3: number of tables (default 48)")
     ap.add_argument("--replicate-mb", type=int, default=64,
                     help="N>1: tables up to this size are replicated on every rank, larger ones are sharded")
@@ -52,7 +53,7 @@ def parse_args():
     return ap.parse_args()
 
 
-def make_tables_on_gpu(torch, eng, rows_list, dim, device, seed=0, keep_host=False):
+def make_tables_on_gpu(torch, eng, rows_list, dim, device, seed=0, keep_host=False, dtype="f32"):
     """W_t ~ U(-sqrt(1/N_t), sqrt(1/N_t)), generated on the GPU and handed to the engine
     device-to-device (no 2 GB host round trip)."""
     g = torch.Generator(device=device)
@@ -62,9 +63,11 @@ def make_tables_on_gpu(torch, eng, rows_list, dim, device, seed=0, keep_host=Fal
         a = float(np.sqrt(1.0 / n))
         w = torch.empty((n, dim), dtype=torch.float32, device=device)
         w.uniform_(-a, a, generator=g)
+        if dtype == "f16":
+            w = w.to(torch.float16)
         eng.load_table(t, w)
         if t < int(keep_host):
-            host.append(w.cpu().numpy())
+            host.append(w.float().cpu().numpy())   # the oracle's fp16 path is exercised by tests; baseline in fp32
         del w
     torch.cuda.empty_cache()
     return host
@@ -88,6 +91,13 @@ def workload_spec(pel, args):
         return dict(rows=pel.workloads.KAGGLE_ROWS, dim=pel.workloads.KAGGLE_DIM, B=B, L=1, dist=dist,
                     name="C2: 26 Criteo-Kaggle tables, dim 16 fp32, B=%d bags/table, L=1, u32 indices+offsets, "
                          "%s indices" % (B, dist))
+    if args.workload == "c5":
+        T = args.tables or 64
+        B = args.batch or 16384
+        return dict(rows=[30_000_000] * T, dim=64, B=B, L=32, dist="mixed", dtype="f16",
+                    name="C5, one GPU's share (512 tables x 50M rows = 3.28 TB does not fit 8 x 288 GB; scaled to "
+                         "512 x 30M = 1.97 TB, 64 tables per GPU): %d tables x 30M rows, dim 64 fp16 rows / fp32 "
+                         "accumulate, B=%d bags/table, L=32, Zipf(1.2) on even tables, uniform on odd ones" % (T, B))
     T = args.tables or 48
     B = args.batch or 16384
     dist = args.index_dist or "zipf"
@@ -98,11 +108,15 @@ def workload_spec(pel, args):
 
 def make_batches(pel, spec, nbatch, seed=1):
     rng = np.random.default_rng(seed)
-    gen = pel.workloads.uniform_indices if spec["dist"] == "uniform" else pel.workloads.zipf_indices
+    def gen(t):
+        if spec["dist"] == "uniform" or (spec["dist"] == "mixed" and t % 2 == 1):
+            return pel.workloads.uniform_indices
+        return pel.workloads.zipf_indices
     batches = []
     off = pel.workloads.fixed_offsets(spec["B"], spec["L"])
     for _ in range(nbatch):
-        batches.append(([gen(rng, n, spec["B"] * spec["L"]) for n in spec["rows"]], [off] * len(spec["rows"])))
+        batches.append(([gen(t)(rng, n, spec["B"] * spec["L"]) for t, n in enumerate(spec["rows"])],
+                        [off] * len(spec["rows"])))
     return batches
 
 
@@ -139,7 +153,8 @@ def run_single(args):
     eng = pel.EmbeddingEngine(device=0, max_tables=T)
     want_cpu = not args.no_cpu_baseline
     n_host = T if args.workload == "c2" else 2        # c3: 5 GB per table, sample two on the host
-    host_tables = make_tables_on_gpu(torch, eng, rows_list, dim, dev, keep_host=n_host if want_cpu else 0)
+    host_tables = make_tables_on_gpu(torch, eng, rows_list, dim, dev, keep_host=n_host if want_cpu else 0,
+                                     dtype=spec.get("dtype", "f32"))
     batches = make_batches(pel, spec, args.nbatch)
 
     plans = []
@@ -174,7 +189,7 @@ def run_single(args):
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall * 1000.0 / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": spec.get("dtype", "f32"), "data": "synthetic",
         "config": {"workload": "%s, %d rotating batches" % (spec["name"], len(plans)),
                    "tables": T, "dim": dim, "bags_per_table": B, "pooling": spec["L"],
                    "table_bytes": eng.stats()["table_bytes"], "parallelism": "single"},
