@@ -29,12 +29,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "pimemb.h"
 
 namespace pimemb {
 
-// One table's share of a fused launch as the kernel sees it (HBM-resident array, 64 B each so a
-// workgroup fetches its descriptor with one scalar load burst).
+// One table's share of a fused launch as the kernel sees it (HBM-resident array, 128 B each: a
+// workgroup fetches its descriptor with scalar loads).
 struct alignas(64) DevDesc {
     const void *weights;    // row-major [nr_rows][dim] of the table dtype
     const void *indices;    // IdxT[n_idx]
@@ -45,8 +47,14 @@ struct alignas(64) DevDesc {
     uint64_t nr_rows;       // only read by the validation kernel
     uint32_t fixed_pooling; // L > 0: offsets[b] = b*L (load_generator.c:88)
     uint32_t n_tiles;       // ceil(n_bags / bags_per_tile) for this launch geometry
+    // hot rows of this table (bag_sum_hot_kernel only; n_hot == 0 switches the LDS path off)
+    const void *hot_rows;     // compact copy [n_hot][dim] of the hot rows, staged into LDS
+    const uint64_t *hot_hash; // open-addressing table: entry = (slot << 32) | row id, empty = ~0
+    uint32_t n_hot;
+    uint32_t hot_log2;        // log2 of the hash table size
+    uint64_t pad_[4];
 };
-static_assert(sizeof(DevDesc) == 64, "DevDesc must stay one 64-byte line");
+static_assert(sizeof(DevDesc) == 128, "DevDesc is two 64-byte lines");
 
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -56,8 +64,9 @@ using f32x8 = __attribute__((ext_vector_type(8))) float;
 // Compile-time knobs of the bag kernels.
 template <int BLOCK = 256, int UNROLL = 8, bool NT_STORE = false, bool NT_META = false,
           int ONEHOT_INFLIGHT = 8, int MIN_WAVES = 1, int BATCHES = 1, bool NT_ROW = false,
-          bool SPECULATE = false>
+          bool SPECULATE = false, bool IDX_SHUFFLE = false>
 struct BagCfg {
+    static constexpr bool kIdxShuffle = IDX_SHUFFLE; // lane group loads a window of indices coalesced, broadcasts by shuffle
     static constexpr bool kSpeculate = SPECULATE; // prefetch indices[bag] before the bounds arrive
     static constexpr int kMinWaves = MIN_WAVES;   // __launch_bounds__ 2nd arg: waves per SIMD wanted
     static constexpr int kBatches = BATCHES;      // 64-bag batches a wavefront takes per step
@@ -182,6 +191,83 @@ __device__ __forceinline__ bool decode_block(const uint32_t *__restrict__ xmap, 
     return false;
 }
 
+// Walk one bag [p, e) in index order, adding the rows `fetch(row)` returns.  Two ways to get at the
+// indices: (a) every lane of the group loads indices[p+k] itself (same address in all LPR lanes),
+// kUnroll at a time; (b) kIdxShuffle: the group loads a WINDOW of indices coalesced -- lane `sub`
+// holds indices[p + sub + i*LPR] -- and broadcasts them with ds_bpermute, one vector-memory
+// instruction per LPR*IPL indices instead of one per index.  Every lane of the wavefront must call
+// this (the shuffles need the whole lane group active); `live` lanes own a 16-byte piece of the row.
+template <typename IdxT, int LPR, class Cfg, class Ops, class Probe, class Fetch>
+__device__ __forceinline__ void walk_bag(const IdxT *__restrict__ indices, uint64_t p, uint64_t e, uint32_t sub,
+                                         uint32_t grp, bool live, typename Ops::Acc &acc, Probe &&probe,
+                                         Fetch &&fetch) {
+    // probe(row) -> 32-bit token computed ONCE per index (e.g. the LDS slot of a hot row);
+    // fetch(row, token) -> the lane's 16-byte piece of that row.
+    constexpr int U = Cfg::kUnroll;
+    constexpr bool kProbe = std::remove_reference_t<Probe>::kUsed;
+    if constexpr (!Cfg::kIdxShuffle) {
+        if (!live) return;
+        for (; p + U <= e; p += U) {
+            uint64_t r[U];
+#pragma unroll
+            for (int k = 0; k < U; k++) r[k] = (uint64_t)load_meta<Cfg::kNtMeta>(indices + p + k);
+            u32x4 v[U];
+#pragma unroll
+            for (int k = 0; k < U; k++) v[k] = fetch(r[k], probe(r[k]));
+#pragma unroll
+            for (int k = 0; k < U; k++) Ops::add(acc, v[k]);
+        }
+        for (; p < e; p++) {
+            const uint64_t r = (uint64_t)load_meta<Cfg::kNtMeta>(indices + p);
+            Ops::add(acc, fetch(r, probe(r)));
+        }
+    } else {
+        constexpr uint32_t IPL = (U + LPR - 1) / LPR;      // indices held per lane
+        constexpr uint32_t W = IPL * LPR;                  // window
+        while (p < e) {
+            const uint32_t cnt = (e - p < W) ? (uint32_t)(e - p) : W;
+            IdxT mine[IPL];
+            uint32_t tok[IPL];
+#pragma unroll
+            for (uint32_t i = 0; i < IPL; i++) {
+                mine[i] = 0;
+                if (sub + i * LPR < cnt) mine[i] = load_meta<Cfg::kNtMeta>(indices + p + sub + i * LPR);
+                tok[i] = probe((uint64_t)mine[i]);         // LPR different probes per instruction
+            }
+            uint32_t k = 0;
+            for (; k + U <= cnt; k += U) {
+                uint64_t r[U];
+                uint32_t t[U];
+#pragma unroll
+                for (int j = 0; j < U; j++) {
+                    const uint32_t q = k + j, src = grp * LPR + q % LPR;   // position in the window
+                    r[j] = shfl_index<IdxT>(mine[(IPL == 1) ? 0 : q / LPR], src);
+                    t[j] = kProbe ? shfl_u32(tok[(IPL == 1) ? 0 : q / LPR], src) : 0u;
+                }
+                if (live) {
+                    u32x4 v[U];
+#pragma unroll
+                    for (int j = 0; j < U; j++) v[j] = fetch(r[j], t[j]);
+#pragma unroll
+                    for (int j = 0; j < U; j++) Ops::add(acc, v[j]);
+                }
+            }
+            for (; k < cnt; k++) {
+                const uint32_t src = grp * LPR + k % LPR;
+                const uint64_t r = shfl_index<IdxT>(mine[(IPL == 1) ? 0 : k / LPR], src);
+                const uint32_t t = kProbe ? shfl_u32(tok[(IPL == 1) ? 0 : k / LPR], src) : 0u;
+                if (live) Ops::add(acc, fetch(r, t));
+            }
+            p += cnt;
+        }
+    }
+}
+
+struct NoProbe {
+    static constexpr bool kUsed = false;
+    __device__ __forceinline__ uint32_t operator()(uint64_t) const { return 0u; }
+};
+
 // ---- v1: one lane group per bag, no cross-lane traffic (kept as the A/B baseline) -------------
 template <typename IdxT, int DT, int LPR, class Cfg>
 __global__ void __launch_bounds__(Cfg::kBlock)
@@ -191,7 +277,6 @@ bag_sum_group_kernel(const DevDesc *__restrict__ descs, uint32_t chunks,
     constexpr uint32_t kWaves = Cfg::kBlock / 64;
     constexpr uint32_t BPW = 64 / LPR;
     constexpr uint32_t BAGS_PER_TILE = BPW * kWaves;
-    constexpr int U = Cfg::kUnroll;
 
     uint32_t desc_i, tile;
     if (!decode_block(xmap, &desc_i, &tile)) return;
@@ -211,7 +296,8 @@ bag_sum_group_kernel(const DevDesc *__restrict__ descs, uint32_t chunks,
 
     if (tile < n_tiles) {
         const uint64_t bag = (uint64_t)tile * BAGS_PER_TILE + wave * BPW + grp;
-        if (bag >= n_bags || sub >= chunks) return;
+        const bool live = sub < chunks;
+        if (bag >= n_bags) return;                     // whole lane group leaves together
         uint64_t p, e;
         if (offsets != nullptr) {
             p = (uint64_t)load_meta<Cfg::kNtMeta>(offsets + bag);
@@ -221,21 +307,11 @@ bag_sum_group_kernel(const DevDesc *__restrict__ descs, uint32_t chunks,
             e = p + fixed_pooling;
         }
         typename Ops::Acc acc = Ops::zero();
-        for (; p + U <= e; p += U) {
-            uint64_t r[U];
-#pragma unroll
-            for (int k = 0; k < U; k++) r[k] = (uint64_t)load_meta<Cfg::kNtMeta>(indices + p + k);
-            u32x4 v[U];
-#pragma unroll
-            for (int k = 0; k < U; k++) v[k] = *reinterpret_cast<const u32x4 *>(wsub + r[k] * row_bytes);
-#pragma unroll
-            for (int k = 0; k < U; k++) Ops::add(acc, v[k]);
-        }
-        for (; p < e; p++) {
-            const uint64_t r = (uint64_t)load_meta<Cfg::kNtMeta>(indices + p);
-            Ops::add(acc, *reinterpret_cast<const u32x4 *>(wsub + r * row_bytes));
-        }
-        Ops::template store<Cfg::kNtStore>(acc, out + bag * out_stride + sub * Ops::kFloatsPerLane);
+        walk_bag<IdxT, LPR, Cfg, Ops>(indices, p, e, sub, grp, live, acc, NoProbe{},
+                                      [&](uint64_t r, uint32_t) -> u32x4 {
+                                          return load_row<Cfg::kNtRow>(wsub + r * row_bytes);
+                                      });
+        if (live) Ops::template store<Cfg::kNtStore>(acc, out + bag * out_stride + sub * Ops::kFloatsPerLane);
     }
 }
 
@@ -377,6 +453,98 @@ bag_sum_wavebatch_kernel(const DevDesc *__restrict__ descs, uint32_t chunks,
                     Ops::template store<Cfg::kNtStore>(acc, out + bag * out_stride + sub * Ops::kFloatsPerLane);
                 }
             }
+        }
+    }
+}
+
+// ---- v3: lane-group kernel with the table's HOT ROWS staged in LDS -------------------------------
+// For skewed (Zipf-like) pooled workloads.  The engine keeps, per table, a compact copy of up to a
+// few hundred hot rows plus a small open-addressing hash (row id -> slot).  A persistent workgroup
+// stages both into LDS once, then walks its share of the table's bags: every index is probed in the
+// LDS hash (two ds_read_b64); a hit reads the row piece from LDS (ds_read_b128), a miss goes to
+// L2/HBM as before.  The hot copy holds the same bits as the table, and the adds stay in index
+// order, so results are bit-identical to the other kernels.
+constexpr uint32_t kHotEmpty = 0xffffffffu;
+constexpr uint32_t kHotProbes = 2;   // the host builder places a row within this many probes or drops it
+
+__device__ __forceinline__ uint32_t hot_hash_pos(uint32_t key, uint32_t log2size) {
+    return (key * 0x9E3779B1u) >> (32u - log2size);
+}
+
+struct HotProbe {
+    static constexpr bool kUsed = true;
+    const uint64_t *lhash;
+    uint32_t n_hot, log2, mask;
+    __device__ __forceinline__ uint32_t operator()(uint64_t r) const {
+        if (n_hot == 0 || r >= 0xffffffffull) return 0u;
+        const uint32_t key = (uint32_t)r, pos = hot_hash_pos(key, log2);
+        const uint64_t e0 = lhash[pos], e1 = lhash[(pos + 1) & mask];
+        if ((uint32_t)e0 == key) return 0x80000000u | (uint32_t)(e0 >> 32);
+        if ((uint32_t)e1 == key) return 0x80000000u | (uint32_t)(e1 >> 32);
+        return 0u;
+    }
+};
+
+template <typename IdxT, int DT, int LPR, class Cfg>
+__global__ void __launch_bounds__(Cfg::kBlock)
+bag_sum_hot_kernel(const DevDesc *__restrict__ descs, uint32_t chunks) {
+    using Ops = RowOps<DT>;
+    constexpr uint32_t kWaves = Cfg::kBlock / 64;
+    constexpr uint32_t BPW = 64 / LPR;
+    constexpr uint32_t BAGS_PER_TILE = BPW * kWaves;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+
+    const DevDesc *dp = descs + blockIdx.y;
+    const char *__restrict__ weights = static_cast<const char *>(dp->weights);
+    const IdxT *__restrict__ indices = static_cast<const IdxT *>(dp->indices);
+    const IdxT *__restrict__ offsets = static_cast<const IdxT *>(dp->offsets);
+    float *__restrict__ out = dp->out;
+    const uint64_t n_idx = dp->n_idx, n_bags = dp->n_bags;
+    const uint32_t fixed_pooling = dp->fixed_pooling, n_tiles = dp->n_tiles;
+    const uint32_t n_hot = dp->n_hot, hot_log2 = dp->hot_log2;
+
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t sub = lane & (LPR - 1), grp = lane / LPR;
+    const uint32_t row_bytes = chunks * 16u;
+    const uint32_t out_stride = chunks * Ops::kFloatsPerLane;
+    const char *__restrict__ wsub = weights + sub * 16u;
+
+    // stage hot rows + hash into LDS (rows first: 16-byte aligned pieces)
+    u32x4 *lrows = reinterpret_cast<u32x4 *>(lds_raw);
+    uint64_t *lhash = reinterpret_cast<uint64_t *>(lds_raw + (size_t)n_hot * row_bytes);
+    const uint32_t hash_mask = (1u << hot_log2) - 1u;
+    if (n_hot) {
+        const u32x4 *src = static_cast<const u32x4 *>(dp->hot_rows);
+        for (uint32_t i = threadIdx.x; i < n_hot * chunks; i += Cfg::kBlock) lrows[i] = src[i];
+        for (uint32_t i = threadIdx.x; i <= hash_mask; i += Cfg::kBlock) lhash[i] = dp->hot_hash[i];
+    }
+    __syncthreads();
+    const u32x4 *lsub = lrows + sub;
+
+    // probe: token = 0x80000000 | LDS slot if the row is hot, 0 otherwise (one probe per INDEX: with
+    // kIdxShuffle each lane probes its own index of the window, 32 probes per instruction pair)
+    HotProbe probe{lhash, n_hot, hot_log2, hash_mask};
+    // one gathered row piece: LDS if the row is hot, L2/HBM otherwise
+    auto fetch = [&](uint64_t r, uint32_t tok) -> u32x4 {
+        if (tok & 0x80000000u) return lsub[(tok & 0x7fffffffu) * chunks];
+        return load_row<Cfg::kNtRow>(wsub + r * row_bytes);
+    };
+
+    const bool live = sub < chunks;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t bag = (uint64_t)tile * BAGS_PER_TILE + wave * BPW + grp;
+        if (bag < n_bags) {                            // (no `continue`: lane groups stay whole for the shuffles)
+            uint64_t p, e;
+            if (offsets != nullptr) {
+                p = (uint64_t)load_meta<Cfg::kNtMeta>(offsets + bag);
+                e = (bag + 1 < n_bags) ? (uint64_t)load_meta<Cfg::kNtMeta>(offsets + bag + 1) : n_idx;
+            } else {
+                p = bag * fixed_pooling;
+                e = p + fixed_pooling;
+            }
+            typename Ops::Acc acc = Ops::zero();
+            walk_bag<IdxT, LPR, Cfg, Ops>(indices, p, e, sub, grp, live, acc, probe, fetch);
+            if (live) Ops::template store<Cfg::kNtStore>(acc, out + bag * out_stride + sub * Ops::kFloatsPerLane);
         }
     }
 }

@@ -163,21 +163,21 @@ int main(int argc, char **argv) {
         }
 
     std::vector<Variant> vars;
-    //                        BLOCK U  ntS   ntM  inflight minW batches ntRow spec
+    //                        BLOCK U  ntS   ntM  inflight minW batches ntRow spec  idxShuffle
     vars.push_back(make_variant<BagCfg<256, 8, false, false, 8>, false>("v1 group blk256"));
-    vars.push_back(make_variant<BagCfg<256, 8, true, false, 8, 8>, true>("v2 ntS minw8"));
-    vars.push_back(make_variant<BagCfg<256, 8, true, false, 8, 8, 1, false, true>, true>("v2 ntS minw8 SPEC"));
+    vars.push_back(make_variant<BagCfg<256, 8, true, false, 8>, false>("v1 group blk256 ntS (old SHIP small)"));
+    vars.push_back(make_variant<BagCfg<256, 8, true, false, 8, 1, 1, false, false, true>, false>("v1 group blk256 ntS idxshfl"));
+    vars.push_back(make_variant<BagCfg<64, 8, true, false, 8, 1, 1, false, false, true>, false>("v1 group blk64 ntS idxshfl"));
+    vars.push_back(make_variant<BagCfg<64, 8, true, false, 8>, false>("v1 group blk64 ntS"));
+    vars.push_back(make_variant<BagCfg<64, 8, true, false, 8, 8, 1, false, true>, true>("v2 SHIP"));
     {
-        Variant v = make_variant<BagCfg<256, 8, true, false, 8, 8>, true>("v2 ntS minw8 XCD r1", true);
+        Variant v = make_variant<BagCfg<64, 8, true, false, 8, 8, 1, false, true>, true>("v2 SHIP XCD r1", true);
         v.xrounds = 1; vars.push_back(v);
-        Variant w = make_variant<BagCfg<256, 8, true, false, 8, 8, 1, false, true>, true>("v2 ntS minw8 SPEC XCD r1", true);
+        Variant w = make_variant<BagCfg<256, 8, true, false, 8, 1, 1, false, false, true>, false>("v1 blk256 ntS idxshfl XCD r1", true);
         w.xrounds = 1; vars.push_back(w);
-        Variant x = make_variant<BagCfg<128, 8, true, false, 8, 8, 1, false, true>, true>("v2 ntS minw8 SPEC blk128 XCD r1", true);
+        Variant x = make_variant<BagCfg<256, 8, true, false, 8>, false>("v1 blk256 ntS XCD r1", true);
         x.xrounds = 1; vars.push_back(x);
-        Variant y = make_variant<BagCfg<64, 8, true, false, 8, 8, 1, false, true>, true>("v2 ntS minw8 SPEC blk64 XCD r1", true);
-        y.xrounds = 1; vars.push_back(y);
     }
-    vars.push_back(make_variant<BagCfg<64, 8, true, false, 8, 8, 1, false, true>, true>("v2 ntS minw8 SPEC blk64"));
     { Variant v; v.name = "ABLATION null kernel same grid"; v.fn = launch_null; v.checked = false; vars.push_back(v); }
     {
         Variant v; v.name = "ABLATION store-only (ntS)"; v.fn = launch_store_only; v.checked = false; vars.push_back(v);

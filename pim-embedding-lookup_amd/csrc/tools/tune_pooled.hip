@@ -13,6 +13,7 @@
 
 #include "../pimemb_bag_kernels.h"
 #include "../pimemb_xcd_map.h"
+#include "../pimemb_hot_rows.h"
 
 using namespace pimemb;
 
@@ -43,6 +44,11 @@ static inline uint64_t xorshift() {
 }
 static inline double urand() { return (double)(xorshift() >> 11) * (1.0 / 9007199254740992.0); }
 
+__global__ void copy_rows(u32x4 *dst, const u32x4 *table, const uint64_t *ids, uint32_t n, uint32_t chunks) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n * chunks; i += gridDim.x * blockDim.x)
+        dst[i] = table[ids[i / chunks] * chunks + i % chunks];
+}
+
 using LaunchFn = void (*)(const DevDesc *, uint32_t, uint32_t, const uint32_t *, uint32_t, hipStream_t);
 struct Variant {
     std::string name;
@@ -50,6 +56,9 @@ struct Variant {
     LaunchFn fn = nullptr;
     bool xcd = false;
     uint64_t cacheable = kXcdCacheableBytes;
+    uint32_t hot = 0;        // hot rows per table staged in LDS (0 = not the hot kernel)
+    uint32_t wgs = 0;        // persistent workgroups per table (hot kernel)
+    size_t lds = 0;
     uint32_t *d_xmap = nullptr;
     uint32_t xgrid = 0;
     std::vector<float> us;
@@ -63,6 +72,24 @@ void do_launch(const DevDesc *d, uint32_t n, uint32_t tiles, const uint32_t *xma
     else
         hipLaunchKernelGGL((bag_sum_group_kernel<uint32_t, EMB_F32, LPR, Cfg>), grid, block, 0, s, d, (uint32_t)LPR, xmap);
 }
+static size_t g_lds = 0;
+static uint32_t g_wgs = 0;
+template <class Cfg>
+void do_launch_hot(const DevDesc *d, uint32_t n, uint32_t, const uint32_t *, uint32_t, hipStream_t s) {
+    hipLaunchKernelGGL((bag_sum_hot_kernel<uint32_t, EMB_F32, LPR, Cfg>), dim3(g_wgs, n, 1), dim3(Cfg::kBlock), g_lds, s,
+                       d, (uint32_t)LPR);
+}
+template <class Cfg>
+Variant make_hot(const char *name, uint32_t hot, uint32_t wgs) {
+    Variant v;
+    v.name = name;
+    v.bags_per_tile = (64u / LPR) * (Cfg::kBlock / 64);
+    v.fn = &do_launch_hot<Cfg>;
+    v.hot = hot;
+    v.wgs = wgs;
+    return v;
+}
+
 template <class Cfg, bool WAVEBATCH>
 Variant make_variant(const char *name, bool xcd = false) {
     Variant v;
@@ -116,18 +143,44 @@ int main(int argc, char **argv) {
         }
 
     std::vector<Variant> vars;
-    //                        BLOCK U  ntS   ntM  inflight minW batches ntRow spec
-    vars.push_back(make_variant<BagCfg<256, 8, false, false, 8>, false>("v1 group blk256 U8"));
-    vars.push_back(make_variant<BagCfg<256, 8, true, false, 8>, false>("v1 blk256 U8 ntS XCD-stream", true));
-    { Variant v = make_variant<BagCfg<256, 8, true, false, 8>, false>("v1 blk256 U8 ntS XCD-pin", true); v.cacheable = ~0ull; vars.push_back(v); }
-    { Variant v = make_variant<BagCfg<256, 16, true, false, 8>, false>("v1 blk256 U16 ntS XCD-pin", true); v.cacheable = ~0ull; vars.push_back(v); }
-    { Variant v = make_variant<BagCfg<256, 4, true, false, 8>, false>("v1 blk256 U4 ntS XCD-pin", true); v.cacheable = ~0ull; vars.push_back(v); }
-    { Variant v = make_variant<BagCfg<128, 8, true, false, 8>, false>("v1 blk128 U8 ntS XCD-pin", true); v.cacheable = ~0ull; vars.push_back(v); }
-    { Variant v = make_variant<BagCfg<512, 8, true, false, 8>, false>("v1 blk512 U8 ntS XCD-pin", true); v.cacheable = ~0ull; vars.push_back(v); }
-    { Variant v = make_variant<BagCfg<64, 8, true, false, 8>, false>("v1 blk64 U8 ntS XCD-pin", true); v.cacheable = ~0ull; vars.push_back(v); }
-    { Variant v = make_variant<BagCfg<256, 8, true, false, 8, 8>, false>("v1 blk256 U8 ntS minw8 XCD-pin", true); v.cacheable = ~0ull; vars.push_back(v); }
-    vars.push_back(make_variant<BagCfg<64, 8, true, false, 8, 8, 1, false, true>, true>("v2 SHIP (blk64 U8 minw8)"));
+    //                        BLOCK U  ntS   ntM  inflight minW batches ntRow spec  idxShuffle
+    vars.push_back(make_variant<BagCfg<256, 8, true, false, 8>, false>("v1 group blk256 U8 ntS (SHIP)"));
+    vars.push_back(make_variant<BagCfg<256, 8, true, false, 8, 1, 1, false, false, true>, false>("v1 + idx shuffle U8"));
+    vars.push_back(make_variant<BagCfg<256, 16, true, false, 8, 1, 1, false, false, true>, false>("v1 + idx shuffle U16"));
+    vars.push_back(make_variant<BagCfg<256, 4, true, false, 8, 1, 1, false, false, true>, false>("v1 + idx shuffle U4"));
+    vars.push_back(make_hot<BagCfg<1024, 8, true, false, 8>>("v3 hot0   wg64  blk1024", 0, 64));
+    vars.push_back(make_hot<BagCfg<1024, 8, true, false, 8>>("v3 hot100 wg64  blk1024", 100, 64));
+    vars.push_back(make_hot<BagCfg<1024, 8, true, false, 8, 1, 1, false, false, true>>("v3 hot0   wg64  blk1024 shfl", 0, 64));
+    vars.push_back(make_hot<BagCfg<1024, 8, true, false, 8, 1, 1, false, false, true>>("v3 hot64  wg64  blk1024 shfl", 64, 64));
+    vars.push_back(make_hot<BagCfg<1024, 8, true, false, 8, 1, 1, false, false, true>>("v3 hot100 wg64  blk1024 shfl", 100, 64));
+    vars.push_back(make_hot<BagCfg<1024, 16, true, false, 8, 1, 1, false, false, true>>("v3 hot100 wg64  blk1024 shfl U16", 100, 64));
+    vars.push_back(make_hot<BagCfg<512, 8, true, false, 8, 1, 1, false, false, true>>("v3 hot64  wg128 blk512 shfl", 64, 128));
 
+    // hot sets: the generator maps Zipf rank k of table t to row (k*2654435761 + 12345 + t) % rows
+    std::vector<std::vector<void *>> hot_dev(vars.size(), std::vector<void *>(T, nullptr));
+    std::vector<std::vector<uint64_t *>> hash_dev(vars.size(), std::vector<uint64_t *>(T, nullptr));
+    std::vector<std::vector<uint32_t>> hot_n(vars.size(), std::vector<uint32_t>(T, 0)), hot_log2(vars.size(), std::vector<uint32_t>(T, 0));
+    for (size_t v = 0; v < vars.size(); v++) {
+        if (!vars[v].hot) continue;
+        for (uint32_t t = 0; t < T; t++) {
+            std::vector<uint64_t> ids(vars[v].hot);
+            for (uint32_t k = 0; k < vars[v].hot; k++) ids[k] = ((uint64_t)k * 2654435761ull + 12345ull + t) % rows;
+            HotSet hs = build_hot_set(ids.data(), vars[v].hot, rows, D * 4, 62 * 1024);
+            hot_n[v][t] = (uint32_t)hs.rows.size();
+            hot_log2[v][t] = hs.log2size;
+            vars[v].lds = std::max(vars[v].lds, hs.lds_bytes(D * 4));
+            uint64_t *d_ids;
+            CK(hipMalloc((void **)&d_ids, hs.rows.size() * 8));
+            CK(hipMemcpy(d_ids, hs.rows.data(), hs.rows.size() * 8, hipMemcpyHostToDevice));
+            CK(hipMalloc(&hot_dev[v][t], hs.rows.size() * D * 4));
+            hipLaunchKernelGGL(copy_rows, dim3(64), dim3(256), 0, s, (u32x4 *)hot_dev[v][t], (const u32x4 *)tables[t], d_ids,
+                               (uint32_t)hs.rows.size(), (uint32_t)LPR);
+            CK(hipMalloc((void **)&hash_dev[v][t], hs.hash.size() * 8));
+            CK(hipMemcpy(hash_dev[v][t], hs.hash.data(), hs.hash.size() * 8, hipMemcpyHostToDevice));
+        }
+        printf("variant %-28s hot rows accepted %u of %u, LDS %zu B\n", vars[v].name.c_str(), hot_n[v][0], vars[v].hot, vars[v].lds);
+    }
+    CK(hipStreamSynchronize(s));
     std::vector<std::vector<DevDesc *>> d_desc(vars.size(), std::vector<DevDesc *>(NB));
     std::vector<uint32_t> tiles(vars.size());
     for (size_t v = 0; v < vars.size(); v++) {
@@ -144,6 +197,12 @@ int main(int argc, char **argv) {
                 hd[t].n_bags = B;
                 hd[t].nr_rows = rows;
                 hd[t].n_tiles = tiles[v];
+                if (vars[v].hot) {
+                    hd[t].hot_rows = hot_dev[v][t];
+                    hd[t].hot_hash = hash_dev[v][t];
+                    hd[t].n_hot = hot_n[v][t];
+                    hd[t].hot_log2 = hot_log2[v][t];
+                }
             }
             CK(hipMalloc((void **)&d_desc[v][b], sizeof(DevDesc) * T));
             CK(hipMemcpy(d_desc[v][b], hd.data(), sizeof(DevDesc) * T, hipMemcpyHostToDevice));
@@ -162,6 +221,7 @@ int main(int argc, char **argv) {
     std::vector<char> ref(out_bytes * T), got(out_bytes * T);
     for (size_t v = 0; v < vars.size(); v++) {
         for (uint32_t t = 0; t < T; t++) CK(hipMemsetAsync(d_out[0][t], 0xff, out_bytes, s));
+        g_lds = vars[v].lds; g_wgs = vars[v].wgs;
         vars[v].fn(d_desc[v][0], T, tiles[v], vars[v].d_xmap, vars[v].xgrid, s);
         CK(hipGetLastError());
         CK(hipStreamSynchronize(s));
@@ -179,6 +239,7 @@ int main(int argc, char **argv) {
     CK(hipEventCreate(&e1));
     for (int r = -1; r < rounds; r++)
         for (size_t v = 0; v < vars.size(); v++) {
+            g_lds = vars[v].lds; g_wgs = vars[v].wgs;
             CK(hipEventRecord(e0, s));
             for (int i = 0; i < iters; i++) vars[v].fn(d_desc[v][i % NB], T, tiles[v], vars[v].d_xmap, vars[v].xgrid, s);
             CK(hipEventRecord(e1, s));
