@@ -135,13 +135,11 @@ struct DeviceGuard {
     }
 };
 
-// Resolve user descriptors against the engine's tables and split them into launch groups that
-// share (dtype, dim).  `base_indices/offsets/out`: if non-null, pointers are taken from these
-// per-desc overrides (staged copies) instead of the user's.
+// User descriptors resolved against the engine's tables and split into launch groups that share
+// (dtype, dim).
 struct Resolved {
     std::vector<DevDesc> descs;       // grouped, contiguous per group
-    std::vector<PlanGroup> groups;    // d_descs left null; n / max_tiles / dtype / geom filled
-    std::vector<uint32_t> order;      // descs[i] came from user desc order[i]
+    std::vector<PlanGroup> groups;    // kernel kind, tile counts, XCD map; device pointers set by bind()
     uint64_t bytes = 0, n_bags = 0, n_indices = 0;
     std::vector<char> image;          // descriptors of every group, then each group's XCD map
 
@@ -172,6 +170,8 @@ struct Resolved {
     }
 };
 
+// st_indices / st_offsets / st_out: if non-null, per-descriptor device pointers that replace the
+// caller's (the staged copies of a host-pointer call).
 int resolve(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs, emb_index_type itype,
             const std::vector<const void *> *st_indices, const std::vector<const void *> *st_offsets,
             const std::vector<float *> *st_out, Resolved *r) {
@@ -228,7 +228,6 @@ int resolve(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs, emb_i
             tiles_of.push_back(d.n_tiles);
             bytes_of.push_back(t.bytes);
             r->descs.push_back(d);
-            r->order.push_back(i);
             r->n_bags += u.n_bags;
             r->n_indices += u.n_indices;
             // algorithmic bytes, SURVEY.md section 8 row D

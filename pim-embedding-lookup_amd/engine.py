@@ -21,7 +21,6 @@ from . import lib as _l
 
 _NP_TABLE_DTYPES = {np.dtype(np.float32): _l.EMB_F32, np.dtype(np.float16): _l.EMB_F16,
                     np.dtype(np.int32): _l.EMB_FIXED32}
-_ELEM = {_l.EMB_F32: 4, _l.EMB_F16: 2, _l.EMB_FIXED32: 4}
 
 
 def _is_torch(x) -> bool:
@@ -184,7 +183,9 @@ class EmbeddingEngine:
             return torch.empty((n_bags, dim), dtype=torch.float32, device=like.device)
         return np.empty((n_bags, dim), dtype=np.float32)
 
-    def _descs(self, table_ids, indices, offsets, outs, fixed_pooling):
+    def _descs(self, table_ids, indices, offsets, outs, fixed_pooling, want_outputs=True):
+        """ctypes descriptor array for a batched call.  want_outputs=False (validation) leaves
+        `pooled` NULL and allocates nothing."""
         n = len(table_ids)
         if not (len(indices) == n and len(offsets) == n):
             raise ValueError("table_ids, indices and offsets must have equal length")
@@ -210,14 +211,18 @@ class EmbeddingEngine:
                 itype, space = it, ia.space
             elif it != itype or ia.space != space:
                 raise TypeError("all tables of one batched lookup must share index width and placement")
-            dim = self._tables[t][1]
-            out = outs[i] if outs is not None else self._alloc_out(indices[i], n_bags, dim)
-            ua = _Arg(out)
-            if ua.space != space:
-                raise TypeError("output placement must match the inputs")
-            arr[i] = _l.EmbLookupDesc(t, L, ia.ptr, oa.ptr, ia.n, n_bags, ua.ptr)
-            keep += [ia.keep, oa.keep, ua.keep]
-            results.append(out)
+            out_ptr = None
+            if want_outputs:
+                dim = self._tables[t][1]
+                out = outs[i] if outs is not None else self._alloc_out(indices[i], n_bags, dim)
+                ua = _Arg(out)
+                if ua.space != space:
+                    raise TypeError("output placement must match the inputs")
+                out_ptr = ua.ptr
+                keep.append(ua.keep)
+                results.append(out)
+            arr[i] = _l.EmbLookupDesc(t, L, ia.ptr, oa.ptr, ia.n, n_bags, out_ptr)
+            keep += [ia.keep, oa.keep]
         return arr, n, itype, space, results, keep
 
     def lookup_batched(self, table_ids: Sequence[int], indices: Sequence, offsets: Sequence,
@@ -246,30 +251,13 @@ class EmbeddingEngine:
 
     def validate(self, table_ids, indices, offsets, fixed_pooling=0) -> int:
         """Debug check: number of out-of-range indices / broken offsets (0 = clean)."""
-        arr, n, itype, space, _r, _k = self._descs_novalidate(table_ids, indices, offsets, fixed_pooling)
+        arr, n, itype, space, _r, _k = self._descs(table_ids, indices, offsets, None, fixed_pooling,
+                                                   want_outputs=False)
         bad = C.c_uint64()
         rc = self._L.emb_validate_inputs(self._h, arr, n, itype, space, C.byref(bad))
         if rc not in (_l.EMB_OK, _l.EMB_ERR_RANGE):
             _l.check(rc)
         return bad.value
-
-    def _descs_novalidate(self, table_ids, indices, offsets, fixed_pooling):
-        n = len(table_ids)
-        arr = (_l.EmbLookupDesc * n)()
-        keep = []
-        itype = space = None
-        for i, t in enumerate(table_ids):
-            ia, oa = _Arg(indices[i]), _Arg(offsets[i])
-            L = 0
-            if oa.ptr is None:
-                L = int(fixed_pooling[i] if isinstance(fixed_pooling, (list, tuple)) else fixed_pooling or 0)
-                n_bags = ia.n // max(L, 1)
-            else:
-                n_bags = oa.n
-            itype, space = _index_type_of(ia.dtype), ia.space
-            arr[i] = _l.EmbLookupDesc(t, L, ia.ptr, oa.ptr, ia.n, n_bags, None)
-            keep += [ia.keep, oa.keep]
-        return arr, n, itype, space, None, keep
 
     # ---- misc --------------------------------------------------------------------------------------
     def stats(self) -> dict:
