@@ -48,6 +48,9 @@ def parse_args():
     ap.add_argument("--tables", type=int, default=None, help="c3: number of tables (default 48)")
     ap.add_argument("--replicate-mb", type=int, default=64,
                     help="N>1: tables up to this size are replicated on every rank, larger ones are sharded")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="N=1: round-robin the independent steps over this many HIP streams (default 1: every "
+                         "step on one stream, which is what roofline.kernel_us assumes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     return ap.parse_args()
@@ -167,14 +170,18 @@ def run_single(args):
 
     stream = torch.cuda.current_stream(dev)
     sh = stream.cuda_stream
+    extra = [torch.cuda.Stream(dev) for _ in range(max(args.streams, 1) - 1)]
+    handles = [sh] + [x.cuda_stream for x in extra]
     for i in range(args.warmup):
-        plans[i % len(plans)].launch(sh)
+        plans[i % len(plans)].launch(handles[i % len(handles)])
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record(stream)
     for i in range(args.steps):
-        plans[i % len(plans)].launch(sh)
+        plans[i % len(plans)].launch(handles[i % len(handles)])
+    for x in extra:
+        stream.wait_stream(x)
     ev1.record(stream)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
@@ -192,7 +199,8 @@ def run_single(args):
         "dtype": spec.get("dtype", "f32"), "data": "synthetic",
         "config": {"workload": "%s, %d rotating batches" % (spec["name"], len(plans)),
                    "tables": T, "dim": dim, "bags_per_table": B, "pooling": spec["L"],
-                   "table_bytes": eng.stats()["table_bytes"], "parallelism": "single"},
+                   "table_bytes": eng.stats()["table_bytes"],
+                   "parallelism": "single" if len(handles) == 1 else "single GPU, %d streams" % len(handles)},
         "roofline": {"bound": "hbm", "achieved": alg_bytes / (kernel_us * 1e-6) / 1e9,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": alg_bytes / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS,

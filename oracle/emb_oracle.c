@@ -20,6 +20,10 @@
  *       names this call on its CLI lines (README.md:6,10,14; upmem/run.sh:72-82,111-121);
  *       the Python that makes it lives in empty submodules (.gitmodules:7-12).
  *
+ * PARITY STATUS: pinned to the reference's only known-answer vector and to nn.EmbeddingBag(sum)
+ * fixtures; "parity unpinned" with respect to outputs of the reference BINARY -- none can be
+ * produced here and the reference ships no asserting test for this path.
+ *
  * Pinning status (see DESIGN.md "Oracle"):
  *   - The reference C cannot be built here (UPMEM SDK + PIM-common submodule absent), so no
  *     reference-binary outputs exist; the reference ships no asserting test for this path.

@@ -180,15 +180,21 @@ __device__ __forceinline__ bool decode_block(const uint32_t *__restrict__ xmap, 
     const uint32_t cls = blockIdx.x & 7u, slot = blockIdx.x >> 3;
     const uint32_t ns = xmap[cls];
     const XcdSegDev *segs = reinterpret_cast<const XcdSegDev *>(xmap + 16) + xmap[8 + cls];
-    for (uint32_t i = 0; i < ns; i++) {
-        const XcdSegDev sg = segs[i];
-        if (slot < sg.slot_end) {
-            *desc_i = sg.desc;
-            *tile = sg.tile0 + (slot - sg.slot_begin);
-            return true;
-        }
+    // first segment whose slot_end exceeds `slot` (segments are sorted by slot): binary search, so a
+    // launch over hundreds of tables costs ~log2 scalar loads per workgroup, not a linear walk
+    uint32_t lo = 0, hi = ns;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (slot < segs[mid].slot_end)
+            hi = mid;
+        else
+            lo = mid + 1;
     }
-    return false;
+    if (lo >= ns) return false;
+    const XcdSegDev sg = segs[lo];
+    *desc_i = sg.desc;
+    *tile = sg.tile0 + (slot - sg.slot_begin);
+    return true;
 }
 
 // Walk one bag [p, e) in index order, adding the rows `fetch(row)` returns.  Two ways to get at the

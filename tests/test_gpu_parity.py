@@ -483,3 +483,28 @@ def test_distributed_bench_two_ranks_on_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert "5 whole" in d["config"]["workload"] and "21 replicated" in d["config"]["workload"]
     assert d["roofline"]["bound"] == "hbm"
+
+
+def test_many_tables_one_launch(pel, oracle):
+    """300 tables in one fused one-hot launch (wave-batch kernel + XCD map with hundreds of segments,
+    decoded by binary search) and 300 tables in one pooled launch (lane-group kernel, 2-D grid)."""
+    rng = np.random.default_rng(31)
+    T, B = 300, 700
+    e = pel.EmbeddingEngine(device=0, max_tables=T)
+    sizes = rng.integers(1, 5000, size=T)
+    tabs = [rng.standard_normal((int(n), 16)).astype(np.float32) for n in sizes]
+    for t in range(T):
+        e.load_table(t, tabs[t])
+    idx = [rng.integers(0, n, size=B).astype(np.uint32) for n in sizes]
+    off = [np.arange(B, dtype=np.uint32)] * T
+    before = e.stats()["n_kernel_launches"]
+    outs = e.lookup_batched(list(range(T)), idx, off)
+    assert e.stats()["n_kernel_launches"] == before + 1
+    for t in range(T):
+        assert np.array_equal(outs[t], tabs[t][idx[t]])
+    idx3 = [rng.integers(0, n, size=3 * B).astype(np.uint32) for n in sizes]
+    off3 = [np.arange(0, 3 * B, 3, dtype=np.uint32)] * T
+    outs = e.lookup_batched(list(range(T)), idx3, off3)
+    for t in range(0, T, 7):
+        assert np.array_equal(outs[t], oracle.c_bag_sum(tabs[t], idx3[t], off3[t]))
+    e.close()

@@ -16,11 +16,12 @@ using namespace pimemb;
 // mirror of decode_block() in pimemb_bag_kernels.h
 static bool decode(const std::vector<uint32_t>& w, uint32_t block, uint32_t* desc, uint32_t* tile) {
     uint32_t cls = block & 7u, slot = block >> 3, ns = w[cls], base = w[8 + cls];
-    for (uint32_t i = 0; i < ns; i++) {
-        const uint32_t* sg = &w[16 + 4 * (base + i)];
-        if (slot < sg[3]) { *desc = sg[0]; *tile = sg[1] + (slot - sg[2]); return true; }
-    }
-    return false;
+    uint32_t lo = 0, hi = ns;
+    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (slot < w[16 + 4 * (base + mid) + 3]) hi = mid; else lo = mid + 1; }
+    if (lo >= ns) return false;
+    const uint32_t* sg = &w[16 + 4 * (base + lo)];
+    *desc = sg[0]; *tile = sg[1] + (slot - sg[2]);
+    return true;
 }
 int main(int argc, char** argv) {
     std::vector<uint32_t> tiles; std::vector<uint64_t> bytes;
