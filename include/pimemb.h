@@ -60,8 +60,9 @@ typedef struct emb_plan emb_plan;     /* opaque; a prepared multi-table lookup (
 typedef struct emb_config {
     int32_t device;      /* HIP device ordinal; -1 = current device */
     uint32_t max_tables; /* table ids are 0 .. max_tables-1 (NR_TABLES, upmem/Makefile:69-81) */
-    uint32_t flags;      /* reserved, 0 */
+    uint32_t flags;      /* EMB_FLAG_* */
 } emb_config;
+#define EMB_FLAG_STAGE_TIMING 1u /* host-pointer calls wait after every stage and clock it (see emb_stats) */
 
 /*
  * One table's share of a batched lookup -- what emb_host.h:234 passes as indices[t], offsets[t],
@@ -91,12 +92,15 @@ typedef struct emb_stats {
     uint64_t n_bags;             /* pooled (table, bag) outputs produced */
     uint64_t n_indices;          /* rows gathered */
     uint64_t table_bytes;        /* HBM held by tables */
-    double us_copy_in_indices;   /* "Indices and offsets copying latency" */
-    double us_copy_in_lengths;   /* "Query copying latency" (descriptor upload here) */
-    double us_launch;            /* "Dpu launch latency" (kernel, host-synchronous paths only) */
-    double us_copy_out;          /* "Results copy latency" */
+    /* host-pointer calls only.  With stage timing on (EMB_FLAG_STAGE_TIMING / emb_set_stage_timing /
+     * emb_trace_enable / lookup(latency_print=1)) the host waits after each stage and clocks it;
+     * otherwise a call is one enqueue chain with one wait and its whole duration goes to us_sync. */
+    double us_copy_in_indices;   /* "Indices and offsets copying latency": pack + host->HBM copy */
+    double us_copy_in_lengths;   /* "Query copying latency": descriptor upload + launch enqueue */
+    double us_launch;            /* "Dpu launch latency": the fused kernel */
+    double us_copy_out;          /* "Results copy latency": HBM->host copy enqueue */
     double us_post_process;      /* "Callback prep latency" -- 0: conversion is fused in the kernel */
-    double us_sync;              /* "DPU sync latency" */
+    double us_sync;              /* "DPU sync latency": the final wait */
 } emb_stats;
 
 /* ------------------------------------------------------------------------------------------ */
@@ -168,6 +172,8 @@ int emb_validate_inputs(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_
 
 int emb_get_stats(emb_engine *e, emb_stats *out);
 int emb_reset_stats(emb_engine *e);
+/* Switch per-stage waits + clocks of host-pointer calls on/off (see emb_stats). */
+int emb_set_stage_timing(emb_engine *e, int on);
 
 /* Per-call stage intervals of the host-pointer path, for the reference's profiling workflow: the
  * interval CSV "DPU, Start, Stop" written by upmem/dputypes.py:87-98 and plotted by

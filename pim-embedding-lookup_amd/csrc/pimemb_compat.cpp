@@ -166,7 +166,9 @@ int32_t *lookup(uint32_t **indices, uint32_t **offsets, float **final_results,
     }
     emb_stats before{}, after{};
     emb_get_stats(e, &before);
+    if (latency_print == 1) emb_set_stage_timing(e, 1);   // the reference's per-stage TIME_NOW brackets
     int rc = emb_lookup_batched(e, descs.data(), g_cfg.nr_tables, EMB_IDX_U32, EMB_MEM_HOST, nullptr);
+    if (latency_print == 1) emb_set_stage_timing(e, 0);
     if (rc != EMB_OK) {
         fprintf(stderr, "pimemb: lookup: %s\n", emb_last_error());
         return nullptr;

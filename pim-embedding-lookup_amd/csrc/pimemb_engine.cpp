@@ -88,6 +88,7 @@ struct emb_engine {
     uint64_t table_bytes = 0;
     double us_copy_in_indices = 0, us_copy_in_lengths = 0, us_launch = 0, us_copy_out = 0,
            us_sync = 0;
+    bool stage_timing = false;  // wait + clock after every stage of a host-pointer call
     // stage trace (host-pointer path)
     std::deque<emb_trace_event> trace;
     uint32_t trace_cap = 0;
@@ -377,64 +378,74 @@ int stage_host_inputs(emb_engine *e, const emb_lookup_desc *descs, uint32_t n, e
     return EMB_OK;
 }
 
+// Host-pointer lookup.  Default: ONE enqueue chain (copy-in -> descriptor upload -> kernel ->
+// copy-out) and ONE wait at the end -- the lowest latency.  With stage timing on (emb_config.flags
+// & EMB_FLAG_STAGE_TIMING, emb_trace_enable, or lookup(latency_print=1)) the host waits after every
+// stage and clocks it, like the reference's six TIME_NOW brackets (emb_host.h:253-355); that costs
+// ~2 extra stream waits per call.  (HIP events between the stages were measured too: they push the
+// small copies onto a slower path, +30 us per call on the reference's presets.)
 int lookup_host(emb_engine *e, const emb_lookup_desc *descs, uint32_t n, emb_index_type itype,
                 hipStream_t s) {
+    const bool timed = e->stage_timing || e->trace_cap != 0;
     HostStage hs;
-    double t0 = now_us();
+    const double t0 = now_us();
     {
         std::lock_guard<std::mutex> lk(e->mu);
         int rc = stage_host_inputs(e, descs, n, itype, s, &hs, true);
         if (rc) return rc;
     }
-    HIP_TRY(hipStreamSynchronize(s));
-    double t1 = now_us();
+    if (timed) HIP_TRY(hipStreamSynchronize(s));
+    const double t1 = now_us();
     Resolved r;
     int rc = resolve(e, descs, n, itype, &hs.d_indices, &hs.d_offsets, &hs.d_out, &r);
     if (rc) return rc;
-    // descriptor upload ("query copying" in the reference's stage list) + launch
+    // descriptor upload ("query copying" in the reference's stage list) + the fused launch
     rc = launch_resolved(e, r, itype, s);
     if (rc) return rc;
-    double t2 = now_us();
-    HIP_TRY(hipStreamSynchronize(s));
-    double t3 = now_us();
+    const double t2 = now_us();
+    if (timed) HIP_TRY(hipStreamSynchronize(s));
+    const double t3 = now_us();
     // Small results (the reference's presets: tens of KB per table): ONE device-to-host copy of the
     // whole output region into pinned staging, then host memcpys -- a per-table hipMemcpy costs
     // ~12 us each.  Large results go straight to the caller's buffers, table by table.
     const bool staged_out = hs.out_bytes > 0 && hs.out_bytes <= (1u << 20) && hs.h_out != nullptr;
-    double t4;
     if (staged_out) {
         HIP_TRY(hipMemcpyAsync(hs.h_out, hs.d_out[0], hs.out_bytes, hipMemcpyDeviceToHost, s));
-        t4 = now_us();
-        HIP_TRY(hipStreamSynchronize(s));
-        for (uint32_t i = 0; i < n; i++) {
-            size_t bytes = descs[i].n_bags * (size_t)e->tables[descs[i].table_id].dim * 4;
-            if (bytes)
-                memcpy(descs[i].pooled, hs.h_out + (reinterpret_cast<char *>(hs.d_out[i]) -
-                                                    reinterpret_cast<char *>(hs.d_out[0])), bytes);
-        }
     } else {
         for (uint32_t i = 0; i < n; i++) {
             size_t bytes = descs[i].n_bags * (size_t)e->tables[descs[i].table_id].dim * 4;
             if (bytes)
                 HIP_TRY(hipMemcpyAsync(descs[i].pooled, hs.d_out[i], bytes, hipMemcpyDeviceToHost, s));
         }
-        t4 = now_us();
-        HIP_TRY(hipStreamSynchronize(s));
     }
-    double t5 = now_us();
-    e->us_copy_in_indices += t1 - t0;
-    e->us_copy_in_lengths += t2 - t1;
-    e->us_launch += t3 - t2;
-    e->us_copy_out += t4 - t3;
-    e->us_sync += t5 - t4;
-    if (e->trace_cap) {
-        std::lock_guard<std::mutex> lk(e->mu);
-        e->record(EMB_STAGE_COPY_IN, t0, t1);
-        e->record(EMB_STAGE_DESCRIPTORS, t1, t2);
-        e->record(EMB_STAGE_LAUNCH, t2, t3);
-        e->record(EMB_STAGE_COPY_OUT, t3, t4);
-        e->record(EMB_STAGE_SYNC, t4, t5);
-        e->host_call_id++;
+    const double t4 = now_us();
+    HIP_TRY(hipStreamSynchronize(s));
+    if (staged_out) {
+        for (uint32_t i = 0; i < n; i++) {
+            size_t bytes = descs[i].n_bags * (size_t)e->tables[descs[i].table_id].dim * 4;
+            if (bytes)
+                memcpy(descs[i].pooled, hs.h_out + (reinterpret_cast<char *>(hs.d_out[i]) -
+                                                    reinterpret_cast<char *>(hs.d_out[0])), bytes);
+        }
+    }
+    const double t5 = now_us();
+    if (timed) {
+        e->us_copy_in_indices += t1 - t0;
+        e->us_copy_in_lengths += t2 - t1;
+        e->us_launch += t3 - t2;
+        e->us_copy_out += t4 - t3;
+        e->us_sync += t5 - t4;
+        if (e->trace_cap) {
+            std::lock_guard<std::mutex> lk(e->mu);
+            e->record(EMB_STAGE_COPY_IN, t0, t1);
+            e->record(EMB_STAGE_DESCRIPTORS, t1, t2);
+            e->record(EMB_STAGE_LAUNCH, t2, t3);
+            e->record(EMB_STAGE_COPY_OUT, t3, t4);
+            e->record(EMB_STAGE_SYNC, t4, t5);
+            e->host_call_id++;
+        }
+    } else {
+        e->us_sync += t5 - t0;   // the whole call: stages are not separated in this mode
     }
     e->n_bags.fetch_add(r.n_bags, std::memory_order_relaxed);
     e->n_indices.fetch_add(r.n_indices, std::memory_order_relaxed);
@@ -472,6 +483,7 @@ int emb_create(const emb_config *cfg, emb_engine **out) {
     emb_engine *e = new (std::nothrow) emb_engine();
     if (!e) return fail(EMB_ERR_NOMEM, "emb_create: out of host memory");
     e->device = dev;
+    e->stage_timing = cfg && (cfg->flags & EMB_FLAG_STAGE_TIMING);
     uint32_t max_tables = (cfg && cfg->max_tables) ? cfg->max_tables : 1024;
     e->tables.resize(max_tables);
     DeviceGuard g(dev);
@@ -771,6 +783,12 @@ int emb_reset_stats(emb_engine *e) {
     e->n_bags = 0;
     e->n_indices = 0;
     e->us_copy_in_indices = e->us_copy_in_lengths = e->us_launch = e->us_copy_out = e->us_sync = 0;
+    return EMB_OK;
+}
+
+int emb_set_stage_timing(emb_engine *e, int on) {
+    if (!e) return fail(EMB_ERR_INVALID, "engine is NULL");
+    e->stage_timing = on != 0;
     return EMB_OK;
 }
 

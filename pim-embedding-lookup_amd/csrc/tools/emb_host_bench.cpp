@@ -132,8 +132,14 @@ int main(int argc, char **argv) {
            lat[iters / 2], lat[0], lat[iters - 1], iters);
     printf("  -> %.3e pooled (table,bag) outputs/s, %.3e row gathers/s (host pointers, PCIe inclusive)\n",
            nr_tables * (double)nr_batches / (mean * 1e-3), nr_tables * (double)indices_len / (mean * 1e-3));
-    printf("stage means (us): copy-in indices+offsets %.1f | descriptors %.1f | launch+kernel %.1f | "
-           "copy-out issue %.1f | post-process %.1f | sync %.1f\n",
+    // stage breakdown: a second, stage-timed loop (the host waits after every stage, so calls are slower)
+    emb_reset_stats(e);
+    emb_set_stage_timing(e, 1);
+    for (uint32_t i = 0; i < iters; i++) lookup(pi.data(), po.data(), pr.data(), handle, 0);
+    emb_set_stage_timing(e, 0);
+    emb_get_stats(e, &st);
+    printf("stage means, stage-timed calls (us): copy-in indices+offsets %.1f | descriptors+enqueue %.1f | kernel %.1f | "
+           "copy-out enqueue %.1f | post-process %.1f | final wait %.1f\n",
            st.us_copy_in_indices / iters, st.us_copy_in_lengths / iters, st.us_launch / iters,
            st.us_copy_out / iters, st.us_post_process / iters, st.us_sync / iters);
 

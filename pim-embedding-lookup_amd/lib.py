@@ -69,6 +69,7 @@ SIGNATURES = {
                                       C.POINTER(_u64)]),
     "emb_get_stats": (C.c_int, [_vp, C.POINTER(EmbStats)]),
     "emb_reset_stats": (C.c_int, [_vp]),
+    "emb_set_stage_timing": (C.c_int, [_vp, C.c_int]),
     "emb_trace_enable": (C.c_int, [_vp, _u32]),
     "emb_trace_read": (C.c_int, [_vp, C.POINTER(EmbTraceEvent), _u32, C.POINTER(_u32)]),
     "emb_device_alloc": (C.c_int, [_vp, _sz, _pp]),

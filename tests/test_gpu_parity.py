@@ -71,7 +71,15 @@ def test_toy_ctest_known_answer_through_reference_entry_points(pel, oracle, gold
     rt = pel.lib.DpuRuntimeTotals()
     h = compat.populate([tab] * T, rt)
     assert h and rt.execution_time_populate_copy_in > 0
+    eng_h = pel.lib.load().emb_compat_engine()
+    import ctypes as C
+    s0 = pel.lib.EmbStats(); pel.lib.load().emb_get_stats(eng_h, C.byref(s0))
     res = compat.lookup(h, [idx] * T, [off] * T, nr_cols=8, latency_print=1)
+    s1 = pel.lib.EmbStats(); pel.lib.load().emb_get_stats(eng_h, C.byref(s1))
+    assert s1.us_launch > s0.us_launch and s1.us_copy_in_indices > s0.us_copy_in_indices   # stage-timed call
+    compat.lookup(h, [idx] * T, [off] * T, nr_cols=8, latency_print=0)
+    s2 = pel.lib.EmbStats(); pel.lib.load().emb_get_stats(eng_h, C.byref(s2))
+    assert s2.us_launch == s1.us_launch and s2.us_sync > s1.us_sync                        # single-wait call
     want = oracle.c_lookup_fixed32(tab, idx, off)
     assert np.array_equal(np.rint(want.astype(np.float64) * 1e9), np.tile(np.arange(10.0, 90.0, 10.0), (32, 1)))
     for t in range(T):
