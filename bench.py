@@ -48,6 +48,9 @@ def parse_args():
     ap.add_argument("--tables", type=int, default=None, help="c3: number of tables (default 48)")
     ap.add_argument("--replicate-mb", type=int, default=64,
                     help="N>1: tables up to this size are replicated on every rank, larger ones are sharded")
+    ap.add_argument("--shard-mode", choices=["whole", "rows"], default="whole",
+                    help="N>1: big tables placed whole on owner ranks (default: fewest enqueues per step) or split "
+                         "by row range over all ranks with GPU-side request routing (balanced xGMI egress)")
     ap.add_argument("--streams", type=int, default=1,
                     help="N=1: round-robin the independent steps over this many HIP streams (default 1: every "
                          "step on one stream, which is what roofline.kernel_us assumes)")

@@ -206,6 +206,32 @@ int emb_synchronize(emb_engine *e, void *stream);
 int emb_device_of(emb_engine *e, int32_t *device);
 
 /* ------------------------------------------------------------------------------------------ */
+/* multi-GPU routing helpers for ROW-RANGE sharded tables, one index per bag                    */
+/* (the Criteo shape; counterpart of the reference's index broadcast / result gather over       */
+/*  per-column DPUs, emb_host.h:258-270, 312-321, for row-range shards over GPUs)                */
+/* ------------------------------------------------------------------------------------------ */
+/* All pointers are DEVICE pointers; both calls only enqueue work on `stream`.
+ *
+ * emb_route_onehot: `indices` holds n_tables x n_bags uint32 row ids (table-major).  Table k is
+ * split over n_shards ranks in ranges of rows_per_shard[k] rows.  Every index goes to shard
+ * d = idx / rows_per_shard[k] as the LOCAL row idx - d*rows_per_shard[k], appended to that shard's
+ * request list: send_base + d*dest_stride_bytes + idx_offset_bytes is a uint32[n_tables][capacity]
+ * array; list slots are handed out with wavefront-aggregated atomics on counts[k*n_shards + d]
+ * (zeroed by this call, on `stream`).  perm[k*n_bags + b] = (d << 24) | slot remembers where
+ * bag b's pooled row will come back.  A list that would exceed `capacity` sets *overflow to 1 (the
+ * step's result is then incomplete -- size capacity with headroom, check the flag). */
+int emb_route_onehot(emb_engine *e, const uint32_t *indices, uint32_t n_tables, uint64_t n_bags,
+                     const uint32_t *rows_per_shard /* host array [n_tables] */, uint32_t n_shards,
+                     uint32_t capacity, void *send_base, uint64_t dest_stride_bytes,
+                     uint64_t idx_offset_bytes, uint32_t *perm, uint32_t *counts, uint32_t *overflow,
+                     void *stream);
+/* emb_unroute_rows: pooled[k][b][:] = the row that came back for bag b: recv_base +
+ * d*src_stride_bytes is a float[n_tables][capacity][dim] array written by shard d. */
+int emb_unroute_rows(emb_engine *e, const void *recv_base, uint64_t src_stride_bytes, uint32_t n_tables,
+                     uint64_t n_bags, uint32_t dim, uint32_t capacity, const uint32_t *perm,
+                     float *pooled /* [n_tables][n_bags][dim] */, void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
 /* (2) reference-compatible entry points (same names, argument meaning and return values)      */
 /* ------------------------------------------------------------------------------------------ */
 

@@ -47,6 +47,18 @@ hipError_t launch_scatter_column(int32_t *table, const int32_t *column, uint64_t
 hipError_t launch_validate(const DevDesc *d_descs, uint32_t n_descs, emb_index_type itype,
                            unsigned long long *d_bad, hipStream_t stream);
 
+// Row-range routing of one-hot requests (multi-GPU; see pimemb.h).  rows_per_shard: up to 64 tables.
+struct RouteParams {
+    uint32_t rows_per_shard[64];
+};
+hipError_t launch_route_onehot(const uint32_t *indices, uint32_t n_tables, uint64_t n_bags,
+                               const RouteParams &rp, uint32_t n_shards, uint32_t capacity, char *send_base,
+                               uint64_t dest_stride_bytes, uint64_t idx_offset_bytes, uint32_t *perm,
+                               uint32_t *counts, uint32_t *overflow, hipStream_t stream);
+hipError_t launch_unroute_rows(const char *recv_base, uint64_t src_stride_bytes, uint32_t n_tables,
+                               uint64_t n_bags, uint32_t dim, uint32_t capacity, const uint32_t *perm,
+                               float *pooled, hipStream_t stream);
+
 // Record the calling thread's error text (returned by emb_last_error()) and hand `code` back.
 int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 

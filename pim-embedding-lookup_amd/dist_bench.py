@@ -46,7 +46,7 @@ def expected_rows(torch, t: int, idx, dim: int):
     return h.to(torch.float32) / 2147483647.0 - 0.5
 
 
-def run(args, hbm_peak_gbs: float) -> None:
+def run_whole(args, hbm_peak_gbs: float) -> None:
     import torch
     import torch.distributed as dist
     import pim_embedding_lookup_amd as pel
@@ -251,6 +251,241 @@ def run(args, hbm_peak_gbs: float) -> None:
                          "frac": ach / hbm_peak_gbs, "traffic": None, "kernel_us": kernel_us,
                          "algorithmic_bytes": alg_bytes,
                          "note": "rank 0's two local launches (replicated + served tables), kernel-only"},
+        }))
+    dist.barrier()
+    for sl in slots:
+        for p in (sl["plan_a"], sl["plan_b"]):
+            if p is not None:
+                p.destroy()
+    eng.close()
+    dist.destroy_process_group()
+
+
+def run(args, hbm_peak_gbs: float) -> None:
+    """--shard-mode whole (default): big tables placed whole on owner ranks -- three enqueues and one
+    collective per step; an owner's links carry all of its table's traffic.
+    --shard-mode rows: big tables split by ROW RANGE over all ranks, requests routed on the GPU
+    (emb_route_onehot / emb_unroute_rows) -- every rank serves 1/N of every big table, so xGMI
+    egress is balanced, at the price of two more kernels and enqueues per step.  Measured on one
+    GPU (RCCL, world size 1): 62 us vs 100 us per step, both bound by the HOST cost of enqueueing
+    (torch's all_to_all_single alone is 25-35 us per call), which is why `whole` is the default
+    until the collective is issued from the C side."""
+    if getattr(args, "shard_mode", "whole") == "rows":
+        return run_rows(args, hbm_peak_gbs)
+    return run_whole(args, hbm_peak_gbs)
+
+
+def run_rows(args, hbm_peak_gbs: float) -> None:
+    import torch
+    import torch.distributed as dist
+    import pim_embedding_lookup_amd as pel
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    backend = os.environ.get("PIMEMB_DIST_BACKEND", "nccl")
+    dev = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
+    torch.cuda.set_device(dev)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group(backend, rank=rank, world_size=world,
+                            **({"device_id": dev} if backend == "nccl" else {}))
+    stage_cpu = backend != "nccl"
+
+    rows_list = pel.workloads.KAGGLE_ROWS
+    dim = pel.workloads.KAGGLE_DIM
+    row_b = dim * 4
+    B = args.batch or pel.workloads.KAGGLE_BATCH
+    T = len(rows_list)
+    NBATCH = max(3, args.nbatch)
+    rep_bytes = int(getattr(args, "replicate_mb", 64)) << 20
+    sharded = [t for t in range(T) if rows_list[t] * row_b > rep_bytes and rows_list[t] >= world]
+    local = [t for t in range(T) if t not in sharded]
+    K = len(sharded)
+    rps = [-(-rows_list[t] // world) for t in sharded]
+    # request-list capacity per (table, source, shard): mean B/world + ~10 sigma + slack, multiple of 4
+    mean = B / world
+    C_ = B if world == 1 else int(mean + 10.0 * np.sqrt(mean) + 64)
+    C_ = min((C_ + 3) // 4 * 4, (B + 3) // 4 * 4)
+    seg = K * C_ * row_b + K * C_ * 4           # bytes exchanged with every peer, both directions
+    idx_off = K * C_ * row_b
+
+    eng = pel.EmbeddingEngine(device=dev.index, max_tables=T + K + 1)
+    for t in local:
+        eng.load_table(t, table_values(torch, t, 0, rows_list[t], dim, dev))
+    for k, t in enumerate(sharded):
+        lo, hi = min(rank * rps[k], rows_list[t]), min((rank + 1) * rps[k], rows_list[t])
+        eng.load_table(T + k, table_values(torch, t, lo, hi, dim, dev))
+    torch.cuda.empty_cache()
+
+    rng = np.random.default_rng(1 + rank)
+    idx_host = [[pel.workloads.uniform_indices(rng, n, B).view(np.int32) for n in rows_list] for _ in range(NBATCH)]
+    off_b = torch.arange(B, dtype=torch.int32, device=dev)
+    off_c = torch.arange(C_, dtype=torch.int32, device=dev)
+    ovf = torch.zeros(1, dtype=torch.int32, device=dev)
+    slots = []
+    for j in range(NBATCH):
+        sl = dict(send=torch.zeros(max(world * seg, 16), dtype=torch.uint8, device=dev),
+                  recv=torch.zeros(max(world * seg, 16), dtype=torch.uint8, device=dev),
+                  perm=torch.zeros(max(K * B, 1), dtype=torch.int32, device=dev),
+                  counts=torch.zeros(max(K * world, 1), dtype=torch.int32, device=dev),
+                  idx_sh=(torch.from_numpy(np.stack([idx_host[j][t] for t in sharded])).to(dev) if K
+                          else torch.zeros(1, dtype=torch.int32, device=dev)),
+                  out_sh=torch.zeros((max(K, 1), B, dim), dtype=torch.float32, device=dev),
+                  idx_local=[torch.from_numpy(idx_host[j][t]).to(dev) for t in local],
+                  out_local=[torch.empty((B, dim), dtype=torch.float32, device=dev) for _ in local])
+        sl["plan_a"] = eng.plan(local, sl["idx_local"], [off_b] * len(local), sl["out_local"]) if local else None
+        slots.append(sl)
+    for j in range(NBATCH):
+        sl, prev = slots[j], slots[(j - 1) % NBATCH]
+        sl["plan_b"] = None
+        if K:   # request lists of batch j arrived with collective(j-1); pooled rows go out with collective(j)
+            ids, ii, oo, uu = [], [], [], []
+            for s in range(world):
+                for k in range(K):
+                    ids.append(T + k)
+                    b0 = s * seg + idx_off + k * C_ * 4
+                    ii.append(prev["recv"][b0:b0 + C_ * 4].view(torch.int32))
+                    oo.append(off_c)
+                    o0 = s * seg + k * C_ * row_b
+                    uu.append(sl["send"][o0:o0 + C_ * row_b].view(torch.float32).view(C_, dim))
+            sl["plan_b"] = eng.plan(ids, ii, oo, uu)
+
+    stream = torch.cuda.current_stream(dev)
+    h = stream.cuda_stream
+    splits = [seg] * world
+    pending = [None]
+
+    def collective(sl):
+        if K == 0:
+            return None
+        if stage_cpu:
+            r, s_ = torch.empty(sl["recv"].shape, dtype=torch.uint8), sl["send"].cpu()
+            dist.all_to_all_single(r, s_, output_split_sizes=splits, input_split_sizes=splits)
+            sl["recv"].copy_(r)
+            return None
+        return dist.all_to_all_single(sl["recv"], sl["send"], async_op=True)   # equal splits: seg bytes per peer
+
+    def unroute(j):      # rows of batch j came back in slots[j].recv
+        if K:
+            sl = slots[j]
+            eng.unroute_rows(sl["recv"].data_ptr(), seg, K, B, dim, C_, sl["perm"].data_ptr(),
+                             sl["out_sh"].data_ptr(), h)
+
+    prof = {} if os.environ.get("PIMEMB_DIST_PROFILE") == "1" else None
+
+    def timed(name, fn, *a):
+        if prof is None:
+            return fn(*a)
+        t = time.perf_counter_ns()
+        r = fn(*a)
+        prof[name] = prof.get(name, 0) + time.perf_counter_ns() - t
+        return r
+
+    def step(i):
+        j, nxt = i % NBATCH, (i + 1) % NBATCH
+        sl = slots[j]
+        if K:            # route batch i+1: its request lists ride in collective(i)
+            timed("route", eng.route_onehot, slots[nxt]["idx_sh"].data_ptr(), K, B, rps, world, C_,
+                  sl["send"].data_ptr(), seg, idx_off, slots[nxt]["perm"].data_ptr(),
+                  slots[nxt]["counts"].data_ptr(), ovf.data_ptr(), h)
+        if sl["plan_a"] is not None:
+            timed("plan_a", sl["plan_a"].launch, h)
+        if pending[0] is not None:
+            timed("wait", pending[0].wait)
+        timed("unroute", unroute, (i - 1) % NBATCH)   # batch i-1 is complete now
+        if sl["plan_b"] is not None:
+            timed("plan_b", sl["plan_b"].launch, h)
+        pending[0] = timed("all_to_all", collective, sl)
+
+    def drain(last_i):
+        if pending[0] is not None:
+            pending[0].wait()
+            pending[0] = None
+        unroute(last_i % NBATCH)
+        torch.cuda.synchronize()
+
+    def outputs(j):
+        res = [None] * T
+        for q, t in enumerate(local):
+            res[t] = slots[j]["out_local"][q]
+        for k, t in enumerate(sharded):
+            res[t] = slots[j]["out_sh"][k]
+        return res
+
+    # ---- prime one rotation, then verify two consecutive pipelined steps bit-exactly ----------------
+    for i in range(NBATCH):
+        step(i)
+    for i in (NBATCH, NBATCH + 1):
+        step(i)
+        drain(i)
+        res = outputs(i % NBATCH)
+        for t in range(T):
+            idx = torch.from_numpy(idx_host[i % NBATCH][t]).to(dev)
+            if not torch.equal(res[t], expected_rows(torch, t, idx, dim) + 0.0):
+                raise AssertionError(f"rank {rank}: step {i} table {t} differs from the expected rows")
+    if int(ovf.item()):
+        raise AssertionError("request-list capacity overflow")
+    it = NBATCH + 2
+
+    kernel_us, alg_bytes = 0.0, 0
+    for key in ("plan_a", "plan_b"):
+        if slots[0][key] is None:
+            continue
+        alg_bytes += slots[0][key].bytes()[0]
+        for i in range(8):
+            slots[i % NBATCH][key].launch(h)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for i in range(64):
+            slots[i % NBATCH][key].launch(h)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        kernel_us += e0.elapsed_time(e1) * 1000.0 / 64
+
+    for _ in range(args.warmup):
+        step(it)
+        it += 1
+    drain(it - 1)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(it)
+        it += 1
+    drain(it - 1)
+    dist.barrier()
+    torch.cuda.synchronize()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if stage_cpu else dev)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    wall = float(el.item())
+    if int(ovf.item()):
+        raise AssertionError("request-list capacity overflow during the timed region")
+    if prof is not None and rank == 0:
+        n_calls = args.steps + args.warmup + NBATCH + 2
+        print("[dist_bench] host microseconds per step by call:",
+              {k: round(v / 1e3 / n_calls, 1) for k, v in prof.items()}, flush=True)
+
+    if rank == 0:
+        ach = alg_bytes / (kernel_us * 1e-6) / 1e9 if kernel_us > 0 else 0.0
+        print(json.dumps({
+            "metric": "pooled-lookups/sec + achieved HBM GB/s, 26-table dim-16 Kaggle, 1/2/4/8 GPU",
+            "value": world * args.steps * T * B / wall, "unit": "pooled-lookups/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall * 1000.0 / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C2 sharded: 26 Criteo-Kaggle tables, dim 16 fp32, B=%d bags/table PER RANK, L=1, "
+                                   "%d rotating batches; %d tables replicated (<= %d MiB), %d row-range sharded over "
+                                   "%d ranks" % (B, NBATCH, len(local), rep_bytes >> 20, K, world),
+                       "tables": T, "dim": dim, "bags_per_table_per_rank": B, "global_bags_per_table": world * B,
+                       "parallelism": "row-range shards; GPU routing of requests (capacity %d per table/shard); ONE "
+                                      "all_to_all per step carries pooled rows of batch i + request lists of batch "
+                                      "i+1 (%d B per peer each way); backend %s, eager steps" % (C_, seg, backend)},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": hbm_peak_gbs, "unit": "GB/s",
+                         "frac": ach / hbm_peak_gbs, "traffic": None, "kernel_us": kernel_us,
+                         "algorithmic_bytes": alg_bytes,
+                         "note": "rank 0's two lookup launches (replicated tables + served shards), kernel-only"},
         }))
     dist.barrier()
     for sl in slots:

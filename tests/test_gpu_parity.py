@@ -472,7 +472,8 @@ def test_plan_launch_is_graph_capturable(pel, eng):
     plan.destroy()
 
 
-def test_distributed_bench_two_ranks_on_one_gpu():
+@pytest.mark.parametrize("mode", ["rows", "whole"])
+def test_distributed_bench_two_ranks_on_one_gpu(mode):
     """The N > 1 path end to end on the real HIP engine: two processes share cuda:0, collectives over
     gloo (host-staged), small batch.  dist_bench verifies all 26 tables of two pipelined steps
     bit-exactly on every rank before it prints its JSON line; here we check that line."""
@@ -482,93 +483,15 @@ def test_distributed_bench_two_ranks_on_one_gpu():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PIMEMB_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29561", os.path.join(root, "bench.py"),
-           "--gpus", "2", "--steps", "6", "--warmup", "3", "--nbatch", "3", "--batch", "4099"]
+           "--master-addr", "127.0.0.1", "--master-port", "29561" if mode == "rows" else "29562",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3", "--nbatch", "3",
+           "--batch", "4099", "--shard-mode", mode]
     res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
-    assert "5 whole" in d["config"]["workload"] and "21 replicated" in d["config"]["workload"]
+    w = d["config"]["workload"]
+    assert ("5 row-range sharded" in w and "21 tables replicated" in w) if mode == "rows" else \
+           ("5 whole" in w and "21 replicated" in w)
     assert d["roofline"]["bound"] == "hbm"
-
-
-def test_many_tables_one_launch(pel, oracle):
-    """300 tables in one fused one-hot launch (wave-batch kernel + XCD map with hundreds of segments,
-    decoded by binary search) and 300 tables in one pooled launch (lane-group kernel, 2-D grid)."""
-    rng = np.random.default_rng(31)
-    T, B = 300, 700
-    e = pel.EmbeddingEngine(device=0, max_tables=T)
-    sizes = rng.integers(1, 5000, size=T)
-    tabs = [rng.standard_normal((int(n), 16)).astype(np.float32) for n in sizes]
-    for t in range(T):
-        e.load_table(t, tabs[t])
-    idx = [rng.integers(0, n, size=B).astype(np.uint32) for n in sizes]
-    off = [np.arange(B, dtype=np.uint32)] * T
-    before = e.stats()["n_kernel_launches"]
-    outs = e.lookup_batched(list(range(T)), idx, off)
-    assert e.stats()["n_kernel_launches"] == before + 1
-    for t in range(T):
-        assert np.array_equal(outs[t], tabs[t][idx[t]])
-    idx3 = [rng.integers(0, n, size=3 * B).astype(np.uint32) for n in sizes]
-    off3 = [np.arange(0, 3 * B, 3, dtype=np.uint32)] * T
-    outs = e.lookup_batched(list(range(T)), idx3, off3)
-    for t in range(0, T, 7):
-        assert np.array_equal(outs[t], oracle.c_bag_sum(tabs[t], idx3[t], off3[t]))
-    e.close()
-
-
-@pytest.mark.parametrize("dim,dtype", [(4, np.float32), (8, np.float32), (32, np.float32), (64, np.float32),
-                                       (128, np.float32), (256, np.float32), (24, np.float32),
-                                       (8, np.float16), (128, np.float16), (512, np.float16), (16, np.int32)])
-def test_wave_batch_fast_path_every_row_width(pel, eng, oracle, dim, dtype):
-    """> 131072 one-hot-ish bags: the wave-batch kernel (one-hot fast path with speculation, its
-    fallback when offsets != arange, and the general rounds) for every lanes-per-row value."""
-    rng = np.random.default_rng(dim + np.dtype(dtype).itemsize)
-    rows, B = 1500, 135_001
-    if dtype == np.int32:
-        tab = rng.integers(-2**31, 2**31 - 1, size=(rows, dim), dtype=np.int64).astype(np.int32)
-        ref = lambda i, o: oracle.c_lookup_fixed32(tab, i, o)
-    else:
-        tab = rng.standard_normal((rows, dim)).astype(dtype)
-        ref = lambda i, o: oracle.c_bag_sum(tab, i, o)
-    eng.load_table(40, tab)
-    # (a) pure one-hot, offsets = arange  (speculative prefetch accepted)
-    idx = rng.integers(0, rows, size=B).astype(np.uint32)
-    off = np.arange(B, dtype=np.uint32)
-    assert np.array_equal(eng.lookup(40, idx, off), ref(idx, off))
-    # (b) bags of 0/1 indices (speculation rejected after the first empty bag)
-    lens = rng.integers(0, 2, size=B)
-    off = np.zeros(B, np.int64); off[1:] = np.cumsum(lens)[:-1]
-    idx = rng.integers(0, rows, size=int(lens.sum())).astype(np.uint32)
-    assert np.array_equal(eng.lookup(40, idx, off.astype(np.uint32)), ref(idx, off.astype(np.uint32)))
-    # (c) mostly one-hot with a few longer bags (general rounds inside some wave batches), int64 indices
-    lens = np.ones(B, np.int64); lens[rng.integers(0, B, size=200)] = rng.integers(2, 20, size=200)
-    off = np.zeros(B, np.int64); off[1:] = np.cumsum(lens)[:-1]
-    idx = rng.integers(0, rows, size=int(lens.sum())).astype(np.int64)
-    want = (oracle.c_lookup_fixed32(tab, idx.astype(np.uint32), off.astype(np.uint32)) if dtype == np.int32
-            else oracle.c_bag_sum(tab, idx, off))
-    assert np.array_equal(eng.lookup(40, idx, off), want)
-
-
-def test_random_shapes_host_path(pel, eng, oracle):
-    """Randomised sweep (seeded): dims, dtypes, index widths, ragged bags through the host path."""
-    rng = np.random.default_rng(2024)
-    for case in range(40):
-        dtype = [np.float32, np.float16, np.int32][case % 3]
-        elem = np.dtype(dtype).itemsize
-        dim = int(rng.integers(1, 1024 // elem // (16 // elem) + 1)) * (16 // elem)
-        rows = int(rng.integers(1, 4000))
-        n_bags = int(rng.integers(0, 3000))
-        itype = np.uint32 if (case % 2 == 0 or dtype == np.int32) else np.int64
-        off, n_idx = pel.workloads.ragged_offsets(rng, n_bags, int(rng.integers(1, 12)), p_empty=0.3, dtype=itype)
-        idx = rng.integers(0, rows, size=n_idx).astype(itype)
-        if dtype == np.int32:
-            tab = rng.integers(-2**31, 2**31 - 1, size=(rows, dim), dtype=np.int64).astype(np.int32)
-            want = oracle.c_lookup_fixed32(tab, idx, off)
-        else:
-            tab = rng.standard_normal((rows, dim)).astype(dtype)
-            want = oracle.c_bag_sum(tab, idx, off)
-        eng.load_table(41, tab)
-        got = eng.lookup(41, idx, off)
-        assert np.array_equal(got, want), f"case {case}: dim {dim} {dtype} rows {rows} bags {n_bags}"
