@@ -495,3 +495,106 @@ def test_distributed_bench_two_ranks_on_one_gpu(mode):
     assert ("5 row-range sharded" in w and "21 tables replicated" in w) if mode == "rows" else \
            ("5 whole" in w and "21 replicated" in w)
     assert d["roofline"]["bound"] == "hbm"
+
+
+@pytest.mark.parametrize("dim,dtype", [(4, np.float32), (8, np.float32), (32, np.float32), (64, np.float32),
+                                       (128, np.float32), (256, np.float32), (24, np.float32),
+                                       (8, np.float16), (128, np.float16), (512, np.float16), (16, np.int32)])
+def test_wave_batch_fast_path_every_row_width(pel, eng, oracle, dim, dtype):
+    """> 131072 one-hot-ish bags: the wave-batch kernel (one-hot fast path with speculation, its
+    fallback when offsets != arange, and the general rounds) for every lanes-per-row value."""
+    rng = np.random.default_rng(dim + np.dtype(dtype).itemsize)
+    rows, B = 1500, 135_001
+    if dtype == np.int32:
+        tab = rng.integers(-2**31, 2**31 - 1, size=(rows, dim), dtype=np.int64).astype(np.int32)
+        ref = lambda i, o: oracle.c_lookup_fixed32(tab, i, o)
+    else:
+        tab = rng.standard_normal((rows, dim)).astype(dtype)
+        ref = lambda i, o: oracle.c_bag_sum(tab, i, o)
+    eng.load_table(40, tab)
+    # (a) pure one-hot, offsets = arange  (speculative prefetch accepted)
+    idx = rng.integers(0, rows, size=B).astype(np.uint32)
+    off = np.arange(B, dtype=np.uint32)
+    assert np.array_equal(eng.lookup(40, idx, off), ref(idx, off))
+    # (b) bags of 0/1 indices (speculation rejected after the first empty bag)
+    lens = rng.integers(0, 2, size=B)
+    off = np.zeros(B, np.int64); off[1:] = np.cumsum(lens)[:-1]
+    idx = rng.integers(0, rows, size=int(lens.sum())).astype(np.uint32)
+    assert np.array_equal(eng.lookup(40, idx, off.astype(np.uint32)), ref(idx, off.astype(np.uint32)))
+    # (c) mostly one-hot with a few longer bags (general rounds inside some wave batches), int64 indices
+    lens = np.ones(B, np.int64); lens[rng.integers(0, B, size=200)] = rng.integers(2, 20, size=200)
+    off = np.zeros(B, np.int64); off[1:] = np.cumsum(lens)[:-1]
+    idx = rng.integers(0, rows, size=int(lens.sum())).astype(np.int64)
+    want = (oracle.c_lookup_fixed32(tab, idx.astype(np.uint32), off.astype(np.uint32)) if dtype == np.int32
+            else oracle.c_bag_sum(tab, idx, off))
+    assert np.array_equal(eng.lookup(40, idx, off), want)
+
+
+def test_random_shapes_host_path(pel, eng, oracle):
+    """Randomised sweep (seeded): dims, dtypes, index widths, ragged bags through the host path."""
+    rng = np.random.default_rng(2024)
+    for case in range(40):
+        dtype = [np.float32, np.float16, np.int32][case % 3]
+        elem = np.dtype(dtype).itemsize
+        dim = int(rng.integers(1, 1024 // elem // (16 // elem) + 1)) * (16 // elem)
+        rows = int(rng.integers(1, 4000))
+        n_bags = int(rng.integers(0, 3000))
+        itype = np.uint32 if (case % 2 == 0 or dtype == np.int32) else np.int64
+        off, n_idx = pel.workloads.ragged_offsets(rng, n_bags, int(rng.integers(1, 12)), p_empty=0.3, dtype=itype)
+        idx = rng.integers(0, rows, size=n_idx).astype(itype)
+        if dtype == np.int32:
+            tab = rng.integers(-2**31, 2**31 - 1, size=(rows, dim), dtype=np.int64).astype(np.int32)
+            want = oracle.c_lookup_fixed32(tab, idx, off)
+        else:
+            tab = rng.standard_normal((rows, dim)).astype(dtype)
+            want = oracle.c_bag_sum(tab, idx, off)
+        eng.load_table(41, tab)
+        got = eng.lookup(41, idx, off)
+        assert np.array_equal(got, want), f"case {case}: dim {dim} {dtype} rows {rows} bags {n_bags}"
+
+
+def test_route_unroute_row_range_shards(pel, eng):
+    """Multi-GPU routing helpers in one process: requests routed to N row-range shards, each shard's
+    answer emulated with a torch gather, rows brought back by the permutation -> W[idx] exactly."""
+    import torch
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    K, B, D, N = 3, 10_000, 16, 8
+    rows = [1_000_003, 50_000, 777_777]
+    rps = [-(-r // N) for r in rows]
+    C_ = int(B / N * 1.3) // 4 * 4 + 64
+    W = [torch.randn(r, D, device=dev, generator=g) for r in rows]
+    idx = torch.stack([torch.randint(0, r, (B,), device=dev, generator=g, dtype=torch.int64) for r in rows]).to(torch.int32)
+    seg = K * C_ * D * 4 + K * C_ * 4
+    send = torch.zeros(N * seg, dtype=torch.uint8, device=dev)
+    recv = torch.zeros(N * seg, dtype=torch.uint8, device=dev)
+    perm = torch.zeros(K * B, dtype=torch.int32, device=dev)
+    counts = torch.full((K * N,), 12345, dtype=torch.int32, device=dev)      # the call zeroes them itself
+    ovf = torch.zeros(1, dtype=torch.int32, device=dev)
+    eng.route_onehot(idx.data_ptr(), K, B, rps, N, C_, send.data_ptr(), seg, K * C_ * D * 4,
+                     perm.data_ptr(), counts.data_ptr(), ovf.data_ptr())
+    torch.cuda.synchronize()
+    assert int(ovf.item()) == 0
+    cnt = counts.view(K, N).cpu().numpy()
+    assert (cnt.sum(axis=1) == B).all()
+    for k in range(K):
+        want = np.bincount((idx[k].cpu().numpy().astype(np.int64) // rps[k]), minlength=N)
+        assert np.array_equal(cnt[k], want)
+    # every shard "serves" its request list: recv[d] out region [K][C][D] = W_k[d*rps + local]
+    for d in range(N):
+        lists = send[d * seg + K * C_ * D * 4:(d + 1) * seg].view(torch.int32).view(K, C_).long()
+        out = recv[d * seg:d * seg + K * C_ * D * 4].view(torch.float32).view(K, C_, D)
+        for k in range(K):
+            n = int(cnt[k, d])
+            assert n == 0 or int(lists[k, :n].max()) < rps[k]
+            out[k, :n] = W[k][lists[k, :n] + d * rps[k]]
+    pooled = torch.full((K, B, D), float("nan"), device=dev)
+    eng.unroute_rows(recv.data_ptr(), seg, K, B, D, C_, perm.data_ptr(), pooled.data_ptr())
+    torch.cuda.synchronize()
+    for k in range(K):
+        assert torch.equal(pooled[k], W[k][idx[k].long()])
+    # capacity too small -> overflow flag, nothing written out of bounds
+    eng.route_onehot(idx.data_ptr(), K, B, rps, N, 64, send.data_ptr(), seg, K * C_ * D * 4,
+                     perm.data_ptr(), counts.data_ptr(), ovf.data_ptr())
+    torch.cuda.synchronize()
+    assert int(ovf.item()) == 1
