@@ -238,7 +238,7 @@ int resolve(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs, emb_i
         // several tables in one big one-hot launch: XCD-aware workgroup map (one table <-> one XCD's
         // L2).  Measured neutral for pooled launches and slightly negative for small ones, which
         // keep the plain 2-D grid.
-        if (g.n > 1 && g.max_tiles > 0 && g.kind == pimemb::KERNEL_WAVEBATCH) {
+        if (g.n > 1 && g.max_tiles > 0 && g.kind != pimemb::KERNEL_GROUP) {
             uint64_t total_tiles = 0;
             for (uint32_t t : tiles_of) total_tiles += t;
             if (total_tiles + 8 * (uint64_t)g.n > 0x7fffffffull)

@@ -18,7 +18,8 @@ struct LaunchGeom {
 // Which bag kernel a launch uses.
 enum KernelKind : uint32_t {
     KERNEL_WAVEBATCH = 0,  // 64 bags per wavefront, coalesced bounds, one-hot fast path: big batches
-    KERNEL_GROUP = 1       // one lane group per bag, finest granularity: small batches (latency)
+    KERNEL_GROUP = 1,      // one lane group per bag, finest granularity: pooled launches, small batches
+    KERNEL_WAVEBATCH2 = 2  // 2 x 64 bags per wavefront: very big one-hot launches
 };
 
 // Returns EMB_OK / EMB_ERR_UNSUPPORTED and fills `g` for a table shape.

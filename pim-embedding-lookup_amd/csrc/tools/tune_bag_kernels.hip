@@ -165,19 +165,15 @@ int main(int argc, char **argv) {
     std::vector<Variant> vars;
     //                        BLOCK U  ntS   ntM  inflight minW batches ntRow spec  idxShuffle
     vars.push_back(make_variant<BagCfg<256, 8, false, false, 8>, false>("v1 group blk256"));
-    vars.push_back(make_variant<BagCfg<256, 8, true, false, 8>, false>("v1 group blk256 ntS (old SHIP small)"));
-    vars.push_back(make_variant<BagCfg<256, 8, true, false, 8, 1, 1, false, false, true>, false>("v1 group blk256 ntS idxshfl"));
-    vars.push_back(make_variant<BagCfg<64, 8, true, false, 8, 1, 1, false, false, true>, false>("v1 group blk64 ntS idxshfl"));
-    vars.push_back(make_variant<BagCfg<64, 8, true, false, 8>, false>("v1 group blk64 ntS"));
-    vars.push_back(make_variant<BagCfg<64, 8, true, false, 8, 8, 1, false, true>, true>("v2 SHIP"));
-    {
-        Variant v = make_variant<BagCfg<64, 8, true, false, 8, 8, 1, false, true>, true>("v2 SHIP XCD r1", true);
-        v.xrounds = 1; vars.push_back(v);
-        Variant w = make_variant<BagCfg<256, 8, true, false, 8, 1, 1, false, false, true>, false>("v1 blk256 ntS idxshfl XCD r1", true);
-        w.xrounds = 1; vars.push_back(w);
-        Variant x = make_variant<BagCfg<256, 8, true, false, 8>, false>("v1 blk256 ntS XCD r1", true);
-        x.xrounds = 1; vars.push_back(x);
-    }
+    auto add = [&](Variant v) { v.xrounds = 1; vars.push_back(v); };
+    add(make_variant<BagCfg<64, 8, true, false, 8, 8, 1, false, true>, true>("v2 SHIP XCD (blk64 minw8 b1)", true));
+    add(make_variant<BagCfg<64, 8, true, false, 8, 8, 2, false, true>, true>("v2 blk64 minw8 b2 XCD", true));
+    add(make_variant<BagCfg<64, 8, true, false, 8, 7, 2, false, true>, true>("v2 blk64 minw7 b2 XCD", true));
+    add(make_variant<BagCfg<128, 8, true, false, 8, 8, 2, false, true>, true>("v2 blk128 minw8 b2 XCD", true));
+    add(make_variant<BagCfg<128, 8, true, false, 8, 7, 2, false, true>, true>("v2 blk128 minw7 b2 XCD", true));
+    add(make_variant<BagCfg<128, 8, true, false, 8, 7, 1, false, true>, true>("v2 blk128 minw7 b1 XCD", true));
+    add(make_variant<BagCfg<128, 4, true, false, 8, 8, 2, false, true>, true>("v2 blk128 minw8 b2 U4 XCD", true));
+    add(make_variant<BagCfg<64, 4, true, false, 8, 8, 2, false, true>, true>("v2 blk64 minw8 b2 U4 XCD", true));
     { Variant v; v.name = "ABLATION null kernel same grid"; v.fn = launch_null; v.checked = false; vars.push_back(v); }
     {
         Variant v; v.name = "ABLATION store-only (ntS)"; v.fn = launch_store_only; v.checked = false; vars.push_back(v);

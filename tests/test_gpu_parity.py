@@ -598,3 +598,20 @@ def test_route_unroute_row_range_shards(pel, eng):
                      perm.data_ptr(), counts.data_ptr(), ovf.data_ptr())
     torch.cuda.synchronize()
     assert int(ovf.item()) == 1
+
+
+@pytest.mark.parametrize("dim,dtype", [(16, np.float32), (128, np.float32), (64, np.float16), (4, np.float32)])
+def test_two_batch_wave_kernel_very_big_launch(pel, eng, oracle, dim, dtype):
+    """>= 524288 one-hot-ish bags: the two-batches-per-wavefront kernel, fast path and general rounds."""
+    rng = np.random.default_rng(7 * dim)
+    rows, B = 2000, 530_003
+    tab = rng.standard_normal((rows, dim)).astype(dtype)
+    eng.load_table(42, tab)
+    idx = rng.integers(0, rows, size=B).astype(np.uint32)
+    off = np.arange(B, dtype=np.uint32)
+    assert np.array_equal(eng.lookup(42, idx, off), tab[idx].astype(np.float32) + np.float32(0))
+    lens = np.ones(B, np.int64)
+    lens[rng.integers(0, B, size=300)] = rng.integers(0, 9, size=300)
+    off = np.zeros(B, np.int64); off[1:] = np.cumsum(lens)[:-1]
+    idx = rng.integers(0, rows, size=int(lens.sum())).astype(np.int64)
+    assert np.array_equal(eng.lookup(42, idx, off), oracle.c_bag_sum(tab, idx, off))
