@@ -240,11 +240,12 @@ KernelKind choose_kernel(uint64_t total_bags, uint64_t total_indices, const Laun
     //   * pooled launches (dim 128, 32 indices per bag) run 1.3x faster on the lane-group kernel:
     //     a bag is already a long stream of gathers, and 64 bags per wavefront leave too few
     //     wavefronts to balance the machine.
-    (void)g;
     const bool one_hot_ish = total_indices <= 2 * total_bags;
     if (!one_hot_ish || total_bags / 64u < 2048u) return KERNEL_GROUP;
-    // two batches per wavefront once that still leaves >= 4 wavefronts per SIMD (>= 524288 bags)
-    return (total_bags / 128u >= 4096u) ? KERNEL_WAVEBATCH2 : KERNEL_WAVEBATCH;
+    // Two batches per wavefront once that still leaves >= 4 wavefronts per SIMD (>= 524288 bags) --
+    // for NARROW rows only (<= 4 lanes per row, e.g. dim 16 fp32): a batch of wider rows already
+    // keeps 8 gathers in flight per lane, and two of them would spill (dim 128: 5.0 vs 5.4 TB/s).
+    return (g.lanes_per_row <= 4 && total_bags / 128u >= 4096u) ? KERNEL_WAVEBATCH2 : KERNEL_WAVEBATCH;
 }
 
 hipError_t launch_bag_sum(const DevDesc *d_descs, uint32_t n_descs, uint32_t max_tiles,

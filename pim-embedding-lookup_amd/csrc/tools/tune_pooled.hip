@@ -144,17 +144,13 @@ int main(int argc, char **argv) {
 
     std::vector<Variant> vars;
     //                        BLOCK U  ntS   ntM  inflight minW batches ntRow spec  idxShuffle
-    vars.push_back(make_variant<BagCfg<256, 8, true, false, 8>, false>("v1 group blk256 U8 ntS (SHIP)"));
-    vars.push_back(make_variant<BagCfg<256, 8, true, false, 8, 1, 1, false, false, true>, false>("v1 + idx shuffle U8"));
-    vars.push_back(make_variant<BagCfg<256, 16, true, false, 8, 1, 1, false, false, true>, false>("v1 + idx shuffle U16"));
-    vars.push_back(make_variant<BagCfg<256, 4, true, false, 8, 1, 1, false, false, true>, false>("v1 + idx shuffle U4"));
-    vars.push_back(make_hot<BagCfg<1024, 8, true, false, 8>>("v3 hot0   wg64  blk1024", 0, 64));
-    vars.push_back(make_hot<BagCfg<1024, 8, true, false, 8>>("v3 hot100 wg64  blk1024", 100, 64));
-    vars.push_back(make_hot<BagCfg<1024, 8, true, false, 8, 1, 1, false, false, true>>("v3 hot0   wg64  blk1024 shfl", 0, 64));
-    vars.push_back(make_hot<BagCfg<1024, 8, true, false, 8, 1, 1, false, false, true>>("v3 hot64  wg64  blk1024 shfl", 64, 64));
-    vars.push_back(make_hot<BagCfg<1024, 8, true, false, 8, 1, 1, false, false, true>>("v3 hot100 wg64  blk1024 shfl", 100, 64));
-    vars.push_back(make_hot<BagCfg<1024, 16, true, false, 8, 1, 1, false, false, true>>("v3 hot100 wg64  blk1024 shfl U16", 100, 64));
-    vars.push_back(make_hot<BagCfg<512, 8, true, false, 8, 1, 1, false, false, true>>("v3 hot64  wg128 blk512 shfl", 64, 128));
+    vars.push_back(make_variant<BagCfg<256, 8, true, false, 8, 1, 1, false, false, true>, false>("v1 group SHIP (blk256 U8 idxshfl)"));
+    vars.push_back(make_variant<BagCfg<64, 8, true, false, 8, 8, 1, false, true>, true>("v2 wave b1 SHIP (blk64 U8 minw8)"));
+    vars.push_back(make_variant<BagCfg<64, 8, true, false, 8, 8, 1, false, true>, true>("v2 wave b1 SHIP XCD", true));
+    vars.push_back(make_variant<BagCfg<128, 4, true, false, 8, 8, 2, false, true>, true>("v2 wave b2 SHIP (blk128 U4 minw8)"));
+    vars.push_back(make_variant<BagCfg<128, 4, true, false, 8, 8, 2, false, true>, true>("v2 wave b2 SHIP XCD", true));
+    vars.push_back(make_variant<BagCfg<64, 8, true, false, 16, 4, 1, false, true>, true>("v2 wave b1 inflight16 minw4"));
+    vars.push_back(make_variant<BagCfg<64, 8, true, false, 4, 8, 1, false, true>, true>("v2 wave b1 inflight4 minw8"));
 
     // hot sets: the generator maps Zipf rank k of table t to row (k*2654435761 + 12345 + t) % rows
     std::vector<std::vector<void *>> hot_dev(vars.size(), std::vector<void *>(T, nullptr));
