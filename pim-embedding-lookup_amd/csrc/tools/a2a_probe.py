@@ -23,3 +23,19 @@ for nbytes in (1 << 16, 13 << 20):
             tot = time.perf_counter() - t0
             print(f"{nbytes>>10:6d} KiB {mode:6s} sync_each={sync_each!s:5s}: call {call/n*1e6:6.1f} us, period {tot/n*1e6:6.1f} us")
 dist.destroy_process_group()
+
+# lower-level entry: the ProcessGroup object itself (skips the Python wrapper's checks)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+pg = dist.distributed_c10d._get_default_group()
+a = torch.zeros(13 << 20, dtype=torch.uint8, device=dev); b = torch.empty_like(a)
+for name, fn in (("wrapper", lambda: dist.all_to_all_single(b, a, async_op=True)),
+                 ("pg.alltoall_base", lambda: pg.alltoall_base(b, a, [], []))):
+    for _ in range(20):
+        fn().wait()
+    torch.cuda.synchronize()
+    n = 500; call = 0.0; t0 = time.perf_counter()
+    for _ in range(n):
+        t = time.perf_counter(); w = fn(); call += time.perf_counter() - t; w.wait()
+    torch.cuda.synchronize()
+    print(f"13312 KiB {name:18s}: call {call/n*1e6:6.1f} us, period {(time.perf_counter()-t0)/n*1e6:6.1f} us")
+dist.destroy_process_group()

@@ -24,7 +24,6 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import Callable, Sequence
 
-import numpy as np
 
 REPLICATED, WHOLE, ROW_SPLIT = "replicated", "whole", "row_split"
 
