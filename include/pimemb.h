@@ -116,7 +116,8 @@ const char *emb_version(void);
 /* Create an engine on one GPU.  Replaces the first-call dpu_alloc + dpu_load (emb_host.h:155-160). */
 int emb_create(const emb_config *cfg, emb_engine **out);
 
-/* Free every table and workspace.  The reference has no destroy function (emb_host.h:33). */
+/* Free every table and workspace.  The reference has no destroy function (emb_host.h:33).
+ * Fails with EMB_ERR_INVALID while prepared plans of this engine are alive. */
 int emb_destroy(emb_engine *e);
 
 /* Upload one whole table, row-major [nr_rows][dim] of `dtype`, into HBM (synchronous copy, like
@@ -151,7 +152,10 @@ int emb_lookup_batched(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_d
                        emb_index_type itype, emb_memspace space, void *stream);
 
 /* Prepared lookup over DEVICE buffers: descriptors are resolved and uploaded once, every launch is
- * then a single kernel enqueue (graph-capturable: no allocation, copy or sync inside). */
+ * then a single kernel enqueue (graph-capturable: no allocation, copy or sync inside).  The plan
+ * holds the pointers it was given: buffers must stay allocated; re-allocating one of its tables
+ * (emb_alloc_table / emb_load_table with another size) makes emb_plan_launch fail with
+ * EMB_ERR_INVALID instead of reading freed memory. */
 int emb_plan_create(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs,
                     emb_index_type itype, emb_plan **out);
 int emb_plan_launch(emb_plan *p, void *stream);

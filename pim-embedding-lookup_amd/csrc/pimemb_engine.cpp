@@ -55,6 +55,7 @@ struct Table {
     emb_dtype dtype = EMB_F32;
     LaunchGeom geom{};
     size_t bytes = 0;
+    uint64_t generation = 0;  // bumped whenever `rows` is (re)allocated: prepared plans check it
 };
 
 // One slot of the descriptor ring used by transient (non-plan) launches: the pinned host copy and
@@ -89,6 +90,8 @@ struct emb_engine {
     double us_copy_in_indices = 0, us_copy_in_lengths = 0, us_launch = 0, us_copy_out = 0,
            us_sync = 0;
     bool stage_timing = false;  // wait + clock after every stage of a host-pointer call
+    std::atomic<uint32_t> live_plans{0};
+    uint64_t next_generation = 1;
     // stage trace (host-pointer path)
     std::deque<emb_trace_event> trace;
     uint32_t trace_cap = 0;
@@ -119,6 +122,7 @@ struct emb_plan {
     std::vector<PlanGroup> groups;
     char *d_image = nullptr;  // descriptors + XCD maps in HBM
     uint64_t bytes = 0, n_bags = 0, n_indices = 0;
+    std::vector<std::pair<uint32_t, uint64_t>> table_gens;  // (table id, generation) the plan was built on
 };
 
 namespace {
@@ -498,6 +502,9 @@ int emb_create(const emb_config *cfg, emb_engine **out) {
 
 int emb_destroy(emb_engine *e) {
     if (!e) return EMB_OK;
+    if (e->live_plans.load() != 0)
+        return fail(EMB_ERR_INVALID, "emb_destroy: %u prepared plan(s) still reference this engine; destroy them first",
+                    e->live_plans.load());
     DeviceGuard g(e->device);
     (void)hipDeviceSynchronize();
     for (Table &t : e->tables)
@@ -538,8 +545,11 @@ int emb_alloc_table(emb_engine *e, uint32_t table_id, uint64_t nr_rows, uint32_t
     if (!t.rows) {
         HIP_TRY(hipMalloc(&t.rows, bytes));
         e->table_bytes += bytes;
+        t.generation = e->next_generation++;
     }
     HIP_TRY(hipMemset(t.rows, 0, bytes));
+    if (t.nr_rows != nr_rows || t.dim != dim || t.dtype != dtype)
+        t.generation = e->next_generation++;   // same bytes, different shape: plans built on the old shape are stale
     t.nr_rows = nr_rows;
     t.dim = dim;
     t.dtype = dtype;
@@ -660,6 +670,9 @@ int emb_plan_create(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_desc
     r.bind(d);
     p->d_image = d;
     p->groups = r.groups;
+    for (uint32_t i = 0; i < n_descs; i++)
+        p->table_gens.emplace_back(descs[i].table_id, e->tables[descs[i].table_id].generation);
+    e->live_plans.fetch_add(1);
     *out = p;
     return EMB_OK;
 }
@@ -667,6 +680,9 @@ int emb_plan_create(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_desc
 int emb_plan_launch(emb_plan *p, void *stream) {
     if (!p) return fail(EMB_ERR_INVALID, "plan is NULL");
     emb_engine *e = p->e;
+    for (const auto &tg : p->table_gens)   // a table re-allocated since emb_plan_create would be a dangling pointer
+        if (e->tables[tg.first].generation != tg.second)
+            return fail(EMB_ERR_INVALID, "plan is stale: table %u was re-allocated after emb_plan_create", tg.first);
     DeviceGuard g(e->device);
     int rc = launch_groups(e, p->groups, p->itype, static_cast<hipStream_t>(stream));
     if (rc) return rc;
@@ -681,6 +697,7 @@ int emb_plan_destroy(emb_plan *p) {
     DeviceGuard g(p->e->device);
     (void)hipDeviceSynchronize();
     if (p->d_image) (void)hipFree(p->d_image);
+    p->e->live_plans.fetch_sub(1);
     delete p;
     return EMB_OK;
 }

@@ -297,7 +297,7 @@ class EmbeddingEngine:
 
     def close(self) -> None:
         if self._h:
-            self._L.emb_destroy(self._h)
+            _l.check(self._L.emb_destroy(self._h))   # raises while plans are alive
             self._h = None
 
     def __enter__(self):

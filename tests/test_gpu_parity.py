@@ -615,3 +615,26 @@ def test_two_batch_wave_kernel_very_big_launch(pel, eng, oracle, dim, dtype):
     off = np.zeros(B, np.int64); off[1:] = np.cumsum(lens)[:-1]
     idx = rng.integers(0, rows, size=int(lens.sum())).astype(np.int64)
     assert np.array_equal(eng.lookup(42, idx, off), oracle.c_bag_sum(tab, idx, off))
+
+
+def test_plan_lifetime_guards(pel):
+    """A plan whose table was re-allocated must fail loudly, and an engine with live plans must
+    refuse to be destroyed (the reference has neither plans nor a destroy function)."""
+    e = pel.EmbeddingEngine(device=0, max_tables=4)
+    tab = np.ones((100, 16), np.float32)
+    e.load_table(0, tab)
+    idx = pel.DeviceBuffer.from_numpy(e, np.arange(10, dtype=np.uint32))
+    off = pel.DeviceBuffer.from_numpy(e, np.arange(10, dtype=np.uint32))
+    plan = e.plan([0], [idx], [off])
+    plan.launch(); e.synchronize()
+    e.load_table(0, tab * 2)                       # same size: storage kept, plan stays valid
+    plan.launch(); e.synchronize()
+    assert np.array_equal(plan.outputs[0].numpy(), np.full((10, 16), 2.0, np.float32))
+    e.load_table(0, np.ones((200, 16), np.float32))   # re-allocated
+    with pytest.raises(pel.PimembError) as ei:
+        plan.launch()
+    assert "stale" in str(ei.value)
+    with pytest.raises(pel.PimembError):
+        e.close()
+    plan.destroy()
+    e.close()
