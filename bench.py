@@ -11,9 +11,11 @@ Inputs are resident in HBM before the timed region; NBATCH distinct index batche
 buffers are rotated so a step never re-reads the previous step's rows out of the 256 MiB
 Infinity Cache (working set per rotation > 1 GB).
 
-N > 1 (one process per GPU, RCCL): tables are sharded by table id across ranks; each rank owns B
-samples; per step: all_to_all indices in -> local fused lookup -> all_to_all pooled rows out
-(SURVEY.md section 8 row E).  Weak scaling: B per rank is fixed, so global batch = N * B.
+N > 1 (one process per GPU, torch.distributed over RCCL; pim-embedding-lookup_amd/dist_bench.py): each
+rank owns B bags per table (weak scaling, global batch N * B).  Tables are replicated while the whole
+set fits a quarter of one GPU's HBM -- the Kaggle tables do, so the metric's config needs no exchange --
+and sharded by table id / row range with all_to_all(indices in, pooled rows out) otherwise
+(SURVEY.md section 8 row E); the sharded exchange is measured in the same run as a secondary leg.
 """
 from __future__ import annotations
 
@@ -46,8 +48,12 @@ def parse_args():
                          "to fit one GPU: 48 tables x 10M rows x dim 128 fp32, B=16384, pooling 32; c5 = one GPU's "
                          "share of configs[4]: 64 tables x 30M rows x dim 64 fp16, mixed Zipf/uniform, pooling 32")
     ap.add_argument("--tables", type=int, default=None, help="c3: number of tables (default 48)")
-    ap.add_argument("--replicate-mb", type=int, default=64,
-                    help="N>1: tables up to this size are replicated on every rank, larger ones are sharded")
+    ap.add_argument("--replicate-mb", type=int, default=None,
+                    help="N>1: tables up to this size are replicated on every rank, larger ones are sharded. "
+                         "Default (auto): replicate everything when the whole table set fits a quarter of one "
+                         "GPU's HBM (the Kaggle config does), else 64")
+    ap.add_argument("--no-exchange-leg", action="store_true",
+                    help="N>1, auto policy: skip the secondary sharded-exchange measurement")
     ap.add_argument("--shard-mode", choices=["whole", "rows"], default="whole",
                     help="N>1: big tables placed whole on owner ranks (default: fewest enqueues per step) or split "
                          "by row range over all ranks with GPU-side request routing (balanced xGMI egress)")

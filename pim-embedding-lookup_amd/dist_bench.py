@@ -1,11 +1,14 @@
 """bench.py's N > 1 leg: one process per GPU (torch.distributed, backend nccl = RCCL over xGMI),
 weak scaling -- every rank owns B bags per table, so the global batch is N * B.
 
-Static-shape fast path of sharding.py for the bench workload (one index per bag, equal B on every
-rank): tables <= --replicate-mb are replicated (no exchange), the rest are placed whole on owner
-ranks by the shard planner.  The two exchanges of a lookup -- indices in, pooled rows out -- are
-software-pipelined over consecutive batches so that ONE all_to_all per step carries both the
-pooled rows of batch i and the indices of batch i+1 (byte payloads with static splits):
+Placement policy (`run`): tables are REPLICATED while the whole table set fits a quarter of one
+GPU's HBM (the 26 Kaggle tables, 2.16 GB, do): `run_dp` -- the single-GPU fused launch on every rank,
+no data-path collective.  Larger sets (or --replicate-mb N) SHARD and exchange:
+
+`run_whole` (static shapes, one index per bag): tables <= the threshold replicated, the rest placed
+whole on owner ranks by the shard planner.  The two exchanges of a lookup -- indices in, pooled rows
+out -- are software-pipelined over consecutive batches so that ONE all_to_all per step carries both
+the pooled rows of batch i and the indices of batch i+1 (byte payloads with static splits):
 
     launch A(i): fused lookup of the replicated tables        HIP engine plan, local bags, no dependency
     wait collective(i-1)                                      stream-level, the CPU never blocks
@@ -15,8 +18,12 @@ pooled rows of batch i and the indices of batch i+1 (byte payloads with static s
     collective(i) = all_to_all([pooled rows of batch i | indices of batch i+1])   RCCL over xGMI
     outputs(i): replicated tables -> own buffers; sharded tables -> views of the receive buffer
 
-All buffers and both engine plans are created once per rotating batch slot; a step enqueues one
-collective and two kernels, nothing else."""
+`run_rows`: the same pipeline with the big tables split by ROW RANGE over all ranks; requests are
+routed on the GPU (emb_route_onehot) and the returned rows put back in bag order (emb_unroute_rows).
+
+With the auto policy the sharded exchange is still measured in the same run as a secondary leg
+(`sharded_exchange` in the JSON line).  All buffers and engine plans are created once per rotating
+batch slot."""
 from __future__ import annotations
 
 import json
@@ -46,25 +53,14 @@ def expected_rows(torch, t: int, idx, dim: int):
     return h.to(torch.float32) / 2147483647.0 - 0.5
 
 
-def run_whole(args, hbm_peak_gbs: float) -> None:
+def run_whole(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
     import torch
     import torch.distributed as dist
     import pim_embedding_lookup_amd as pel
     from importlib import import_module
     sh = import_module("pim-embedding-lookup_amd.sharding")
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
-    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
-    backend = os.environ.get("PIMEMB_DIST_BACKEND", "nccl")
-    n_dev = torch.cuda.device_count()
-    dev = torch.device("cuda", local_rank % max(n_dev, 1))
-    torch.cuda.set_device(dev)
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
-    dist.init_process_group(backend, rank=rank, world_size=world,
-                            **({"device_id": dev} if backend == "nccl" else {}))
-    stage_cpu = backend != "nccl"          # gloo rehearsal: collectives on host copies
+    rank, world, dev, backend, stage_cpu = ctx["rank"], ctx["world"], ctx["dev"], ctx["backend"], ctx["stage_cpu"]
 
     rows_list = pel.workloads.KAGGLE_ROWS
     dim = pel.workloads.KAGGLE_DIM
@@ -72,7 +68,6 @@ def run_whole(args, hbm_peak_gbs: float) -> None:
     Bp = (B + 3) // 4 * 4                   # index slots per (table, rank): keeps every piece 16-B aligned
     T = len(rows_list)
     NBATCH = max(2, args.nbatch)
-    rep_bytes = int(getattr(args, "replicate_mb", 64)) << 20
     plan = sh.plan_shards(rows_list, dim, 4, world, replicate_bytes=rep_bytes, split_bytes=1 << 62)
     served = plan.owned_units(rank)
     local = plan.replicated_units()
@@ -231,9 +226,10 @@ def run_whole(args, hbm_peak_gbs: float) -> None:
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
     wall = float(el.item())
 
+    result = None
     if rank == 0:
         ach = alg_bytes / (kernel_us * 1e-6) / 1e9 if kernel_us > 0 else 0.0
-        print(json.dumps({
+        result = ({
             "metric": "pooled-lookups/sec + achieved HBM GB/s, 26-table dim-16 Kaggle, 1/2/4/8 GPU",
             "value": world * args.steps * T * B / wall, "unit": "pooled-lookups/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -251,46 +247,22 @@ def run_whole(args, hbm_peak_gbs: float) -> None:
                          "frac": ach / hbm_peak_gbs, "traffic": None, "kernel_us": kernel_us,
                          "algorithmic_bytes": alg_bytes,
                          "note": "rank 0's two local launches (replicated + served tables), kernel-only"},
-        }))
+        })
     dist.barrier()
     for sl in slots:
         for p in (sl["plan_a"], sl["plan_b"]):
             if p is not None:
                 p.destroy()
     eng.close()
-    dist.destroy_process_group()
+    return result
 
 
-def run(args, hbm_peak_gbs: float) -> None:
-    """--shard-mode whole (default): big tables placed whole on owner ranks -- three enqueues and one
-    collective per step; an owner's links carry all of its table's traffic.
-    --shard-mode rows: big tables split by ROW RANGE over all ranks, requests routed on the GPU
-    (emb_route_onehot / emb_unroute_rows) -- every rank serves 1/N of every big table, so xGMI
-    egress is balanced, at the price of two more kernels and enqueues per step.  Measured on one
-    GPU (RCCL, world size 1): 62 us vs 100 us per step, both bound by the HOST cost of enqueueing
-    (torch's all_to_all_single alone is 25-35 us per call), which is why `whole` is the default
-    until the collective is issued from the C side."""
-    if getattr(args, "shard_mode", "whole") == "rows":
-        return run_rows(args, hbm_peak_gbs)
-    return run_whole(args, hbm_peak_gbs)
-
-
-def run_rows(args, hbm_peak_gbs: float) -> None:
+def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
     import torch
     import torch.distributed as dist
     import pim_embedding_lookup_amd as pel
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
-    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
-    backend = os.environ.get("PIMEMB_DIST_BACKEND", "nccl")
-    dev = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
-    torch.cuda.set_device(dev)
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
-    dist.init_process_group(backend, rank=rank, world_size=world,
-                            **({"device_id": dev} if backend == "nccl" else {}))
-    stage_cpu = backend != "nccl"
+    rank, world, dev, backend, stage_cpu = ctx["rank"], ctx["world"], ctx["dev"], ctx["backend"], ctx["stage_cpu"]
 
     rows_list = pel.workloads.KAGGLE_ROWS
     dim = pel.workloads.KAGGLE_DIM
@@ -298,7 +270,6 @@ def run_rows(args, hbm_peak_gbs: float) -> None:
     B = args.batch or pel.workloads.KAGGLE_BATCH
     T = len(rows_list)
     NBATCH = max(3, args.nbatch)
-    rep_bytes = int(getattr(args, "replicate_mb", 64)) << 20
     sharded = [t for t in range(T) if rows_list[t] * row_b > rep_bytes and rows_list[t] >= world]
     local = [t for t in range(T) if t not in sharded]
     K = len(sharded)
@@ -466,9 +437,10 @@ def run_rows(args, hbm_peak_gbs: float) -> None:
         print("[dist_bench] host microseconds per step by call:",
               {k: round(v / 1e3 / n_calls, 1) for k, v in prof.items()}, flush=True)
 
+    result = None
     if rank == 0:
         ach = alg_bytes / (kernel_us * 1e-6) / 1e9 if kernel_us > 0 else 0.0
-        print(json.dumps({
+        result = ({
             "metric": "pooled-lookups/sec + achieved HBM GB/s, 26-table dim-16 Kaggle, 1/2/4/8 GPU",
             "value": world * args.steps * T * B / wall, "unit": "pooled-lookups/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -486,11 +458,149 @@ def run_rows(args, hbm_peak_gbs: float) -> None:
                          "frac": ach / hbm_peak_gbs, "traffic": None, "kernel_us": kernel_us,
                          "algorithmic_bytes": alg_bytes,
                          "note": "rank 0's two lookup launches (replicated tables + served shards), kernel-only"},
-        }))
+        })
     dist.barrier()
     for sl in slots:
         for p in (sl["plan_a"], sl["plan_b"]):
             if p is not None:
                 p.destroy()
     eng.close()
+    return result
+
+
+def run_dp(args, hbm_peak_gbs: float, ctx):
+    """Every table replicated on every rank: each rank looks its own B bags up locally -- the
+    single-GPU fused launch, N times, no data-path collective."""
+    import torch
+    import torch.distributed as dist
+    import pim_embedding_lookup_amd as pel
+    rank, world, dev, stage_cpu = ctx["rank"], ctx["world"], ctx["dev"], ctx["stage_cpu"]
+    rows_list = pel.workloads.KAGGLE_ROWS
+    dim = pel.workloads.KAGGLE_DIM
+    B = args.batch or pel.workloads.KAGGLE_BATCH
+    T = len(rows_list)
+    NBATCH = max(2, args.nbatch)
+    eng = pel.EmbeddingEngine(device=dev.index, max_tables=T)
+    for t in range(T):
+        eng.load_table(t, table_values(torch, t, 0, rows_list[t], dim, dev))
+    torch.cuda.empty_cache()
+    rng = np.random.default_rng(1 + rank)
+    off = torch.arange(B, dtype=torch.int32, device=dev)
+    idx_host = [[pel.workloads.uniform_indices(rng, n, B).view(np.int32) for n in rows_list] for _ in range(NBATCH)]
+    plans = []
+    for j in range(NBATCH):
+        plans.append(eng.plan(list(range(T)), [torch.from_numpy(i).to(dev) for i in idx_host[j]], [off] * T))
+    stream = torch.cuda.current_stream(dev)
+    h = stream.cuda_stream
+    plans[0].launch(h)
+    torch.cuda.synchronize()
+    for t in range(T):       # parity on every rank: one-hot => pooled row == table row
+        idx = torch.from_numpy(idx_host[0][t]).to(dev)
+        if not torch.equal(plans[0].outputs[t], expected_rows(torch, t, idx, dim) + 0.0):
+            raise AssertionError(f"rank {rank}: table {t} differs from the expected rows")
+    for i in range(args.warmup):
+        plans[i % NBATCH].launch(h)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(stream)
+    for i in range(args.steps):
+        plans[i % NBATCH].launch(h)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if stage_cpu else dev)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    wall = float(el.item())
+    kernel_us = e0.elapsed_time(e1) * 1000.0 / args.steps
+    alg_bytes = plans[0].bytes()[0]
+    result = None
+    if rank == 0:
+        ach = alg_bytes / (kernel_us * 1e-6) / 1e9
+        result = {
+            "metric": "pooled-lookups/sec + achieved HBM GB/s, 26-table dim-16 Kaggle, 1/2/4/8 GPU",
+            "value": world * args.steps * T * B / wall, "unit": "pooled-lookups/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall * 1000.0 / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C2: 26 Criteo-Kaggle tables, dim 16 fp32, B=%d bags/table PER RANK, L=1, u32 "
+                                   "indices+offsets, uniform indices, %d rotating batches" % (B, NBATCH),
+                       "tables": T, "dim": dim, "bags_per_table_per_rank": B, "global_bags_per_table": world * B,
+                       "parallelism": "all 26 tables (2.16 GB) replicated on every rank (they fit the per-GPU "
+                                      "replication budget); bags data-parallel, no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": hbm_peak_gbs, "unit": "GB/s",
+                         "frac": ach / hbm_peak_gbs, "traffic": None, "kernel_us": kernel_us,
+                         "algorithmic_bytes": alg_bytes, "note": "rank 0's fused launch, HIP events over the timed region"},
+        }
+    for p in plans:
+        p.destroy()
+    eng.close()
+    return result
+
+
+def run(args, hbm_peak_gbs: float) -> None:
+    """N > 1 entry.  Placement policy (--replicate-mb, default auto): tables are replicated while the
+    whole set fits a quarter of one GPU's HBM -- the 26 Kaggle tables (2.16 GB) do, so the metric's
+    config runs data-parallel with no exchange; anything larger shards (table id / row range) and
+    exchanges indices and pooled rows with all_to_all.  With the auto policy the exchange path is
+    still MEASURED in the same run, as a secondary leg forced to shard the five big tables
+    (`sharded_exchange` in the JSON line): that is the xGMI all-to-all curve, link- and host-bound
+    for one index per bag."""
+    import threading
+    import torch
+    import torch.distributed as dist
+    import pim_embedding_lookup_amd as pel
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    backend = os.environ.get("PIMEMB_DIST_BACKEND", "nccl")
+    dev = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
+    torch.cuda.set_device(dev)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group(backend, rank=rank, world_size=world,
+                            **({"device_id": dev} if backend == "nccl" else {}))
+    ctx = dict(rank=rank, world=world, dev=dev, backend=backend, stage_cpu=backend != "nccl")
+
+    total_bytes = sum(pel.workloads.KAGGLE_ROWS) * pel.workloads.KAGGLE_DIM * 4
+    hbm = torch.cuda.get_device_properties(dev).total_memory
+    auto = getattr(args, "replicate_mb", None) is None
+    shard_leg = run_rows if getattr(args, "shard_mode", "whole") == "rows" else run_whole
+    if auto and total_bytes <= hbm // 4:
+        result = run_dp(args, hbm_peak_gbs, ctx)
+        if not getattr(args, "no_exchange_leg", False):
+            # secondary leg: the sharded exchange, fewer steps; a hang must not lose the primary result
+            import copy
+            a2 = copy.copy(args)
+            a2.steps, a2.warmup = min(args.steps, 400), min(args.warmup, 40)
+
+            def give_up():
+                if rank == 0 and result is not None:
+                    result["sharded_exchange"] = "timed out after 180 s"
+                    print(json.dumps(result), flush=True)
+                os._exit(0)
+
+            dog = threading.Timer(180.0, give_up)
+            dog.daemon = True
+            dog.start()
+            try:
+                sec = shard_leg(a2, hbm_peak_gbs, ctx, 64 << 20)
+                if rank == 0:
+                    result["sharded_exchange"] = {k: sec[k] for k in ("value", "unit", "ms_per_step", "steps")}
+                    result["sharded_exchange"]["config"] = sec["config"]["workload"] + "; " + sec["config"]["parallelism"]
+            except Exception as ex:  # noqa: BLE001 -- the primary result stands on its own
+                if rank == 0:
+                    result["sharded_exchange"] = f"failed: {type(ex).__name__}: {ex}"
+            dog.cancel()
+    else:
+        rep_mb = 64 if auto else int(args.replicate_mb)
+        result = shard_leg(args, hbm_peak_gbs, ctx, rep_mb << 20)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    dist.barrier()
     dist.destroy_process_group()

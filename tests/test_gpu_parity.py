@@ -472,29 +472,40 @@ def test_plan_launch_is_graph_capturable(pel, eng):
     plan.destroy()
 
 
-@pytest.mark.parametrize("mode", ["rows", "whole"])
+@pytest.mark.parametrize("mode", ["rows", "whole", "auto"])
 def test_distributed_bench_two_ranks_on_one_gpu(mode):
     """The N > 1 path end to end on the real HIP engine: two processes share cuda:0, collectives over
-    gloo (host-staged), small batch.  dist_bench verifies all 26 tables of two pipelined steps
-    bit-exactly on every rank before it prints its JSON line; here we check that line."""
+    gloo (host-staged), small batch.  dist_bench verifies all 26 tables bit-exactly on every rank
+    (two pipelined steps for the sharded legs) before it prints its JSON line; here we check that line.
+    rows / whole: sharding forced with --replicate-mb 64; auto: the default placement policy
+    (everything replicated, data-parallel) plus the secondary sharded-exchange leg."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PIMEMB_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    port = {"rows": "29561", "whole": "29562", "auto": "29563"}[mode]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29561" if mode == "rows" else "29562",
+           "--master-addr", "127.0.0.1", "--master-port", port,
            os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3", "--nbatch", "3",
-           "--batch", "4099", "--shard-mode", mode]
+           "--batch", "4099"]
+    if mode != "auto":
+        cmd += ["--shard-mode", mode, "--replicate-mb", "64"]
     res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
-    w = d["config"]["workload"]
-    assert ("5 row-range sharded" in w and "21 tables replicated" in w) if mode == "rows" else \
-           ("5 whole" in w and "21 replicated" in w)
     assert d["roofline"]["bound"] == "hbm"
+    w = d["config"]["workload"]
+    if mode == "rows":
+        assert "5 row-range sharded" in w and "21 tables replicated" in w
+    elif mode == "whole":
+        assert "5 whole" in w and "21 replicated" in w
+    else:
+        assert "replicated on every rank" in d["config"]["parallelism"]
+        sec = d["sharded_exchange"]
+        assert isinstance(sec, dict) and sec["value"] > 0 and "5 whole" in sec["config"]
 
 
 @pytest.mark.parametrize("dim,dtype", [(4, np.float32), (8, np.float32), (32, np.float32), (64, np.float32),
