@@ -571,23 +571,31 @@ def run(args, hbm_peak_gbs: float) -> None:
     hbm = torch.cuda.get_device_properties(dev).total_memory
     auto = getattr(args, "replicate_mb", None) is None
     shard_leg = run_rows if getattr(args, "shard_mode", "whole") == "rows" else run_whole
+    state = {"printed": False, "dog": None}
+
+    def emit(res):
+        if rank == 0 and res is not None and not state["printed"]:
+            state["printed"] = True
+            print(json.dumps(res), flush=True)
+
     if auto and total_bytes <= hbm // 4:
         result = run_dp(args, hbm_peak_gbs, ctx)
         if not getattr(args, "no_exchange_leg", False):
-            # secondary leg: the sharded exchange, fewer steps; a hang must not lose the primary result
+            # secondary leg: the sharded exchange, fewer steps.  A hang (or a rank that dropped out)
+            # must not lose the primary result: after 180 s every rank gives up, rank 0 prints what it has.
             import copy
             a2 = copy.copy(args)
             a2.steps, a2.warmup = min(args.steps, 400), min(args.warmup, 40)
 
             def give_up():
-                if rank == 0 and result is not None:
-                    result["sharded_exchange"] = "timed out after 180 s"
-                    print(json.dumps(result), flush=True)
+                if rank == 0 and result is not None and not isinstance(result.get("sharded_exchange"), dict):
+                    result["sharded_exchange"] = result.get("sharded_exchange") or "timed out after 180 s"
+                emit(result)
                 os._exit(0)
 
-            dog = threading.Timer(180.0, give_up)
-            dog.daemon = True
-            dog.start()
+            state["dog"] = threading.Timer(180.0, give_up)
+            state["dog"].daemon = True
+            state["dog"].start()
             try:
                 sec = shard_leg(a2, hbm_peak_gbs, ctx, 64 << 20)
                 if rank == 0:
@@ -596,11 +604,11 @@ def run(args, hbm_peak_gbs: float) -> None:
             except Exception as ex:  # noqa: BLE001 -- the primary result stands on its own
                 if rank == 0:
                     result["sharded_exchange"] = f"failed: {type(ex).__name__}: {ex}"
-            dog.cancel()
     else:
         rep_mb = 64 if auto else int(args.replicate_mb)
         result = shard_leg(args, hbm_peak_gbs, ctx, rep_mb << 20)
-    if rank == 0:
-        print(json.dumps(result), flush=True)
+    emit(result)
     dist.barrier()
+    if state["dog"] is not None:
+        state["dog"].cancel()
     dist.destroy_process_group()
