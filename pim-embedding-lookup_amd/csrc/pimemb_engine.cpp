@@ -279,7 +279,7 @@ int ensure_slot(DescSlot &sl, size_t n) {
         sl.d = nullptr;
         sl.cap = 0;
         size_t cap = n < 8192 ? 8192 : n + n / 4;
-        HIP_TRY(hipHostMalloc((void **)&sl.h, cap, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&sl.h, cap, hipHostMallocMapped | hipHostMallocCoherent));
         HIP_TRY(hipMalloc((void **)&sl.d, cap));
         sl.cap = cap;
     }
@@ -288,7 +288,8 @@ int ensure_slot(DescSlot &sl, size_t n) {
 }
 
 // Transient launch over device-resident buffers described by `r`.
-int launch_resolved(emb_engine *e, Resolved &r, emb_index_type itype, hipStream_t s) {
+int launch_resolved(emb_engine *e, Resolved &r, emb_index_type itype, hipStream_t s,
+                    bool descriptors_in_host_memory = false) {
     if (r.descs.empty()) return EMB_OK;
     std::lock_guard<std::mutex> lk(e->mu);
     DescSlot &sl = e->slots[e->next_slot];
@@ -296,8 +297,12 @@ int launch_resolved(emb_engine *e, Resolved &r, emb_index_type itype, hipStream_
     int rc = ensure_slot(sl, r.image.size());
     if (rc) return rc;
     memcpy(sl.h, r.image.data(), r.image.size());
-    HIP_TRY(hipMemcpyAsync(sl.d, sl.h, r.image.size(), hipMemcpyHostToDevice, s));
-    r.bind(sl.d);
+    if (descriptors_in_host_memory) {
+        r.bind(sl.h);      // small host-pointer call: the kernel's scalar loads read the pinned slot itself
+    } else {
+        HIP_TRY(hipMemcpyAsync(sl.d, sl.h, r.image.size(), hipMemcpyHostToDevice, s));
+        r.bind(sl.d);
+    }
     rc = launch_groups(e, r.groups, itype, s);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(sl.done, s));
@@ -414,7 +419,7 @@ int lookup_host(emb_engine *e, const emb_lookup_desc *descs, uint32_t n, emb_ind
     int rc = resolve(e, descs, n, itype, &hs.d_indices, &hs.d_offsets, &hs.d_out, &r);
     if (rc) return rc;
     // descriptor upload ("query copying" in the reference's stage list) + the fused launch
-    rc = launch_resolved(e, r, itype, s);
+    rc = launch_resolved(e, r, itype, s, hs.zero_copy);
     if (rc) return rc;
     const double t2 = now_us();
     if (timed) HIP_TRY(hipStreamSynchronize(s));
