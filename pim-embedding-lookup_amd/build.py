@@ -36,5 +36,18 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+def build_clamped(out_dir: str) -> str:
+    """Build the input-clamping flavour (-DPIMEMB_CLAMP_INPUTS=1: malformed indices / offsets give garbage
+    rows instead of out-of-bounds accesses, ~2.5 % slower on the headline shape) into out_dir."""
+    out = os.path.join(out_dir, "libpimemb_clamp.so")
+    flags = "-O3 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter -I../../include -I. -DPIMEMB_CLAMP_INPUTS=1"
+    res = subprocess.run(["make", "-C", CSRC_DIR, "-j8", f"CXXFLAGS={flags}", f"OUT={out}",
+                          f"OBJDIR={os.path.join(out_dir, 'obj_clamp')}"],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0 or not os.path.exists(out):
+        raise RuntimeError("building the clamped flavour failed:\n" + res.stdout)
+    return out
+
+
 if __name__ == "__main__":
     print(build(verbose=True))

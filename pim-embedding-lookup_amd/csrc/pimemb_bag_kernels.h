@@ -44,7 +44,7 @@ struct alignas(64) DevDesc {
     float *out;             // float[n_bags][dim]
     uint64_t n_idx;
     uint64_t n_bags;
-    uint64_t nr_rows;       // only read by the validation kernel
+    uint64_t nr_rows;       // row ids are clamped to nr_rows-1 (kClamp); also read by the validation kernel
     uint32_t fixed_pooling; // L > 0: offsets[b] = b*L (load_generator.c:88)
     uint32_t n_tiles;       // ceil(n_bags / bags_per_tile) for this launch geometry
     // hot rows of this table (bag_sum_hot_kernel only; n_hot == 0 switches the LDS path off)
@@ -64,8 +64,10 @@ using f32x8 = __attribute__((ext_vector_type(8))) float;
 // Compile-time knobs of the bag kernels.
 template <int BLOCK = 256, int UNROLL = 8, bool NT_STORE = false, bool NT_META = false,
           int ONEHOT_INFLIGHT = 8, int MIN_WAVES = 1, int BATCHES = 1, bool NT_ROW = false,
-          bool SPECULATE = false, bool IDX_SHUFFLE = false>
+          bool SPECULATE = false, bool IDX_SHUFFLE = false, bool CLAMP = false>
 struct BagCfg {
+    static constexpr bool kClamp = CLAMP;         // clamp row ids to the table and bag ends to n_idx: malformed
+                                                  // input gives garbage rows, never an out-of-bounds access
     static constexpr bool kIdxShuffle = IDX_SHUFFLE; // lane group loads a window of indices coalesced, broadcasts by shuffle
     static constexpr bool kSpeculate = SPECULATE; // prefetch indices[bag] before the bounds arrive
     static constexpr int kMinWaves = MIN_WAVES;   // __launch_bounds__ 2nd arg: waves per SIMD wanted
@@ -139,6 +141,22 @@ __device__ __forceinline__ T load_meta(const T *p) {
         return __builtin_nontemporal_load(p);
     else
         return *p;
+}
+
+// Row id -> row id inside the table.  A 64-bit row id that came from a uint32 index is clamped with
+// one 32-bit min (the high half is known to be zero); int64 indices (negative = huge unsigned) take
+// the 64-bit compare.
+template <bool CLAMP, typename IdxT = int64_t>
+__device__ __forceinline__ uint64_t clamp_row(uint64_t r, uint64_t last_row) {
+    if constexpr (!CLAMP) {
+        return r;
+    } else if constexpr (sizeof(IdxT) == 4) {
+        const uint32_t last32 = last_row > 0xffffffffull ? 0xffffffffu : (uint32_t)last_row;
+        const uint32_t r32 = (uint32_t)r;
+        return (uint64_t)(r32 < last32 ? r32 : last32);
+    } else {
+        return r < last_row ? r : last_row;
+    }
 }
 
 template <bool NT>
@@ -291,7 +309,7 @@ bag_sum_group_kernel(const DevDesc *__restrict__ descs, uint32_t chunks,
     const IdxT *__restrict__ indices = static_cast<const IdxT *>(dp->indices);
     const IdxT *__restrict__ offsets = static_cast<const IdxT *>(dp->offsets);
     float *__restrict__ out = dp->out;
-    const uint64_t n_idx = dp->n_idx, n_bags = dp->n_bags;
+    const uint64_t n_idx = dp->n_idx, n_bags = dp->n_bags, last_row = dp->nr_rows - 1;
     const uint32_t fixed_pooling = dp->fixed_pooling, n_tiles = dp->n_tiles;
 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -312,10 +330,11 @@ bag_sum_group_kernel(const DevDesc *__restrict__ descs, uint32_t chunks,
             p = bag * fixed_pooling;
             e = p + fixed_pooling;
         }
+        if (Cfg::kClamp && e > n_idx) e = n_idx;
         typename Ops::Acc acc = Ops::zero();
         walk_bag<IdxT, LPR, Cfg, Ops>(indices, p, e, sub, grp, live, acc, NoProbe{},
                                       [&](uint64_t r, uint32_t) -> u32x4 {
-                                          return load_row<Cfg::kNtRow>(wsub + r * row_bytes);
+                                          return load_row<Cfg::kNtRow>(wsub + clamp_row<Cfg::kClamp, IdxT>(r, last_row) * row_bytes);
                                       });
         if (live) Ops::template store<Cfg::kNtStore>(acc, out + bag * out_stride + sub * Ops::kFloatsPerLane);
     }
@@ -341,7 +360,7 @@ bag_sum_wavebatch_kernel(const DevDesc *__restrict__ descs, uint32_t chunks,
     const IdxT *__restrict__ indices = static_cast<const IdxT *>(dp->indices);
     const IdxT *__restrict__ offsets = static_cast<const IdxT *>(dp->offsets);
     float *__restrict__ out = dp->out;
-    const uint64_t n_idx = dp->n_idx, n_bags = dp->n_bags;
+    const uint64_t n_idx = dp->n_idx, n_bags = dp->n_bags, last_row = dp->nr_rows - 1;
     const uint32_t fixed_pooling = dp->fixed_pooling, n_tiles = dp->n_tiles;
 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -382,6 +401,10 @@ bag_sum_wavebatch_kernel(const DevDesc *__restrict__ descs, uint32_t chunks,
                 st[q] = (mb < n_bags ? mb : n_bags) * fixed_pooling;
                 en = (mb + 1 < n_bags ? mb + 1 : n_bags) * fixed_pooling;
             }
+            if (Cfg::kClamp) {                       // malformed offsets: keep [st, en) inside [0, n_idx]
+                if (en > n_idx) en = n_idx;
+                if (st[q] > en) st[q] = en;
+            }
             len[q] = (uint32_t)(en - st[q]);
             small = small && (len[q] <= 1u);
         }
@@ -409,7 +432,7 @@ bag_sum_wavebatch_kernel(const DevDesc *__restrict__ descs, uint32_t chunks,
 #pragma unroll
                     for (uint32_t jj = 0; jj < RU; jj++) {
                         const uint32_t src = (j0 + jj) * BPR + grp;
-                        const uint64_t r = shfl_index<IdxT>(my[q], src);
+                        const uint64_t r = clamp_row<Cfg::kClamp, IdxT>(shfl_index<IdxT>(my[q], src), last_row);
                         has[q][jj] = shfl_u32(len[q], src) != 0u;
                         v[q][jj] = u32x4{0u, 0u, 0u, 0u};
                         if (has[q][jj] && lane_live) v[q][jj] = load_row<Cfg::kNtRow>(wsub + r * row_bytes);
@@ -448,12 +471,13 @@ bag_sum_wavebatch_kernel(const DevDesc *__restrict__ descs, uint32_t chunks,
                         for (int k = 0; k < U; k++) r[k] = (uint64_t)load_meta<Cfg::kNtMeta>(indices + p + k);
                         u32x4 v[U];
 #pragma unroll
-                        for (int k = 0; k < U; k++) v[k] = load_row<Cfg::kNtRow>(wsub + r[k] * row_bytes);
+                        for (int k = 0; k < U; k++)
+                            v[k] = load_row<Cfg::kNtRow>(wsub + clamp_row<Cfg::kClamp, IdxT>(r[k], last_row) * row_bytes);
 #pragma unroll
                         for (int k = 0; k < U; k++) Ops::add(acc, v[k]);
                     }
                     for (; p < e; p++) {
-                        const uint64_t r = (uint64_t)load_meta<Cfg::kNtMeta>(indices + p);
+                        const uint64_t r = clamp_row<Cfg::kClamp, IdxT>((uint64_t)load_meta<Cfg::kNtMeta>(indices + p), last_row);
                         Ops::add(acc, load_row<Cfg::kNtRow>(wsub + r * row_bytes));
                     }
                     Ops::template store<Cfg::kNtStore>(acc, out + bag * out_stride + sub * Ops::kFloatsPerLane);
@@ -508,6 +532,7 @@ bag_sum_hot_kernel(const DevDesc *__restrict__ descs, uint32_t chunks) {
     const uint64_t n_idx = dp->n_idx, n_bags = dp->n_bags;
     const uint32_t fixed_pooling = dp->fixed_pooling, n_tiles = dp->n_tiles;
     const uint32_t n_hot = dp->n_hot, hot_log2 = dp->hot_log2;
+    const uint64_t last_row = dp->nr_rows - 1;
 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t sub = lane & (LPR - 1), grp = lane / LPR;
@@ -533,7 +558,7 @@ bag_sum_hot_kernel(const DevDesc *__restrict__ descs, uint32_t chunks) {
     // one gathered row piece: LDS if the row is hot, L2/HBM otherwise
     auto fetch = [&](uint64_t r, uint32_t tok) -> u32x4 {
         if (tok & 0x80000000u) return lsub[(tok & 0x7fffffffu) * chunks];
-        return load_row<Cfg::kNtRow>(wsub + r * row_bytes);
+        return load_row<Cfg::kNtRow>(wsub + clamp_row<Cfg::kClamp, IdxT>(r, last_row) * row_bytes);
     };
 
     const bool live = sub < chunks;
@@ -548,6 +573,7 @@ bag_sum_hot_kernel(const DevDesc *__restrict__ descs, uint32_t chunks) {
                 p = bag * fixed_pooling;
                 e = p + fixed_pooling;
             }
+            if (Cfg::kClamp && e > n_idx) e = n_idx;
             typename Ops::Acc acc = Ops::zero();
             walk_bag<IdxT, LPR, Cfg, Ops>(indices, p, e, sub, grp, live, acc, probe, fetch);
             if (live) Ops::template store<Cfg::kNtStore>(acc, out + bag * out_stride + sub * Ops::kFloatsPerLane);

@@ -12,12 +12,21 @@ namespace {
 //   pooled launches and small batches: lane-group kernel, 256-thread workgroups, a lane group
 //                 loads a window of indices coalesced and broadcasts them by shuffle (-8 % on
 //                 dim-128 pooling-32 Zipf, neutral elsewhere).
+// Like the reference (an out-of-range index is a wild MRAM read, emb_dpu_lookup.c:113) the shipped
+// kernels do not check indices or offsets: clamping row ids and bag ends costs 2.5 % on the headline
+// shape (tools/tune_bag_kernels.hip).  Build with -DPIMEMB_CLAMP_INPUTS=1 for kernels that turn
+// malformed input into garbage rows instead of out-of-bounds accesses; emb_validate_inputs checks
+// inputs explicitly.
+#ifndef PIMEMB_CLAMP_INPUTS
+#define PIMEMB_CLAMP_INPUTS 0
+#endif
+constexpr bool kClampInputs = PIMEMB_CLAMP_INPUTS != 0;
 //                        BLOCK U  ntS   ntM   inflight minW batches ntRow  spec
-using WaveCfg = BagCfg<64, 8, true, false, 8, 8, 1, false, true>;
+using WaveCfg = BagCfg<64, 8, true, false, 8, 8, 1, false, true, false, kClampInputs>;
 // very big one-hot launches: two 64-bag batches per wavefront (8 gathers in flight per lane), 128-thread
 // workgroups, unroll 4 on the general path so the kernel still fits 64 VGPRs without spilling: -4.5 %
-using Wave2Cfg = BagCfg<128, 4, true, false, 8, 8, 2, false, true>;
-using GroupCfg = BagCfg<256, 8, true, false, 8, 1, 1, false, false, /*IDX_SHUFFLE*/ true>;
+using Wave2Cfg = BagCfg<128, 4, true, false, 8, 8, 2, false, true, false, kClampInputs>;
+using GroupCfg = BagCfg<256, 8, true, false, 8, 1, 1, false, false, /*IDX_SHUFFLE*/ true, kClampInputs>;
 constexpr int kBlock = 256;  // helper kernels below
 
 template <typename IdxT, int DT, int L>

@@ -163,17 +163,13 @@ int main(int argc, char **argv) {
         }
 
     std::vector<Variant> vars;
-    //                        BLOCK U  ntS   ntM  inflight minW batches ntRow spec  idxShuffle
+    //                        BLOCK U  ntS   ntM  inflight minW batches ntRow spec  idxShuffle clamp
     vars.push_back(make_variant<BagCfg<256, 8, false, false, 8>, false>("v1 group blk256"));
     auto add = [&](Variant v) { v.xrounds = 1; vars.push_back(v); };
-    add(make_variant<BagCfg<64, 8, true, false, 8, 8, 1, false, true>, true>("v2 SHIP XCD (blk64 minw8 b1)", true));
-    add(make_variant<BagCfg<64, 8, true, false, 8, 8, 2, false, true>, true>("v2 blk64 minw8 b2 XCD", true));
-    add(make_variant<BagCfg<64, 8, true, false, 8, 7, 2, false, true>, true>("v2 blk64 minw7 b2 XCD", true));
-    add(make_variant<BagCfg<128, 8, true, false, 8, 8, 2, false, true>, true>("v2 blk128 minw8 b2 XCD", true));
-    add(make_variant<BagCfg<128, 8, true, false, 8, 7, 2, false, true>, true>("v2 blk128 minw7 b2 XCD", true));
-    add(make_variant<BagCfg<128, 8, true, false, 8, 7, 1, false, true>, true>("v2 blk128 minw7 b1 XCD", true));
-    add(make_variant<BagCfg<128, 4, true, false, 8, 8, 2, false, true>, true>("v2 blk128 minw8 b2 U4 XCD", true));
-    add(make_variant<BagCfg<64, 4, true, false, 8, 8, 2, false, true>, true>("v2 blk64 minw8 b2 U4 XCD", true));
+    add(make_variant<BagCfg<128, 4, true, false, 8, 8, 2, false, true, false, true>, true>("v2 SHIP b2 XCD clamp", true));
+    add(make_variant<BagCfg<128, 4, true, false, 8, 8, 2, false, true, false, false>, true>("v2 SHIP b2 XCD no-clamp", true));
+    add(make_variant<BagCfg<64, 8, true, false, 8, 8, 1, false, true, false, true>, true>("v2 b1 XCD clamp", true));
+    add(make_variant<BagCfg<64, 8, true, false, 8, 8, 1, false, true, false, false>, true>("v2 b1 XCD no-clamp", true));
     { Variant v; v.name = "ABLATION null kernel same grid"; v.fn = launch_null; v.checked = false; vars.push_back(v); }
     {
         Variant v; v.name = "ABLATION store-only (ntS)"; v.fn = launch_store_only; v.checked = false; vars.push_back(v);

@@ -130,8 +130,9 @@ class Plan:
 class EmbeddingEngine:
     """One engine per GPU: tables resident in HBM, lookups as fused HIP launches."""
 
-    def __init__(self, device: int = -1, max_tables: int = 1024):
-        self._L = _l.load()
+    def __init__(self, device: int = -1, max_tables: int = 1024, lib_path: str | None = None):
+        # lib_path: another build of libpimemb.so (e.g. the -DPIMEMB_CLAMP_INPUTS=1 flavour)
+        self._L = _l.load(lib_path)
         cfg = _l.EmbConfig(device, max_tables, 0)
         h = C.c_void_p()
         _l.check(self._L.emb_create(C.byref(cfg), C.byref(h)))

@@ -649,3 +649,33 @@ def test_plan_lifetime_guards(pel):
         e.close()
     plan.destroy()
     e.close()
+
+
+def test_clamped_build_survives_malformed_input(pel, oracle, tmp_path):
+    """-DPIMEMB_CLAMP_INPUTS=1 flavour: out-of-range indices and broken offsets must not fault the GPU;
+    bags with clean inputs still get exact results.  (The shipped flavour, like the reference, does
+    not check: emb_dpu_lookup.c:113.)"""
+    import shutil
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc on this box")
+    from importlib import import_module
+    path = import_module("pim-embedding-lookup_amd.build").build_clamped(str(tmp_path))
+    e = pel.EmbeddingEngine(device=0, max_tables=4, lib_path=path)
+    rng = np.random.default_rng(17)
+    tab = rng.standard_normal((1000, 16)).astype(np.float32)
+    e.load_table(0, tab)
+    for B in (300, 140_000):                       # lane-group kernel, wave-batch kernel
+        idx = rng.integers(0, 1000, size=B).astype(np.int64)
+        off = np.arange(B, dtype=np.int64)
+        bad = idx.copy()
+        bad[::7] = 2**40
+        bad[3::11] = -3
+        got = e.lookup(0, bad, off)
+        clean = np.ones(B, bool); clean[::7] = False; clean[3::11] = False
+        assert np.array_equal(got[clean], tab[idx[clean]])
+        assert np.array_equal(got[~clean], np.tile(tab[999], ((~clean).sum(), 1)))   # clamped to the last row
+        # offsets running past n_indices / going backwards: no fault, clean prefix still exact
+        off2 = off.copy(); off2[B // 2:] = off2[B // 2:][::-1] + 10 * B
+        got = e.lookup(0, idx, off2)
+        assert np.array_equal(got[: B // 2 - 1], tab[idx[: B // 2 - 1]])
+    e.close()
