@@ -188,12 +188,20 @@ __device__ __forceinline__ uint64_t shfl_index(IdxT v, uint32_t src) {
 struct XcdSegDev {
     uint32_t desc, tile0, slot_begin, slot_end;
 };
-__device__ __forceinline__ bool decode_block(const uint32_t *__restrict__ xmap, uint32_t *desc_i,
-                                             uint32_t *tile) {
+constexpr uint32_t kXmapDirect = 0x80000000u;   // flag in the `chunks` kernel argument: xmap is a per-workgroup table
+
+__device__ __forceinline__ bool decode_block(const uint32_t *__restrict__ xmap, uint32_t direct,
+                                             uint32_t *desc_i, uint32_t *tile) {
     if (xmap == nullptr) {
         *desc_i = blockIdx.y;
         *tile = blockIdx.x;
         return true;
+    }
+    if (direct) {   // one 8-byte scalar load: {descriptor, tile} of this workgroup (0xffffffff = idle slot)
+        const uint2 ent = reinterpret_cast<const uint2 *>(xmap)[blockIdx.x];
+        *desc_i = ent.x;
+        *tile = ent.y;
+        return ent.x != 0xffffffffu;
     }
     const uint32_t cls = blockIdx.x & 7u, slot = blockIdx.x >> 3;
     const uint32_t ns = xmap[cls];
@@ -295,7 +303,7 @@ struct NoProbe {
 // ---- v1: one lane group per bag, no cross-lane traffic (kept as the A/B baseline) -------------
 template <typename IdxT, int DT, int LPR, class Cfg>
 __global__ void __launch_bounds__(Cfg::kBlock)
-bag_sum_group_kernel(const DevDesc *__restrict__ descs, uint32_t chunks,
+bag_sum_group_kernel(const DevDesc *__restrict__ descs, uint32_t chunks_arg,
                      const uint32_t *__restrict__ xmap) {
     using Ops = RowOps<DT>;
     constexpr uint32_t kWaves = Cfg::kBlock / 64;
@@ -303,7 +311,8 @@ bag_sum_group_kernel(const DevDesc *__restrict__ descs, uint32_t chunks,
     constexpr uint32_t BAGS_PER_TILE = BPW * kWaves;
 
     uint32_t desc_i, tile;
-    if (!decode_block(xmap, &desc_i, &tile)) return;
+    if (!decode_block(xmap, chunks_arg & kXmapDirect, &desc_i, &tile)) return;
+    const uint32_t chunks = chunks_arg & ~kXmapDirect;
     const DevDesc *dp = descs + desc_i;
     const char *__restrict__ weights = static_cast<const char *>(dp->weights);
     const IdxT *__restrict__ indices = static_cast<const IdxT *>(dp->indices);
@@ -343,7 +352,7 @@ bag_sum_group_kernel(const DevDesc *__restrict__ descs, uint32_t chunks,
 // ---- v2: wave batches of 64 bags, coalesced bounds, shuffle-distributed, one-hot fast path -------
 template <typename IdxT, int DT, int LPR, class Cfg>
 __global__ void __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves)
-bag_sum_wavebatch_kernel(const DevDesc *__restrict__ descs, uint32_t chunks,
+bag_sum_wavebatch_kernel(const DevDesc *__restrict__ descs, uint32_t chunks_arg,
                          const uint32_t *__restrict__ xmap) {
     using Ops = RowOps<DT>;
     constexpr uint32_t kWaves = Cfg::kBlock / 64;
@@ -354,7 +363,8 @@ bag_sum_wavebatch_kernel(const DevDesc *__restrict__ descs, uint32_t chunks,
     constexpr uint32_t RU = (ROUNDS < (uint32_t)Cfg::kOneHot) ? ROUNDS : (uint32_t)Cfg::kOneHot;
 
     uint32_t desc_i, tile;
-    if (!decode_block(xmap, &desc_i, &tile)) return;
+    if (!decode_block(xmap, chunks_arg & kXmapDirect, &desc_i, &tile)) return;
+    const uint32_t chunks = chunks_arg & ~kXmapDirect;
     const DevDesc *dp = descs + desc_i;
     const char *__restrict__ weights = static_cast<const char *>(dp->weights);
     const IdxT *__restrict__ indices = static_cast<const IdxT *>(dp->indices);

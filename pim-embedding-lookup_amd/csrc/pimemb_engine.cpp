@@ -112,6 +112,7 @@ struct PlanGroup {
     KernelKind kind = pimemb::KERNEL_WAVEBATCH;
     uint32_t *d_xmap = nullptr;      // XCD-aware workgroup map, or null (2-D grid)
     uint32_t xgrid = 0;
+    bool xdirect = false;            // map expanded to one {descriptor, tile} entry per workgroup
     size_t desc_off = 0, xmap_off = 0;  // byte offsets of this group's pieces in the launch image
     std::vector<uint32_t> xmap_words;
 };
@@ -248,6 +249,12 @@ int resolve(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs, emb_i
             if (total_tiles + 8 * (uint64_t)g.n > 0x7fffffffull)
                 return fail(EMB_ERR_UNSUPPORTED, "launch too large for one grid");
             g.xgrid = pimemb::build_xcd_map(tiles_of, bytes_of, &g.xmap_words, 1);
+            if (g.xgrid <= (1u << 20)) {   // <= 8 MB of map: one scalar load per workgroup instead of a search
+                std::vector<uint32_t> direct;
+                pimemb::expand_xcd_map(g.xmap_words, g.xgrid, &direct);
+                g.xmap_words.swap(direct);
+                g.xdirect = true;
+            }
         } else if (g.n > 65535u) {
             return fail(EMB_ERR_UNSUPPORTED, "more than 65535 descriptors of one shape");
         }
@@ -261,7 +268,7 @@ int launch_groups(emb_engine *e, const std::vector<PlanGroup> &groups, emb_index
                   hipStream_t s) {
     for (const PlanGroup &g : groups) {
         HIP_TRY(pimemb::launch_bag_sum(g.d_descs, g.n, g.max_tiles, g.dtype, itype, g.geom, g.kind, g.d_xmap,
-                                       g.xgrid, s));
+                                       g.xgrid, g.xdirect, s));
         e->n_kernel_launches.fetch_add(1, std::memory_order_relaxed);
     }
     return EMB_OK;

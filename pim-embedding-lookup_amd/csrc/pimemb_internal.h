@@ -33,10 +33,11 @@ KernelKind choose_kernel(uint64_t total_bags, uint64_t total_indices, const Laun
 
 // Enqueue the fused gather + segment-sum over `n_descs` descriptors (all of one dtype/dim).
 // d_xmap == nullptr: 2-D grid (max_tiles x n_descs).  Otherwise the XCD-aware 1-D map built by
-// pimemb_xcd_map.h with `xgrid` workgroups.  Pure enqueue: no allocation, copy or sync.
+// pimemb_xcd_map.h with `xgrid` workgroups (xdirect: expanded to one entry per workgroup).
+// Pure enqueue: no allocation, copy or sync.
 hipError_t launch_bag_sum(const DevDesc *d_descs, uint32_t n_descs, uint32_t max_tiles,
                           emb_dtype dtype, emb_index_type itype, const LaunchGeom &g,
-                          KernelKind kind, const uint32_t *d_xmap, uint32_t xgrid,
+                          KernelKind kind, const uint32_t *d_xmap, uint32_t xgrid, bool xdirect,
                           hipStream_t stream);
 
 // Scatter an int32 column (device buffer, nr_rows entries) into column `col` of a row-major

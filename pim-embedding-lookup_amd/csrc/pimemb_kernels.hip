@@ -30,9 +30,10 @@ using GroupCfg = BagCfg<256, 8, true, false, 8, 1, 1, false, false, /*IDX_SHUFFL
 constexpr int kBlock = 256;  // helper kernels below
 
 template <typename IdxT, int DT, int L>
-void launch_one(const DevDesc *d, uint32_t n, uint32_t max_tiles, const LaunchGeom &g, KernelKind kind,
-                const uint32_t *xmap, uint32_t xgrid, hipStream_t s) {
+void launch_one(const DevDesc *d, uint32_t n, uint32_t max_tiles, const LaunchGeom &g_in, KernelKind kind,
+                const uint32_t *xmap, uint32_t xgrid, bool xdirect, hipStream_t s) {
     const dim3 grid = xmap ? dim3(xgrid, 1, 1) : dim3(max_tiles, n, 1);
+    struct { uint32_t chunks; } g{g_in.chunks | ((xmap && xdirect) ? kXmapDirect : 0u)};
     if (kind == KERNEL_WAVEBATCH)
         hipLaunchKernelGGL((bag_sum_wavebatch_kernel<IdxT, DT, L, WaveCfg>), grid, dim3(WaveCfg::kBlock), 0,
                            s, d, g.chunks, xmap);
@@ -46,11 +47,11 @@ void launch_one(const DevDesc *d, uint32_t n, uint32_t max_tiles, const LaunchGe
 
 template <typename IdxT, int DT>
 hipError_t launch_lpr(const DevDesc *d, uint32_t n, uint32_t max_tiles, const LaunchGeom &g,
-                      KernelKind kind, const uint32_t *xmap, uint32_t xgrid, hipStream_t s) {
+                      KernelKind kind, const uint32_t *xmap, uint32_t xgrid, bool xdirect, hipStream_t s) {
     switch (g.lanes_per_row) {
 #define PIMEMB_CASE(L)                                                          \
     case L:                                                                     \
-        launch_one<IdxT, DT, L>(d, n, max_tiles, g, kind, xmap, xgrid, s);      \
+        launch_one<IdxT, DT, L>(d, n, max_tiles, g, kind, xmap, xgrid, xdirect, s); \
         break;
         PIMEMB_CASE(1)
         PIMEMB_CASE(2)
@@ -69,14 +70,14 @@ hipError_t launch_lpr(const DevDesc *d, uint32_t n, uint32_t max_tiles, const La
 template <typename IdxT>
 hipError_t launch_dtype(const DevDesc *d, uint32_t n, uint32_t max_tiles, emb_dtype dtype,
                         const LaunchGeom &g, KernelKind kind, const uint32_t *xmap, uint32_t xgrid,
-                        hipStream_t s) {
+                        bool xdirect, hipStream_t s) {
     switch (dtype) {
         case EMB_F32:
-            return launch_lpr<IdxT, EMB_F32>(d, n, max_tiles, g, kind, xmap, xgrid, s);
+            return launch_lpr<IdxT, EMB_F32>(d, n, max_tiles, g, kind, xmap, xgrid, xdirect, s);
         case EMB_F16:
-            return launch_lpr<IdxT, EMB_F16>(d, n, max_tiles, g, kind, xmap, xgrid, s);
+            return launch_lpr<IdxT, EMB_F16>(d, n, max_tiles, g, kind, xmap, xgrid, xdirect, s);
         case EMB_FIXED32:
-            return launch_lpr<IdxT, EMB_FIXED32>(d, n, max_tiles, g, kind, xmap, xgrid, s);
+            return launch_lpr<IdxT, EMB_FIXED32>(d, n, max_tiles, g, kind, xmap, xgrid, xdirect, s);
     }
     return hipErrorInvalidValue;
 }
@@ -259,13 +260,13 @@ KernelKind choose_kernel(uint64_t total_bags, uint64_t total_indices, const Laun
 
 hipError_t launch_bag_sum(const DevDesc *d_descs, uint32_t n_descs, uint32_t max_tiles,
                           emb_dtype dtype, emb_index_type itype, const LaunchGeom &g,
-                          KernelKind kind, const uint32_t *d_xmap, uint32_t xgrid,
+                          KernelKind kind, const uint32_t *d_xmap, uint32_t xgrid, bool xdirect,
                           hipStream_t stream) {
     if (n_descs == 0 || max_tiles == 0) return hipSuccess;
     if (d_xmap == nullptr && n_descs > 65535u) return hipErrorInvalidValue;
     if (itype == EMB_IDX_U32)
-        return launch_dtype<uint32_t>(d_descs, n_descs, max_tiles, dtype, g, kind, d_xmap, xgrid, stream);
-    return launch_dtype<int64_t>(d_descs, n_descs, max_tiles, dtype, g, kind, d_xmap, xgrid, stream);
+        return launch_dtype<uint32_t>(d_descs, n_descs, max_tiles, dtype, g, kind, d_xmap, xgrid, xdirect, stream);
+    return launch_dtype<int64_t>(d_descs, n_descs, max_tiles, dtype, g, kind, d_xmap, xgrid, xdirect, stream);
 }
 
 hipError_t launch_scatter_column(int32_t *table, const int32_t *column, uint64_t nr_rows,

@@ -134,4 +134,23 @@ inline uint32_t build_xcd_map(const std::vector<uint32_t> &n_tiles, const std::v
     return max_slots * kXcdGroups;
 }
 
+// Expand a segment map (build_xcd_map) into the per-workgroup table the kernels read with ONE scalar
+// load: entry[block] = {descriptor, tile}, 0xffffffff = idle slot.  8 bytes per workgroup.
+inline void expand_xcd_map(const std::vector<uint32_t> &words, uint32_t grid, std::vector<uint32_t> *direct) {
+    direct->assign((size_t)grid * 2, 0xffffffffu);
+    for (uint32_t cls = 0; cls < kXcdGroups; cls++) {
+        const uint32_t ns = words[cls], base = words[8 + cls];
+        for (uint32_t i = 0; i < ns; i++) {
+            const uint32_t *sg = &words[16 + 4 * (base + i)];
+            for (uint32_t slot = sg[2]; slot < sg[3]; slot++) {
+                const uint32_t block = slot * kXcdGroups + cls;
+                if (block < grid) {
+                    (*direct)[2 * (size_t)block] = sg[0];
+                    (*direct)[2 * (size_t)block + 1] = sg[1] + (slot - sg[2]);
+                }
+            }
+        }
+    }
+}
+
 }  // namespace pimemb

@@ -94,6 +94,7 @@ struct Variant {
     uint32_t bags_per_tile = 256;
     LaunchFn fn = nullptr;
     bool xcd = false;            // use the XCD-aware 1-D map (pimemb_xcd_map.h)
+    bool direct = false;         // ... expanded to a per-workgroup table
     uint32_t xrounds = 4;
     bool checked = true;         // ablations are timing-only
     uint32_t *d_xmap = nullptr;
@@ -101,13 +102,14 @@ struct Variant {
     std::vector<float> us;
 };
 
+static uint32_t g_direct_flag = 0;
 template <class Cfg, bool WAVEBATCH, int LPR>
 void do_launch(const DevDesc *d, uint32_t n, uint32_t tiles, const uint32_t *xmap, uint32_t xgrid, hipStream_t s) {
     dim3 grid = xmap ? dim3(xgrid, 1, 1) : dim3(tiles, n, 1), block(Cfg::kBlock, 1, 1);
     if (WAVEBATCH)
-        hipLaunchKernelGGL((bag_sum_wavebatch_kernel<uint32_t, EMB_F32, LPR, Cfg>), grid, block, 0, s, d, (uint32_t)LPR, xmap);
+        hipLaunchKernelGGL((bag_sum_wavebatch_kernel<uint32_t, EMB_F32, LPR, Cfg>), grid, block, 0, s, d, (uint32_t)LPR | g_direct_flag, xmap);
     else
-        hipLaunchKernelGGL((bag_sum_group_kernel<uint32_t, EMB_F32, LPR, Cfg>), grid, block, 0, s, d, (uint32_t)LPR, xmap);
+        hipLaunchKernelGGL((bag_sum_group_kernel<uint32_t, EMB_F32, LPR, Cfg>), grid, block, 0, s, d, (uint32_t)LPR | g_direct_flag, xmap);
 }
 
 template <class Cfg, bool WAVEBATCH, int LPR = 4>
@@ -165,11 +167,12 @@ int main(int argc, char **argv) {
     std::vector<Variant> vars;
     //                        BLOCK U  ntS   ntM  inflight minW batches ntRow spec  idxShuffle clamp
     vars.push_back(make_variant<BagCfg<256, 8, false, false, 8>, false>("v1 group blk256"));
-    auto add = [&](Variant v) { v.xrounds = 1; vars.push_back(v); };
-    add(make_variant<BagCfg<128, 4, true, false, 8, 8, 2, false, true, false, true>, true>("v2 SHIP b2 XCD clamp", true));
-    add(make_variant<BagCfg<128, 4, true, false, 8, 8, 2, false, true, false, false>, true>("v2 SHIP b2 XCD no-clamp", true));
-    add(make_variant<BagCfg<64, 8, true, false, 8, 8, 1, false, true, false, true>, true>("v2 b1 XCD clamp", true));
-    add(make_variant<BagCfg<64, 8, true, false, 8, 8, 1, false, true, false, false>, true>("v2 b1 XCD no-clamp", true));
+    auto add = [&](Variant v, bool direct) { v.xrounds = 1; v.direct = direct; vars.push_back(v); };
+    add(make_variant<BagCfg<128, 4, true, false, 8, 8, 2, false, true>, true>("v2 SHIP b2 XCD segments", true), false);
+    add(make_variant<BagCfg<128, 4, true, false, 8, 8, 2, false, true>, true>("v2 SHIP b2 XCD direct", true), true);
+    add(make_variant<BagCfg<64, 8, true, false, 8, 8, 1, false, true>, true>("v2 b1 XCD segments", true), false);
+    add(make_variant<BagCfg<64, 8, true, false, 8, 8, 1, false, true>, true>("v2 b1 XCD direct", true), true);
+    add(make_variant<BagCfg<64, 4, true, false, 8, 8, 2, false, true>, true>("v2 blk64 b2 U4 XCD direct", true), true);
     { Variant v; v.name = "ABLATION null kernel same grid"; v.fn = launch_null; v.checked = false; vars.push_back(v); }
     {
         Variant v; v.name = "ABLATION store-only (ntS)"; v.fn = launch_store_only; v.checked = false; vars.push_back(v);
@@ -205,6 +208,11 @@ int main(int argc, char **argv) {
         std::vector<uint64_t> bytes(T);
         for (uint32_t t = 0; t < T; t++) bytes[t] = kKaggleRows[t] * D * 4;
         vars[v].xgrid = build_xcd_map(nt, bytes, &words, vars[v].xrounds);
+        if (vars[v].direct) {
+            std::vector<uint32_t> d;
+            expand_xcd_map(words, vars[v].xgrid, &d);
+            words.swap(d);
+        }
         CK(hipMalloc((void **)&vars[v].d_xmap, words.size() * 4));
         CK(hipMemcpy(vars[v].d_xmap, words.data(), words.size() * 4, hipMemcpyHostToDevice));
     }
@@ -216,6 +224,7 @@ int main(int argc, char **argv) {
     for (size_t v = 0; v < vars.size(); v++) {
         if (!vars[v].checked) continue;
         for (uint32_t t = 0; t < T; t++) CK(hipMemsetAsync(d_out[0][t], 0xff, out_bytes, s));
+        g_direct_flag = vars[v].direct ? kXmapDirect : 0u;
         vars[v].fn(d_desc[v][0], T, tiles[v], vars[v].d_xmap, vars[v].xgrid, s);
         CK(hipGetLastError());
         CK(hipStreamSynchronize(s));
@@ -234,6 +243,7 @@ int main(int argc, char **argv) {
     CK(hipEventCreate(&e1));
     for (int r = -1; r < rounds; r++) {  // round -1 = warm-up
         for (size_t v = 0; v < vars.size(); v++) {
+            g_direct_flag = vars[v].direct ? kXmapDirect : 0u;
             CK(hipEventRecord(e0, s));
             for (int i = 0; i < iters; i++) vars[v].fn(d_desc[v][i % NB], T, tiles[v], vars[v].d_xmap, vars[v].xgrid, s);
             CK(hipEventRecord(e1, s));

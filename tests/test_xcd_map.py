@@ -28,6 +28,16 @@ int main(int argc, char** argv) {
     for (int i = 1; i + 1 < argc; i += 2) { tiles.push_back(atoi(argv[i])); bytes.push_back(strtoull(argv[i + 1], 0, 10)); }
     std::vector<uint32_t> w;
     uint32_t grid = build_xcd_map(tiles, bytes, &w, 1);
+    std::vector<uint32_t> direct;
+    expand_xcd_map(w, grid, &direct);   // the per-workgroup table must agree with the segment decode
+    for (uint32_t b = 0; b < grid; b++) {
+        uint32_t d, t;
+        bool ok = decode(w, b, &d, &t);
+        if (ok != (direct[2 * b] != 0xffffffffu) || (ok && (direct[2 * b] != d || direct[2 * b + 1] != t))) {
+            printf("DIRECT_MISMATCH at %u\n", b);
+            return 1;
+        }
+    }
     std::map<std::pair<uint32_t, uint32_t>, int> seen;
     std::vector<uint32_t> per_class(8, 0);
     std::vector<std::set<uint32_t>> classes_of(tiles.size());
