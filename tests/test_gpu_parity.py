@@ -679,3 +679,42 @@ def test_clamped_build_survives_malformed_input(pel, oracle, tmp_path):
         got = e.lookup(0, idx, off2)
         assert np.array_equal(got[: B // 2 - 1], tab[idx[: B // 2 - 1]])
     e.close()
+
+
+def test_c_programs_against_the_abi(pel):
+    """Plain C / C++ consumers of libpimemb.so, no Python in the loop: the native API example (C99)
+    and the load_generator counterpart over populate_mram / lookup (g++), both self-validating."""
+    import subprocess
+    libdir = os.path.dirname(pel.LIB_PATH)
+    ex = os.path.join(libdir, "native_example")
+    hb = os.path.join(libdir, "emb_host_bench")
+    if not (os.path.exists(ex) and os.path.exists(hb)):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(os.path.dirname(libdir), "csrc"), "-f",
+                               "Makefile.tools"])
+    r = subprocess.run([ex], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "mismatches: 0" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([hb, "4", "16", "20000", "65", "7", "5"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "Validation result: true" in r.stdout, r.stdout + r.stderr
+
+
+def test_many_transient_launches_on_two_streams(pel, eng, oracle):
+    """Device-pointer emb_lookup_batched without a plan: 24 back-to-back calls on two streams reuse
+    the 4-slot descriptor ring; every output must still be right."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(77)
+    tab = rng.standard_normal((3000, 16)).astype(np.float32)
+    eng.load_table(50, tab)
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    cases = []
+    for i in range(24):
+        off, n = pel.workloads.ragged_offsets(rng, 500 + i, 6, dtype=np.int64)
+        idx = rng.integers(0, 3000, size=n).astype(np.int64)
+        ti, to = torch.from_numpy(idx).to(dev), torch.from_numpy(off).to(dev)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(streams[i % 2]):
+            out = eng.lookup(50, ti, to)
+        cases.append((idx, off, out))
+    torch.cuda.synchronize()
+    for idx, off, out in cases:
+        assert np.array_equal(out.cpu().numpy(), oracle.c_bag_sum(tab, idx, off))
