@@ -43,10 +43,15 @@ def parse_args():
     ap.add_argument("--nbatch", type=int, default=8, help="distinct index batches rotated through")
     ap.add_argument("--index-dist", choices=["uniform", "zipf"], default=None,
                     help="default: uniform for c2, zipf(1.2) for c3")
-    ap.add_argument("--workload", choices=["c2", "c3", "c5"], default="c2",
+    ap.add_argument("--workload", choices=["c2", "c3", "c4", "c5"], default="c2",
                     help="c2 = BASELINE configs[1] (the metric's config, default); c3 = configs[2] scaled "
                          "to fit one GPU: 48 tables x 10M rows x dim 128 fp32, B=16384, pooling 32; c5 = one GPU's "
-                         "share of configs[4]: 64 tables x 30M rows x dim 64 fp16, mixed Zipf/uniform, pooling 32")
+                         "share of configs[4]: 64 tables x 30M rows x dim 64 fp16, mixed Zipf/uniform, pooling 32; "
+                         "c4 = configs[3], the Terabyte-shaped 26 tables at dim 128: with --gpus N the row-range "
+                         "sharded exchange, at N=1 the lookups one of 8 ranks serves (its row shards + small tables)")
+    ap.add_argument("--rows-scale", type=float, default=1.0,
+                    help="N>1: shrink every table of the set by this factor (rehearse an 8-rank layout on fewer GPUs)")
+    ap.add_argument("--pooling", type=int, default=None, help="c4 at N=1: indices per bag (default 1; SURVEY asks 1 and 32)")
     ap.add_argument("--tables", type=int, default=None, help="c3: number of tables (default 48)")
     ap.add_argument("--replicate-mb", type=int, default=None,
                     help="N>1: tables up to this size are replicated on every rank, larger ones are sharded. "
@@ -54,9 +59,9 @@ def parse_args():
                          "GPU's HBM (the Kaggle config does), else 64")
     ap.add_argument("--no-exchange-leg", action="store_true",
                     help="N>1, auto policy: skip the secondary sharded-exchange measurement")
-    ap.add_argument("--shard-mode", choices=["whole", "rows"], default="whole",
-                    help="N>1: big tables placed whole on owner ranks (default: fewest enqueues per step) or split "
-                         "by row range over all ranks with GPU-side request routing (balanced xGMI egress)")
+    ap.add_argument("--shard-mode", choices=["whole", "rows"], default=None,
+                    help="N>1: big tables placed whole on owner ranks (default for c2: fewest enqueues per step) or split "
+                         "by row range over all ranks with GPU-side request routing (balanced xGMI egress; default for c4)")
     ap.add_argument("--streams", type=int, default=1,
                     help="N=1: round-robin the independent steps over this many HIP streams (default 1: every "
                          "step on one stream, which is what roofline.kernel_us assumes)")
@@ -110,6 +115,21 @@ def workload_spec(pel, args):
                     name="C5, one GPU's share (512 tables x 50M rows = 3.28 TB does not fit 8 x 288 GB; scaled to "
                          "512 x 30M = 1.97 TB, 64 tables per GPU): %d tables x 30M rows, dim 64 fp16 rows / fp32 "
                          "accumulate, B=%d bags/table, L=32, Zipf(1.2) on even tables, uniform on odd ones" % (T, B))
+    if args.workload == "c4":
+        # what ONE of 8 ranks serves per step: its 1/8 row range of every table above 64 MiB (requests of
+        # all 8 ranks that fall in the range: ~B per table) and the small tables replicated (its own B bags)
+        B = args.batch or pel.workloads.TERABYTE_BATCH
+        L = args.pooling or 1
+        dim = pel.workloads.TERABYTE_DIM
+        rows = [(-(-n // 8) if n * dim * 4 > (64 << 20) else n) for n in pel.workloads.TERABYTE_ROWS]
+        dist = args.index_dist or "uniform"
+        return dict(rows=rows, dim=dim, B=B, L=L, dist=dist,
+                    name="C4, one of 8 ranks' share (26 Criteo-Terabyte-shaped tables, 452 GB as written): row "
+                         "shards 1/8 of the %d tables above 64 MiB + %d small tables whole, %.1f GB, dim 128 fp32, "
+                         "B=%d bags/table, L=%d, %s indices"
+                         % (sum(n * dim * 4 > (64 << 20) for n in pel.workloads.TERABYTE_ROWS),
+                            sum(n * dim * 4 <= (64 << 20) for n in pel.workloads.TERABYTE_ROWS),
+                            sum(rows) * dim * 4 / 1e9, B, L, dist))
     T = args.tables or 48
     B = args.batch or 16384
     dist = args.index_dist or "zipf"

@@ -53,6 +53,14 @@ def expected_rows(torch, t: int, idx, dim: int):
     return h.to(torch.float32) / 2147483647.0 - 0.5
 
 
+def table_set_of(pel, args):
+    """rows, dim, default batch, label of the table set the N > 1 legs run (--workload c2 | c4)."""
+    name = getattr(args, "workload", "c2")
+    if name not in ("c2", "c4"):
+        raise SystemExit("bench.py --gpus N > 1 runs --workload c2 or c4 (c3/c5 are single-GPU lines)")
+    return pel.workloads.table_set(name, float(getattr(args, "rows_scale", 1.0) or 1.0))
+
+
 def run_whole(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
     import torch
     import torch.distributed as dist
@@ -62,9 +70,8 @@ def run_whole(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
 
     rank, world, dev, backend, stage_cpu = ctx["rank"], ctx["world"], ctx["dev"], ctx["backend"], ctx["stage_cpu"]
 
-    rows_list = pel.workloads.KAGGLE_ROWS
-    dim = pel.workloads.KAGGLE_DIM
-    B = args.batch or pel.workloads.KAGGLE_BATCH
+    rows_list, dim, B0, label = table_set_of(pel, args)
+    B = args.batch or B0
     Bp = (B + 3) // 4 * 4                   # index slots per (table, rank): keeps every piece 16-B aligned
     T = len(rows_list)
     NBATCH = max(2, args.nbatch)
@@ -236,8 +243,8 @@ def run_whole(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
             "ms_per_step": wall * 1000.0 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C2 sharded: 26 Criteo-Kaggle tables, dim 16 fp32, B=%d bags/table PER RANK, "
-                                   "L=1, %d rotating batches; %s" % (B, NBATCH, plan.describe()),
+            "config": {"workload": "%s sharded, dim %d fp32, B=%d bags/table PER RANK, "
+                                   "L=1, %d rotating batches; %s" % (label, dim, B, NBATCH, plan.describe()),
                        "tables": T, "dim": dim, "bags_per_table_per_rank": B, "global_bags_per_table": world * B,
                        "parallelism": "tables sharded by id (replicate <= %d MiB); one all_to_all per step carries "
                                       "pooled rows of batch i + indices of batch i+1 (%d B out / %d B in per rank); "
@@ -264,10 +271,9 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
 
     rank, world, dev, backend, stage_cpu = ctx["rank"], ctx["world"], ctx["dev"], ctx["backend"], ctx["stage_cpu"]
 
-    rows_list = pel.workloads.KAGGLE_ROWS
-    dim = pel.workloads.KAGGLE_DIM
+    rows_list, dim, B0, label = table_set_of(pel, args)
     row_b = dim * 4
-    B = args.batch or pel.workloads.KAGGLE_BATCH
+    B = args.batch or B0
     T = len(rows_list)
     NBATCH = max(3, args.nbatch)
     sharded = [t for t in range(T) if rows_list[t] * row_b > rep_bytes and rows_list[t] >= world]
@@ -447,9 +453,9 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
             "ms_per_step": wall * 1000.0 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C2 sharded: 26 Criteo-Kaggle tables, dim 16 fp32, B=%d bags/table PER RANK, L=1, "
+            "config": {"workload": "%s sharded, dim %d fp32, B=%d bags/table PER RANK, L=1, "
                                    "%d rotating batches; %d tables replicated (<= %d MiB), %d row-range sharded over "
-                                   "%d ranks" % (B, NBATCH, len(local), rep_bytes >> 20, K, world),
+                                   "%d ranks" % (label, dim, B, NBATCH, len(local), rep_bytes >> 20, K, world),
                        "tables": T, "dim": dim, "bags_per_table_per_rank": B, "global_bags_per_table": world * B,
                        "parallelism": "row-range shards; GPU routing of requests (capacity %d per table/shard); ONE "
                                       "all_to_all per step carries pooled rows of batch i + request lists of batch "
@@ -475,9 +481,8 @@ def run_dp(args, hbm_peak_gbs: float, ctx):
     import torch.distributed as dist
     import pim_embedding_lookup_amd as pel
     rank, world, dev, stage_cpu = ctx["rank"], ctx["world"], ctx["dev"], ctx["stage_cpu"]
-    rows_list = pel.workloads.KAGGLE_ROWS
-    dim = pel.workloads.KAGGLE_DIM
-    B = args.batch or pel.workloads.KAGGLE_BATCH
+    rows_list, dim, B0, label = table_set_of(pel, args)
+    B = args.batch or B0
     T = len(rows_list)
     NBATCH = max(2, args.nbatch)
     eng = pel.EmbeddingEngine(device=dev.index, max_tables=T)
@@ -527,11 +532,12 @@ def run_dp(args, hbm_peak_gbs: float, ctx):
             "ms_per_step": wall * 1000.0 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C2: 26 Criteo-Kaggle tables, dim 16 fp32, B=%d bags/table PER RANK, L=1, u32 "
-                                   "indices+offsets, uniform indices, %d rotating batches" % (B, NBATCH),
+            "config": {"workload": "%s, dim %d fp32, B=%d bags/table PER RANK, L=1, u32 "
+                                   "indices+offsets, uniform indices, %d rotating batches" % (label, dim, B, NBATCH),
                        "tables": T, "dim": dim, "bags_per_table_per_rank": B, "global_bags_per_table": world * B,
-                       "parallelism": "all 26 tables (2.16 GB) replicated on every rank (they fit the per-GPU "
-                                      "replication budget); bags data-parallel, no data-path collective"},
+                       "parallelism": "all %d tables (%.2f GB) replicated on every rank (they fit the per-GPU "
+                                      "replication budget); bags data-parallel, no data-path collective"
+                                      % (T, sum(rows_list) * dim * 4 / 1e9)},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": hbm_peak_gbs, "unit": "GB/s",
                          "frac": ach / hbm_peak_gbs, "traffic": None, "kernel_us": kernel_us,
                          "algorithmic_bytes": alg_bytes, "note": "rank 0's fused launch, HIP events over the timed region"},
@@ -567,10 +573,12 @@ def run(args, hbm_peak_gbs: float) -> None:
                             **({"device_id": dev} if backend == "nccl" else {}))
     ctx = dict(rank=rank, world=world, dev=dev, backend=backend, stage_cpu=backend != "nccl")
 
-    total_bytes = sum(pel.workloads.KAGGLE_ROWS) * pel.workloads.KAGGLE_DIM * 4
+    rows_list, dim, _, _ = table_set_of(pel, args)
+    total_bytes = sum(rows_list) * dim * 4
     hbm = torch.cuda.get_device_properties(dev).total_memory
     auto = getattr(args, "replicate_mb", None) is None
-    shard_leg = run_rows if getattr(args, "shard_mode", "whole") == "rows" else run_whole
+    mode = getattr(args, "shard_mode", None) or ("rows" if getattr(args, "workload", "c2") == "c4" else "whole")
+    shard_leg = run_rows if mode == "rows" else run_whole
     state = {"printed": False, "dog": None}
 
     def emit(res):

@@ -8,6 +8,15 @@ import numpy as np
 # values the reference's kaggle runs use, README.md:6,10,14).  Sum = 33 762 577 rows.
 KAGGLE_ROWS = [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 5683, 8351593, 3194,
                27, 14992, 5461306, 10, 5652, 2173, 4, 7046547, 18, 15, 286181, 105, 142572]
+# BASELINE config C4, "Criteo-Terabyte-shaped 26 tables (largest ~200M rows) dim=128".  The reference
+# holds no such list ([EXT]); these are the categorical cardinalities of the
+# Criteo Terabyte click logs without the 40M hashing cap, as the public DLRM recipes quote them:
+# 882 774 559 rows, 452 GB at dim 128 fp32 -> ~56.5 GB per GPU on 8.
+TERABYTE_ROWS = [227605432, 39060, 17295, 7424, 20265, 3, 7122, 1543, 63, 130229467, 3067956, 405282, 10,
+                 2209, 11938, 155, 4, 976, 14, 292775614, 40790948, 187188510, 590152, 12973, 108, 36]
+TERABYTE_DIM = 128
+TERABYTE_BATCH = 16384
+
 KAGGLE_DIM = 16       # --arch-sparse-feature-size=16
 KAGGLE_BATCH = 39292  # --mini-batch-size=39292 (README.md:14)
 
@@ -59,3 +68,18 @@ def algorithmic_bytes(n_idx: int, n_bags: int, dim: int, elem: int, idx_bytes: i
                       has_offsets: bool = True) -> int:
     """n_idx*(D*elem + idx) + n_bags*off + n_bags*D*4."""
     return n_idx * (dim * elem + idx_bytes) + (n_bags * idx_bytes if has_offsets else 0) + n_bags * dim * 4
+
+
+def table_set(name: str, rows_scale: float = 1.0):
+    """(rows per table, dim, default bags per table per rank, label) of a named multi-GPU table set:
+    "c2" = the 26 Criteo-Kaggle tables (BASELINE configs[1]); "c4" = the Terabyte-shaped set
+    (configs[3]).  rows_scale < 1 shrinks every table (at least one row) so that an N-rank layout can
+    be rehearsed on fewer GPUs."""
+    if name == "c4":
+        rows, dim, batch, label = TERABYTE_ROWS, TERABYTE_DIM, TERABYTE_BATCH, "C4: 26 Criteo-Terabyte-shaped tables"
+    else:
+        rows, dim, batch, label = KAGGLE_ROWS, KAGGLE_DIM, KAGGLE_BATCH, "C2: 26 Criteo-Kaggle tables"
+    if rows_scale != 1.0:
+        rows = [max(1, int(n * rows_scale)) for n in rows]
+        label += " (rows x %g)" % rows_scale
+    return list(rows), dim, batch, label

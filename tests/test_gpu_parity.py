@@ -508,6 +508,27 @@ def test_distributed_bench_two_ranks_on_one_gpu(mode):
         assert isinstance(sec, dict) and sec["value"] > 0 and "5 whole" in sec["config"]
 
 
+def test_distributed_terabyte_shaped_row_shards_two_ranks():
+    """BASELINE configs[3] (Terabyte-shaped tables, dim 128, row-range sharded), rows scaled by 1/256 so
+    that two ranks sharing cuda:0 hold it: dist_bench routes requests on the GPU, exchanges them (gloo
+    here), looks the shards up, un-routes the rows and verifies all 26 tables bit-exactly per rank."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PIMEMB_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29564",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "c4", "--rows-scale", str(1 / 256),
+           "--steps", "4", "--warmup", "2", "--nbatch", "3", "--batch", "2051", "--replicate-mb", "8"]
+    res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["dim"] == 128 and d["value"] > 0
+    w = d["config"]["workload"]
+    assert "Terabyte" in w and "row-range sharded over 2 ranks" in w and "5 row-range" in w
+
+
 @pytest.mark.parametrize("dim,dtype", [(4, np.float32), (8, np.float32), (32, np.float32), (64, np.float32),
                                        (128, np.float32), (256, np.float32), (24, np.float32),
                                        (8, np.float16), (128, np.float16), (512, np.float16), (16, np.int32)])

@@ -40,6 +40,28 @@ def test_planner_kaggle_8_ranks(pel):
     assert "21 replicated" in plan.describe()
 
 
+def test_planner_terabyte_shaped_8_ranks(pel):
+    """BASELINE configs[3]: 26 Terabyte-shaped tables at dim 128 (452 GB) over 8 ranks: the tables
+    above 1/8 of the sharded bytes are row-split over all ranks, the load is balanced, every rank's
+    share fits its 288 GB HBM with room to spare."""
+    sh = _sharding()
+    rows, dim, _, _ = pel.workloads.table_set("c4")
+    assert len(rows) == 26 and sum(rows) == 882_774_559 and max(rows) == 292_775_614
+    plan = sh.plan_shards(rows, dim, 4, world=8)
+    split = [t for t, k in enumerate(plan.kinds) if k == sh.ROW_SPLIT]
+    assert sorted(rows[t] for t in split) == [130229467, 187188510, 227605432, 292775614]
+    assert plan.kinds[20] in (sh.WHOLE, sh.ROW_SPLIT)           # the 40.8M-row table (20.9 GB)
+    for t, ids in enumerate(plan.units_of_table):
+        us = [plan.units[i] for i in ids]
+        assert us[0].row_lo == 0 and us[-1].row_hi == rows[t]
+        assert all(a.row_hi == b.row_lo for a, b in zip(us, us[1:]))
+    loads = [plan.bytes_on(r) for r in range(8)]
+    assert max(loads) < 90e9 and max(loads) < 1.5 * (sum(loads) / 8)
+    # scaled copies keep the shape (used to rehearse the layout on fewer GPUs)
+    small, _, _, label = pel.workloads.table_set("c4", 1 / 256)
+    assert small[19] == 292775614 // 256 and min(small) == 1 and "rows x" in label
+
+
 def test_planner_policies():
     sh = _sharding()
     # world 1: small tables local; a big one is "owned" by rank 0 (self exchange, used to rehearse RCCL)
