@@ -104,6 +104,26 @@ int oracle_bag_sum_f32(const float *table, uint64_t nr_rows, uint32_t dim, const
     return 0;
 }
 
+/* Bags [b0, b1) of one fp32 table: the loop body of oracle_bag_sum_f32, so that the threaded
+ * baseline below computes bit-identical results (each bag is still summed sequentially). */
+static int bag_sum_f32_range(const float *table, uint64_t nr_rows, uint32_t dim, const void *indices,
+                             uint64_t n_idx, const void *offsets, uint64_t n_bags, int idx_is64,
+                             float *out, uint64_t b0, uint64_t b1) {
+    for (uint64_t b = b0; b < b1; b++) {
+        float *o = out + b * dim;
+        for (uint32_t d = 0; d < dim; d++) o[d] = 0.0f;
+        uint64_t p = ld_index(offsets, idx_is64, b);
+        uint64_t e = bag_end(offsets, idx_is64, b, n_bags, n_idx);
+        for (; p < e; p++) {
+            uint64_t r = ld_index(indices, idx_is64, p);
+            if (r >= nr_rows) return -1;
+            const float *w = table + r * dim;
+            for (uint32_t d = 0; d < dim; d++) o[d] = o[d] + w[d];
+        }
+    }
+    return 0;
+}
+
 /* fp16 storage, fp32 accumulate/output (BASELINE config C5). */
 int oracle_bag_sum_f16(const uint16_t *table, uint64_t nr_rows, uint32_t dim, const void *indices,
                        uint64_t n_idx, const void *offsets, uint64_t n_bags, int idx_is64,
@@ -218,4 +238,32 @@ int oracle_lookup_tables_f32(uint32_t n_tables, const float *const *tables,
         if (rc) return rc;
     }
     return 0;
+}
+
+/*
+ * The same driver with the bags of every table split over n_threads OpenMP threads (SURVEY.md
+ * section 8(d): "ref_cpu (OpenMP over bags)"; BASELINE.md section 3 asks for threads=1 and threads=all).
+ * Bags are independent, so the result is bit-identical to the scalar driver.
+ */
+int oracle_lookup_tables_f32_mt(uint32_t n_tables, const float *const *tables,
+                                const uint64_t *nr_rows, uint32_t dim, const void *const *indices,
+                                const uint64_t *n_idx, const void *const *offsets,
+                                const uint64_t *n_bags, int idx_is64, float *const *out,
+                                int n_threads) {
+    int bad = 0;
+    if (n_threads < 1) n_threads = 1;
+#pragma omp parallel num_threads(n_threads) reduction(| : bad)
+    {
+        for (uint32_t t = 0; t < n_tables; t++) {
+            const int64_t chunks = (int64_t)((n_bags[t] + 1023) / 1024);
+#pragma omp for schedule(static) nowait
+            for (int64_t c = 0; c < chunks; c++) {
+                uint64_t b0 = (uint64_t)c * 1024, b1 = b0 + 1024 < n_bags[t] ? b0 + 1024 : n_bags[t];
+                if (bag_sum_f32_range(tables[t], nr_rows[t], dim, indices[t], n_idx[t], offsets[t],
+                                      n_bags[t], idx_is64, out[t], b0, b1))
+                    bad |= 1;
+            }
+        }
+    }
+    return bad ? -1 : 0;
 }

@@ -38,6 +38,7 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is None:
         build()
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # spinning idle threads distort the threaded baseline
         L = C.CDLL(_LIB_PATH)
         vp, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
         L.oracle_bag_sum_f32.argtypes = [vp, u64, u32, vp, u64, vp, u64, C.c_int, vp]
@@ -54,6 +55,8 @@ def lib() -> C.CDLL:
         L.oracle_validate_result.restype = C.c_uint64
         L.oracle_lookup_tables_f32.argtypes = [u32, vp, vp, u32, vp, vp, vp, vp, C.c_int, vp]
         L.oracle_lookup_tables_f32.restype = C.c_int
+        L.oracle_lookup_tables_f32_mt.argtypes = [u32, vp, vp, u32, vp, vp, vp, vp, C.c_int, vp, C.c_int]
+        L.oracle_lookup_tables_f32_mt.restype = C.c_int
         _lib = L
     return _lib
 
@@ -136,8 +139,9 @@ def c_validate_result(table_i32, indices, offsets, results) -> int:
                                             _p(results)))
 
 
-def c_lookup_tables(tables, indices, offsets):
-    """Multi-table fp32 lookup with the reference's per-table pointer arrays (emb_host.h:234)."""
+def c_lookup_tables(tables, indices, offsets, threads: int = 1):
+    """Multi-table fp32 lookup with the reference's per-table pointer arrays (emb_host.h:234).
+    threads > 1: the bags of every table split over that many OpenMP threads (same bits)."""
     T = len(tables)
     tables = [np.ascontiguousarray(t, dtype=np.float32) for t in tables]
     indices = [np.ascontiguousarray(i) for i in indices]
@@ -152,10 +156,10 @@ def c_lookup_tables(tables, indices, offsets):
     def u64arr(vals):
         return (C.c_uint64 * T)(*vals)
 
-    rc = lib().oracle_lookup_tables_f32(
-        T, parr(tables), u64arr([t.shape[0] for t in tables]), dim, parr(indices),
-        u64arr([i.shape[0] for i in indices]), parr(offsets), u64arr([o.shape[0] for o in offsets]),
-        is64, parr(outs))
+    a = (T, parr(tables), u64arr([t.shape[0] for t in tables]), dim, parr(indices),
+         u64arr([i.shape[0] for i in indices]), parr(offsets), u64arr([o.shape[0] for o in offsets]),
+         is64, parr(outs))
+    rc = lib().oracle_lookup_tables_f32(*a) if threads <= 1 else lib().oracle_lookup_tables_f32_mt(*a, int(threads))
     if rc:
         raise IndexError("index out of range")
     return outs
