@@ -32,7 +32,7 @@ extern "C" {
 #define EMB_ERR_INVALID (-1)     /* bad argument (null pointer, unknown table, bad dtype/dim ...) */
 #define EMB_ERR_NOMEM (-2)       /* host or HBM allocation failed (replaces enomem(), emb_host.h:87) */
 #define EMB_ERR_DEVICE (-3)      /* HIP runtime error, text in emb_last_error() */
-#define EMB_ERR_UNSUPPORTED (-4) /* e.g. row bytes not a multiple of 16 or wider than 1 KiB */
+#define EMB_ERR_UNSUPPORTED (-4) /* e.g. dim 0, more tiles than one grid holds */
 #define EMB_ERR_RANGE (-5)       /* emb_validate_inputs found an out-of-range index / bad offsets */
 
 /* element type of a table as it sits in HBM; pooled output is always fp32 [bag][dim]

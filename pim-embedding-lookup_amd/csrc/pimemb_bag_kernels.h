@@ -349,6 +349,60 @@ bag_sum_group_kernel(const DevDesc *__restrict__ descs, uint32_t chunks_arg,
     }
 }
 
+// ---- any row width: one thread per output element --------------------------------------------
+// Rows whose byte size is not a multiple of 16 (dim 2, 3, 10, 100 ... -- nn.EmbeddingBag takes any
+// dim, dlrm_s_pytorch.py's default sparse feature size is 2) or exceeds 1 KiB cannot use the 16-byte
+// lane pieces above.  `lanes` (power of two, <= 256) consecutive threads own one bag and stride over
+// its columns; each output element is still summed by one thread in index order from +0, so results
+// are bit-identical to the vector kernels and the oracle.  Generality path, not a tuned one.
+template <int DT> struct ElemOps;
+template <> struct ElemOps<EMB_F32> {
+    using Elem = float; using Acc = float;
+    static __device__ __forceinline__ void add(Acc &a, Elem v) { a = a + v; }
+    static __device__ __forceinline__ float out(Acc a) { return a; }
+};
+template <> struct ElemOps<EMB_F16> {
+    using Elem = _Float16; using Acc = float;
+    static __device__ __forceinline__ void add(Acc &a, Elem v) { a = a + (float)v; }
+    static __device__ __forceinline__ float out(Acc a) { return a; }
+};
+template <> struct ElemOps<EMB_FIXED32> {
+    using Elem = uint32_t; using Acc = uint32_t;
+    static __device__ __forceinline__ void add(Acc &a, Elem v) { a += v; }
+    static __device__ __forceinline__ float out(Acc a) { return RowOps<EMB_FIXED32>::conv(a); }
+};
+
+template <typename IdxT, int DT, bool CLAMP>
+__global__ void __launch_bounds__(256)
+bag_sum_anydim_kernel(const DevDesc *__restrict__ descs, uint32_t dim, uint32_t lanes) {
+    using E = ElemOps<DT>;
+    const DevDesc *dp = descs + blockIdx.y;
+    const typename E::Elem *__restrict__ weights = static_cast<const typename E::Elem *>(dp->weights);
+    const IdxT *__restrict__ indices = static_cast<const IdxT *>(dp->indices);
+    const IdxT *__restrict__ offsets = static_cast<const IdxT *>(dp->offsets);
+    float *__restrict__ out = dp->out;
+    const uint64_t n_idx = dp->n_idx, n_bags = dp->n_bags, last_row = dp->nr_rows - 1;
+    const uint64_t bag = (uint64_t)blockIdx.x * (256u / lanes) + threadIdx.x / lanes;
+    if (blockIdx.x >= dp->n_tiles || bag >= n_bags) return;
+    uint64_t p0, e;
+    if (offsets != nullptr) {
+        p0 = (uint64_t)offsets[bag];
+        e = (bag + 1 < n_bags) ? (uint64_t)offsets[bag + 1] : n_idx;
+    } else {
+        p0 = bag * dp->fixed_pooling;
+        e = p0 + dp->fixed_pooling;
+    }
+    if (CLAMP && e > n_idx) e = n_idx;
+    for (uint32_t col = threadIdx.x & (lanes - 1); col < dim; col += lanes) {
+        typename E::Acc acc = 0;
+        for (uint64_t p = p0; p < e; p++) {
+            const uint64_t r = clamp_row<CLAMP, IdxT>((uint64_t)indices[p], last_row);
+            E::add(acc, weights[r * dim + col]);
+        }
+        out[bag * dim + col] = E::out(acc);
+    }
+}
+
 // ---- v2: wave batches of 64 bags, coalesced bounds, shuffle-distributed, one-hot fast path -------
 template <typename IdxT, int DT, int LPR, class Cfg>
 __global__ void __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves)

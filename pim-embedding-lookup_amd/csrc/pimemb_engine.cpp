@@ -243,7 +243,8 @@ int resolve(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs, emb_i
         // several tables in one big one-hot launch: XCD-aware workgroup map (one table <-> one XCD's
         // L2).  Measured neutral for pooled launches and slightly negative for small ones, which
         // keep the plain 2-D grid.
-        if (g.n > 1 && g.max_tiles > 0 && g.kind != pimemb::KERNEL_GROUP) {
+        if (g.n > 1 && g.max_tiles > 0 &&
+            (g.kind == pimemb::KERNEL_WAVEBATCH || g.kind == pimemb::KERNEL_WAVEBATCH2)) {
             uint64_t total_tiles = 0;
             for (uint32_t t : tiles_of) total_tiles += t;
             if (total_tiles + 8 * (uint64_t)g.n > 0x7fffffffull)
@@ -553,8 +554,7 @@ int emb_alloc_table(emb_engine *e, uint32_t table_id, uint64_t nr_rows, uint32_t
     LaunchGeom geom;
     int rc = pimemb::geometry_for(dtype, dim, &geom);
     if (rc == EMB_ERR_UNSUPPORTED)
-        return fail(rc, "table %u: dim %u of dtype %d: row bytes must be a multiple of 16 and <= 1024",
-                    table_id, dim, (int)dtype);
+        return fail(rc, "table %u: dim %u of dtype %d is not supported (dim must be > 0)", table_id, dim, (int)dtype);
     if (rc) return fail(rc, "table %u: bad dtype %d", table_id, (int)dtype);
     DeviceGuard g(e->device);
     std::lock_guard<std::mutex> lk(e->mu);

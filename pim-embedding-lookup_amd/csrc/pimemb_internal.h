@@ -13,13 +13,16 @@ namespace pimemb {
 struct LaunchGeom {
     uint32_t lanes_per_row;   // power of two, 1..64: lanes that cooperate on one bag
     uint32_t chunks;          // 16-byte pieces per row actually used (<= lanes_per_row)
+    uint32_t scalar_lanes;    // != 0: rows that are not 16-byte multiples (or wider than 1 KiB) -- the
+                              // element-per-thread kernel with this many threads per bag; chunks = dim
 };
 
 // Which bag kernel a launch uses.
 enum KernelKind : uint32_t {
     KERNEL_WAVEBATCH = 0,  // 64 bags per wavefront, coalesced bounds, one-hot fast path: big batches
     KERNEL_GROUP = 1,      // one lane group per bag, finest granularity: pooled launches, small batches
-    KERNEL_WAVEBATCH2 = 2  // 2 x 64 bags per wavefront: very big one-hot launches
+    KERNEL_WAVEBATCH2 = 2, // 2 x 64 bags per wavefront: very big one-hot launches
+    KERNEL_ANYDIM = 3      // one thread per output element: any dim (e.g. DLRM's default 2), not a tuned path
 };
 
 // Returns EMB_OK / EMB_ERR_UNSUPPORTED and fills `g` for a table shape.

@@ -82,6 +82,26 @@ hipError_t launch_dtype(const DevDesc *d, uint32_t n, uint32_t max_tiles, emb_dt
     return hipErrorInvalidValue;
 }
 
+template <typename IdxT>
+hipError_t launch_anydim(const DevDesc *d, uint32_t n, uint32_t max_tiles, emb_dtype dtype, const LaunchGeom &g,
+                         hipStream_t s) {
+    const dim3 grid(max_tiles, n, 1), block(256);
+    switch (dtype) {
+        case EMB_F32:
+            hipLaunchKernelGGL((bag_sum_anydim_kernel<IdxT, EMB_F32, kClampInputs>), grid, block, 0, s, d, g.chunks, g.scalar_lanes);
+            break;
+        case EMB_F16:
+            hipLaunchKernelGGL((bag_sum_anydim_kernel<IdxT, EMB_F16, kClampInputs>), grid, block, 0, s, d, g.chunks, g.scalar_lanes);
+            break;
+        case EMB_FIXED32:
+            hipLaunchKernelGGL((bag_sum_anydim_kernel<IdxT, EMB_FIXED32, kClampInputs>), grid, block, 0, s, d, g.chunks, g.scalar_lanes);
+            break;
+        default:
+            return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 // ---- column scatter for populate_mram-style uploads -----------------------------------------
 __global__ void __launch_bounds__(kBlock)
 scatter_column_kernel(int32_t *__restrict__ table, const int32_t *__restrict__ column,
@@ -227,7 +247,16 @@ int geometry_for(emb_dtype dtype, uint32_t dim, LaunchGeom *g) {
     uint32_t elem = (dtype == EMB_F16) ? 2u : 4u;
     if (dtype != EMB_F32 && dtype != EMB_F16 && dtype != EMB_FIXED32) return EMB_ERR_INVALID;
     uint64_t row_bytes = (uint64_t)dim * elem;
-    if (dim == 0 || row_bytes % 16 != 0 || row_bytes > 1024) return EMB_ERR_UNSUPPORTED;
+    if (dim == 0) return EMB_ERR_UNSUPPORTED;
+    if (row_bytes % 16 != 0 || row_bytes > 1024) {   // no 16-byte lane pieces: element-per-thread kernel
+        uint32_t lanes = 1;
+        while (lanes < dim && lanes < 256u) lanes <<= 1;
+        g->lanes_per_row = 0;
+        g->chunks = dim;
+        g->scalar_lanes = lanes;
+        return EMB_OK;
+    }
+    g->scalar_lanes = 0;
     uint32_t chunks = (uint32_t)(row_bytes / 16);
     uint32_t lpr = 1;
     while (lpr < chunks) lpr <<= 1;
@@ -237,6 +266,7 @@ int geometry_for(emb_dtype dtype, uint32_t dim, LaunchGeom *g) {
 }
 
 uint32_t bags_per_tile(KernelKind kind, const LaunchGeom &g) {
+    if (kind == KERNEL_ANYDIM) return 256u / g.scalar_lanes;
     if (kind == KERNEL_WAVEBATCH) return 64u * WaveCfg::kBatches * (WaveCfg::kBlock / 64);
     if (kind == KERNEL_WAVEBATCH2) return 64u * Wave2Cfg::kBatches * (Wave2Cfg::kBlock / 64);
     return (64u / g.lanes_per_row) * (GroupCfg::kBlock / 64);
@@ -250,6 +280,7 @@ KernelKind choose_kernel(uint64_t total_bags, uint64_t total_indices, const Laun
     //   * pooled launches (dim 128, 32 indices per bag) run 1.3x faster on the lane-group kernel:
     //     a bag is already a long stream of gathers, and 64 bags per wavefront leave too few
     //     wavefronts to balance the machine.
+    if (g.scalar_lanes) return KERNEL_ANYDIM;
     const bool one_hot_ish = total_indices <= 2 * total_bags;
     if (!one_hot_ish || total_bags / 64u < 2048u) return KERNEL_GROUP;
     // Two batches per wavefront once that still leaves >= 4 wavefronts per SIMD (>= 524288 bags) --
@@ -264,6 +295,11 @@ hipError_t launch_bag_sum(const DevDesc *d_descs, uint32_t n_descs, uint32_t max
                           hipStream_t stream) {
     if (n_descs == 0 || max_tiles == 0) return hipSuccess;
     if (d_xmap == nullptr && n_descs > 65535u) return hipErrorInvalidValue;
+    if (kind == KERNEL_ANYDIM) {
+        if (g.scalar_lanes == 0 || d_xmap != nullptr) return hipErrorInvalidValue;
+        return itype == EMB_IDX_U32 ? launch_anydim<uint32_t>(d_descs, n_descs, max_tiles, dtype, g, stream)
+                                    : launch_anydim<int64_t>(d_descs, n_descs, max_tiles, dtype, g, stream);
+    }
     if (itype == EMB_IDX_U32)
         return launch_dtype<uint32_t>(d_descs, n_descs, max_tiles, dtype, g, kind, d_xmap, xgrid, xdirect, stream);
     return launch_dtype<int64_t>(d_descs, n_descs, max_tiles, dtype, g, kind, d_xmap, xgrid, xdirect, stream);
