@@ -61,14 +61,33 @@ struct Table {
 // One slot of the descriptor ring used by transient (non-plan) launches: the pinned host copy and
 // the HBM copy must both outlive the asynchronous upload + kernel, so a slot is reused only after
 // its event has completed.
+// Launch images (descriptors + any uncached XCD map) of transient calls live in a ring of pinned,
+// device-visible segments.  Calls bump-allocate inside the current segment; ONE event per segment
+// (recorded when it fills up or the caller switches streams) tells when its images may be overwritten,
+// so a call costs no event record of its own -- an event between two kernels of a stream also costs
+// ~4 us of GPU time.
 struct DescSlot {
     char *h = nullptr;
-    char *d = nullptr;
-    size_t cap = 0;  // bytes
+    char *d = nullptr;       // HBM twin (PIMEMB_DESC_MODE=copy only)
+    size_t cap = 0;          // bytes
+    size_t used = 0;
+    hipStream_t stream = nullptr;   // stream of the launches whose images sit in this segment
     hipEvent_t done = nullptr;
     bool pending = false;
 };
 constexpr int kSlots = 4;
+constexpr size_t kSlotBytes = 256u << 10;
+
+// XCD-aware workgroup maps of transient (plan-less) launches, kept in HBM and found again by launch
+// shape: the map depends on the tile counts and table sizes only, never on the buffers of a call.
+struct XmapCacheEntry {
+    std::vector<uint64_t> key;   // kernel kind, bags per tile, then (tiles, table bytes) per descriptor
+    uint32_t *d_map = nullptr;
+    uint32_t xgrid = 0;
+    bool direct = false;
+    uint64_t last_use = 0;
+};
+constexpr size_t kXmapCacheEntries = 8;
 
 }  // namespace
 
@@ -78,6 +97,10 @@ struct emb_engine {
     std::mutex mu;  // guards tables / workspaces; launches on device buffers do not take it
     DescSlot slots[kSlots];
     int next_slot = 0;
+    std::vector<XmapCacheEntry> xmap_cache;
+    uint64_t xmap_clock = 0;
+    int desc_mode = 1;          // 1: kernels read descriptors from the pinned segment; 0: copied into HBM per call
+    unsigned slot_flags = 0;    // hipHostMalloc flags of the descriptor slots
     // staging for EMB_MEM_HOST calls
     char *h_stage = nullptr;
     size_t h_stage_cap = 0;
@@ -113,6 +136,7 @@ struct PlanGroup {
     uint32_t *d_xmap = nullptr;      // XCD-aware workgroup map, or null (2-D grid)
     uint32_t xgrid = 0;
     bool xdirect = false;            // map expanded to one {descriptor, tile} entry per workgroup
+    uint32_t *cached_xmap = nullptr; // transient launches: map owned by the engine's cache (not in the image)
     size_t desc_off = 0, xmap_off = 0;  // byte offsets of this group's pieces in the launch image
     std::vector<uint32_t> xmap_words;
 };
@@ -171,16 +195,69 @@ struct Resolved {
     void bind(char *d_base) {
         for (PlanGroup &g : groups) {
             g.d_descs = reinterpret_cast<DevDesc *>(d_base + g.desc_off);
-            g.d_xmap = g.xmap_words.empty() ? nullptr : reinterpret_cast<uint32_t *>(d_base + g.xmap_off);
+            g.d_xmap = g.cached_xmap ? g.cached_xmap
+                       : g.xmap_words.empty() ? nullptr : reinterpret_cast<uint32_t *>(d_base + g.xmap_off);
         }
     }
 };
+
+// Transient launches: find (or build, upload and remember) the XCD map of this launch shape.  On
+// success the group points at the cached device copy and carries no map words of its own.
+int cached_xcd_map(emb_engine *e, PlanGroup &g, uint32_t bpt, const std::vector<uint32_t> &tiles_of,
+                   const std::vector<uint64_t> &bytes_of) {
+    std::vector<uint64_t> key;
+    key.reserve(2 + 2 * tiles_of.size());
+    key.push_back((uint64_t)g.kind);
+    key.push_back(bpt);
+    for (size_t i = 0; i < tiles_of.size(); i++) {
+        key.push_back(tiles_of[i]);
+        key.push_back(bytes_of[i]);
+    }
+    std::lock_guard<std::mutex> lk(e->mu);
+    for (XmapCacheEntry &c : e->xmap_cache)
+        if (c.key == key) {
+            c.last_use = ++e->xmap_clock;
+            g.cached_xmap = c.d_map;
+            g.xgrid = c.xgrid;
+            g.xdirect = c.direct;
+            return EMB_OK;
+        }
+    XmapCacheEntry n;
+    std::vector<uint32_t> words;
+    n.xgrid = pimemb::build_xcd_map(tiles_of, bytes_of, &words, 1);
+    if (n.xgrid <= (1u << 20)) {
+        std::vector<uint32_t> direct;
+        pimemb::expand_xcd_map(words, n.xgrid, &direct);
+        words.swap(direct);
+        n.direct = true;
+    }
+    if (hipMalloc((void **)&n.d_map, words.size() * 4) != hipSuccess) return EMB_ERR_NOMEM;   // caller builds inline
+    if (hipMemcpy(n.d_map, words.data(), words.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(n.d_map);
+        return EMB_ERR_DEVICE;
+    }
+    if (e->xmap_cache.size() >= kXmapCacheEntries) {   // evict the least recently used shape (rare)
+        size_t victim = 0;
+        for (size_t i = 1; i < e->xmap_cache.size(); i++)
+            if (e->xmap_cache[i].last_use < e->xmap_cache[victim].last_use) victim = i;
+        (void)hipDeviceSynchronize();                  // a launch in flight may still read it
+        (void)hipFree(e->xmap_cache[victim].d_map);
+        e->xmap_cache.erase(e->xmap_cache.begin() + (long)victim);
+    }
+    n.key.swap(key);
+    n.last_use = ++e->xmap_clock;
+    g.cached_xmap = n.d_map;
+    g.xgrid = n.xgrid;
+    g.xdirect = n.direct;
+    e->xmap_cache.push_back(std::move(n));
+    return EMB_OK;
+}
 
 // st_indices / st_offsets / st_out: if non-null, per-descriptor device pointers that replace the
 // caller's (the staged copies of a host-pointer call).
 int resolve(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs, emb_index_type itype,
             const std::vector<const void *> *st_indices, const std::vector<const void *> *st_offsets,
-            const std::vector<float *> *st_out, Resolved *r) {
+            const std::vector<float *> *st_out, Resolved *r, bool cache_maps = false) {
     if (itype != EMB_IDX_U32 && itype != EMB_IDX_I64) return fail(EMB_ERR_INVALID, "bad index type");
     std::map<std::pair<int, uint32_t>, std::vector<uint32_t>> by_shape;
     for (uint32_t i = 0; i < n_descs; i++) {
@@ -249,12 +326,14 @@ int resolve(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs, emb_i
             for (uint32_t t : tiles_of) total_tiles += t;
             if (total_tiles + 8 * (uint64_t)g.n > 0x7fffffffull)
                 return fail(EMB_ERR_UNSUPPORTED, "launch too large for one grid");
-            g.xgrid = pimemb::build_xcd_map(tiles_of, bytes_of, &g.xmap_words, 1);
-            if (g.xgrid <= (1u << 20)) {   // <= 8 MB of map: one scalar load per workgroup instead of a search
-                std::vector<uint32_t> direct;
-                pimemb::expand_xcd_map(g.xmap_words, g.xgrid, &direct);
-                g.xmap_words.swap(direct);
-                g.xdirect = true;
+            if (!cache_maps || cached_xcd_map(e, g, bpt, tiles_of, bytes_of) != EMB_OK) {
+                g.xgrid = pimemb::build_xcd_map(tiles_of, bytes_of, &g.xmap_words, 1);
+                if (g.xgrid <= (1u << 20)) {   // <= 8 MB of map: one scalar load per workgroup instead of a search
+                    std::vector<uint32_t> direct;
+                    pimemb::expand_xcd_map(g.xmap_words, g.xgrid, &direct);
+                    g.xmap_words.swap(direct);
+                    g.xdirect = true;
+                }
             }
         } else if (g.n > 65535u) {
             return fail(EMB_ERR_UNSUPPORTED, "more than 65535 descriptors of one shape");
@@ -275,46 +354,78 @@ int launch_groups(emb_engine *e, const std::vector<PlanGroup> &groups, emb_index
     return EMB_OK;
 }
 
-int ensure_slot(DescSlot &sl, size_t n) {
-    if (sl.pending) {
-        HIP_TRY(hipEventSynchronize(sl.done));
-        sl.pending = false;
+// Space for an n-byte launch image on stream s: *h (host view) and *d (HBM twin or null).
+int take_image_space(emb_engine *e, size_t n, hipStream_t s, char **h, char **d) {
+    n = (n + 127) / 128 * 128;
+    DescSlot *sl = &e->slots[e->next_slot];
+    if (sl->used && (sl->used + n > sl->cap || sl->stream != s)) {   // close the segment, move on
+        HIP_TRY(hipEventRecord(sl->done, sl->stream));
+        sl->pending = true;
+        e->next_slot = (e->next_slot + 1) % kSlots;
+        sl = &e->slots[e->next_slot];
     }
-    if (sl.cap < n) {
-        if (sl.h) (void)hipHostFree(sl.h);
-        if (sl.d) (void)hipFree(sl.d);
-        sl.h = nullptr;
-        sl.d = nullptr;
-        sl.cap = 0;
-        size_t cap = n < 8192 ? 8192 : n + n / 4;
-        HIP_TRY(hipHostMalloc((void **)&sl.h, cap, hipHostMallocMapped | hipHostMallocCoherent));
-        HIP_TRY(hipMalloc((void **)&sl.d, cap));
-        sl.cap = cap;
+    if (sl->pending) {
+        HIP_TRY(hipEventSynchronize(sl->done));
+        sl->pending = false;
+        sl->used = 0;
     }
-    if (!sl.done) HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    if (sl->cap < n) {      // first use, or an image larger than a segment (huge uncached map)
+        if (sl->used) {     // images of launches in flight on sl->stream
+            HIP_TRY(hipStreamSynchronize(sl->stream));
+            sl->used = 0;
+        }
+        if (sl->h) (void)hipHostFree(sl->h);
+        if (sl->d) (void)hipFree(sl->d);
+        sl->h = nullptr;
+        sl->d = nullptr;
+        sl->cap = 0;
+        const size_t cap = n < kSlotBytes ? kSlotBytes : n + n / 4;
+        HIP_TRY(hipHostMalloc((void **)&sl->h, cap, e->slot_flags));
+        if (e->desc_mode == 0) HIP_TRY(hipMalloc((void **)&sl->d, cap));
+        sl->cap = cap;
+    }
+    if (!sl->done) HIP_TRY(hipEventCreateWithFlags(&sl->done, hipEventDisableTiming));
+    *h = sl->h + sl->used;
+    *d = sl->d ? sl->d + sl->used : nullptr;
+    sl->used += n;
+    sl->stream = s;
     return EMB_OK;
 }
+
+// PIMEMB_HOST_PROFILE=1: accumulate where a transient device-pointer call spends its host time
+// (printed by emb_destroy).  Developer aid; one getenv per process.
+struct HostProfile {
+    bool on = getenv("PIMEMB_HOST_PROFILE") != nullptr;
+    double resolve = 0, slot = 0, image = 0, h2d = 0, launch = 0;
+    uint64_t calls = 0;
+};
+HostProfile g_prof;
 
 // Transient launch over device-resident buffers described by `r`.
 int launch_resolved(emb_engine *e, Resolved &r, emb_index_type itype, hipStream_t s,
                     bool descriptors_in_host_memory = false) {
     if (r.descs.empty()) return EMB_OK;
     std::lock_guard<std::mutex> lk(e->mu);
-    DescSlot &sl = e->slots[e->next_slot];
-    e->next_slot = (e->next_slot + 1) % kSlots;
-    int rc = ensure_slot(sl, r.image.size());
+    const double p0 = g_prof.on ? now_us() : 0;
+    char *h = nullptr, *d = nullptr;
+    int rc = take_image_space(e, r.image.size(), s, &h, &d);
     if (rc) return rc;
-    memcpy(sl.h, r.image.data(), r.image.size());
-    if (descriptors_in_host_memory) {
-        r.bind(sl.h);      // small host-pointer call: the kernel's scalar loads read the pinned slot itself
+    const double p1 = g_prof.on ? now_us() : 0;
+    memcpy(h, r.image.data(), r.image.size());
+    const double p2 = g_prof.on ? now_us() : 0;
+    if (d == nullptr || descriptors_in_host_memory) {
+        r.bind(h);         // the kernel's scalar loads read the pinned, device-visible segment itself
     } else {
-        HIP_TRY(hipMemcpyAsync(sl.d, sl.h, r.image.size(), hipMemcpyHostToDevice, s));
-        r.bind(sl.d);
+        HIP_TRY(hipMemcpyAsync(d, h, r.image.size(), hipMemcpyHostToDevice, s));
+        r.bind(d);
     }
+    const double p3 = g_prof.on ? now_us() : 0;
     rc = launch_groups(e, r.groups, itype, s);
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(sl.done, s));
-    sl.pending = true;
+    if (g_prof.on) {
+        g_prof.slot += p1 - p0; g_prof.image += p2 - p1; g_prof.h2d += p3 - p2; g_prof.launch += now_us() - p3;
+        g_prof.calls++;
+    }
     return EMB_OK;
 }
 
@@ -424,7 +535,7 @@ int lookup_host(emb_engine *e, const emb_lookup_desc *descs, uint32_t n, emb_ind
     if (timed) HIP_TRY(hipStreamSynchronize(s));
     const double t1 = now_us();
     Resolved r;
-    int rc = resolve(e, descs, n, itype, &hs.d_indices, &hs.d_offsets, &hs.d_out, &r);
+    int rc = resolve(e, descs, n, itype, &hs.d_indices, &hs.d_offsets, &hs.d_out, &r, /*cache_maps=*/true);
     if (rc) return rc;
     // descriptor upload ("query copying" in the reference's stage list) + the fused launch
     rc = launch_resolved(e, r, itype, s, hs.zero_copy);
@@ -513,6 +624,13 @@ int emb_create(const emb_config *cfg, emb_engine **out) {
     if (!e) return fail(EMB_ERR_NOMEM, "emb_create: out of host memory");
     e->device = dev;
     e->stage_timing = cfg && (cfg->flags & EMB_FLAG_STAGE_TIMING);
+    {   // transient launches read their descriptors straight from the pinned segment (measured with
+        // tools/transient_probe.py: 20.6 vs 22.4 us per C2-shaped call, 5.6 vs 8.7 us at 2048 bags per
+        // table); PIMEMB_DESC_MODE=copy stages them into HBM with an in-stream copy instead
+        const char *m = getenv("PIMEMB_DESC_MODE");
+        e->desc_mode = (m && m[0] == 'c') ? 0 : 1;
+        e->slot_flags = hipHostMallocMapped | hipHostMallocCoherent;
+    }
     uint32_t max_tables = (cfg && cfg->max_tables) ? cfg->max_tables : 1024;
     e->tables.resize(max_tables);
     DeviceGuard g(dev);
@@ -532,6 +650,12 @@ int emb_destroy(emb_engine *e) {
                     e->live_plans.load());
     DeviceGuard g(e->device);
     (void)hipDeviceSynchronize();
+    if (g_prof.on && g_prof.calls) {
+        const double n = (double)g_prof.calls;
+        fprintf(stderr, "[pimemb host profile] %llu transient calls, us/call: resolve %.2f  slot %.2f  image memcpy %.2f  "
+                        "h2d enqueue %.2f  kernel enqueue %.2f\n", (unsigned long long)g_prof.calls,
+                g_prof.resolve / n, g_prof.slot / n, g_prof.image / n, g_prof.h2d / n, g_prof.launch / n);
+    }
     for (Table &t : e->tables)
         if (t.rows) (void)hipFree(t.rows);
     for (DescSlot &sl : e->slots) {
@@ -539,6 +663,7 @@ int emb_destroy(emb_engine *e) {
         if (sl.d) (void)hipFree(sl.d);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
+    for (XmapCacheEntry &c : e->xmap_cache) (void)hipFree(c.d_map);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
     if (e->d_stage) (void)hipFree(e->d_stage);
     if (e->d_bad) (void)hipFree(e->d_bad);
@@ -641,8 +766,10 @@ int emb_lookup_batched(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_d
     e->n_lookup_calls.fetch_add(1, std::memory_order_relaxed);
     if (space == EMB_MEM_HOST) return lookup_host(e, descs, n_descs, itype, s);
     Resolved r;
-    int rc = resolve(e, descs, n_descs, itype, nullptr, nullptr, nullptr, &r);
+    const double p0 = g_prof.on ? now_us() : 0;
+    int rc = resolve(e, descs, n_descs, itype, nullptr, nullptr, nullptr, &r, /*cache_maps=*/true);
     if (rc) return rc;
+    if (g_prof.on) g_prof.resolve += now_us() - p0;
     rc = launch_resolved(e, r, itype, s);
     if (rc) return rc;
     e->n_bags.fetch_add(r.n_bags, std::memory_order_relaxed);

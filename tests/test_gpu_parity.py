@@ -796,3 +796,25 @@ def test_compat_lookup_with_ten_columns(pel, oracle):
     for t in range(T):
         assert np.array_equal(res[t], oracle.c_lookup_fixed32(tabs[t], idx[t], off[t]))
     compat.reset()
+
+
+def test_transient_launch_shapes_cycle_through_the_map_cache(pel, eng, oracle):
+    """Plan-less multi-table launches big enough for the XCD-aware map (>= 131072 one-hot bags): the
+    engine caches the map per launch shape (8 shapes).  Twelve different shapes, each called twice in
+    rotation, force evictions and re-builds; every result is checked."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(99)
+    tabs = [rng.standard_normal((r, 16)).astype(np.float32) for r in (5000, 300)]
+    eng.load_table(52, tabs[0])
+    eng.load_table(53, tabs[1])
+    shapes = [(70_000 + 64 * k, 66_000 + 128 * k) for k in range(12)]
+    for rep in range(2):
+        for (b0, b1) in shapes:
+            idx = [rng.integers(0, 5000, size=b0).astype(np.int64), rng.integers(0, 300, size=b1).astype(np.int64)]
+            off = [np.arange(b0, dtype=np.int64), np.arange(b1, dtype=np.int64)]
+            outs = eng.lookup_batched([52, 53], [torch.from_numpy(i).to(dev) for i in idx],
+                                      [torch.from_numpy(o).to(dev) for o in off])
+            torch.cuda.synchronize()
+            for t in range(2):
+                assert np.array_equal(outs[t].cpu().numpy(), tabs[t][idx[t]])
