@@ -65,6 +65,10 @@ def parse_args():
     ap.add_argument("--streams", type=int, default=1,
                     help="N=1: round-robin the independent steps over this many HIP streams (default 1: every "
                          "step on one stream, which is what roofline.kernel_us assumes)")
+    ap.add_argument("--hot-rows", type=int, default=0,
+                    help="pooled workloads (c3/c5/c4 --pooling): hint each table's K most frequent rows of the first "
+                         "batch to the engine (emb_set_hot_rows: served from LDS) when they cover >= 5 %% of "
+                         "that table's accesses; 0 = no hint")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     return ap.parse_args()
@@ -218,6 +222,9 @@ def run_single(args):
     host_tables = make_tables_on_gpu(torch, eng, rows_list, dim, dev, keep_host=n_host if want_cpu else 0,
                                      dtype=spec.get("dtype", "f32"))
     batches = make_batches(pel, spec, args.nbatch)
+    if args.hot_rows > 0:
+        for t in range(T):
+            eng.set_hot_rows(t, pel.workloads.top_rows(batches[0][0][t], args.hot_rows, min_share=0.05))
 
     plans = []
     for idx, off in batches:
@@ -258,7 +265,8 @@ def run_single(args):
         "dtype": spec.get("dtype", "f32"), "data": "synthetic",
         "config": {"workload": "%s, %d rotating batches" % (spec["name"], len(plans)),
                    "tables": T, "dim": dim, "bags_per_table": B, "pooling": spec["L"],
-                   "table_bytes": eng.stats()["table_bytes"],
+                   "table_bytes": eng.stats()["table_bytes"], "hot_rows_hint": args.hot_rows,
+                   "launches_by_kind": eng.stats()["n_launches_by_kind"],
                    "parallelism": "single" if len(handles) == 1 else "single GPU, %d streams" % len(handles)},
         "roofline": {"bound": "hbm", "achieved": alg_bytes / (kernel_us * 1e-6) / 1e9,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -19,6 +19,7 @@
 #include <utility>
 #include <vector>
 
+#include "pimemb_hot_rows.h"
 #include "pimemb_internal.h"
 #include "pimemb_xcd_map.h"
 
@@ -56,11 +57,14 @@ struct Table {
     LaunchGeom geom{};
     size_t bytes = 0;
     uint64_t generation = 0;  // bumped whenever `rows` is (re)allocated: prepared plans check it
+    // optional hot-row set (emb_set_hot_rows): compact copy of the rows + row id -> slot hash, in HBM,
+    // staged into LDS by bag_sum_hot_kernel
+    void *hot_rows = nullptr;
+    uint64_t *hot_hash = nullptr;
+    uint32_t n_hot = 0, hot_log2 = 0;
+    size_t hot_lds = 0;
 };
 
-// One slot of the descriptor ring used by transient (non-plan) launches: the pinned host copy and
-// the HBM copy must both outlive the asynchronous upload + kernel, so a slot is reused only after
-// its event has completed.
 // Launch images (descriptors + any uncached XCD map) of transient calls live in a ring of pinned,
 // device-visible segments.  Calls bump-allocate inside the current segment; ONE event per segment
 // (recorded when it fills up or the caller switches streams) tells when its images may be overwritten,
@@ -109,6 +113,7 @@ struct emb_engine {
     unsigned long long *d_bad = nullptr;
     // stats
     std::atomic<uint64_t> n_lookup_calls{0}, n_kernel_launches{0}, n_bags{0}, n_indices{0};
+    std::atomic<uint64_t> n_by_kind[5] = {};
     uint64_t table_bytes = 0;
     double us_copy_in_indices = 0, us_copy_in_lengths = 0, us_launch = 0, us_copy_out = 0,
            us_sync = 0;
@@ -136,6 +141,8 @@ struct PlanGroup {
     uint32_t *d_xmap = nullptr;      // XCD-aware workgroup map, or null (2-D grid)
     uint32_t xgrid = 0;
     bool xdirect = false;            // map expanded to one {descriptor, tile} entry per workgroup
+    uint32_t hot_wgs = 0;            // KERNEL_HOT: persistent workgroups per descriptor
+    uint32_t hot_lds = 0;            // KERNEL_HOT: dynamic LDS bytes (largest hot set of the group)
     uint32_t *cached_xmap = nullptr; // transient launches: map owned by the engine's cache (not in the image)
     size_t desc_off = 0, xmap_off = 0;  // byte offsets of this group's pieces in the launch image
     std::vector<uint32_t> xmap_words;
@@ -151,6 +158,16 @@ struct emb_plan {
 };
 
 namespace {
+
+// Drop a table's hot-row set (caller holds e->mu; any launch that may read it must have finished).
+void clear_hot(Table &t) {
+    if (t.hot_rows) (void)hipFree(t.hot_rows);
+    if (t.hot_hash) (void)hipFree(t.hot_hash);
+    t.hot_rows = nullptr;
+    t.hot_hash = nullptr;
+    t.n_hot = t.hot_log2 = 0;
+    t.hot_lds = 0;
+}
 
 struct DeviceGuard {
     int prev = -1;
@@ -289,6 +306,13 @@ int resolve(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs, emb_i
             group_idx += descs[i].n_indices;
         }
         g.kind = pimemb::choose_kernel(group_bags, group_idx, g.geom);
+        if (g.kind == pimemb::KERNEL_GROUP) {   // pooled launch over tables with a hot-row set: LDS-staged kernel
+            for (uint32_t i : kv.second) {
+                const Table &t = e->tables[descs[i].table_id];
+                if (t.n_hot && t.hot_lds > g.hot_lds) g.hot_lds = (uint32_t)t.hot_lds;
+            }
+            if (g.hot_lds) g.kind = pimemb::KERNEL_HOT;
+        }
         const uint32_t bpt = pimemb::bags_per_tile(g.kind, g.geom);
         std::vector<uint32_t> tiles_of;
         std::vector<uint64_t> bytes_of;
@@ -307,6 +331,12 @@ int resolve(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs, emb_i
             d.nr_rows = t.nr_rows;
             d.fixed_pooling = u.offsets ? 0u : u.fixed_pooling;
             d.n_tiles = (uint32_t)tiles;
+            if (g.kind == pimemb::KERNEL_HOT) {
+                d.hot_rows = t.hot_rows;
+                d.hot_hash = t.hot_hash;
+                d.n_hot = t.n_hot;
+                d.hot_log2 = t.hot_log2;
+            }
             if (d.n_tiles > g.max_tiles) g.max_tiles = d.n_tiles;
             tiles_of.push_back(d.n_tiles);
             bytes_of.push_back(t.bytes);
@@ -338,6 +368,17 @@ int resolve(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs, emb_i
         } else if (g.n > 65535u) {
             return fail(EMB_ERR_UNSUPPORTED, "more than 65535 descriptors of one shape");
         }
+        if (g.kind == pimemb::KERNEL_HOT) {
+            // ~8192 1024-thread workgroups per launch, each staging its table's hot set once and striding
+            // over that table's tiles.  Swept on the 48-table C3 run (bench.py --workload c3 --hot-rows 100):
+            // 512: 0.774 ms, 1024: 0.705, 2048: 0.674, 4096: 0.652, 8192: 0.642, 12288: 0.641, 16384: 0.701,
+            // one workgroup per tile: 0.732; the plain lane-group kernel without hints: 0.671.
+            static const uint32_t total = getenv("PIMEMB_HOT_WGS_TOTAL") ? (uint32_t)atoi(getenv("PIMEMB_HOT_WGS_TOTAL")) : 8192u;
+            // ... and at least two tiles per workgroup, so staging is amortised (16 tables: 4096 in all, neutral)
+            const uint32_t cap = g.max_tiles / 2u ? g.max_tiles / 2u : 1u;
+            uint32_t w = total / g.n;
+            g.hot_wgs = w < 1u ? 1u : (w > cap ? cap : w);
+        }
         r->groups.push_back(std::move(g));
     }
     r->build_image();
@@ -347,9 +388,13 @@ int resolve(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs, emb_i
 int launch_groups(emb_engine *e, const std::vector<PlanGroup> &groups, emb_index_type itype,
                   hipStream_t s) {
     for (const PlanGroup &g : groups) {
-        HIP_TRY(pimemb::launch_bag_sum(g.d_descs, g.n, g.max_tiles, g.dtype, itype, g.geom, g.kind, g.d_xmap,
-                                       g.xgrid, g.xdirect, s));
+        if (g.kind == pimemb::KERNEL_HOT)
+            HIP_TRY(pimemb::launch_bag_sum_hot(g.d_descs, g.n, g.hot_wgs, g.hot_lds, g.dtype, itype, g.geom, s));
+        else
+            HIP_TRY(pimemb::launch_bag_sum(g.d_descs, g.n, g.max_tiles, g.dtype, itype, g.geom, g.kind, g.d_xmap,
+                                           g.xgrid, g.xdirect, s));
         e->n_kernel_launches.fetch_add(1, std::memory_order_relaxed);
+        e->n_by_kind[g.kind].fetch_add(1, std::memory_order_relaxed);
     }
     return EMB_OK;
 }
@@ -656,8 +701,10 @@ int emb_destroy(emb_engine *e) {
                         "h2d enqueue %.2f  kernel enqueue %.2f\n", (unsigned long long)g_prof.calls,
                 g_prof.resolve / n, g_prof.slot / n, g_prof.image / n, g_prof.h2d / n, g_prof.launch / n);
     }
-    for (Table &t : e->tables)
+    for (Table &t : e->tables) {
+        clear_hot(t);
         if (t.rows) (void)hipFree(t.rows);
+    }
     for (DescSlot &sl : e->slots) {
         if (sl.h) (void)hipHostFree(sl.h);
         if (sl.d) (void)hipFree(sl.d);
@@ -685,6 +732,11 @@ int emb_alloc_table(emb_engine *e, uint32_t table_id, uint64_t nr_rows, uint32_t
     std::lock_guard<std::mutex> lk(e->mu);
     Table &t = e->tables[table_id];
     size_t bytes = (size_t)nr_rows * dim * elem_size(dtype);
+    if (t.n_hot) {   // (re)loading a table invalidates its hot-row copy
+        HIP_TRY(hipDeviceSynchronize());
+        clear_hot(t);
+        t.generation = e->next_generation++;
+    }
     if (t.rows && t.bytes != bytes) {
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipFree(t.rows));
@@ -732,6 +784,11 @@ int emb_load_table_column(emb_engine *e, uint32_t table_id, uint32_t col, const 
                     (unsigned long long)nr_rows, (unsigned long long)t.nr_rows);
     DeviceGuard g(e->device);
     std::lock_guard<std::mutex> lk(e->mu);
+    if (t.n_hot) {
+        HIP_TRY(hipDeviceSynchronize());
+        clear_hot(t);
+        t.generation = e->next_generation++;
+    }
     size_t bytes = nr_rows * sizeof(int32_t);
     int rc = ensure_stage(e, 0, bytes);
     if (rc) return rc;
@@ -740,6 +797,38 @@ int emb_load_table_column(emb_engine *e, uint32_t table_id, uint32_t col, const 
                                           reinterpret_cast<const int32_t *>(e->d_stage), nr_rows,
                                           t.dim, col, nullptr));
     HIP_TRY(hipStreamSynchronize(nullptr));
+    return EMB_OK;
+}
+
+int emb_set_hot_rows(emb_engine *e, uint32_t table_id, const uint64_t *row_ids, uint32_t n_rows) {
+    if (!e) return fail(EMB_ERR_INVALID, "engine is NULL");
+    if (table_id >= e->tables.size() || !e->tables[table_id].rows)
+        return fail(EMB_ERR_INVALID, "table %u is not loaded", table_id);
+    if (n_rows && !row_ids) return fail(EMB_ERR_INVALID, "row_ids is NULL");
+    DeviceGuard g(e->device);
+    std::lock_guard<std::mutex> lk(e->mu);
+    Table &t = e->tables[table_id];
+    HIP_TRY(hipDeviceSynchronize());             // launches that still read the previous set
+    clear_hot(t);
+    t.generation = e->next_generation++;         // prepared plans carry the old pointers: stale now
+    if (n_rows == 0) return EMB_OK;
+    if (t.geom.scalar_lanes) return EMB_OK;      // element-per-thread rows: no LDS path, the hint is ignored
+    const uint32_t row_bytes = t.geom.chunks * 16u;
+    pimemb::HotSet hs = pimemb::build_hot_set(row_ids, n_rows, t.nr_rows, row_bytes, pimemb::kHotLdsBudget);
+    if (hs.rows.empty()) return EMB_OK;
+    HIP_TRY(hipMalloc(&t.hot_rows, hs.rows.size() * (size_t)row_bytes));
+    hipError_t err = hipMalloc((void **)&t.hot_hash, hs.hash.size() * 8);
+    for (size_t i = 0; err == hipSuccess && i < hs.rows.size(); i++)   // cold path: one small copy per hot row
+        err = hipMemcpy(static_cast<char *>(t.hot_rows) + i * row_bytes,
+                        static_cast<const char *>(t.rows) + hs.rows[i] * row_bytes, row_bytes, hipMemcpyDeviceToDevice);
+    if (err == hipSuccess) err = hipMemcpy(t.hot_hash, hs.hash.data(), hs.hash.size() * 8, hipMemcpyHostToDevice);
+    if (err != hipSuccess) {
+        clear_hot(t);
+        return fail(EMB_ERR_DEVICE, "emb_set_hot_rows: %s", hipGetErrorString(err));
+    }
+    t.n_hot = (uint32_t)hs.rows.size();
+    t.hot_log2 = hs.log2size;
+    t.hot_lds = hs.lds_bytes(row_bytes);
     return EMB_OK;
 }
 
@@ -941,6 +1030,7 @@ int emb_get_stats(emb_engine *e, emb_stats *out) {
     out->us_copy_out = e->us_copy_out;
     out->us_post_process = 0.0;
     out->us_sync = e->us_sync;
+    for (int k = 0; k < 5; k++) out->n_launches_by_kind[k] = e->n_by_kind[k].load();
     return EMB_OK;
 }
 
@@ -950,6 +1040,7 @@ int emb_reset_stats(emb_engine *e) {
     e->n_kernel_launches = 0;
     e->n_bags = 0;
     e->n_indices = 0;
+    for (auto &k : e->n_by_kind) k = 0;
     e->us_copy_in_indices = e->us_copy_in_lengths = e->us_launch = e->us_copy_out = e->us_sync = 0;
     return EMB_OK;
 }

@@ -22,8 +22,11 @@ enum KernelKind : uint32_t {
     KERNEL_WAVEBATCH = 0,  // 64 bags per wavefront, coalesced bounds, one-hot fast path: big batches
     KERNEL_GROUP = 1,      // one lane group per bag, finest granularity: pooled launches, small batches
     KERNEL_WAVEBATCH2 = 2, // 2 x 64 bags per wavefront: very big one-hot launches
-    KERNEL_ANYDIM = 3      // one thread per output element: any dim (e.g. DLRM's default 2), not a tuned path
+    KERNEL_ANYDIM = 3,     // one thread per output element: any dim (e.g. DLRM's default 2), not a tuned path
+    KERNEL_HOT = 4         // lane-group kernel with the tables' hot rows staged in LDS (emb_set_hot_rows)
 };
+
+constexpr size_t kHotLdsBudget = 62u << 10;   // LDS bytes a hot set (rows + hash) may take per workgroup
 
 // Returns EMB_OK / EMB_ERR_UNSUPPORTED and fills `g` for a table shape.
 int geometry_for(emb_dtype dtype, uint32_t dim, LaunchGeom *g);
@@ -42,6 +45,10 @@ hipError_t launch_bag_sum(const DevDesc *d_descs, uint32_t n_descs, uint32_t max
                           emb_dtype dtype, emb_index_type itype, const LaunchGeom &g,
                           KernelKind kind, const uint32_t *d_xmap, uint32_t xgrid, bool xdirect,
                           hipStream_t stream);
+
+// Pooled launch with hot rows in LDS: `wgs` persistent workgroups per descriptor, `lds_bytes` of dynamic LDS.
+hipError_t launch_bag_sum_hot(const DevDesc *d_descs, uint32_t n_descs, uint32_t wgs, uint32_t lds_bytes,
+                              emb_dtype dtype, emb_index_type itype, const LaunchGeom &g, hipStream_t stream);
 
 // Scatter an int32 column (device buffer, nr_rows entries) into column `col` of a row-major
 // [nr_rows][dim] int32 table: the inverse of alloc_buffers' split (emb_host.h:116-118).

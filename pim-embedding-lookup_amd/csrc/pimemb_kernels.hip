@@ -27,6 +27,8 @@ using WaveCfg = BagCfg<64, 8, true, false, 8, 8, 1, false, true, false, kClampIn
 // workgroups, unroll 4 on the general path so the kernel still fits 64 VGPRs without spilling: -4.5 %
 using Wave2Cfg = BagCfg<128, 4, true, false, 8, 8, 2, false, true, false, kClampInputs>;
 using GroupCfg = BagCfg<256, 8, true, false, 8, 1, 1, false, false, /*IDX_SHUFFLE*/ true, kClampInputs>;
+// pooled launches over tables with a hot-row set: persistent 1024-thread workgroups stage the set into LDS
+using HotCfg = BagCfg<1024, 8, true, false, 8, 1, 1, false, false, /*IDX_SHUFFLE*/ true, kClampInputs>;
 constexpr int kBlock = 256;  // helper kernels below
 
 template <typename IdxT, int DT, int L>
@@ -78,6 +80,39 @@ hipError_t launch_dtype(const DevDesc *d, uint32_t n, uint32_t max_tiles, emb_dt
             return launch_lpr<IdxT, EMB_F16>(d, n, max_tiles, g, kind, xmap, xgrid, xdirect, s);
         case EMB_FIXED32:
             return launch_lpr<IdxT, EMB_FIXED32>(d, n, max_tiles, g, kind, xmap, xgrid, xdirect, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+template <typename IdxT, int DT>
+hipError_t launch_hot_lpr(const DevDesc *d, uint32_t n, uint32_t wgs, uint32_t lds, const LaunchGeom &g, hipStream_t s) {
+    const dim3 grid(wgs, n, 1), block(HotCfg::kBlock);
+    switch (g.lanes_per_row) {
+#define PIMEMB_CASE(L)                                                                                       \
+    case L:                                                                                                  \
+        hipLaunchKernelGGL((bag_sum_hot_kernel<IdxT, DT, L, HotCfg>), grid, block, lds, s, d, g.chunks);     \
+        break;
+        PIMEMB_CASE(1)
+        PIMEMB_CASE(2)
+        PIMEMB_CASE(4)
+        PIMEMB_CASE(8)
+        PIMEMB_CASE(16)
+        PIMEMB_CASE(32)
+        PIMEMB_CASE(64)
+#undef PIMEMB_CASE
+        default:
+            return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+template <typename IdxT>
+hipError_t launch_hot_dtype(const DevDesc *d, uint32_t n, uint32_t wgs, uint32_t lds, emb_dtype dtype,
+                            const LaunchGeom &g, hipStream_t s) {
+    switch (dtype) {
+        case EMB_F32: return launch_hot_lpr<IdxT, EMB_F32>(d, n, wgs, lds, g, s);
+        case EMB_F16: return launch_hot_lpr<IdxT, EMB_F16>(d, n, wgs, lds, g, s);
+        case EMB_FIXED32: return launch_hot_lpr<IdxT, EMB_FIXED32>(d, n, wgs, lds, g, s);
     }
     return hipErrorInvalidValue;
 }
@@ -267,6 +302,7 @@ int geometry_for(emb_dtype dtype, uint32_t dim, LaunchGeom *g) {
 
 uint32_t bags_per_tile(KernelKind kind, const LaunchGeom &g) {
     if (kind == KERNEL_ANYDIM) return 256u / g.scalar_lanes;
+    if (kind == KERNEL_HOT) return (64u / g.lanes_per_row) * (HotCfg::kBlock / 64);
     if (kind == KERNEL_WAVEBATCH) return 64u * WaveCfg::kBatches * (WaveCfg::kBlock / 64);
     if (kind == KERNEL_WAVEBATCH2) return 64u * Wave2Cfg::kBatches * (Wave2Cfg::kBlock / 64);
     return (64u / g.lanes_per_row) * (GroupCfg::kBlock / 64);
@@ -303,6 +339,14 @@ hipError_t launch_bag_sum(const DevDesc *d_descs, uint32_t n_descs, uint32_t max
     if (itype == EMB_IDX_U32)
         return launch_dtype<uint32_t>(d_descs, n_descs, max_tiles, dtype, g, kind, d_xmap, xgrid, xdirect, stream);
     return launch_dtype<int64_t>(d_descs, n_descs, max_tiles, dtype, g, kind, d_xmap, xgrid, xdirect, stream);
+}
+
+hipError_t launch_bag_sum_hot(const DevDesc *d_descs, uint32_t n_descs, uint32_t wgs, uint32_t lds_bytes,
+                              emb_dtype dtype, emb_index_type itype, const LaunchGeom &g, hipStream_t stream) {
+    if (n_descs == 0 || wgs == 0) return hipSuccess;
+    if (n_descs > 65535u || lds_bytes > kHotLdsBudget || g.scalar_lanes) return hipErrorInvalidValue;
+    return itype == EMB_IDX_U32 ? launch_hot_dtype<uint32_t>(d_descs, n_descs, wgs, lds_bytes, dtype, g, stream)
+                                : launch_hot_dtype<int64_t>(d_descs, n_descs, wgs, lds_bytes, dtype, g, stream);
 }
 
 hipError_t launch_scatter_column(int32_t *table, const int32_t *column, uint64_t nr_rows,

@@ -171,6 +171,12 @@ class EmbeddingEngine:
         column = np.ascontiguousarray(column, dtype=np.int32)
         _l.check(self._L.emb_load_table_column(self._h, table_id, col, column.ctypes.data, column.shape[0]))
 
+    def set_hot_rows(self, table_id: int, row_ids) -> None:
+        """Hint: the table's hottest rows, hottest first (empty clears).  Pooled launches then serve
+        them from LDS (emb_set_hot_rows in pimemb.h); results do not change."""
+        ids = np.ascontiguousarray(row_ids, dtype=np.uint64)
+        _l.check(self._L.emb_set_hot_rows(self._h, table_id, ids.ctypes.data_as(C.POINTER(C.c_uint64)), ids.shape[0]))
+
     def table_info(self, table_id: int):
         ptr, n, d, dt = C.c_void_p(), C.c_uint64(), C.c_uint32(), C.c_int()
         _l.check(self._L.emb_table_info(self._h, table_id, C.byref(ptr), C.byref(n), C.byref(d), C.byref(dt)))
@@ -282,7 +288,9 @@ class EmbeddingEngine:
     def stats(self) -> dict:
         s = _l.EmbStats()
         _l.check(self._L.emb_get_stats(self._h, C.byref(s)))
-        return {k: getattr(s, k) for k, _ in s._fields_}
+        d = {k: getattr(s, k) for k, _ in s._fields_}
+        d["n_launches_by_kind"] = list(d["n_launches_by_kind"])
+        return d
 
     def reset_stats(self) -> None:
         _l.check(self._L.emb_reset_stats(self._h))

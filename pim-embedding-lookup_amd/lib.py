@@ -30,7 +30,8 @@ class EmbStats(C.Structure):
                 ("n_bags", C.c_uint64), ("n_indices", C.c_uint64), ("table_bytes", C.c_uint64),
                 ("us_copy_in_indices", C.c_double), ("us_copy_in_lengths", C.c_double),
                 ("us_launch", C.c_double), ("us_copy_out", C.c_double),
-                ("us_post_process", C.c_double), ("us_sync", C.c_double)]
+                ("us_post_process", C.c_double), ("us_sync", C.c_double),
+                ("n_launches_by_kind", C.c_uint64 * 5)]
 
 
 class EmbTraceEvent(C.Structure):
@@ -57,6 +58,7 @@ SIGNATURES = {
     "emb_load_table": (C.c_int, [_vp, _u32, _u64, _u32, C.c_int, _vp, C.c_int]),
     "emb_alloc_table": (C.c_int, [_vp, _u32, _u64, _u32, C.c_int]),
     "emb_load_table_column": (C.c_int, [_vp, _u32, _u32, _vp, _u64]),
+    "emb_set_hot_rows": (C.c_int, [_vp, _u32, C.POINTER(_u64), _u32]),
     "emb_table_info": (C.c_int, [_vp, _u32, _pp, C.POINTER(_u64), C.POINTER(_u32), C.POINTER(C.c_int)]),
     "emb_lookup": (C.c_int, [_vp, _u32, _vp, _u64, _vp, _u64, _vp, C.c_int, C.c_int, _vp]),
     "emb_lookup_batched": (C.c_int, [_vp, C.POINTER(EmbLookupDesc), _u32, C.c_int, C.c_int, _vp]),

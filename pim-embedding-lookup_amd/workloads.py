@@ -83,3 +83,15 @@ def table_set(name: str, rows_scale: float = 1.0):
         rows = [max(1, int(n * rows_scale)) for n in rows]
         label += " (rows x %g)" % rows_scale
     return list(rows), dim, batch, label
+
+
+def top_rows(indices: np.ndarray, k: int, min_share: float = 0.0) -> np.ndarray:
+    """The k most frequent row ids of an index sample, most frequent first (for emb_set_hot_rows).
+    min_share > 0: return no rows unless those k cover at least that share of the sample -- a table
+    with near-uniform accesses gains nothing from an LDS copy of k of its rows."""
+    indices = np.asarray(indices)
+    ids, counts = np.unique(indices, return_counts=True)
+    order = np.argsort(-counts, kind="stable")[:k]
+    if min_share > 0.0 and counts[order].sum() < min_share * max(indices.shape[0], 1):
+        return np.zeros(0, dtype=np.uint64)
+    return ids[order].astype(np.uint64)

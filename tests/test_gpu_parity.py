@@ -762,8 +762,11 @@ def test_any_row_width(pel, eng, oracle, dim, dtype, itype):
         tab = rng.standard_normal((rows, dim)).astype(dtype)
         eng.load_table(40, tab)
         want = oracle.c_bag_sum(tab, idx, off)
+    eng.reset_stats()
     got = eng.lookup(40, idx, off)
     assert got.shape == (n_bags, dim) and np.array_equal(got, want)
+    rb = dim * np.dtype(dtype).itemsize
+    assert eng.stats()["n_launches_by_kind"][3] == int(rb % 16 != 0 or rb > 1024)   # element-per-thread kernel
     # fixed pooling (no offsets array) and a fused call mixing this table with a 16-byte-multiple one
     L = 3
     idx2 = rng.integers(0, rows, size=n_bags * L).astype(itype)
@@ -818,3 +821,69 @@ def test_transient_launch_shapes_cycle_through_the_map_cache(pel, eng, oracle):
             torch.cuda.synchronize()
             for t in range(2):
                 assert np.array_equal(outs[t].cpu().numpy(), tabs[t][idx[t]])
+
+
+@pytest.mark.parametrize("dim,dtype", [(16, np.float32), (128, np.float32), (64, np.float16), (24, np.float32),
+                                       (8, np.int32), (256, np.float32)])
+def test_hot_rows_in_lds_do_not_change_results(pel, eng, oracle, dim, dtype):
+    """emb_set_hot_rows: pooled Zipf lookups served partly from LDS are bit-identical to the oracle,
+    for every dtype; duplicates / out-of-range ids in the hint are ignored; ragged bags with empties;
+    a second table without a hint shares the launch; clearing the hint restores the plain kernel."""
+    import torch
+    rng = np.random.default_rng(dim)
+    rows, n_bags = 20_000, 3000
+    if dtype == np.int32:
+        tab = rng.integers(-2**31, 2**31 - 1, size=(rows, dim), dtype=np.int64).astype(np.int32)
+        eng.load_table(44, tab, dtype=pel.EMB_FIXED32)
+        ref = lambda i, o: oracle.c_lookup_fixed32(tab, i.astype(np.uint32), o.astype(np.uint32))
+    else:
+        tab = rng.standard_normal((rows, dim)).astype(dtype)
+        eng.load_table(44, tab)
+        ref = lambda i, o: oracle.c_bag_sum(tab, i, o)
+    tab2 = rng.standard_normal((500, dim)).astype(np.float32)
+    if dtype == np.float32:
+        eng.load_table(45, tab2)
+    off, n = pel.workloads.ragged_offsets(rng, n_bags, 40, dtype=np.uint32)
+    idx = pel.workloads.zipf_indices(rng, rows, n)
+    hot = pel.workloads.top_rows(idx, 300)                      # more than fit: the engine keeps what fits
+    hint = np.concatenate([hot[:5], hot, np.array([rows + 7, 2**40], dtype=np.uint64)])
+    eng.set_hot_rows(44, hint)
+    want = ref(idx, off)
+    eng.reset_stats()
+    assert np.array_equal(eng.lookup(44, idx, off), want)
+    assert eng.stats()["n_launches_by_kind"] == [0, 0, 0, 0, 1]      # the LDS hot-row kernel ran
+    if dtype == np.float32:
+        idx2 = rng.integers(0, 500, size=n).astype(np.uint32)
+        outs = eng.lookup_batched([44, 45], [idx, idx2], [off, off])
+        assert np.array_equal(outs[0], want) and np.array_equal(outs[1], oracle.c_bag_sum(tab2, idx2, off))
+    # int64 indices on device tensors, fixed pooling
+    dev = torch.device("cuda", 0)
+    L = 32
+    idx3 = pel.workloads.zipf_indices(rng, rows, n_bags * L).astype(np.int64)
+    off3 = (np.arange(n_bags) * L).astype(np.int64)
+    got = eng.lookup(44, torch.from_numpy(idx3).to(dev), torch.from_numpy(off3).to(dev))
+    assert np.array_equal(got.cpu().numpy(), ref(idx3, off3))
+    # a plan built on the hinted table is refused once the hint changes
+    d_idx, d_off = torch.from_numpy(idx3).to(dev), torch.from_numpy(off3).to(dev)
+    plan = eng.plan([44], [d_idx], [d_off])
+    plan.launch()
+    torch.cuda.synchronize()
+    assert np.array_equal(plan.outputs[0].cpu().numpy(), ref(idx3, off3))
+    eng.set_hot_rows(44, [])
+    with pytest.raises(pel.PimembError):
+        plan.launch()
+    plan.destroy()
+    assert np.array_equal(eng.lookup(44, idx, off), want)
+
+
+def test_hot_rows_dropped_when_the_table_is_reloaded(pel, eng, oracle):
+    rng = np.random.default_rng(4)
+    tab = rng.standard_normal((1000, 32)).astype(np.float32)
+    eng.load_table(46, tab)
+    off, n = pel.workloads.ragged_offsets(rng, 500, 20, dtype=np.uint32)
+    idx = pel.workloads.zipf_indices(rng, 1000, n)
+    eng.set_hot_rows(46, pel.workloads.top_rows(idx, 64))
+    assert np.array_equal(eng.lookup(46, idx, off), oracle.c_bag_sum(tab, idx, off))
+    tab_b = (tab * 3.0 + 1.0).astype(np.float32)
+    eng.load_table(46, tab_b)                                   # same shape, new contents: stale copy must go
+    assert np.array_equal(eng.lookup(46, idx, off), oracle.c_bag_sum(tab_b, idx, off))
