@@ -13,6 +13,13 @@
  *   (2) the two reference signatures, byte-for-byte, so existing callers of emblib.so relink
  *       unchanged: `populate_mram`, `lookup` (+ `emb_configure` replacing the -D macros).
  *
+ * Threading.  The reference assumes a single caller thread (unguarded globals, emb_host.h:32-33).
+ * Here: table management (emb_alloc_table / emb_load_* / emb_set_hot_rows / emb_destroy) must not run
+ * concurrently with lookups on the same engine.  Lookups may be issued from several threads:
+ * host-pointer calls are serialised inside the engine (they share one staging buffer),
+ * device-pointer calls and emb_plan_launch only enqueue work on the caller's stream.  populate_mram /
+ * lookup serialise themselves.  emb_last_error() is thread-local.
+ *
  * Paths cited as upmem/... are relative to the reference checkout.
  */
 #ifndef PIMEMB_H

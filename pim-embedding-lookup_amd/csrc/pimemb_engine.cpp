@@ -98,7 +98,9 @@ constexpr size_t kXmapCacheEntries = 8;
 struct emb_engine {
     int device = 0;
     std::vector<Table> tables;
-    std::mutex mu;  // guards tables / workspaces; launches on device buffers do not take it
+    std::mutex mu;       // guards tables, staging buffers, the launch-image ring and the map cache;
+                         // emb_plan_launch does not take it
+    std::mutex host_mu;  // serialises host-pointer calls (they share one staging buffer) -- held for the whole call
     DescSlot slots[kSlots];
     int next_slot = 0;
     std::vector<XmapCacheEntry> xmap_cache;
@@ -404,10 +406,15 @@ int take_image_space(emb_engine *e, size_t n, hipStream_t s, char **h, char **d)
     n = (n + 127) / 128 * 128;
     DescSlot *sl = &e->slots[e->next_slot];
     if (sl->used && (sl->used + n > sl->cap || sl->stream != s)) {   // close the segment, move on
-        HIP_TRY(hipEventRecord(sl->done, sl->stream));
-        sl->pending = true;
-        e->next_slot = (e->next_slot + 1) % kSlots;
-        sl = &e->slots[e->next_slot];
+        if (hipEventRecord(sl->done, sl->stream) == hipSuccess) {
+            sl->pending = true;
+            e->next_slot = (e->next_slot + 1) % kSlots;
+            sl = &e->slots[e->next_slot];
+        } else {                       // e.g. the caller destroyed that stream: drain everything instead
+            (void)hipGetLastError();
+            HIP_TRY(hipDeviceSynchronize());
+            sl->used = 0;
+        }
     }
     if (sl->pending) {
         HIP_TRY(hipEventSynchronize(sl->done));
@@ -415,8 +422,8 @@ int take_image_space(emb_engine *e, size_t n, hipStream_t s, char **h, char **d)
         sl->used = 0;
     }
     if (sl->cap < n) {      // first use, or an image larger than a segment (huge uncached map)
-        if (sl->used) {     // images of launches in flight on sl->stream
-            HIP_TRY(hipStreamSynchronize(sl->stream));
+        if (sl->used) {     // images of launches that may still be in flight
+            HIP_TRY(hipDeviceSynchronize());
             sl->used = 0;
         }
         if (sl->h) (void)hipHostFree(sl->h);
@@ -569,6 +576,7 @@ int stage_host_inputs(emb_engine *e, const emb_lookup_desc *descs, uint32_t n, e
 // small copies onto a slower path, +30 us per call on the reference's presets.)
 int lookup_host(emb_engine *e, const emb_lookup_desc *descs, uint32_t n, emb_index_type itype,
                 hipStream_t s) {
+    std::lock_guard<std::mutex> host_lk(e->host_mu);
     const bool timed = e->stage_timing || e->trace_cap != 0;
     HostStage hs;
     const double t0 = now_us();
@@ -985,6 +993,8 @@ int emb_validate_inputs(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_
     HostStage hs;
     Resolved r;
     int rc;
+    std::unique_lock<std::mutex> host_lk(e->host_mu, std::defer_lock);
+    if (space == EMB_MEM_HOST) host_lk.lock();
     std::unique_lock<std::mutex> lk(e->mu);
     if (space == EMB_MEM_HOST) {
         rc = stage_host_inputs(e, descs, n_descs, itype, s, &hs, false);

@@ -887,3 +887,40 @@ def test_hot_rows_dropped_when_the_table_is_reloaded(pel, eng, oracle):
     tab_b = (tab * 3.0 + 1.0).astype(np.float32)
     eng.load_table(46, tab_b)                                   # same shape, new contents: stale copy must go
     assert np.array_equal(eng.lookup(46, idx, off), oracle.c_bag_sum(tab_b, idx, off))
+
+
+def test_lookups_from_several_threads(pel, eng, oracle):
+    """Host-pointer calls (serialised inside the engine: one staging buffer) and device-pointer calls
+    issued from four threads at once; every result is checked against the oracle."""
+    import threading
+    import torch
+    dev = torch.device("cuda", 0)
+    tab = np.random.default_rng(8).standard_normal((4000, 32)).astype(np.float32)
+    eng.load_table(55, tab)
+    errors = []
+
+    def worker(seed, use_device):
+        try:
+            rng = np.random.default_rng(seed)
+            stream = torch.cuda.Stream(dev) if use_device else None
+            for it in range(30):
+                off, n = pel.workloads.ragged_offsets(rng, 200 + it, 9, dtype=np.int64)
+                idx = rng.integers(0, 4000, size=n).astype(np.int64)
+                if use_device:
+                    with torch.cuda.stream(stream):
+                        got = eng.lookup(55, torch.from_numpy(idx).to(dev), torch.from_numpy(off).to(dev))
+                    stream.synchronize()
+                    got = got.cpu().numpy()
+                else:
+                    got = eng.lookup(55, idx, off)
+                if not np.array_equal(got, oracle.c_bag_sum(tab, idx, off)):
+                    errors.append((seed, it))
+        except Exception as ex:  # noqa: BLE001
+            errors.append(repr(ex))
+
+    threads = [threading.Thread(target=worker, args=(s, s % 2 == 0)) for s in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
