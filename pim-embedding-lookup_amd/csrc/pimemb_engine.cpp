@@ -726,7 +726,8 @@ int emb_destroy(emb_engine *e) {
     return EMB_OK;
 }
 
-int emb_alloc_table(emb_engine *e, uint32_t table_id, uint64_t nr_rows, uint32_t dim, emb_dtype dtype) {
+static int alloc_table(emb_engine *e, uint32_t table_id, uint64_t nr_rows, uint32_t dim, emb_dtype dtype,
+                       bool zero_fill) {
     if (!e) return fail(EMB_ERR_INVALID, "engine is NULL");
     if (table_id >= e->tables.size())
         return fail(EMB_ERR_INVALID, "table id %u >= max_tables %zu", table_id, e->tables.size());
@@ -756,7 +757,7 @@ int emb_alloc_table(emb_engine *e, uint32_t table_id, uint64_t nr_rows, uint32_t
         e->table_bytes += bytes;
         t.generation = e->next_generation++;
     }
-    HIP_TRY(hipMemset(t.rows, 0, bytes));
+    if (zero_fill) HIP_TRY(hipMemset(t.rows, 0, bytes));   // emb_load_table overwrites every byte anyway
     if (t.nr_rows != nr_rows || t.dim != dim || t.dtype != dtype)
         t.generation = e->next_generation++;   // same bytes, different shape: plans built on the old shape are stale
     t.nr_rows = nr_rows;
@@ -767,10 +768,14 @@ int emb_alloc_table(emb_engine *e, uint32_t table_id, uint64_t nr_rows, uint32_t
     return EMB_OK;
 }
 
+int emb_alloc_table(emb_engine *e, uint32_t table_id, uint64_t nr_rows, uint32_t dim, emb_dtype dtype) {
+    return alloc_table(e, table_id, nr_rows, dim, dtype, /*zero_fill=*/true);
+}
+
 int emb_load_table(emb_engine *e, uint32_t table_id, uint64_t nr_rows, uint32_t dim, emb_dtype dtype,
                    const void *rows, emb_memspace space) {
     if (!rows) return fail(EMB_ERR_INVALID, "table %u: rows is NULL", table_id);
-    int rc = emb_alloc_table(e, table_id, nr_rows, dim, dtype);
+    int rc = alloc_table(e, table_id, nr_rows, dim, dtype, /*zero_fill=*/false);
     if (rc) return rc;
     DeviceGuard g(e->device);
     Table &t = e->tables[table_id];

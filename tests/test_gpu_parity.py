@@ -924,3 +924,4 @@ def test_lookups_from_several_threads(pel, eng, oracle):
     for t in threads:
         t.join()
     assert not errors, errors
+
