@@ -43,8 +43,9 @@ def parse_args():
     ap.add_argument("--nbatch", type=int, default=8, help="distinct index batches rotated through")
     ap.add_argument("--index-dist", choices=["uniform", "zipf"], default=None,
                     help="default: uniform for c2, zipf(1.2) for c3")
-    ap.add_argument("--workload", choices=["c2", "c3", "c4", "c5"], default="c2",
-                    help="c2 = BASELINE configs[1] (the metric's config, default); c3 = configs[2] scaled "
+    ap.add_argument("--workload", choices=["c1", "c2", "c3", "c4", "c5"], default="c2",
+                    help="c1 = configs[0]'s shape on the GPU (the 26 Kaggle tables, mini-batch 1: launch latency); "
+                         "c2 = BASELINE configs[1] (the metric's config, default); c3 = configs[2] scaled "
                          "to fit one GPU: 48 tables x 10M rows x dim 128 fp32, B=16384, pooling 32; c5 = one GPU's "
                          "share of configs[4]: 64 tables x 30M rows x dim 64 fp16, mixed Zipf/uniform, pooling 32; "
                          "c4 = configs[3], the Terabyte-shaped 26 tables at dim 128: with --gpus N the row-range "
@@ -106,12 +107,12 @@ def measured_traffic(workload: str):
 
 def workload_spec(pel, args):
     """rows per table, dim, bags per table, pooling, index distribution, description."""
-    if args.workload == "c2":
-        B = args.batch or pel.workloads.KAGGLE_BATCH
+    if args.workload in ("c1", "c2"):
+        B = args.batch or (1 if args.workload == "c1" else pel.workloads.KAGGLE_BATCH)
         dist = args.index_dist or "uniform"
         return dict(rows=pel.workloads.KAGGLE_ROWS, dim=pel.workloads.KAGGLE_DIM, B=B, L=1, dist=dist,
-                    name="C2: 26 Criteo-Kaggle tables, dim 16 fp32, B=%d bags/table, L=1, u32 indices+offsets, "
-                         "%s indices" % (B, dist))
+                    name="%s: 26 Criteo-Kaggle tables, dim 16 fp32, B=%d bags/table, L=1, u32 indices+offsets, "
+                         "%s indices" % (args.workload.upper(), B, dist))
     if args.workload == "c5":
         T = args.tables or 64
         B = args.batch or 16384
@@ -218,7 +219,7 @@ def run_single(args):
     T = len(rows_list)
     eng = pel.EmbeddingEngine(device=0, max_tables=T)
     want_cpu = not args.no_cpu_baseline
-    n_host = T if args.workload == "c2" else 2        # c3: 5 GB per table, sample two on the host
+    n_host = T if args.workload in ("c1", "c2") else 2        # c3: 5 GB per table, sample two on the host
     host_tables = make_tables_on_gpu(torch, eng, rows_list, dim, dev, keep_host=n_host if want_cpu else 0,
                                      dtype=spec.get("dtype", "f32"))
     batches = make_batches(pel, spec, args.nbatch)
