@@ -168,12 +168,14 @@ def _free_port():
          expect_kinds=["replicated", "whole", "row_split"]),
     dict(rows=[100, 200, 300], dim=16, rep=0, split=10**12, bags=11, max_len=4, expect_kinds=["whole"]),
 ])
-def test_two_rank_gloo_exchange_matches_single_process_oracle(cfg):
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_exchange_matches_single_process_oracle(cfg, world):
+    """world 3: row ranges that do not divide evenly, a rank that owns no whole table."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, cfg, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, cfg, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]
