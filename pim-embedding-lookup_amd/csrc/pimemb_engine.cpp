@@ -19,6 +19,7 @@
 #include <utility>
 #include <vector>
 
+#include "pimemb_hostcopy.h"
 #include "pimemb_hot_rows.h"
 #include "pimemb_internal.h"
 #include "pimemb_xcd_map.h"
@@ -101,6 +102,8 @@ struct emb_engine {
     std::mutex mu;       // guards tables, staging buffers, the launch-image ring and the map cache;
                          // emb_plan_launch does not take it
     std::mutex host_mu;  // serialises host-pointer calls (they share one staging buffer) -- held for the whole call
+    pimemb::HostCopier copier;   // packs inputs / unpacks results of host-pointer calls (used under host_mu)
+    hipEvent_t pipe_ev[4] = {};  // pipelined zero-copy calls: "tables of part k are done"
     DescSlot slots[kSlots];
     int next_slot = 0;
     std::vector<XmapCacheEntry> xmap_cache;
@@ -513,48 +516,64 @@ struct HostStage {
     bool zero_copy = false; // the kernel reads/writes the pinned host staging itself (no copies)
 };
 
-// Small calls (the reference's presets: tens to hundreds of KB) skip both copies: the pinned staging
-// buffer is device-visible, so the kernel gathers its indices from host memory and stores the pooled
-// rows straight back over PCIe -- two copy-engine launches (~10-25 us each) less per call.
-constexpr size_t kZeroCopyBytes = 1u << 20;
+// Host-pointer calls up to 40 MB skip both copy-engine transfers: the pinned staging buffer is
+// device-visible, so the kernel gathers its indices from host memory and stores the pooled rows
+// straight back over PCIe; the host then unpacks them into the caller's buffers (a few threads, and
+// for >= 4 MB overlapped with the kernel in up to four parts, lookup_host_pipelined).  Measured with
+// emb_host_bench (26 tables x 16 columns, one index per bag, ms per lookup(); zero-copy as shipped vs
+// copy-engine transfers): 512 bags 0.053 / 0.082, 2048 bags 0.15 / 0.43-0.51, 8192 bags 0.40 / 0.92,
+// 16384 bags 0.80 / 1.70, 20000 bags 0.92 / 2.0.  The exception: when every table returns >= 1.5e6
+// bytes the runtime's device-to-host copies into pageable memory run at link speed and are used
+// instead (24000 bags: 1.19 ms either way, 39292 bags: 1.75 vs 1.92 zero-copy); smaller pieces take a
+// slow staged path in the runtime (17 us + ~16 GB/s per copy).  Both limits can be overridden with
+// PIMEMB_ZERO_COPY_BYTES / PIMEMB_FAST_PIECE_BYTES (tools/emb_host_bench.cpp is the probe).
+static const size_t kZeroCopyBytes = getenv("PIMEMB_ZERO_COPY_BYTES") ? strtoull(getenv("PIMEMB_ZERO_COPY_BYTES"), nullptr, 10) : (40u << 20);
+static const size_t kStagedOutBytes = kZeroCopyBytes > (1u << 20) ? kZeroCopyBytes : (1u << 20);
+static const size_t kFastPieceBytes = getenv("PIMEMB_FAST_PIECE_BYTES") ? strtoull(getenv("PIMEMB_FAST_PIECE_BYTES"), nullptr, 10) : 1500000;   // measured boundary: 1.28 MB pieces slow, 1.536 MB pieces fast
 
 int stage_host_inputs(emb_engine *e, const emb_lookup_desc *descs, uint32_t n, emb_index_type itype,
                       hipStream_t s, HostStage *hs, bool with_outputs, bool allow_zero_copy = false) {
     const size_t isz = index_size(itype);
-    size_t in_bytes = 0, out_bytes = 0;
+    size_t in_bytes = 0, out_bytes = 0, min_piece = SIZE_MAX;
     for (uint32_t i = 0; i < n; i++) {
         if (descs[i].table_id >= e->tables.size() || !e->tables[descs[i].table_id].rows)
             return fail(EMB_ERR_INVALID, "desc %u: table %u is not loaded", i, descs[i].table_id);
         in_bytes += align_up(descs[i].n_indices * isz, 16);
         if (descs[i].offsets) in_bytes += align_up(descs[i].n_bags * isz, 16);
-        out_bytes += align_up(descs[i].n_bags * (size_t)e->tables[descs[i].table_id].dim * 4, 16);
+        const size_t piece = descs[i].n_bags * (size_t)e->tables[descs[i].table_id].dim * 4;
+        out_bytes += align_up(piece, 16);
+        if (piece && piece < min_piece) min_piece = piece;
     }
+    const bool fast_pieces = min_piece != SIZE_MAX && min_piece >= kFastPieceBytes;   // copies run at link speed
     if (!with_outputs) out_bytes = 0;
-    const size_t h_out_bytes = (out_bytes <= (1u << 20)) ? out_bytes : 0;
+    const size_t h_out_bytes = (out_bytes <= kStagedOutBytes && !fast_pieces) ? out_bytes : 0;
     int rc = ensure_stage(e, in_bytes + h_out_bytes, in_bytes + out_bytes);
     if (rc) return rc;
     hs->h_out = h_out_bytes ? e->h_stage + in_bytes : nullptr;
-    hs->zero_copy = allow_zero_copy && with_outputs && h_out_bytes == out_bytes &&
+    hs->zero_copy = allow_zero_copy && with_outputs && h_out_bytes == out_bytes && !fast_pieces &&
                     in_bytes + out_bytes <= kZeroCopyBytes;
     char *in_base = hs->zero_copy ? e->h_stage : e->d_stage;   // what the kernel will read
     size_t off = 0;
     hs->d_indices.resize(n);
     hs->d_offsets.resize(n);
     hs->d_out.resize(n);
+    std::vector<pimemb::CopyPiece> pack;
+    pack.reserve(2 * n);
     for (uint32_t i = 0; i < n; i++) {
         const emb_lookup_desc &u = descs[i];
         if (u.n_indices && !u.indices) return fail(EMB_ERR_INVALID, "desc %u: indices is NULL", i);
-        memcpy(e->h_stage + off, u.indices, u.n_indices * isz);
+        pack.push_back({e->h_stage + off, u.indices, u.n_indices * isz});
         hs->d_indices[i] = in_base + off;
         off += align_up(u.n_indices * isz, 16);
         if (u.offsets) {
-            memcpy(e->h_stage + off, u.offsets, u.n_bags * isz);
+            pack.push_back({e->h_stage + off, u.offsets, u.n_bags * isz});
             hs->d_offsets[i] = in_base + off;
             off += align_up(u.n_bags * isz, 16);
         } else {
             hs->d_offsets[i] = nullptr;
         }
     }
+    e->copier.copy(pack);
     size_t oo = in_bytes;
     for (uint32_t i = 0; i < n; i++) {
         hs->d_out[i] = reinterpret_cast<float *>((hs->zero_copy ? e->h_stage : e->d_stage) + oo);
@@ -565,6 +584,60 @@ int stage_host_inputs(emb_engine *e, const emb_lookup_desc *descs, uint32_t n, e
     hs->out_bytes = out_bytes;
     if (in_bytes && !hs->zero_copy)
         HIP_TRY(hipMemcpyAsync(e->d_stage, e->h_stage, in_bytes, hipMemcpyHostToDevice, s));
+    return EMB_OK;
+}
+
+// Mid-size zero-copy calls: the kernel's stores into pinned host memory are PCIe-bound and the
+// host-side unpack into the caller's buffers takes about as long.  Split the tables into up to four
+// parts of similar output size, launch them back to back, and unpack part k (a few host threads)
+// while the kernel of part k+1 is still storing: 26 tables x 16 columns, 16384 bags: 0.96 -> 0.80 ms,
+// 8192 bags: 0.53 -> 0.40 ms.
+constexpr size_t kPipelineBytes = 4u << 20;
+
+int lookup_host_pipelined(emb_engine *e, const emb_lookup_desc *descs, uint32_t n, emb_index_type itype,
+                          hipStream_t s, const HostStage &hs, double t0) {
+    auto piece = [&](uint32_t i) { return descs[i].n_bags * (size_t)e->tables[descs[i].table_id].dim * 4; };
+    const uint32_t parts = n < 4 ? n : 4;
+    uint32_t bounds[5] = {0, 0, 0, 0, 0};
+    {   // contiguous parts of ~equal output bytes
+        size_t acc = 0;
+        uint32_t k = 1;
+        for (uint32_t i = 0; i < n && k < parts; i++) {
+            acc += piece(i);
+            if (acc * parts >= hs.out_bytes * k && n - (i + 1) >= parts - k) bounds[k++] = i + 1;
+        }
+        for (; k < parts; k++) bounds[k] = bounds[k - 1] + 1;   // (degenerate size distributions)
+        bounds[parts] = n;
+    }
+    uint64_t bags = 0, idx = 0;
+    for (uint32_t k = 0; k < parts; k++) {
+        const uint32_t lo = bounds[k], cnt = bounds[k + 1] - lo;
+        std::vector<const void *> di(hs.d_indices.begin() + lo, hs.d_indices.begin() + lo + cnt);
+        std::vector<const void *> dof(hs.d_offsets.begin() + lo, hs.d_offsets.begin() + lo + cnt);
+        std::vector<float *> dout(hs.d_out.begin() + lo, hs.d_out.begin() + lo + cnt);
+        Resolved r;
+        int rc = resolve(e, descs + lo, cnt, itype, &di, &dof, &dout, &r, /*cache_maps=*/true);
+        if (rc == EMB_OK) rc = launch_resolved(e, r, itype, s, true);
+        if (rc) {
+            (void)hipStreamSynchronize(s);   // parts already launched write into the staging buffer
+            return rc;
+        }
+        if (!e->pipe_ev[k]) HIP_TRY(hipEventCreateWithFlags(&e->pipe_ev[k], hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(e->pipe_ev[k], s));
+        bags += r.n_bags;
+        idx += r.n_indices;
+    }
+    std::vector<pimemb::CopyPiece> unpack;
+    for (uint32_t k = 0; k < parts; k++) {
+        HIP_TRY(hipEventSynchronize(e->pipe_ev[k]));
+        unpack.clear();
+        for (uint32_t i = bounds[k]; i < bounds[k + 1]; i++)
+            if (piece(i)) unpack.push_back({descs[i].pooled, hs.d_out[i], piece(i)});
+        e->copier.copy(unpack);
+    }
+    e->us_sync += now_us() - t0;
+    e->n_bags.fetch_add(bags, std::memory_order_relaxed);
+    e->n_indices.fetch_add(idx, std::memory_order_relaxed);
     return EMB_OK;
 }
 
@@ -587,6 +660,8 @@ int lookup_host(emb_engine *e, const emb_lookup_desc *descs, uint32_t n, emb_ind
     }
     if (timed) HIP_TRY(hipStreamSynchronize(s));
     const double t1 = now_us();
+    if (hs.zero_copy && !timed && hs.out_bytes >= kPipelineBytes && n >= 2)
+        return lookup_host_pipelined(e, descs, n, itype, s, hs, t0);
     Resolved r;
     int rc = resolve(e, descs, n, itype, &hs.d_indices, &hs.d_offsets, &hs.d_out, &r, /*cache_maps=*/true);
     if (rc) return rc;
@@ -599,7 +674,7 @@ int lookup_host(emb_engine *e, const emb_lookup_desc *descs, uint32_t n, emb_ind
     // Small results (the reference's presets: tens of KB per table): ONE device-to-host copy of the
     // whole output region into pinned staging, then host memcpys -- a per-table hipMemcpy costs
     // ~12 us each.  Large results go straight to the caller's buffers, table by table.
-    const bool staged_out = hs.out_bytes > 0 && hs.out_bytes <= (1u << 20) && hs.h_out != nullptr;
+    const bool staged_out = hs.out_bytes > 0 && hs.out_bytes <= kStagedOutBytes && hs.h_out != nullptr;
     if (hs.zero_copy) {
         // nothing to copy: the kernel already wrote hs.h_out
     } else if (staged_out) {
@@ -614,12 +689,15 @@ int lookup_host(emb_engine *e, const emb_lookup_desc *descs, uint32_t n, emb_ind
     const double t4 = now_us();
     HIP_TRY(hipStreamSynchronize(s));
     if (staged_out) {
+        std::vector<pimemb::CopyPiece> unpack;
+        unpack.reserve(n);
         for (uint32_t i = 0; i < n; i++) {
             size_t bytes = descs[i].n_bags * (size_t)e->tables[descs[i].table_id].dim * 4;
             if (bytes)
-                memcpy(descs[i].pooled, hs.h_out + (reinterpret_cast<char *>(hs.d_out[i]) -
-                                                    reinterpret_cast<char *>(hs.d_out[0])), bytes);
+                unpack.push_back({descs[i].pooled, hs.h_out + (reinterpret_cast<char *>(hs.d_out[i]) -
+                                                                reinterpret_cast<char *>(hs.d_out[0])), bytes});
         }
+        e->copier.copy(unpack);
     }
     const double t5 = now_us();
     if (timed) {
@@ -719,6 +797,8 @@ int emb_destroy(emb_engine *e) {
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
     for (XmapCacheEntry &c : e->xmap_cache) (void)hipFree(c.d_map);
+    for (hipEvent_t ev : e->pipe_ev)
+        if (ev) (void)hipEventDestroy(ev);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
     if (e->d_stage) (void)hipFree(e->d_stage);
     if (e->d_bad) (void)hipFree(e->d_bad);

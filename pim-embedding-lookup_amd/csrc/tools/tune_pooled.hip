@@ -26,7 +26,10 @@ using namespace pimemb;
         }                                                                                  \
     } while (0)
 
-constexpr int D = 128, LPR = 32;
+#ifndef TUNE_DIM
+#define TUNE_DIM 128
+#endif
+constexpr int D = TUNE_DIM, LPR = TUNE_DIM / 4;   // -DTUNE_DIM=64: the reference's NR_COLS=64 presets
 
 __global__ void fill_table(float *w, uint64_t n, uint32_t seed) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -145,6 +148,14 @@ int main(int argc, char **argv) {
     std::vector<Variant> vars;
     //                        BLOCK U  ntS   ntM  inflight minW batches ntRow spec  idxShuffle
     vars.push_back(make_variant<BagCfg<256, 8, true, false, 8, 1, 1, false, false, true>, false>("v1 group SHIP (blk256 U8 idxshfl)"));
+    if (getenv("TUNE_SMALL")) {   // small pooled launches (reference presets): gathers in flight per lane x workgroup size
+        vars.push_back(make_variant<BagCfg<256, 16, true, false, 8, 1, 1, false, false, true>, false>("v1 group blk256 U16"));
+        vars.push_back(make_variant<BagCfg<256, 32, true, false, 8, 1, 1, false, false, true>, false>("v1 group blk256 U32"));
+        vars.push_back(make_variant<BagCfg<64, 8, true, false, 8, 1, 1, false, false, true>, false>("v1 group blk64 U8"));
+        vars.push_back(make_variant<BagCfg<64, 16, true, false, 8, 1, 1, false, false, true>, false>("v1 group blk64 U16"));
+        vars.push_back(make_variant<BagCfg<64, 32, true, false, 8, 1, 1, false, false, true>, false>("v1 group blk64 U32"));
+        vars.push_back(make_variant<BagCfg<128, 16, true, false, 8, 1, 1, false, false, true>, false>("v1 group blk128 U16"));
+    }
     vars.push_back(make_variant<BagCfg<64, 8, true, false, 8, 8, 1, false, true>, true>("v2 wave b1 SHIP (blk64 U8 minw8)"));
     vars.push_back(make_variant<BagCfg<64, 8, true, false, 8, 8, 1, false, true>, true>("v2 wave b1 SHIP XCD", true));
     vars.push_back(make_variant<BagCfg<128, 4, true, false, 8, 8, 2, false, true>, true>("v2 wave b2 SHIP (blk128 U4 minw8)"));

@@ -925,3 +925,24 @@ def test_lookups_from_several_threads(pel, eng, oracle):
         t.join()
     assert not errors, errors
 
+
+@pytest.mark.parametrize("bags", [(70_000, 0, 3, 40_000, 0, 10), (90_000, 1), (5, 5, 5, 120_000), (30_000,) * 7,
+                                  (0, 0, 110_000)])
+def test_host_pointer_calls_in_the_pipelined_range(pel, eng, oracle, bags):
+    """Host-pointer calls with 4-40 MB of pooled rows run zero-copy in up to four parts whose unpack
+    overlaps the next part's kernel: skewed, empty and single-heavy table mixes, u32 and i64 indices."""
+    rng = np.random.default_rng(len(bags) * 1000 + sum(bags) % 97)
+    tabs = [rng.standard_normal((3000 + 17 * t, 16)).astype(np.float32) for t in range(len(bags))]
+    for t, w in enumerate(tabs):
+        eng.load_table(20 + t, w)
+    for itype in (np.uint32, np.int64):
+        idx, off = [], []
+        for t, b in enumerate(bags):
+            o, n = pel.workloads.ragged_offsets(rng, b, 3, dtype=itype) if b else (np.zeros(0, itype), 0)
+            off.append(o)
+            idx.append(rng.integers(0, tabs[t].shape[0], size=n).astype(itype))
+        outs = eng.lookup_batched([20 + t for t in range(len(bags))], idx, off)
+        for t in range(len(bags)):
+            assert outs[t].shape == (bags[t], 16)
+            if bags[t]:
+                assert np.array_equal(outs[t], oracle.c_bag_sum(tabs[t], idx[t], off[t])), (t, itype)
