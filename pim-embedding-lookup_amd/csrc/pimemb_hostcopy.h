@@ -8,6 +8,8 @@
 // Workers start lazily on the first large copy and sleep on a condition variable in between.
 #pragma once
 
+#include <unistd.h>
+
 #include <atomic>
 #include <condition_variable>
 #include <cstring>
@@ -30,6 +32,7 @@ public:
     static constexpr size_t kChunk = 256u << 10;
 
     ~HostCopier() {
+        forget_workers_after_fork();
         {
             std::lock_guard<std::mutex> lk(mu_);
             stop_ = true;
@@ -43,6 +46,7 @@ public:
     void copy(const std::vector<CopyPiece> &pieces) {
         size_t total = 0;
         for (const CopyPiece &p : pieces) total += p.bytes;
+        forget_workers_after_fork();
         if (total < kParallelBytes || !ensure_workers()) {
             for (const CopyPiece &p : pieces)
                 if (p.bytes) memcpy(p.dst, p.src, p.bytes);
@@ -72,6 +76,15 @@ public:
     }
 
 private:
+    // A fork()ed child inherits this object but not the threads: their handles must neither be
+    // joined nor destroyed (std::terminate), so the child leaks them and starts its own on demand.
+    void forget_workers_after_fork() {
+        if (owner_pid_ == getpid()) return;
+        if (!workers_.empty()) new std::vector<std::thread>(std::move(workers_));   // intentionally leaked
+        workers_.clear();
+        active_.store(0);
+        owner_pid_ = getpid();
+    }
     bool ensure_workers() {
         if (!workers_.empty()) return true;
         if (failed_) return false;
@@ -115,6 +128,7 @@ private:
     std::condition_variable cv_;
     uint64_t generation_ = 0;
     bool stop_ = false, failed_ = false;
+    pid_t owner_pid_ = getpid();
 };
 
 }  // namespace pimemb
