@@ -946,3 +946,30 @@ def test_host_pointer_calls_in_the_pipelined_range(pel, eng, oracle, bags):
             assert outs[t].shape == (bags[t], 16)
             if bags[t]:
                 assert np.array_equal(outs[t], oracle.c_bag_sum(tabs[t], idx[t], off[t])), (t, itype)
+
+
+def test_special_values_are_bit_exact(pel, eng, oracle):
+    """fp32 / fp16 rows holding denormals, signed zeros, infinities and extreme magnitudes: the sums
+    match the oracle bit for bit (no flush-to-zero, same rounding; NaN-producing mixes are left out
+    because x86 and the GPU pick different NaN payloads)."""
+    rng = np.random.default_rng(21)
+    specials32 = np.array([0.0, -0.0, 1e-45, -1e-45, 1e-40, 3e-39, -2e-39, 1.1754944e-38, 3.4e38, -3.4e38, 1.0,
+                           -1.0, 1e-7, 16777216.0, 16777217.0, np.inf], dtype=np.float32)
+    tab = rng.choice(specials32, size=(4096, 16)).astype(np.float32)
+    tab[::7] = rng.standard_normal((len(tab[::7]), 16)).astype(np.float32) * 1e-39       # denormal rows
+    eng.load_table(57, tab)
+    off, n = pel.workloads.ragged_offsets(rng, 3000, 9, dtype=np.uint32)
+    idx = rng.integers(0, 4096, size=n).astype(np.uint32)
+    want = oracle.c_bag_sum(tab, idx, off)
+    got = eng.lookup(57, idx, off)
+    ok = ~np.isnan(want)
+    assert ok.mean() > 0.5 and np.array_equal(np.isnan(got), ~ok)
+    assert np.array_equal(got.view(np.uint32)[ok], want.view(np.uint32)[ok])
+    specials16 = np.array([0.0, -0.0, 6e-8, -6e-8, 6.1e-5, 65504.0, -65504.0, 1.0, 0.333, np.inf], dtype=np.float16)
+    tab16 = rng.choice(specials16, size=(2048, 24)).astype(np.float16)
+    eng.load_table(58, tab16)
+    idx16 = rng.integers(0, 2048, size=n).astype(np.uint32)
+    want = oracle.c_bag_sum(tab16, idx16, off)
+    got = eng.lookup(58, idx16, off)
+    ok = ~np.isnan(want)
+    assert np.array_equal(got.view(np.uint32)[ok], want.view(np.uint32)[ok])
