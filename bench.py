@@ -52,7 +52,8 @@ def parse_args():
                          "sharded exchange, at N=1 the lookups one of 8 ranks serves (its row shards + small tables)")
     ap.add_argument("--rows-scale", type=float, default=1.0,
                     help="N>1: shrink every table of the set by this factor (rehearse an 8-rank layout on fewer GPUs)")
-    ap.add_argument("--pooling", type=int, default=None, help="c4 at N=1: indices per bag (default 1; SURVEY asks 1 and 32)")
+    ap.add_argument("--pooling", type=int, default=None, help="c4 at N=1, and the N>1 legs (data-parallel / --shard-mode whole): indices per bag "
+                         "(default 1; the exchange is link-bound for 1 and index-volume-bound for 32)")
     ap.add_argument("--tables", type=int, default=None, help="c3: number of tables (default 48)")
     ap.add_argument("--replicate-mb", type=int, default=None,
                     help="N>1: tables up to this size are replicated on every rank, larger ones are sharded. "

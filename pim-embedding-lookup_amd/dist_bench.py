@@ -53,6 +53,15 @@ def expected_rows(torch, t: int, idx, dim: int):
     return h.to(torch.float32) / 2147483647.0 - 0.5
 
 
+def expected_pooled(torch, t: int, idx, dim: int, L: int):
+    """Pooled rows of fixed-size bags, summed in index order in fp32 (what the kernel does): bit-exact."""
+    rows = expected_rows(torch, t, idx, dim).view(-1, L, dim)
+    acc = rows[:, 0, :] + 0.0
+    for j in range(1, L):
+        acc = acc + rows[:, j, :]
+    return acc
+
+
 def table_set_of(pel, args):
     """rows, dim, default batch, label of the table set the N > 1 legs run (--workload c2 | c4)."""
     name = getattr(args, "workload", "c2")
@@ -72,7 +81,8 @@ def run_whole(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
 
     rows_list, dim, B0, label = table_set_of(pel, args)
     B = args.batch or B0
-    Bp = (B + 3) // 4 * 4                   # index slots per (table, rank): keeps every piece 16-B aligned
+    L = max(1, int(getattr(args, "pooling", None) or 1))      # indices per bag (fixed pooling)
+    Bp = (B * L + 3) // 4 * 4               # index slots per (table, rank): keeps every piece 16-B aligned
     T = len(rows_list)
     NBATCH = max(2, args.nbatch)
     plan = sh.plan_shards(rows_list, dim, 4, world, replicate_bytes=rep_bytes, split_bytes=1 << 62)
@@ -106,8 +116,8 @@ def run_whole(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
         return buf[byte_off:byte_off + n * 4].view(torch.int32)
 
     rng = np.random.default_rng(1 + rank)
-    off_dev = torch.arange(B, dtype=torch.int32, device=dev)
-    idx_host = [[pel.workloads.uniform_indices(rng, n, B).view(np.int32) for n in rows_list]
+    off_dev = torch.arange(B, dtype=torch.int32, device=dev) * L
+    idx_host = [[pel.workloads.uniform_indices(rng, n, B * L).view(np.int32) for n in rows_list]
                 for _ in range(NBATCH)]
     slots = []
     for j in range(NBATCH):
@@ -120,7 +130,7 @@ def run_whole(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
         for d in range(world):
             base = int(in_off[d]) + K * B * row_b
             for q, u in enumerate(send_units[d]):
-                i32_view(sl["send"], base + q * Bp * 4, B).copy_(torch.from_numpy(idx_host[nxt][u.table]))
+                i32_view(sl["send"], base + q * Bp * 4, B * L).copy_(torch.from_numpy(idx_host[nxt][u.table]))
         sl["idx_local"] = {u.table: torch.from_numpy(idx_host[j][u.table]).to(dev) for u in local}
         sl["out_local"] = {u.table: torch.empty((B, dim), dtype=torch.float32, device=dev) for u in local}
         sl["plan_a"] = None
@@ -135,7 +145,7 @@ def run_whole(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
             for s in range(world):
                 for k, u in enumerate(served):
                     ids.append(u.uid)
-                    ii.append(i32_view(prev["recv"], int(out_off[s]) + n_send[s] * B * row_b + k * Bp * 4, B))
+                    ii.append(i32_view(prev["recv"], int(out_off[s]) + n_send[s] * B * row_b + k * Bp * 4, B * L))
                     oo.append(off_dev)
                     uu.append(f32_view(sl["send"], int(in_off[s]) + k * B * row_b, B))
             sl["plan_b"] = eng.plan(ids, ii, oo, uu)
@@ -190,7 +200,7 @@ def run_whole(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
         res = outputs(slots[i % NBATCH])
         for t in range(T):
             idx = torch.from_numpy(idx_host[i % NBATCH][t]).to(dev)
-            if not torch.equal(res[t], expected_rows(torch, t, idx, dim) + 0.0):
+            if not torch.equal(res[t], expected_pooled(torch, t, idx, dim, L)):
                 raise AssertionError(f"rank {rank}: step {i} table {t} ({plan.kinds[t]}) differs from the expected rows")
     n_primed = NBATCH + 2
 
@@ -244,8 +254,9 @@ def run_whole(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s sharded, dim %d fp32, B=%d bags/table PER RANK, "
-                                   "L=1, %d rotating batches; %s" % (label, dim, B, NBATCH, plan.describe()),
+                                   "L=%d, %d rotating batches; %s" % (label, dim, B, L, NBATCH, plan.describe()),
                        "tables": T, "dim": dim, "bags_per_table_per_rank": B, "global_bags_per_table": world * B,
+                       "pooling": L,
                        "parallelism": "tables sharded by id (replicate <= %d MiB); one all_to_all per step carries "
                                       "pooled rows of batch i + indices of batch i+1 (%d B out / %d B in per rank); "
                                       "backend %s, eager steps" %
@@ -272,6 +283,8 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
     rank, world, dev, backend, stage_cpu = ctx["rank"], ctx["world"], ctx["dev"], ctx["backend"], ctx["stage_cpu"]
 
     rows_list, dim, B0, label = table_set_of(pel, args)
+    if int(getattr(args, "pooling", None) or 1) != 1:
+        raise SystemExit("--shard-mode rows routes one-hot requests; use --shard-mode whole with --pooling")
     row_b = dim * 4
     B = args.batch or B0
     T = len(rows_list)
@@ -483,6 +496,7 @@ def run_dp(args, hbm_peak_gbs: float, ctx):
     rank, world, dev, stage_cpu = ctx["rank"], ctx["world"], ctx["dev"], ctx["stage_cpu"]
     rows_list, dim, B0, label = table_set_of(pel, args)
     B = args.batch or B0
+    L = max(1, int(getattr(args, "pooling", None) or 1))
     T = len(rows_list)
     NBATCH = max(2, args.nbatch)
     eng = pel.EmbeddingEngine(device=dev.index, max_tables=T)
@@ -490,8 +504,8 @@ def run_dp(args, hbm_peak_gbs: float, ctx):
         eng.load_table(t, table_values(torch, t, 0, rows_list[t], dim, dev))
     torch.cuda.empty_cache()
     rng = np.random.default_rng(1 + rank)
-    off = torch.arange(B, dtype=torch.int32, device=dev)
-    idx_host = [[pel.workloads.uniform_indices(rng, n, B).view(np.int32) for n in rows_list] for _ in range(NBATCH)]
+    off = torch.arange(B, dtype=torch.int32, device=dev) * L
+    idx_host = [[pel.workloads.uniform_indices(rng, n, B * L).view(np.int32) for n in rows_list] for _ in range(NBATCH)]
     plans = []
     for j in range(NBATCH):
         plans.append(eng.plan(list(range(T)), [torch.from_numpy(i).to(dev) for i in idx_host[j]], [off] * T))
@@ -501,7 +515,7 @@ def run_dp(args, hbm_peak_gbs: float, ctx):
     torch.cuda.synchronize()
     for t in range(T):       # parity on every rank: one-hot => pooled row == table row
         idx = torch.from_numpy(idx_host[0][t]).to(dev)
-        if not torch.equal(plans[0].outputs[t], expected_rows(torch, t, idx, dim) + 0.0):
+        if not torch.equal(plans[0].outputs[t], expected_pooled(torch, t, idx, dim, L)):
             raise AssertionError(f"rank {rank}: table {t} differs from the expected rows")
     for i in range(args.warmup):
         plans[i % NBATCH].launch(h)
@@ -532,8 +546,8 @@ def run_dp(args, hbm_peak_gbs: float, ctx):
             "ms_per_step": wall * 1000.0 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s, dim %d fp32, B=%d bags/table PER RANK, L=1, u32 "
-                                   "indices+offsets, uniform indices, %d rotating batches" % (label, dim, B, NBATCH),
+            "config": {"workload": "%s, dim %d fp32, B=%d bags/table PER RANK, L=%d, u32 "
+                                   "indices+offsets, uniform indices, %d rotating batches" % (label, dim, B, L, NBATCH),
                        "tables": T, "dim": dim, "bags_per_table_per_rank": B, "global_bags_per_table": world * B,
                        "parallelism": "all %d tables (%.2f GB) replicated on every rank (they fit the per-GPU "
                                       "replication budget); bags data-parallel, no data-path collective"

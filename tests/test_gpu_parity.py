@@ -472,7 +472,7 @@ def test_plan_launch_is_graph_capturable(pel, eng):
     plan.destroy()
 
 
-@pytest.mark.parametrize("mode", ["rows", "whole", "auto"])
+@pytest.mark.parametrize("mode", ["rows", "whole", "auto", "whole-pooled"])
 def test_distributed_bench_two_ranks_on_one_gpu(mode):
     """The N > 1 path end to end on the real HIP engine: two processes share cuda:0, collectives over
     gloo (host-staged), small batch.  dist_bench verifies all 26 tables bit-exactly on every rank
@@ -484,13 +484,17 @@ def test_distributed_bench_two_ranks_on_one_gpu(mode):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PIMEMB_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    port = {"rows": "29561", "whole": "29562", "auto": "29563"}[mode]
+    port = {"rows": "29561", "whole": "29562", "auto": "29563", "whole-pooled": "29565"}[mode]
+    pooled = mode == "whole-pooled"       # 5 indices per bag: the exchange carries 5x the index volume
+    mode = "whole" if pooled else mode
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", port,
            os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3", "--nbatch", "3",
            "--batch", "4099"]
     if mode != "auto":
         cmd += ["--shard-mode", mode, "--replicate-mb", "64"]
+    if pooled:
+        cmd += ["--pooling", "5"]
     res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
@@ -502,6 +506,7 @@ def test_distributed_bench_two_ranks_on_one_gpu(mode):
         assert "5 row-range sharded" in w and "21 tables replicated" in w
     elif mode == "whole":
         assert "5 whole" in w and "21 replicated" in w
+        assert d["config"]["pooling"] == (5 if pooled else 1)
     else:
         assert "replicated on every rank" in d["config"]["parallelism"]
         sec = d["sharded_exchange"]
