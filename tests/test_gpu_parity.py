@@ -704,6 +704,23 @@ def test_clamped_build_survives_malformed_input(pel, oracle, tmp_path):
         off2 = off.copy(); off2[B // 2:] = off2[B // 2:][::-1] + 10 * B
         got = e.lookup(0, idx, off2)
         assert np.array_equal(got[: B // 2 - 1], tab[idx[: B // 2 - 1]])
+    # the element-per-thread kernel (10-column rows) and the LDS hot-row kernel clamp too
+    tab10 = rng.standard_normal((500, 10)).astype(np.float32)
+    e.load_table(1, tab10)
+    idx = rng.integers(0, 500, size=2000).astype(np.int64)
+    bad = idx.copy(); bad[::5] = 2**33
+    got = e.lookup(1, bad, np.arange(2000, dtype=np.int64))
+    clean = np.ones(2000, bool); clean[::5] = False
+    assert np.array_equal(got[clean], tab10[idx[clean]])
+    assert np.array_equal(got[~clean], np.tile(tab10[499], ((~clean).sum(), 1)))
+    e.set_hot_rows(0, np.arange(64, dtype=np.uint64))
+    idx = rng.integers(0, 1000, size=4000).astype(np.int64)
+    bad = idx.copy(); bad[::9] = 2**35
+    off = (np.arange(500) * 8).astype(np.int64)
+    got = e.lookup(0, bad, off)
+    fixed = np.where(np.arange(4000) % 9 == 0, 999, idx)
+    assert np.array_equal(got, oracle.c_bag_sum(tab, fixed, off))
+    assert e.stats()["n_launches_by_kind"][4] == 1
     e.close()
 
 
