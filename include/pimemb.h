@@ -257,6 +257,24 @@ int emb_unroute_rows(emb_engine *e, const void *recv_base, uint64_t src_stride_b
                      uint64_t n_bags, uint32_t dim, uint32_t capacity, const uint32_t *perm,
                      float *pooled /* [n_tables][n_bags][dim] */, void *stream);
 
+/* ---- optional native exchange (multi-GPU sharded lookup) --------------------------------------- */
+/* All-to-all of byte ranges issued directly to RCCL (grouped ncclSend/ncclRecv) on the caller's stream:
+ * the "indices in / pooled rows out" step of the sharded lookup without torch.distributed's per-call
+ * host cost.  One emb_comm per process (= per GPU).  Bootstrap like NCCL: rank 0 calls
+ * emb_comm_unique_id, sends the 128 bytes to the other ranks by any means (the Python side uses
+ * torch.distributed.broadcast), every rank calls emb_comm_create.  RCCL is resolved at run time
+ * (EMB_ERR_UNSUPPORTED if librccl.so cannot be found).  The reference's counterpart is the broadcast
+ * push / gather pull of dpu_push_xfer (emb_host.h:258-287, :321).  Exercised with one rank only so
+ * far; bench.py uses torch.distributed unless --collective native is given. */
+typedef struct emb_comm emb_comm;
+int emb_comm_unique_id(void *id128);
+int emb_comm_create(emb_engine *e, const void *id128, int32_t rank, int32_t world, emb_comm **out);
+/* send_off / recv_off: world+1 byte offsets each; peer p gets send[send_off[p] .. send_off[p+1]) and
+ * delivers into recv[recv_off[p] .. recv_off[p+1]).  Enqueues only. */
+int emb_comm_all_to_all(emb_comm *c, const void *send, const uint64_t *send_off, void *recv,
+                        const uint64_t *recv_off, void *stream);
+int emb_comm_destroy(emb_comm *c);
+
 /* ------------------------------------------------------------------------------------------ */
 /* (2) reference-compatible entry points (same names, argument meaning and return values)      */
 /* ------------------------------------------------------------------------------------------ */

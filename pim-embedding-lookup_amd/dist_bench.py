@@ -62,6 +62,23 @@ def expected_pooled(torch, t: int, idx, dim: int, L: int):
     return acc
 
 
+def native_exchange(pel, args, eng, ctx):
+    """--collective native: the all-to-all goes straight to RCCL on the compute stream (emb_comm_*),
+    no torch work object, no extra waits.  None for the default (torch.distributed)."""
+    if getattr(args, "collective", "torch") != "native":
+        return None
+    if ctx["stage_cpu"]:
+        raise SystemExit("--collective native needs the nccl backend (RCCL), not " + ctx["backend"])
+    import torch.distributed as dist
+
+    def bcast(raw: bytes) -> bytes:
+        box = [raw]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    return pel.NativeExchange(eng, ctx["rank"], ctx["world"], bcast)
+
+
 def table_set_of(pel, args):
     """rows, dim, default batch, label of the table set the N > 1 legs run (--workload c2 | c4)."""
     name = getattr(args, "workload", "c2")
@@ -153,9 +170,15 @@ def run_whole(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
     stream = torch.cuda.current_stream(dev)
     sh_handle = stream.cuda_stream
     pending = [None]
+    native = native_exchange(pel, args, eng, ctx)
+    if native is not None:
+        a_in, a_out = native.offsets(in_off), native.offsets(out_off)
 
     def collective(sl):
         if n_sharded == 0:
+            return None
+        if native is not None:      # stream-ordered: the next launch on this stream sees the received bytes
+            native.all_to_all(sl["send"].data_ptr(), a_in, sl["recv"].data_ptr(), a_out, sh_handle)
             return None
         if stage_cpu:
             r, s_ = torch.empty(sl["recv"].shape, dtype=torch.uint8), sl["send"].cpu()
@@ -259,8 +282,10 @@ def run_whole(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
                        "pooling": L,
                        "parallelism": "tables sharded by id (replicate <= %d MiB); one all_to_all per step carries "
                                       "pooled rows of batch i + indices of batch i+1 (%d B out / %d B in per rank); "
-                                      "backend %s, eager steps" %
-                                      (rep_bytes >> 20, int(in_off[-1]), int(out_off[-1]), backend)},
+                                      "backend %s, %s, eager steps" %
+                                      (rep_bytes >> 20, int(in_off[-1]), int(out_off[-1]), backend,
+                                       "collective issued natively to RCCL on the compute stream" if native is not None
+                                       else "torch.distributed.all_to_all_single")},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": hbm_peak_gbs, "unit": "GB/s",
                          "frac": ach / hbm_peak_gbs, "traffic": None, "kernel_us": kernel_us,
                          "algorithmic_bytes": alg_bytes,
@@ -271,6 +296,9 @@ def run_whole(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
         for p in (sl["plan_a"], sl["plan_b"]):
             if p is not None:
                 p.destroy()
+    if native is not None:
+        torch.cuda.synchronize()
+        native.close()
     eng.close()
     return result
 
@@ -345,9 +373,14 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
     h = stream.cuda_stream
     splits = [seg] * world
     pending = [None]
+    native = native_exchange(pel, args, eng, ctx)
+    seg_off = native.offsets([p_ * seg for p_ in range(world + 1)]) if native is not None else None
 
     def collective(sl):
         if K == 0:
+            return None
+        if native is not None:
+            native.all_to_all(sl["send"].data_ptr(), seg_off, sl["recv"].data_ptr(), seg_off, h)
             return None
         if stage_cpu:
             r, s_ = torch.empty(sl["recv"].shape, dtype=torch.uint8), sl["send"].cpu()
@@ -472,7 +505,9 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
                        "tables": T, "dim": dim, "bags_per_table_per_rank": B, "global_bags_per_table": world * B,
                        "parallelism": "row-range shards; GPU routing of requests (capacity %d per table/shard); ONE "
                                       "all_to_all per step carries pooled rows of batch i + request lists of batch "
-                                      "i+1 (%d B per peer each way); backend %s, eager steps" % (C_, seg, backend)},
+                                      "i+1 (%d B per peer each way); backend %s, %s, eager steps" %
+                                      (C_, seg, backend, "collective issued natively to RCCL on the compute stream"
+                                       if native is not None else "torch.distributed.all_to_all_single")},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": hbm_peak_gbs, "unit": "GB/s",
                          "frac": ach / hbm_peak_gbs, "traffic": None, "kernel_us": kernel_us,
                          "algorithmic_bytes": alg_bytes,
@@ -483,6 +518,9 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
         for p in (sl["plan_a"], sl["plan_b"]):
             if p is not None:
                 p.destroy()
+    if native is not None:
+        torch.cuda.synchronize()
+        native.close()
     eng.close()
     return result
 

@@ -127,6 +127,46 @@ class Plan:
             self._p = None
 
 
+class NativeExchange:
+    """All-to-all of byte ranges issued straight to RCCL on a HIP stream (emb_comm_* in pimemb.h).
+    Bootstrap: rank 0 draws the RCCL unique id, `broadcast` (a callable bytes -> bytes that returns rank
+    0's value on every rank, e.g. built on torch.distributed.broadcast_object_list) spreads it."""
+
+    def __init__(self, engine: "EmbeddingEngine", rank: int, world: int, broadcast):
+        self._L = engine._L
+        buf = C.create_string_buffer(128)
+        if rank == 0:
+            _l.check(self._L.emb_comm_unique_id(buf))
+        uid = broadcast(buf.raw)
+        self._h = C.c_void_p()
+        _l.check(self._L.emb_comm_create(engine._h, C.create_string_buffer(uid, 128), rank, world, C.byref(self._h)))
+        self.world = world
+        self._offs = {}
+
+    def offsets(self, offsets):
+        """world+1 byte offsets as a reusable handle (pass it to all_to_all instead of a list)."""
+        return self._arr(offsets)
+
+    def _arr(self, offsets):
+        if isinstance(offsets, C.Array):
+            return offsets
+        key = tuple(int(x) for x in offsets)
+        a = self._offs.get(key)
+        if a is None:
+            if len(key) != self.world + 1:
+                raise ValueError("need world+1 byte offsets")
+            a = self._offs[key] = (C.c_uint64 * len(key))(*key)
+        return a
+
+    def all_to_all(self, send_ptr: int, send_off, recv_ptr: int, recv_off, stream: int | None = None) -> None:
+        _l.check(self._L.emb_comm_all_to_all(self._h, send_ptr, self._arr(send_off), recv_ptr, self._arr(recv_off), stream))
+
+    def close(self) -> None:
+        if self._h:
+            self._L.emb_comm_destroy(self._h)
+            self._h = None
+
+
 class EmbeddingEngine:
     """One engine per GPU: tables resident in HBM, lookups as fused HIP launches."""
 

@@ -59,6 +59,10 @@ SIGNATURES = {
     "emb_alloc_table": (C.c_int, [_vp, _u32, _u64, _u32, C.c_int]),
     "emb_load_table_column": (C.c_int, [_vp, _u32, _u32, _vp, _u64]),
     "emb_set_hot_rows": (C.c_int, [_vp, _u32, C.POINTER(_u64), _u32]),
+    "emb_comm_unique_id": (C.c_int, [_vp]),
+    "emb_comm_create": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32, _pp]),
+    "emb_comm_all_to_all": (C.c_int, [_vp, _vp, C.POINTER(_u64), _vp, C.POINTER(_u64), _vp]),
+    "emb_comm_destroy": (C.c_int, [_vp]),
     "emb_table_info": (C.c_int, [_vp, _u32, _pp, C.POINTER(_u64), C.POINTER(_u32), C.POINTER(C.c_int)]),
     "emb_lookup": (C.c_int, [_vp, _u32, _vp, _u64, _vp, _u64, _vp, C.c_int, C.c_int, _vp]),
     "emb_lookup_batched": (C.c_int, [_vp, C.POINTER(EmbLookupDesc), _u32, C.c_int, C.c_int, _vp]),

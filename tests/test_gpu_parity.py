@@ -995,3 +995,32 @@ def test_special_values_are_bit_exact(pel, eng, oracle):
     got = eng.lookup(58, idx16, off)
     ok = ~np.isnan(want)
     assert np.array_equal(got.view(np.uint32)[ok], want.view(np.uint32)[ok])
+
+
+def test_native_exchange_single_rank(pel, eng):
+    """emb_comm_*: grouped ncclSend/ncclRecv issued from the C side (one rank, self exchange): byte
+    ranges land where the offsets say, ordered on the stream between two engine launches."""
+    import torch
+    dev = torch.device("cuda", 0)
+    try:
+        ex = pel.NativeExchange(eng, 0, 1, lambda raw: raw)
+    except pel.PimembError as e:
+        if e.code == pel.lib.EMB_ERR_UNSUPPORTED:
+            pytest.skip("librccl.so not available")
+        raise
+    w = torch.randn(5000, 16, device=dev)
+    eng.load_table(59, w)
+    B = 20_000
+    idx = torch.randint(0, 5000, (B,), dtype=torch.int32, device=dev)
+    off = torch.arange(B, dtype=torch.int32, device=dev)
+    send = torch.empty((B, 16), device=dev)
+    recv = torch.zeros((B + 3, 16), device=dev)
+    plan = eng.plan([59], [idx], [off], [send])
+    s = torch.cuda.Stream(dev)
+    with torch.cuda.stream(s):
+        plan.launch(s.cuda_stream)
+        ex.all_to_all(send.data_ptr(), [0, B * 64], recv.data_ptr() + 3 * 64, [0, B * 64], s.cuda_stream)
+    s.synchronize()
+    assert torch.equal(recv[3:], w[idx.long()]) and float(recv[:3].abs().sum()) == 0.0
+    plan.destroy()
+    ex.close()
