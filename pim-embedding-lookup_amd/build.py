@@ -7,8 +7,9 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "lib", "libpimemb.so")
-SOURCES = ["pimemb_kernels.hip", "pimemb_engine.cpp", "pimemb_compat.cpp", "pimemb_internal.h", "pimemb_bag_kernels.h",
-           "Makefile", os.path.join("..", "..", "include", "pimemb.h")]
+SOURCES = ["pimemb_kernels.hip", "pimemb_engine.cpp", "pimemb_compat.cpp", "pimemb_comm.cpp", "pimemb_internal.h",
+           "pimemb_bag_kernels.h", "pimemb_xcd_map.h", "pimemb_hot_rows.h", "pimemb_hostcopy.h", "Makefile",
+           os.path.join("..", "..", "include", "pimemb.h")]
 
 
 def is_stale() -> bool:

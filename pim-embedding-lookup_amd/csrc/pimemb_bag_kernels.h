@@ -96,6 +96,7 @@ template <>
 struct RowOps<EMB_F32> {
     using Acc = f32x4;
     static constexpr uint32_t kFloatsPerLane = 4;
+    static constexpr bool kGroupStore = false;
     static __device__ __forceinline__ Acc zero() { return Acc{0.f, 0.f, 0.f, 0.f}; }
     static __device__ __forceinline__ void add(Acc &a, u32x4 raw) { a += __builtin_bit_cast(f32x4, raw); }
     template <bool NT>
@@ -108,6 +109,12 @@ template <>
 struct RowOps<EMB_F16> {
     using Acc = f32x8;
     static constexpr uint32_t kFloatsPerLane = 8;
+    // A lane holds 8 consecutive output floats (32 B): storing them as two 16-byte pieces per lane makes
+    // every store instruction hit alternate 16-byte pieces (32-B lane stride), which non-temporal stores
+    // cannot combine -- measured 3.5 TB/s on one-hot fp16 lookups against ~7 for fp32.  store_row()
+    // therefore re-deals the pieces inside the lane group so that each instruction writes a contiguous run
+    // (rows of >= 8 lanes; narrower rows use plain stores and leave the merging to the L2).
+    static constexpr bool kGroupStore = true;
     static __device__ __forceinline__ Acc zero() { return Acc{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; }
     static __device__ __forceinline__ void add(Acc &a, u32x4 raw) {
         a += __builtin_convertvector(__builtin_bit_cast(f16x8, raw), f32x8);
@@ -123,6 +130,7 @@ template <>
 struct RowOps<EMB_FIXED32> {
     using Acc = u32x4;  // unsigned add == int32 two's-complement wrap (emb_dpu_lookup.c:114)
     static constexpr uint32_t kFloatsPerLane = 4;
+    static constexpr bool kGroupStore = false;
     static __device__ __forceinline__ Acc zero() { return Acc{0u, 0u, 0u, 0u}; }
     static __device__ __forceinline__ void add(Acc &a, u32x4 raw) { a += raw; }
     static __device__ __forceinline__ float conv(uint32_t acc) {
@@ -180,6 +188,46 @@ __device__ __forceinline__ uint64_t shfl_index(IdxT v, uint32_t src) {
         return shfl_u64((uint64_t)v, src);
     else
         return (uint64_t)shfl_u32((uint32_t)v, src);
+}
+
+__device__ __forceinline__ float shfl_f32(float v, uint32_t src) {
+    return __builtin_bit_cast(float, shfl_u32(__builtin_bit_cast(uint32_t, v), src));
+}
+
+// Store one pooled row held by a lane group.  `row` = out + bag * out_stride (the row's first float);
+// `valid`: this lane owns a piece of a real bag.  Ops without kGroupStore: every lane stores its own
+// 16 bytes (already contiguous across the group).  kGroupStore (fp16 tables: 32 B of output per lane):
+// the row is 2*chunks 16-byte pieces, lane s holds pieces 2s and 2s+1; instruction 1 lets lane j write
+// piece j, instruction 2 piece LPR + j, both fetched from the owning lane with ds_bpermute -- EVERY lane
+// of the group must call this (the shuffles read the neighbours' registers).
+template <class Ops, class Cfg, int LPR>
+__device__ __forceinline__ void store_row(const typename Ops::Acc &acc, float *__restrict__ row, uint32_t sub,
+                                          uint32_t grp, uint32_t chunks, bool valid) {
+    if constexpr (!Ops::kGroupStore) {
+        if (valid) Ops::template store<Cfg::kNtStore>(acc, row + sub * Ops::kFloatsPerLane);
+    } else if constexpr (LPR <= 4) {
+        // narrow rows: the shuffles cost more than they save (fp16 dim 16 one-hot: 42 us with them, 21 us
+        // without); two plain 16-byte stores per lane instead, which the L2 merges into full lines
+        if (valid) Ops::template store<false>(acc, row + sub * Ops::kFloatsPerLane);
+    } else {
+        const uint32_t pieces = 2u * chunks;
+#pragma unroll
+        for (uint32_t inst = 0; inst < 2; inst++) {
+            const uint32_t p = inst * LPR + sub;               // piece this lane writes
+            const uint32_t src = grp * LPR + (p >> 1);         // lane that holds it
+            const bool hi = (p & 1u) != 0u;
+            f32x4 v;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const float lo_c = shfl_f32(acc[c], src), hi_c = shfl_f32(acc[4 + c], src);
+                v[c] = hi ? hi_c : lo_c;
+            }
+            // (validity is uniform over a lane group except for lanes beyond `chunks`, whose own
+            // `valid` is false but which still write pieces of the row when p < pieces)
+            const bool bag_ok = __shfl((int)valid, (int)(grp * LPR), 64) != 0;
+            if (bag_ok && p < pieces) store_f32x4<Cfg::kNtStore>(row + 4u * p, v);
+        }
+    }
 }
 
 // Workgroup -> (descriptor, tile).  xmap == nullptr: 2-D grid (x = tile, y = descriptor).
@@ -345,7 +393,7 @@ bag_sum_group_kernel(const DevDesc *__restrict__ descs, uint32_t chunks_arg,
                                       [&](uint64_t r, uint32_t) -> u32x4 {
                                           return load_row<Cfg::kNtRow>(wsub + clamp_row<Cfg::kClamp, IdxT>(r, last_row) * row_bytes);
                                       });
-        if (live) Ops::template store<Cfg::kNtStore>(acc, out + bag * out_stride + sub * Ops::kFloatsPerLane);
+        store_row<Ops, Cfg, LPR>(acc, out + bag * out_stride, sub, grp, chunks, live);
     }
 }
 
@@ -506,11 +554,18 @@ bag_sum_wavebatch_kernel(const DevDesc *__restrict__ descs, uint32_t chunks_arg,
 #pragma unroll
                     for (uint32_t jj = 0; jj < RU; jj++) {
                         const uint64_t bag = step_base + 64u * q + (j0 + jj) * BPR + grp;
-                        if (bag < n_bags && lane_live) {
+                        if constexpr (!Ops::kGroupStore) {
+                            if (bag < n_bags && lane_live) {
+                                typename Ops::Acc acc = Ops::zero();
+                                if (has[q][jj]) Ops::add(acc, v[q][jj]);
+                                Ops::template store<Cfg::kNtStore>(
+                                    acc, out + bag * out_stride + sub * Ops::kFloatsPerLane);
+                            }
+                        } else {   // all lanes take part in the group store's shuffles
                             typename Ops::Acc acc = Ops::zero();
-                            if (has[q][jj]) Ops::add(acc, v[q][jj]);
-                            Ops::template store<Cfg::kNtStore>(
-                                acc, out + bag * out_stride + sub * Ops::kFloatsPerLane);
+                            if (has[q][jj] && lane_live) Ops::add(acc, v[q][jj]);
+                            store_row<Ops, Cfg, LPR>(acc, out + bag * out_stride, sub, grp, chunks,
+                                                     bag < n_bags && lane_live);
                         }
                     }
             }
@@ -527,8 +582,8 @@ bag_sum_wavebatch_kernel(const DevDesc *__restrict__ descs, uint32_t chunks_arg,
                 const uint64_t e = p + shfl_u32(len[q], src);
                 const uint64_t bag = step_base + 64u * q + src;
                 // (no early `continue`: every lane must reach the next round's shuffles)
+                typename Ops::Acc acc = Ops::zero();
                 if (bag < n_bags && lane_live) {
-                    typename Ops::Acc acc = Ops::zero();
                     for (; p + U <= e; p += U) {
                         uint64_t r[U];
 #pragma unroll
@@ -544,8 +599,11 @@ bag_sum_wavebatch_kernel(const DevDesc *__restrict__ descs, uint32_t chunks_arg,
                         const uint64_t r = clamp_row<Cfg::kClamp, IdxT>((uint64_t)load_meta<Cfg::kNtMeta>(indices + p), last_row);
                         Ops::add(acc, load_row<Cfg::kNtRow>(wsub + r * row_bytes));
                     }
-                    Ops::template store<Cfg::kNtStore>(acc, out + bag * out_stride + sub * Ops::kFloatsPerLane);
+                    if constexpr (!Ops::kGroupStore)
+                        Ops::template store<Cfg::kNtStore>(acc, out + bag * out_stride + sub * Ops::kFloatsPerLane);
                 }
+                if constexpr (Ops::kGroupStore)
+                    store_row<Ops, Cfg, LPR>(acc, out + bag * out_stride, sub, grp, chunks, bag < n_bags && lane_live);
             }
         }
     }
@@ -640,7 +698,7 @@ bag_sum_hot_kernel(const DevDesc *__restrict__ descs, uint32_t chunks) {
             if (Cfg::kClamp && e > n_idx) e = n_idx;
             typename Ops::Acc acc = Ops::zero();
             walk_bag<IdxT, LPR, Cfg, Ops>(indices, p, e, sub, grp, live, acc, probe, fetch);
-            if (live) Ops::template store<Cfg::kNtStore>(acc, out + bag * out_stride + sub * Ops::kFloatsPerLane);
+            store_row<Ops, Cfg, LPR>(acc, out + bag * out_stride, sub, grp, chunks, live);
         }
     }
 }

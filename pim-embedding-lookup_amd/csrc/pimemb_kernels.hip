@@ -27,6 +27,19 @@ using WaveCfg = BagCfg<64, 8, true, false, 8, 8, 1, false, true, false, kClampIn
 // workgroups, unroll 4 on the general path so the kernel still fits 64 VGPRs without spilling: -4.5 %
 using Wave2Cfg = BagCfg<128, 4, true, false, 8, 8, 2, false, true, false, kClampInputs>;
 using GroupCfg = BagCfg<256, 8, true, false, 8, 1, 1, false, false, /*IDX_SHUFFLE*/ true, kClampInputs>;
+// fp16 rows accumulate into 8 fp32 registers per gather instead of 4 and re-deal their output pieces by
+// shuffle (store_row): under the 64-VGPR cap of the fp32 configurations the wave-batch kernels would spill
+// 36-340 bytes per lane, so the fp16 instantiations target 4 waves per SIMD (128 VGPRs, no spills).
+// One-hot fp16 lookups, 26 Kaggle-sized tables, B = 39292, us per launch before -> after (store_row +
+// this occupancy; tools/f16_onehot_probe.py): dim 16 31.9 -> 21, dim 32 58.8 -> 31, dim 64 109 -> 52,
+// dim 128 222 -> 97 (8.2 TB/s algorithmic).
+#ifndef PIMEMB_F16_MINW
+#define PIMEMB_F16_MINW 4
+#endif
+using WaveCfgF16 = BagCfg<64, 8, true, false, 8, PIMEMB_F16_MINW, 1, false, true, false, kClampInputs>;
+using Wave2CfgF16 = BagCfg<128, 4, true, false, 8, PIMEMB_F16_MINW, 2, false, true, false, kClampInputs>;
+template <int DT> struct WaveCfgOf { using One = WaveCfg; using Two = Wave2Cfg; };
+template <> struct WaveCfgOf<EMB_F16> { using One = WaveCfgF16; using Two = Wave2CfgF16; };
 // pooled launches over tables with a hot-row set: persistent 1024-thread workgroups stage the set into LDS
 using HotCfg = BagCfg<1024, 8, true, false, 8, 1, 1, false, false, /*IDX_SHUFFLE*/ true, kClampInputs>;
 constexpr int kBlock = 256;  // helper kernels below
@@ -36,13 +49,16 @@ void launch_one(const DevDesc *d, uint32_t n, uint32_t max_tiles, const LaunchGe
                 const uint32_t *xmap, uint32_t xgrid, bool xdirect, hipStream_t s) {
     const dim3 grid = xmap ? dim3(xgrid, 1, 1) : dim3(max_tiles, n, 1);
     struct { uint32_t chunks; } g{g_in.chunks | ((xmap && xdirect) ? kXmapDirect : 0u)};
-    if (kind == KERNEL_WAVEBATCH)
-        hipLaunchKernelGGL((bag_sum_wavebatch_kernel<IdxT, DT, L, WaveCfg>), grid, dim3(WaveCfg::kBlock), 0,
-                           s, d, g.chunks, xmap);
-    else if (kind == KERNEL_WAVEBATCH2)
-        hipLaunchKernelGGL((bag_sum_wavebatch_kernel<IdxT, DT, L, Wave2Cfg>), grid, dim3(Wave2Cfg::kBlock), 0,
-                           s, d, g.chunks, xmap);
-    else
+    using One = typename WaveCfgOf<DT>::One;
+    using Two = typename WaveCfgOf<DT>::Two;
+    if (kind == KERNEL_WAVEBATCH) {
+        hipLaunchKernelGGL((bag_sum_wavebatch_kernel<IdxT, DT, L, One>), grid, dim3(One::kBlock), 0, s, d, g.chunks, xmap);
+    } else if (kind == KERNEL_WAVEBATCH2) {
+        // choose_kernel hands out the two-batch geometry for <= 4 lanes per row only; wider rows are not
+        // instantiated (they would spill under the 64-VGPR cap and are never launched)
+        if constexpr (L <= 4)
+            hipLaunchKernelGGL((bag_sum_wavebatch_kernel<IdxT, DT, L, Two>), grid, dim3(Two::kBlock), 0, s, d, g.chunks, xmap);
+    } else
         hipLaunchKernelGGL((bag_sum_group_kernel<IdxT, DT, L, GroupCfg>), grid, dim3(GroupCfg::kBlock), 0,
                            s, d, g.chunks, xmap);
 }
