@@ -451,6 +451,81 @@ bag_sum_anydim_kernel(const DevDesc *__restrict__ descs, uint32_t dim, uint32_t 
     }
 }
 
+// Rows whose byte size is a multiple of 4 (every fp32 / fixed-point dim, even fp16 dims) but not of 16:
+// one thread per 16-byte PIECE instead of per element.  A piece of an unpadded row starts at a 4-byte
+// aligned address, which global_load/store_dwordx4 accept on gfx950, so full pieces move as vectors and
+// only the last, partial piece of a row goes element by element.  Same summation order, same bits.
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+template <typename IdxT, int DT, bool CLAMP>
+__global__ void __launch_bounds__(256)
+bag_sum_anydim_vec_kernel(const DevDesc *__restrict__ descs, uint32_t dim, uint32_t lanes) {
+    using Ops = RowOps<DT>;
+    constexpr uint32_t EP = Ops::kFloatsPerLane;            // elements per 16-byte piece (4, or 8 halves)
+    constexpr uint32_t ESZ = 16u / EP;
+    constexpr int U = 4;
+    const DevDesc *dp = descs + blockIdx.y;
+    const char *__restrict__ weights = static_cast<const char *>(dp->weights);
+    const IdxT *__restrict__ indices = static_cast<const IdxT *>(dp->indices);
+    const IdxT *__restrict__ offsets = static_cast<const IdxT *>(dp->offsets);
+    float *__restrict__ out = dp->out;
+    const uint64_t n_idx = dp->n_idx, n_bags = dp->n_bags, last_row = dp->nr_rows - 1;
+    const uint64_t bag = (uint64_t)blockIdx.x * (256u / lanes) + threadIdx.x / lanes;
+    if (blockIdx.x >= dp->n_tiles || bag >= n_bags) return;
+    uint64_t p0, e;
+    if (offsets != nullptr) {
+        p0 = (uint64_t)offsets[bag];
+        e = (bag + 1 < n_bags) ? (uint64_t)offsets[bag + 1] : n_idx;
+    } else {
+        p0 = bag * dp->fixed_pooling;
+        e = p0 + dp->fixed_pooling;
+    }
+    if (CLAMP && e > n_idx) e = n_idx;
+    const uint32_t row_bytes = dim * ESZ, pieces = (dim + EP - 1) / EP;
+    for (uint32_t piece = threadIdx.x & (lanes - 1); piece < pieces; piece += lanes) {
+        const uint32_t n_el = (dim - piece * EP < EP) ? dim - piece * EP : EP;
+        const char *__restrict__ wp = weights + piece * 16u;
+        auto fetch = [&](uint64_t r) -> u32x4 {
+            const char *src = wp + clamp_row<CLAMP, IdxT>(r, last_row) * row_bytes;
+            if (n_el == EP) return *reinterpret_cast<const u32x4_a4 *>(src);
+            u32x4 v = {0u, 0u, 0u, 0u};                     // partial last piece: whole dwords only
+            const uint32_t n_dw = n_el * ESZ / 4u;
+            for (uint32_t d = 0; d < n_dw; d++) v[d] = reinterpret_cast<const uint32_t *>(src)[d];
+            return v;
+        };
+        typename Ops::Acc acc = Ops::zero();
+        uint64_t p = p0;
+        for (; p + U <= e; p += U) {
+            uint64_t r[U];
+#pragma unroll
+            for (int k = 0; k < U; k++) r[k] = (uint64_t)indices[p + k];
+            u32x4 v[U];
+#pragma unroll
+            for (int k = 0; k < U; k++) v[k] = fetch(r[k]);
+#pragma unroll
+            for (int k = 0; k < U; k++) Ops::add(acc, v[k]);
+        }
+        for (; p < e; p++) Ops::add(acc, fetch((uint64_t)indices[p]));
+        float *o = out + bag * dim + piece * EP;
+        float res[EP];
+        if constexpr (DT == EMB_FIXED32) {
+#pragma unroll
+            for (uint32_t c = 0; c < EP; c++) res[c] = RowOps<EMB_FIXED32>::conv(acc[c]);
+        } else {
+#pragma unroll
+            for (uint32_t c = 0; c < EP; c++) res[c] = acc[c];
+        }
+        if (n_el == EP) {
+#pragma unroll
+            for (uint32_t c = 0; c < EP; c += 4)
+                *reinterpret_cast<f32x4_a4 *>(o + c) = f32x4{res[c], res[c + 1], res[c + 2], res[c + 3]};
+        } else {
+            for (uint32_t c = 0; c < n_el; c++) o[c] = res[c];
+        }
+    }
+}
+
 // ---- v2: wave batches of 64 bags, coalesced bounds, shuffle-distributed, one-hot fast path -------
 template <typename IdxT, int DT, int LPR, class Cfg>
 __global__ void __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves)

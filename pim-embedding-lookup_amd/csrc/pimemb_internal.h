@@ -14,7 +14,8 @@ struct LaunchGeom {
     uint32_t lanes_per_row;   // power of two, 1..64: lanes that cooperate on one bag
     uint32_t chunks;          // 16-byte pieces per row actually used (<= lanes_per_row)
     uint32_t scalar_lanes;    // != 0: rows that are not 16-byte multiples (or wider than 1 KiB) -- the
-                              // element-per-thread kernel with this many threads per bag; chunks = dim
+                              // any-dim kernels with this many threads per bag; chunks = dim
+    bool anydim_vec;          // rows are 4-byte multiples: one thread per 16-byte piece (else per element)
 };
 
 // Which bag kernel a launch uses.

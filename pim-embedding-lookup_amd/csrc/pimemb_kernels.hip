@@ -137,6 +137,22 @@ template <typename IdxT>
 hipError_t launch_anydim(const DevDesc *d, uint32_t n, uint32_t max_tiles, emb_dtype dtype, const LaunchGeom &g,
                          hipStream_t s) {
     const dim3 grid(max_tiles, n, 1), block(256);
+    if (g.anydim_vec) {
+        switch (dtype) {
+            case EMB_F32:
+                hipLaunchKernelGGL((bag_sum_anydim_vec_kernel<IdxT, EMB_F32, kClampInputs>), grid, block, 0, s, d, g.chunks, g.scalar_lanes);
+                break;
+            case EMB_F16:
+                hipLaunchKernelGGL((bag_sum_anydim_vec_kernel<IdxT, EMB_F16, kClampInputs>), grid, block, 0, s, d, g.chunks, g.scalar_lanes);
+                break;
+            case EMB_FIXED32:
+                hipLaunchKernelGGL((bag_sum_anydim_vec_kernel<IdxT, EMB_FIXED32, kClampInputs>), grid, block, 0, s, d, g.chunks, g.scalar_lanes);
+                break;
+            default:
+                return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     switch (dtype) {
         case EMB_F32:
             hipLaunchKernelGGL((bag_sum_anydim_kernel<IdxT, EMB_F32, kClampInputs>), grid, block, 0, s, d, g.chunks, g.scalar_lanes);
@@ -299,9 +315,15 @@ int geometry_for(emb_dtype dtype, uint32_t dim, LaunchGeom *g) {
     if (dtype != EMB_F32 && dtype != EMB_F16 && dtype != EMB_FIXED32) return EMB_ERR_INVALID;
     uint64_t row_bytes = (uint64_t)dim * elem;
     if (dim == 0) return EMB_ERR_UNSUPPORTED;
-    if (row_bytes % 16 != 0 || row_bytes > 1024) {   // no 16-byte lane pieces: element-per-thread kernel
+    g->anydim_vec = false;
+    if (row_bytes % 16 != 0 || row_bytes > 1024) {   // no aligned 16-byte lane pieces: the any-dim kernels
+        // a thread per 16-byte piece (rows of >= 32 B that are 4-byte multiples), else a thread per element
+        // (fp32 one-hot, us per launch, piece vs element: dim 2 12.9 / 11.2, dim 6 19.9 / 25.5, dim 10 25.8 / 44.8,
+        // dim 30 52.9 / 91.5; tools/anydim_probe.py)
+        g->anydim_vec = row_bytes % 4 == 0 && row_bytes >= 32;
+        const uint64_t units = g->anydim_vec ? (row_bytes + 15) / 16 : dim;
         uint32_t lanes = 1;
-        while (lanes < dim && lanes < 256u) lanes <<= 1;
+        while (lanes < units && lanes < 256u) lanes <<= 1;
         g->lanes_per_row = 0;
         g->chunks = dim;
         g->scalar_lanes = lanes;

@@ -788,7 +788,7 @@ def test_any_row_width(pel, eng, oracle, dim, dtype, itype):
     got = eng.lookup(40, idx, off)
     assert got.shape == (n_bags, dim) and np.array_equal(got, want)
     rb = dim * np.dtype(dtype).itemsize
-    assert eng.stats()["n_launches_by_kind"][3] == int(rb % 16 != 0 or rb > 1024)   # element-per-thread kernel
+    assert eng.stats()["n_launches_by_kind"][3] == int(rb % 16 != 0 or rb > 1024)   # the any-dim kernels
     # fixed pooling (no offsets array) and a fused call mixing this table with a 16-byte-multiple one
     L = 3
     idx2 = rng.integers(0, rows, size=n_bags * L).astype(itype)
