@@ -139,16 +139,18 @@ def c_validate_result(table_i32, indices, offsets, results) -> int:
                                             _p(results)))
 
 
-def c_lookup_tables(tables, indices, offsets, threads: int = 1):
+def c_lookup_tables(tables, indices, offsets, threads: int = 1, outs=None):
     """Multi-table fp32 lookup with the reference's per-table pointer arrays (emb_host.h:234).
-    threads > 1: the bags of every table split over that many OpenMP threads (same bits)."""
+    threads > 1: the bags of every table split over that many OpenMP threads (same bits).
+    outs: optional preallocated float32 [B_t, dim] arrays to write into (timing loops reuse them)."""
     T = len(tables)
     tables = [np.ascontiguousarray(t, dtype=np.float32) for t in tables]
     indices = [np.ascontiguousarray(i) for i in indices]
     offsets = [np.ascontiguousarray(o) for o in offsets]
     is64 = _idx_kind(indices[0], offsets[0])
     dim = tables[0].shape[1]
-    outs = [np.empty((o.shape[0], dim), dtype=np.float32) for o in offsets]
+    if outs is None:
+        outs = [np.empty((o.shape[0], dim), dtype=np.float32) for o in offsets]
 
     def parr(arrs):
         return (C.c_void_p * T)(*[a.ctypes.data for a in arrs])
