@@ -44,6 +44,7 @@ class EmbeddingBagCollection:
                 w = w.to(torch.float16)
             self.engine.load_table(k, w)
         self._plans = {}
+        self._ids = list(range(len(self.ln_emb)))
 
     @classmethod
     def from_checkpoint(cls, path: str, device: int = 0):
@@ -53,22 +54,22 @@ class EmbeddingBagCollection:
 
     def apply_emb(self, lS_o, lS_i):
         """lS_o[k], lS_i[k]: offsets / indices of table k (torch CUDA tensors, int64 or int32, or
-        numpy arrays -> host path).  Returns ly: list of [B_k, m] fp32."""
+        numpy arrays -> host path).  Returns ly: list of [B_k, m] fp32, freshly allocated -- one fused
+        launch on torch's current stream, no plan and no state kept (every batch brings new tensors)."""
         if len(lS_o) != len(self.ln_emb) or len(lS_i) != len(self.ln_emb):
             raise ValueError("need one (offsets, indices) pair per table")
-        if hasattr(lS_i[0], "is_cuda") and lS_i[0].is_cuda:
-            key = tuple((o.data_ptr(), i.data_ptr(), o.numel(), i.numel()) for o, i in zip(lS_o, lS_i))
-            plan = self._plans.get(key)
-            if plan is None:
-                if len(self._plans) > 64:
-                    for p in self._plans.values():
-                        p.destroy()
-                    self._plans.clear()
-                plan = self.engine.plan(list(range(len(self.ln_emb))), list(lS_i), list(lS_o))
-                self._plans[key] = plan
-            plan.launch(self.torch.cuda.current_stream(self.device).cuda_stream)
-            return plan.outputs
-        return self.engine.lookup_batched(list(range(len(self.ln_emb))), list(lS_i), list(lS_o))
+        if hasattr(lS_i, "dim") and hasattr(lS_o, "dim") and lS_i.dim() == 2 and lS_o.dim() == 2 and lS_i.is_cuda:
+            # DLRM stacks fixed-size batches into [T, N] / [T, B] tensors: one [T, B, m] result, unbound
+            return list(self.engine.lookup_stacked(self._ids, lS_i, lS_o).unbind(0))
+        return self.engine.lookup_batched(self._ids, list(lS_i), list(lS_o))
+
+    def prepare(self, lS_o, lS_i):
+        """For callers that reuse the SAME device tensors every step (static-shape serving, hipGraph
+        capture): a prepared plan over these buffers.  plan.launch() enqueues the lookup (3-4 us of host
+        time), plan.outputs are its fixed output tensors.  The caller keeps the inputs alive."""
+        plan = self.engine.plan(self._ids, list(lS_i), list(lS_o))
+        self._plans[id(plan)] = plan
+        return plan
 
     forward = __call__ = apply_emb
 
@@ -154,6 +155,16 @@ def main(argv=None):
     n_bags = sum(int(x.shape[0]) for x in ly)
     print(f"apply_emb: {len(ebc.ln_emb)} tables, m={ebc.m}, batch {B}: {dt * 1e3:.4f} ms/batch, "
           f"{n_bags / dt:.3e} pooled lookups/s")
+    plans = [ebc.prepare(o, i) for o, i in batches]        # same buffers every step: prepared plans
+    for p in plans:
+        p.launch()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for b in range(args.num_batches):
+        plans[b % len(plans)].launch()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.num_batches
+    print(f"prepared plans (static buffers): {dt * 1e3:.4f} ms/batch, {n_bags / dt:.3e} pooled lookups/s")
     ebc.close()
     return 0
 

@@ -13,6 +13,7 @@ Buffers may be
 from __future__ import annotations
 
 import ctypes as C
+import struct
 from typing import Sequence
 
 import numpy as np
@@ -178,6 +179,8 @@ class EmbeddingEngine:
         _l.check(self._L.emb_create(C.byref(cfg), C.byref(h)))
         self._h = h.value
         self._tables: dict[int, tuple[int, int, int]] = {}  # id -> (nr_rows, dim, dtype)
+        self._desc_bufs: dict[int, tuple] = {}              # n descriptors -> (packed buffer, typed pointer)
+        self._stacked: dict[tuple, tuple] = {}              # table ids -> descriptor array of lookup_stacked
         self._rps_cache: dict = {}
 
     # ---- tables (populate_mram's job, emb_host.h:136) ------------------------------------------
@@ -273,10 +276,112 @@ class EmbeddingEngine:
             keep += [ia.keep, oa.keep]
         return arr, n, itype, space, results, keep
 
+    _DESC = struct.Struct("<IIQQQQQ")    # emb_lookup_desc: table_id, fixed_pooling, indices, offsets, n_indices, n_bags, pooled
+
+    def _lookup_batched_cuda(self, table_ids, indices, offsets, outs, stream):
+        """Fast path of lookup_batched for torch CUDA tensors with explicit offsets -- what an
+        `apply_emb` loop hands over, fresh tensors every batch.  Same C call as the general path, but
+        the descriptors are packed without per-buffer helper objects and the outputs of tables that
+        share a dim come from ONE allocation (views).  Returns None if the arguments do not qualify.
+        26 tables: ~150 us -> ~40 us of Python per call."""
+        import torch
+        n = len(table_ids)
+        i0 = indices[0]
+        if type(i0) is not torch.Tensor or not i0.is_cuda or len(indices) != n or len(offsets) != n:
+            return None
+        dt, dev, tables = i0.dtype, i0.device, self._tables
+        if dt is torch.int64:
+            itype = _l.EMB_IDX_I64
+        elif dt is torch.int32:
+            itype = _l.EMB_IDX_U32
+        else:
+            return None
+        slot = self._desc_bufs.get(n)
+        if slot is None:
+            raw = C.create_string_buffer(self._DESC.size * n)
+            slot = self._desc_bufs[n] = (raw, C.cast(raw, C.POINTER(_l.EmbLookupDesc)))
+        buf, buf_ptr = slot
+        pack, size = self._DESC.pack_into, self._DESC.size
+        nbs, dims = [], []
+        for t, ia, oa in zip(table_ids, indices, offsets):
+            if type(ia) is not torch.Tensor or type(oa) is not torch.Tensor or ia.dtype is not dt or oa.dtype is not dt \
+                    or ia.device != dev or oa.device != dev or not ia.is_contiguous() or not oa.is_contiguous():
+                return None
+            nbs.append(oa.numel())
+            dims.append(tables[t][1])        # KeyError: table not loaded
+        if outs is None:
+            d0 = dims[0]
+            if all(d == d0 for d in dims):   # one allocation, one view per table
+                outs = torch.empty((sum(nbs), d0), dtype=torch.float32, device=dev).split(nbs)
+            else:
+                outs = [torch.empty((b, d), dtype=torch.float32, device=dev) for b, d in zip(nbs, dims)]
+        else:
+            for o, b, d in zip(outs, nbs, dims):
+                if type(o) is not torch.Tensor or o.device != dev or o.dtype is not torch.float32 \
+                        or not o.is_contiguous() or o.numel() != b * d:
+                    return None
+        off = 0
+        for t, ia, oa, b, o in zip(table_ids, indices, offsets, nbs, outs):
+            pack(buf, off, t, 0, ia.data_ptr(), oa.data_ptr(), ia.numel(), b, o.data_ptr())
+            off += size
+        if stream is None:
+            stream = torch.cuda.current_stream(dev).cuda_stream
+        _l.check(self._L.emb_lookup_batched(self._h, buf_ptr, n, itype, _l.EMB_MEM_DEVICE, stream))
+        return list(outs)
+
+    _DESC_DT = np.dtype([("table_id", "<u4"), ("fixed_pooling", "<u4"), ("indices", "<u8"), ("offsets", "<u8"),
+                         ("n_indices", "<u8"), ("n_bags", "<u8"), ("pooled", "<u8")])
+
+    def lookup_stacked(self, table_ids: Sequence[int], indices, offsets, out=None, stream: int | None = None):
+        """The stacked form DLRM uses for fixed-size batches: `indices` [T, N] and `offsets` [T, B] as two
+        2-D torch CUDA tensors (row t belongs to table_ids[t]; all tables share one dim).  Returns ONE
+        [T, B, dim] fp32 tensor (out[t] is table t's pooled rows).  The per-table pointers are computed
+        arithmetically, so the Python cost does not grow with T (~10 us for 26 tables, against ~40 us for
+        lists of per-table tensors)."""
+        import torch
+        T = len(table_ids)
+        if indices.dim() != 2 or offsets.dim() != 2 or indices.shape[0] != T or offsets.shape[0] != T:
+            raise ValueError("indices must be [T, N] and offsets [T, B]")
+        if not (indices.is_cuda and offsets.is_cuda and indices.is_contiguous() and offsets.is_contiguous()):
+            raise ValueError("lookup_stacked needs contiguous CUDA tensors")
+        if indices.dtype != offsets.dtype:
+            raise TypeError("indices and offsets must share dtype width")
+        itype = _index_type_of(indices.dtype)
+        key = tuple(table_ids)
+        cached = self._stacked.get(key)
+        if cached is None:
+            dims = {self._tables[t][1] for t in table_ids}        # KeyError: table not loaded
+            if len(dims) != 1:
+                raise ValueError("lookup_stacked needs tables of one dim")
+            arr = np.zeros(T, dtype=self._DESC_DT)
+            arr["table_id"] = np.asarray(table_ids, dtype=np.uint32)
+            cached = self._stacked[key] = (arr, np.arange(T, dtype=np.uint64), dims.pop(),
+                                           C.cast(arr.ctypes.data, C.POINTER(_l.EmbLookupDesc)))
+        arr, steps, dim, arr_ptr = cached
+        N, B = indices.shape[1], offsets.shape[1]
+        if out is None:
+            out = torch.empty((T, B, dim), dtype=torch.float32, device=indices.device)
+        elif tuple(out.shape) != (T, B, dim) or not out.is_contiguous() or out.dtype != torch.float32:
+            raise ValueError("out must be a contiguous float32 [T, B, dim] tensor")
+        esz = indices.element_size()
+        arr["indices"] = indices.data_ptr() + steps * np.uint64(N * esz)
+        arr["offsets"] = offsets.data_ptr() + steps * np.uint64(B * esz)
+        arr["pooled"] = out.data_ptr() + steps * np.uint64(B * dim * 4)
+        arr["n_indices"] = N
+        arr["n_bags"] = B
+        if stream is None:
+            stream = torch.cuda.current_stream(indices.device).cuda_stream
+        _l.check(self._L.emb_lookup_batched(self._h, arr_ptr, T, itype, _l.EMB_MEM_DEVICE, stream))
+        return out
+
     def lookup_batched(self, table_ids: Sequence[int], indices: Sequence, offsets: Sequence,
                        outs: Sequence | None = None, fixed_pooling=0, stream: int | None = None):
         """All tables in one fused launch; returns the list of pooled [B_t, D] outputs
         (the `apply_emb` contract: one [B, D] per table)."""
+        if not fixed_pooling and len(table_ids) and _is_torch(indices[0]):
+            res = self._lookup_batched_cuda(table_ids, indices, offsets, outs, stream)
+            if res is not None:
+                return res
         arr, n, itype, space, results, _keep = self._descs(table_ids, indices, offsets, outs, fixed_pooling)
         if stream is None and space == _l.EMB_MEM_DEVICE:
             stream = _current_stream_for(*indices)
