@@ -65,7 +65,8 @@ def _run(tmp_path, pairs):
     exe = tmp_path / "chk"
     if not exe.exists():
         src.write_text(CHECKER)
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-I",
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined",
+                               "-fno-sanitize-recover=all", "-I",
                                os.path.join(ROOT, "pim-embedding-lookup_amd", "csrc"), str(src), "-o", str(exe)])
     args = [str(x) for p in pairs for x in p]
     out = subprocess.check_output([str(exe)] + args, text=True)
