@@ -220,6 +220,19 @@ class EmbeddingEngine:
         ids = np.ascontiguousarray(row_ids, dtype=np.uint64)
         _l.check(self._L.emb_set_hot_rows(self._h, table_id, ids.ctypes.data_as(C.POINTER(C.c_uint64)), ids.shape[0]))
 
+    def table_tensor(self, table_id: int):
+        """Zero-copy torch view of a table's rows in HBM ([nr_rows, dim], the table's dtype) -- for saving a
+        checkpoint or inspecting weights.  Valid until the table is reloaded or the engine closed; writing
+        through it changes what lookups return (and leaves any hot-row copy stale)."""
+        import torch
+        ptr, n, d, dt = self.table_info(table_id)
+        typestr = {_l.EMB_F32: "<f4", _l.EMB_F16: "<f2", _l.EMB_FIXED32: "<i4"}[dt]
+
+        class _View:
+            __cuda_array_interface__ = {"shape": (n, d), "typestr": typestr, "data": (ptr, False), "version": 2,
+                                        "strides": None}
+        return torch.as_tensor(_View(), device=torch.device("cuda", self.device))
+
     def table_info(self, table_id: int):
         ptr, n, d, dt = C.c_void_p(), C.c_uint64(), C.c_uint32(), C.c_int()
         _l.check(self._L.emb_table_info(self._h, table_id, C.byref(ptr), C.byref(n), C.byref(d), C.byref(dt)))

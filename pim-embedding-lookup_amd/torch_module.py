@@ -93,6 +93,11 @@ class EmbeddingBag(torch.nn.Module):
         return cls(module.num_embeddings, module.embedding_dim, mode=module.mode, sparse=module.sparse,
                    _weight=module.weight.detach(), include_last_offset=module.include_last_offset, **kw)
 
+    @property
+    def weight(self):
+        """The table's rows in HBM as a torch tensor (zero-copy view; not a Parameter -- inference only)."""
+        return self.engine.table_tensor(self.table_id)
+
     def forward(self, input, offsets=None, per_sample_weights=None):
         if per_sample_weights is not None:
             raise NotImplementedError("per_sample_weights are not part of the reference path")

@@ -1089,6 +1089,8 @@ def test_torch_modules_replace_nn_embeddingbag(pel, oracle):
     ours_ilo = tm.EmbeddingBag.from_torch(ilo)
     off_ilo = torch.cat([lS_o[1], torch.tensor([lS_i[1].numel()])])
     assert torch.equal(ours_ilo(lS_i[1].to(dev), off_ilo.to(dev)).cpu(), ilo(lS_i[1], off_ilo).detach())
+    assert torch.equal(ours[2].weight.cpu(), emb_l[2].weight.detach())          # zero-copy view of the HBM table
+    assert ours[2].weight.data_ptr() == ours[2].engine.table_info(ours[2].table_id)[0]
     with pytest.raises(NotImplementedError):
         tm.EmbeddingBag(10, 16, mode="mean")
     with pytest.raises(NotImplementedError):
