@@ -114,6 +114,7 @@ def main(argv=None):
     ap.add_argument("--data-generation", type=str, default="random", choices=["random", "dataset"])
     ap.add_argument("--processed-data-file", type=str, default="")
     ap.add_argument("--load-model", type=str, default="")
+    ap.add_argument("--save-model", type=str, default="")
     ap.add_argument("--numpy-rand-seed", type=int, default=123)
     args, ignored = ap.parse_known_args(argv)
     if ignored:   # MLP / training / logging flags of the reference command lines (README.md:6,10,14)
@@ -165,6 +166,11 @@ def main(argv=None):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.num_batches
     print(f"prepared plans (static buffers): {dt * 1e3:.4f} ms/batch, {n_bags / dt:.3e} pooled lookups/s")
+    if args.save_model:      # the embedding part of a DLRM checkpoint: emb_l.<k>.weight, straight out of HBM
+        from .formats import save_dlrm_embedding_weights
+        save_dlrm_embedding_weights(args.save_model, [ebc.engine.table_tensor(k).float().cpu().numpy()
+                                                      for k in range(len(ebc.ln_emb))])
+        print("saved", args.save_model)
     ebc.close()
     return 0
 

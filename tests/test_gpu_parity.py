@@ -411,8 +411,12 @@ def test_apply_emb_harness_matches_torch_embeddingbag(pel, oracle, tmp_path):
     for k in range(len(ln_emb)):
         assert np.array_equal(ly[k], oracle.c_bag_sum(tabs[k], lS_i[k], lS_o[k]))
     ebc.close()
+    saved = tmp_path / "saved.pt"
     assert hz.main(["--arch-embedding-size=100-200-300", "--mini-batch-size=32", "--num-batches=3",
-                    "--num-indices-per-lookup=4", "--inference-only"]) == 0
+                    "--num-indices-per-lookup=4", "--inference-only", f"--save-model={saved}"]) == 0
+    ws = fm.load_dlrm_embedding_weights(str(saved))                     # --save-model / --load-model round trip
+    assert [w.shape for w in ws] == [(100, 16), (200, 16), (300, 16)]
+    assert hz.main([f"--load-model={saved}", "--mini-batch-size=8", "--num-batches=2", "--inference-only"]) == 0
 
 
 def test_stage_trace_export(pel, eng, tmp_path):
