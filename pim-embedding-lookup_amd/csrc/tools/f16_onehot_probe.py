@@ -9,10 +9,10 @@ sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..",
 import torch  # noqa: E402
 import pim_embedding_lookup_amd as pel  # noqa: E402
 
-lib_path = sys.argv[1] if len(sys.argv) > 1 else None
+lib_path = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] != "-" else None
 dev = torch.device("cuda", 0)
 rows = pel.workloads.KAGGLE_ROWS
-B = pel.workloads.KAGGLE_BATCH
+B = int(sys.argv[2]) if len(sys.argv) > 2 else pel.workloads.KAGGLE_BATCH
 rng = np.random.default_rng(1)
 for dim in (16, 32, 64, 128):
     eng = pel.EmbeddingEngine(device=0, max_tables=26, lib_path=lib_path)
