@@ -127,6 +127,18 @@ def main():
         arrays[f"expect_{t}"] = torch_bag_sum(tab, idx, off)
     save("kaggle26_capped_b4", **arrays)
 
+    # ---- 6. row widths off the 16-byte grid (dlrm_s_pytorch.py's default sparse feature size is 2) and
+    #         beyond 1 KiB: the any-dim kernels.  Own generator, so sections 1-5 stay byte-identical. ----
+    rng6 = np.random.default_rng(4321)
+    for dim, dt in ((2, np.float32), (3, np.float32), (10, np.float32), (30, np.float32), (300, np.float32),
+                    (6, np.float16), (5, np.float16)):
+        n_rows, n_bags = int(rng6.integers(40, 300)), int(rng6.integers(10, 50))
+        tab = rng6.standard_normal((n_rows, dim)).astype(dt)
+        off, n_idx = ragged_offsets(rng6, n_bags, 12)
+        idx = rng6.integers(0, n_rows, size=n_idx)
+        save(f"anydim_d{dim}_{np.dtype(dt).name}_ragged", table=tab, indices=idx.astype(np.int64), offsets=off,
+             expect=torch_bag_sum(tab.astype(np.float32), idx, off))
+
 
 if __name__ == "__main__":
     main()
