@@ -749,7 +749,7 @@ def test_c_programs_against_the_abi(pel):
 
 def test_many_transient_launches_on_two_streams(pel, eng, oracle):
     """Device-pointer emb_lookup_batched without a plan: 24 back-to-back calls on two streams reuse
-    the 4-slot descriptor ring; every output must still be right."""
+    the pinned launch-image segments (a stream switch closes a segment); every output must still be right."""
     import torch
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(77)
