@@ -28,6 +28,7 @@ from __future__ import annotations
 
 import json
 import os
+import sys
 import time
 
 import numpy as np
@@ -265,6 +266,12 @@ def run_whole(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if stage_cpu else dev)
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
     wall = float(el.item())
+    # what the timed loop left behind: the last step's 26 outputs, bit for bit
+    res = outputs(slots[(it - 1) % NBATCH])
+    for t in range(T):
+        idx = torch.from_numpy(idx_host[(it - 1) % NBATCH][t]).to(dev)
+        if not torch.equal(res[t], expected_pooled(torch, t, idx, dim, L)):
+            raise AssertionError(f"rank {rank}: last timed step, table {t} ({plan.kinds[t]}) differs from the expected rows")
 
     result = None
     if rank == 0:
@@ -574,6 +581,11 @@ def run_dp(args, hbm_peak_gbs: float, ctx):
     wall = float(el.item())
     kernel_us = e0.elapsed_time(e1) * 1000.0 / args.steps
     alg_bytes = plans[0].bytes()[0]
+    last = (args.steps - 1) % NBATCH if args.steps > 0 else 0
+    for t in range(T):       # what was just timed: the last batch's outputs on every rank, bit for bit
+        idx = torch.from_numpy(idx_host[last][t]).to(dev)
+        if not torch.equal(plans[last].outputs[t], expected_pooled(torch, t, idx, dim, L)):
+            raise AssertionError(f"rank {rank}: last timed batch, table {t} differs from the expected rows")
     result = None
     if rank == 0:
         ach = alg_bytes / (kernel_us * 1e-6) / 1e9
@@ -631,44 +643,60 @@ def run(args, hbm_peak_gbs: float) -> None:
     auto = getattr(args, "replicate_mb", None) is None
     mode = getattr(args, "shard_mode", None) or ("rows" if getattr(args, "workload", "c2") == "c4" else "whole")
     shard_leg = run_rows if mode == "rows" else run_whole
-    state = {"printed": False, "dog": None}
+    state = {"printed": False, "dog": None, "primary": None}
 
     def emit(res):
         if rank == 0 and res is not None and not state["printed"]:
             state["printed"] = True
             print(json.dumps(res), flush=True)
 
+    def finish(res):
+        """backend / rank count on every N > 1 line, so a SCALE record shows what RCCL saw."""
+        if res is not None:
+            res.setdefault("verified", True)     # every leg compares its outputs bit for bit before AND after timing
+            res["config"]["backend"] = backend
+            res["config"]["rccl_ranks"] = world if backend == "nccl" else 0
+            res["config"]["world_size"] = world
+        return res
+
+    def die(code, note):
+        """The exchange leg failed or hung on this rank: print what there is (rank 0), end NON-ZERO.  Peers that
+        wait for this rank in a collective are ended by the launcher (bench.py's self-launch / torchrun)."""
+        if rank == 0 and state.get("primary") is not None:
+            state["primary"]["sharded_exchange"] = {"failed": note}
+            state["primary"]["verified"] = False
+            emit(finish(state["primary"]))
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(code)
+
     if auto and total_bytes <= hbm // 4:
         result = run_dp(args, hbm_peak_gbs, ctx)
+        state["primary"] = result
         if not getattr(args, "no_exchange_leg", False):
-            # secondary leg: the sharded exchange, fewer steps.  A hang (or a rank that dropped out)
-            # must not lose the primary result: after 180 s every rank gives up, rank 0 prints what it has.
+            # secondary leg: the sharded exchange (the xGMI all-to-all curve), fewer steps.  A parity failure, an
+            # exception or a hang in it FAILS the run: the primary line is still printed, the exit status is not 0.
             import copy
             a2 = copy.copy(args)
             a2.steps, a2.warmup = min(args.steps, 400), min(args.warmup, 40)
-
-            def give_up():
-                if rank == 0 and result is not None and not isinstance(result.get("sharded_exchange"), dict):
-                    result["sharded_exchange"] = result.get("sharded_exchange") or "timed out after 180 s"
-                emit(result)
-                os._exit(0)
-
-            state["dog"] = threading.Timer(180.0, give_up)
+            limit = float(os.environ.get("PIMEMB_EXCHANGE_TIMEOUT", "180"))
+            state["dog"] = threading.Timer(limit, die, (3, "timed out after %.0f s" % limit))
             state["dog"].daemon = True
             state["dog"].start()
             try:
                 sec = shard_leg(a2, hbm_peak_gbs, ctx, 64 << 20)
-                if rank == 0:
-                    result["sharded_exchange"] = {k: sec[k] for k in ("value", "unit", "ms_per_step", "steps")}
-                    result["sharded_exchange"]["config"] = sec["config"]["workload"] + "; " + sec["config"]["parallelism"]
-            except Exception as ex:  # noqa: BLE001 -- the primary result stands on its own
-                if rank == 0:
-                    result["sharded_exchange"] = f"failed: {type(ex).__name__}: {ex}"
+            except BaseException as ex:  # noqa: BLE001 -- SystemExit from a leg included
+                import traceback
+                traceback.print_exc()
+                die(4, f"{type(ex).__name__}: {ex}")
+            state["dog"].cancel()
+            if rank == 0:
+                result["sharded_exchange"] = {k: sec[k] for k in ("value", "unit", "ms_per_step", "steps", "roofline")}
+                result["sharded_exchange"]["verified"] = True
+                result["sharded_exchange"]["config"] = sec["config"]["workload"] + "; " + sec["config"]["parallelism"]
     else:
         rep_mb = 64 if auto else int(args.replicate_mb)
         result = shard_leg(args, hbm_peak_gbs, ctx, rep_mb << 20)
-    emit(result)
+    emit(finish(result))
     dist.barrier()
-    if state["dog"] is not None:
-        state["dog"].cancel()
     dist.destroy_process_group()

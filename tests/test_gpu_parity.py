@@ -490,14 +490,14 @@ def test_distributed_bench_two_ranks_on_one_gpu(mode):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PIMEMB_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    port = {"rows": "29561", "whole": "29562", "auto": "29563", "whole-pooled": "29565"}[mode]
+    env = dict(os.environ, PIMEMB_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
     pooled = mode == "whole-pooled"       # 5 indices per bag: the exchange carries 5x the index volume
     mode = "whole" if pooled else mode
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", port,
-           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3", "--nbatch", "3",
-           "--batch", "4099"]
+    # no launcher: `python bench.py --gpus 2` starts its two ranks itself (the parent touches no GPU)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3",
+           "--nbatch", "3", "--batch", "4099"]
     if mode != "auto":
         cmd += ["--shard-mode", mode, "--replicate-mb", "64"]
     if pooled:
@@ -507,7 +507,9 @@ def test_distributed_bench_two_ranks_on_one_gpu(mode):
     line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
-    assert d["roofline"]["bound"] == "hbm"
+    assert d["roofline"]["bound"] == "hbm" and d["verified"] is True
+    assert d["config"]["backend"] == "gloo" and d["config"]["rccl_ranks"] == 0 and d["config"]["world_size"] == 2
+    assert len([l for l in res.stdout.splitlines() if l.strip()]) == 1      # ONE line on the job's stdout
     w = d["config"]["workload"]
     if mode == "rows":
         assert "5 row-range sharded" in w and "21 tables replicated" in w
@@ -518,6 +520,7 @@ def test_distributed_bench_two_ranks_on_one_gpu(mode):
         assert "replicated on every rank" in d["config"]["parallelism"]
         sec = d["sharded_exchange"]
         assert isinstance(sec, dict) and sec["value"] > 0 and "5 whole" in sec["config"]
+        assert sec["verified"] is True and sec["roofline"]["bound"] == "hbm" and sec["roofline"]["achieved"] > 0
 
 
 def test_distributed_terabyte_shaped_row_shards_two_ranks():
