@@ -257,6 +257,50 @@ int emb_unroute_rows(emb_engine *e, const void *recv_base, uint64_t src_stride_b
                      uint64_t n_bags, uint32_t dim, uint32_t capacity, const uint32_t *perm,
                      float *pooled /* [n_tables][n_bags][dim] */, void *stream);
 
+/* ------------------------------------------------------------------------------------------ */
+/* row-range shards, VARIABLE-LENGTH bags (pooled lookups): counts first, payload second          */
+/* ------------------------------------------------------------------------------------------ */
+/* The bag loop being sharded is upmem/src/dpu/emb_dpu_lookup.c:106-116; the reference tells its devices the
+ * lengths before every launch (emb_host.h:280-287) -- here the lengths are computed on the GPU and are the
+ * FIRST message of the exchange, the payload is sized from them (no capacity to overflow, whatever the skew).
+ *
+ * A bag of a row-split table is cut into one SUB-BAG per shard owning some of its rows (indices keep their
+ * order inside a sub-bag).  Shard d receives, per (source rank, table), an ordinary lookup -- local row ids +
+ * bag-start offsets, exactly emb_lookup_desc's format -- and returns one partial pooled row per sub-bag;
+ * the bag's owner adds the partial rows in shard order d = 0 .. n_shards-1 starting from +0: deterministic,
+ * bit-identical to an unsharded lookup when a bag lives in one shard (one index per bag), within fp32
+ * re-association (<= 1e-6 on DLRM-scale tables) otherwise.
+ *
+ * emb_route_bags enqueues four small kernels on `stream` and fills (all DEVICE memory, sizes from
+ * emb_route_bags_sizes; K = n_tables, N = n_shards, pad4(x) = x rounded up to a multiple of 4):
+ *   meta  uint32 words:  counts[N][K][2] = {n_sub, n_idx} of the request to shard d for table k  <- send to d first
+ *                        base  [N][K][2] = word offsets in `send` of that request's offsets / indices arrays
+ *                        piece [N+1]     = word offset of destination d's piece (piece[N] = words in all)
+ *                        ret_row0[N][K]  = first partial row of (d, k) in the returned rows (see below)
+ *   send  uint32 words:  for d: for k: offsets[pad4(n_sub)] then local row ids[pad4(n_idx)]  (every array
+ *                        16-byte aligned; the host derives the split sizes from `counts` with the same rule)
+ *   slots uint32[K][N][n_bags]: slot of bag b's sub-bag in (d, k)'s request, 0xffffffff = none (kept by the
+ *                        source for emb_unroute_bags; valid until the next emb_route_bags into the same buffer)
+ * The serving rank runs emb_lookup_batched over the received pieces (n_bags = n_sub, n_indices = n_idx, device
+ * pointers) and returns, per source, the partial rows of k = 0 .. K-1 back to back (float[n_sub][dim], no
+ * padding).  emb_unroute_bags then reads `recv` = the returned rows of shard 0, shard 1, ... back to back
+ * and writes pooled[k][b][:].  dim must be a multiple of 4; indices are uint32; at most 64 tables per call. */
+typedef struct emb_route_table {
+    const uint32_t *indices;  /* DEVICE uint32[n_indices]: global row ids */
+    const uint32_t *offsets;  /* DEVICE uint32[n_bags] bag starts (last bag runs to n_indices), or NULL */
+    uint64_t n_indices;
+    uint32_t fixed_pooling;   /* offsets == NULL: offsets[b] = b * fixed_pooling */
+    uint32_t rows_per_shard;  /* shard d owns rows [d*rows_per_shard, (d+1)*rows_per_shard) */
+} emb_route_table;
+int emb_route_bags_sizes(uint32_t n_tables, uint64_t n_bags, uint64_t total_indices, uint32_t n_shards,
+                         uint64_t *send_bytes, uint64_t *meta_bytes, uint64_t *slots_bytes, uint64_t *work_bytes);
+int emb_route_bags(emb_engine *e, const emb_route_table *tables /* host array */, uint32_t n_tables,
+                   uint64_t n_bags, uint32_t n_shards, void *send, uint32_t *meta, uint32_t *slots,
+                   void *work, void *stream);
+int emb_unroute_bags(emb_engine *e, const float *recv, const uint32_t *meta, const uint32_t *slots,
+                     uint32_t n_tables, uint64_t n_bags, uint32_t n_shards, uint32_t dim,
+                     float *pooled /* [n_tables][n_bags][dim] */, void *stream);
+
 /* ---- optional native exchange (multi-GPU sharded lookup) --------------------------------------- */
 /* All-to-all of byte ranges issued directly to RCCL (grouped ncclSend/ncclRecv) on the caller's stream:
  * the "indices in / pooled rows out" step of the sharded lookup without torch.distributed's per-call

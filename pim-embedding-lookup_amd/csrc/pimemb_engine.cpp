@@ -6,6 +6,7 @@
 //   post_process  (:186-222)  -> gone (conversion and [bag][col] layout are fused in the kernel)
 // There is NO CPU compute path in this file: every lookup is a HIP kernel launch; if the GPU or
 // the runtime is unavailable the call fails with EMB_ERR_DEVICE.
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdarg>
@@ -1252,6 +1253,56 @@ int emb_unroute_rows(emb_engine *e, const void *recv_base, uint64_t src_stride_b
     DeviceGuard g(e->device);
     HIP_TRY(pimemb::launch_unroute_rows(static_cast<const char *>(recv_base), src_stride_bytes, n_tables, n_bags, dim,
                                         capacity, perm, pooled, static_cast<hipStream_t>(stream)));
+    return EMB_OK;
+}
+
+int emb_route_bags_sizes(uint32_t n_tables, uint64_t n_bags, uint64_t total_indices, uint32_t n_shards,
+                         uint64_t *send_bytes, uint64_t *meta_bytes, uint64_t *slots_bytes, uint64_t *work_bytes) {
+    if (n_tables == 0 || n_tables > pimemb::kRouteBagMaxTables || n_shards == 0 || n_shards > 255)
+        return fail(EMB_ERR_INVALID, "emb_route_bags_sizes: 1..64 tables and 1..255 shards");
+    const uint64_t nk = (uint64_t)n_tables * n_shards;
+    // every index once, at most min(indices, bags x shards) sub-bag offsets, < 4 padding words per array
+    const uint64_t sub_max = std::min<uint64_t>(total_indices, n_bags * nk);
+    if (send_bytes) *send_bytes = (total_indices + sub_max + 8 * nk + 4) * 4;
+    if (meta_bytes) *meta_bytes = (5 * nk + n_shards + 1 + 3) / 4 * 16;
+    if (slots_bytes) *slots_bytes = (nk * n_bags + 3) / 4 * 16;
+    if (work_bytes) *work_bytes = (nk * n_bags + 3) / 4 * 16;
+    return EMB_OK;
+}
+
+int emb_route_bags(emb_engine *e, const emb_route_table *tables, uint32_t n_tables, uint64_t n_bags,
+                   uint32_t n_shards, void *send, uint32_t *meta, uint32_t *slots, void *work, void *stream) {
+    if (!e || !tables || !send || !meta || !slots || !work) return fail(EMB_ERR_INVALID, "emb_route_bags: NULL argument");
+    if (n_tables == 0 || n_tables > pimemb::kRouteBagMaxTables)
+        return fail(EMB_ERR_UNSUPPORTED, "emb_route_bags: 1..%u tables per call", pimemb::kRouteBagMaxTables);
+    if (n_shards == 0 || n_shards > 255 || n_bags == 0 || n_bags * n_shards > 0x7fffffffull * 256)
+        return fail(EMB_ERR_INVALID, "emb_route_bags: n_shards must be 1..255 and n_bags > 0");
+    pimemb::RouteBagDesc d[pimemb::kRouteBagMaxTables];
+    for (uint32_t k = 0; k < n_tables; k++) {
+        const emb_route_table &t = tables[k];
+        if (t.rows_per_shard == 0) return fail(EMB_ERR_INVALID, "emb_route_bags: tables[%u].rows_per_shard is 0", k);
+        if (t.n_indices && !t.indices) return fail(EMB_ERR_INVALID, "emb_route_bags: tables[%u].indices is NULL", k);
+        if (t.n_indices > 0xffffffffull) return fail(EMB_ERR_UNSUPPORTED, "emb_route_bags: tables[%u]: more than 2^32-1 indices", k);
+        if (!t.offsets && (uint64_t)t.fixed_pooling * n_bags != t.n_indices)
+            return fail(EMB_ERR_INVALID, "emb_route_bags: tables[%u]: fixed_pooling*n_bags != n_indices", k);
+        d[k] = pimemb::RouteBagDesc{t.indices, t.offsets, t.n_indices, t.fixed_pooling, t.rows_per_shard};
+    }
+    DeviceGuard g(e->device);
+    HIP_TRY(pimemb::launch_route_bags(d, n_tables, n_bags, n_shards, static_cast<uint32_t *>(send), meta, slots,
+                                      static_cast<uint32_t *>(work), static_cast<hipStream_t>(stream)));
+    return EMB_OK;
+}
+
+int emb_unroute_bags(emb_engine *e, const float *recv, const uint32_t *meta, const uint32_t *slots,
+                     uint32_t n_tables, uint64_t n_bags, uint32_t n_shards, uint32_t dim, float *pooled,
+                     void *stream) {
+    if (!e || !recv || !meta || !slots || !pooled) return fail(EMB_ERR_INVALID, "emb_unroute_bags: NULL argument");
+    if (dim == 0 || dim % 4) return fail(EMB_ERR_UNSUPPORTED, "emb_unroute_bags: dim must be a multiple of 4");
+    if (n_tables == 0 || n_tables > pimemb::kRouteBagMaxTables || n_shards == 0 || n_shards > 255)
+        return fail(EMB_ERR_INVALID, "emb_unroute_bags: 1..64 tables and 1..255 shards");
+    DeviceGuard g(e->device);
+    HIP_TRY(pimemb::launch_unroute_bags(recv, meta, slots, n_tables, n_bags, n_shards, dim, pooled,
+                                        static_cast<hipStream_t>(stream)));
     return EMB_OK;
 }
 

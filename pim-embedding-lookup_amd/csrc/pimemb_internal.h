@@ -72,6 +72,21 @@ hipError_t launch_unroute_rows(const char *recv_base, uint64_t src_stride_bytes,
                                uint64_t n_bags, uint32_t dim, uint32_t capacity, const uint32_t *perm,
                                float *pooled, hipStream_t stream);
 
+// Row-range routing of variable-length bags (pooled lookups over row-split tables; see pimemb.h,
+// emb_route_bags).  All pointers are device pointers; the four kernels are enqueued on `stream`.
+constexpr uint32_t kRouteBagMaxTables = 64;
+struct RouteBagDesc {
+    const uint32_t *indices;
+    const uint32_t *offsets;
+    uint64_t n_indices;
+    uint32_t fixed_pooling;
+    uint32_t rows_per_shard;
+};
+hipError_t launch_route_bags(const RouteBagDesc *tables, uint32_t n_tables, uint64_t n_bags, uint32_t n_shards,
+                             uint32_t *send, uint32_t *meta, uint32_t *slots, uint32_t *work, hipStream_t stream);
+hipError_t launch_unroute_bags(const float *recv, const uint32_t *meta, const uint32_t *slots, uint32_t n_tables,
+                               uint64_t n_bags, uint32_t n_shards, uint32_t dim, float *pooled, hipStream_t stream);
+
 // Record the calling thread's error text (returned by emb_last_error()) and hand `code` back.
 int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 

@@ -442,6 +442,33 @@ class EmbeddingEngine:
         _l.check(self._L.emb_unroute_rows(self._h, recv_base, src_stride_bytes, n_tables, n_bags, dim, capacity,
                                           perm_ptr, pooled_ptr, stream))
 
+    # ---- multi-GPU routing helpers (row-range shards, variable-length bags: counts first) ---------------
+    def route_bags_sizes(self, n_tables: int, n_bags: int, total_indices: int, n_shards: int) -> dict:
+        """Bytes of the four device buffers emb_route_bags works with: send, meta, slots, work."""
+        v = [C.c_uint64() for _ in range(4)]
+        _l.check(self._L.emb_route_bags_sizes(n_tables, n_bags, total_indices, n_shards, *[C.byref(x) for x in v]))
+        return dict(zip(("send", "meta", "slots", "work"), (x.value for x in v)))
+
+    def route_bags(self, tables, n_bags: int, n_shards: int, send_ptr: int, meta_ptr: int, slots_ptr: int,
+                   work_ptr: int, stream: int | None = None) -> None:
+        """tables: sequence of (indices_ptr, offsets_ptr or None, n_indices, fixed_pooling, rows_per_shard) or a
+        prepared array from route_tables().  Enqueue only (emb_route_bags in pimemb.h)."""
+        arr = tables if isinstance(tables, C.Array) else self.route_tables(tables)
+        _l.check(self._L.emb_route_bags(self._h, arr, len(arr), n_bags, n_shards, send_ptr, meta_ptr, slots_ptr,
+                                        work_ptr, stream))
+
+    @staticmethod
+    def route_tables(tables):
+        arr = (_l.EmbRouteTable * len(tables))()
+        for k, (ip, op, n, L, rps) in enumerate(tables):
+            arr[k] = _l.EmbRouteTable(ip, op, int(n), int(L), int(rps))
+        return arr
+
+    def unroute_bags(self, recv_ptr: int, meta_ptr: int, slots_ptr: int, n_tables: int, n_bags: int, n_shards: int,
+                     dim: int, pooled_ptr: int, stream: int | None = None) -> None:
+        _l.check(self._L.emb_unroute_bags(self._h, recv_ptr, meta_ptr, slots_ptr, n_tables, n_bags, n_shards, dim,
+                                          pooled_ptr, stream))
+
     # ---- misc --------------------------------------------------------------------------------------
     def stats(self) -> dict:
         s = _l.EmbStats()

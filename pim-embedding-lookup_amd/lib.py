@@ -34,6 +34,11 @@ class EmbStats(C.Structure):
                 ("n_launches_by_kind", C.c_uint64 * 5)]
 
 
+class EmbRouteTable(C.Structure):
+    _fields_ = [("indices", C.c_void_p), ("offsets", C.c_void_p), ("n_indices", C.c_uint64),
+                ("fixed_pooling", C.c_uint32), ("rows_per_shard", C.c_uint32)]
+
+
 class EmbTraceEvent(C.Structure):
     _fields_ = [("stage", C.c_uint32), ("call_id", C.c_uint32), ("start_us", C.c_double), ("stop_us", C.c_double)]
 
@@ -88,6 +93,10 @@ SIGNATURES = {
     "emb_route_onehot": (C.c_int, [_vp, _vp, _u32, _u64, C.POINTER(_u32), _u32, _u32, _vp, _u64, _u64, _vp, _vp,
                                    _vp, _vp]),
     "emb_unroute_rows": (C.c_int, [_vp, _vp, _u64, _u32, _u64, _u32, _u32, _vp, _vp, _vp]),
+    "emb_route_bags_sizes": (C.c_int, [_u32, _u64, _u64, _u32, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64),
+                                       C.POINTER(_u64)]),
+    "emb_route_bags": (C.c_int, [_vp, C.POINTER(EmbRouteTable), _u32, _u64, _u32, _vp, _vp, _vp, _vp, _vp]),
+    "emb_unroute_bags": (C.c_int, [_vp, _vp, _vp, _vp, _u32, _u64, _u32, _u32, _vp, _vp]),
     "emb_configure": (C.c_int, [_u32, _u32, _u32, _u32]),
     "populate_mram": (_vp, [_u32, _u64, _u32, _vp, C.POINTER(DpuRuntimeTotals)]),
     "lookup": (_vp, [_pp, _pp, _pp, _vp, C.c_int64]),

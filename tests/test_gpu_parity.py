@@ -1107,3 +1107,4 @@ def test_torch_modules_replace_nn_embeddingbag(pel, oracle):
     ly = fused(stacked_o, stacked_i)
     for k, m in enumerate(emb_l):
         assert torch.equal(ly[k].cpu(), m(stacked_i[k].cpu(), stacked_o[k].cpu()).detach())
+
