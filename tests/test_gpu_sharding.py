@@ -161,7 +161,7 @@ def test_route_bags_one_index_per_bag_is_exact(pel, eng, oracle):
     tabs = [pel.workloads.dlrm_table(rng, r, dim) for r in rows]
     idxs = [pel.workloads.zipf_indices(rng, rows[0], B, permute=False),          # un-permuted Zipf: all in shard 0
             pel.workloads.uniform_indices(rng, rows[1], B)]
-    assert (idxs[0] // rps[0] == 0).mean() > 0.99
+    assert (idxs[0] // rps[0] == 0).mean() > 0.9
     for k in range(K):
         for d in range(N):
             lo, hi = min(d * rps[k], rows[k]), min((d + 1) * rps[k], rows[k])
