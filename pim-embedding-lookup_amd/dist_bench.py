@@ -18,14 +18,18 @@ the pooled rows of batch i and the indices of batch i+1 (byte payloads with stat
     collective(i) = all_to_all([pooled rows of batch i | indices of batch i+1])   RCCL over xGMI
     outputs(i): replicated tables -> own buffers; sharded tables -> views of the receive buffer
 
-`run_rows`: the same pipeline with the big tables split by ROW RANGE over all ranks; requests are
-routed on the GPU (emb_route_onehot) and the returned rows put back in bag order (emb_unroute_rows).
+`run_rows`: the big tables split by ROW RANGE over all ranks, any number of indices per bag.  Every bag
+is cut into per-shard sub-bags on the GPU (emb_route_bags); the per-(peer, table) counts are exchanged
+FIRST and the request pieces / partial rows travel as all_to_all with split sizes taken from them
+(alltoallv -- nothing has a capacity that skewed indices could overflow); the bag's owner adds the
+partial rows in shard order (emb_unroute_bags).  Pipelined over consecutive batches like `run_whole`.
 
 With the auto policy the sharded exchange is still measured in the same run as a secondary leg
 (`sharded_exchange` in the JSON line).  All buffers and engine plans are created once per rotating
 batch slot."""
 from __future__ import annotations
 
+import ctypes as C
 import json
 import os
 import sys
@@ -34,16 +38,21 @@ import time
 import numpy as np
 
 
+TABLE_SCALE: dict[int, float] = {}     # table id -> 2/sqrt(rows): DLRM's U(-sqrt(1/n), sqrt(1/n)) range, set by run()
+
+
 def table_values(torch, t: int, row_lo: int, row_hi: int, dim: int, device):
-    """Deterministic table contents any rank can recompute: W_t[r][c] from a hash of (t, r, c), scaled
-    to DLRM's U(-sqrt(1/n), sqrt(1/n)) range by the caller.  Chunked to bound temporaries."""
+    """Deterministic table contents any rank can recompute: W_t[r][c] from a hash of (t, r, c), in DLRM's
+    U(-sqrt(1/n), sqrt(1/n)) range (the scale the 1e-6 tolerance of load_generator.c:58 is meant for).
+    Chunked to bound temporaries."""
     out = torch.empty((row_hi - row_lo, dim), dtype=torch.float32, device=device)
     step = 1 << 22
+    scale = TABLE_SCALE.get(t, 1.0)
     for lo in range(row_lo, row_hi, step):
         hi = min(lo + step, row_hi)
         e = torch.arange(lo * dim, hi * dim, dtype=torch.int64, device=device)
         h = (e * 2654435761 + (t + 1) * 40503) % 2147483647
-        out[lo - row_lo:hi - row_lo] = (h.to(torch.float32) / 2147483647.0 - 0.5).reshape(hi - lo, dim)
+        out[lo - row_lo:hi - row_lo] = ((h.to(torch.float32) / 2147483647.0 - 0.5) * scale).reshape(hi - lo, dim)
     return out
 
 
@@ -51,7 +60,7 @@ def expected_rows(torch, t: int, idx, dim: int):
     """Rows idx of table t recomputed from the formula (fp32, same ops as table_values)."""
     e = idx.to(torch.int64)[:, None] * dim + torch.arange(dim, dtype=torch.int64, device=idx.device)[None, :]
     h = (e * 2654435761 + (t + 1) * 40503) % 2147483647
-    return h.to(torch.float32) / 2147483647.0 - 0.5
+    return (h.to(torch.float32) / 2147483647.0 - 0.5) * TABLE_SCALE.get(t, 1.0)
 
 
 def expected_pooled(torch, t: int, idx, dim: int, L: int):
@@ -134,9 +143,9 @@ def run_whole(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
         return buf[byte_off:byte_off + n * 4].view(torch.int32)
 
     rng = np.random.default_rng(1 + rank)
+    gen, dist_name = index_generator(pel, args)
     off_dev = torch.arange(B, dtype=torch.int32, device=dev) * L
-    idx_host = [[pel.workloads.uniform_indices(rng, n, B * L).view(np.int32) for n in rows_list]
-                for _ in range(NBATCH)]
+    idx_host = [[gen(rng, n, B * L).view(np.int32) for n in rows_list] for _ in range(NBATCH)]
     slots = []
     for j in range(NBATCH):
         send = torch.zeros(max(int(in_off[-1]), 16), dtype=torch.uint8, device=dev)
@@ -284,7 +293,7 @@ def run_whole(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s sharded, dim %d fp32, B=%d bags/table PER RANK, "
-                                   "L=%d, %d rotating batches; %s" % (label, dim, B, L, NBATCH, plan.describe()),
+                                   "L=%d, %s indices, %d rotating batches; %s" % (label, dim, B, L, dist_name, NBATCH, plan.describe()),
                        "tables": T, "dim": dim, "bags_per_table_per_rank": B, "global_bags_per_table": world * B,
                        "pooling": L,
                        "parallelism": "tables sharded by id (replicate <= %d MiB); one all_to_all per step carries "
@@ -310,7 +319,41 @@ def run_whole(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
     return result
 
 
+def expected_row_split(torch, t: int, idx, dim: int, L: int, rps: int, n_shards: int):
+    """What the row-range sharded path returns for fixed-size bags, bit for bit: per shard d the rows of the bag
+    that live in d, summed in index order from +0 (the serving rank's kernel), the per-shard partial sums then
+    added in shard order from +0 (emb_unroute_bags).  Adding +0.0 where a row belongs to another shard leaves
+    every intermediate value unchanged, so the masked adds below reproduce the kernels' arithmetic exactly."""
+    rows = expected_rows(torch, t, idx, dim).view(-1, L, dim)
+    dest = torch.clamp(idx.to(torch.int64) // rps, max=n_shards - 1).view(-1, L)
+    acc = torch.zeros_like(rows[:, 0, :])
+    zero = torch.zeros_like(acc)
+    for d in range(n_shards):
+        part = torch.zeros_like(acc)
+        for j in range(L):
+            part = part + torch.where((dest[:, j] == d)[:, None], rows[:, j, :], zero)
+        acc = acc + part
+    return acc
+
+
+def index_generator(pel, args):
+    dist_name = getattr(args, "index_dist", None) or "uniform"
+    return (pel.workloads.zipf_indices if dist_name == "zipf" else pel.workloads.uniform_indices), dist_name
+
+
 def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
+    """Big tables split by ROW RANGE over all ranks, any number of indices per bag.  Counts first, payload second
+    (the reference sends its lengths before every launch, emb_host.h:280-287):
+
+        route(i+1)      GPU: every bag of a row-split table cut into per-shard sub-bags (emb_route_bags)
+        counts(i+1)     all_to_all of {sub-bags, indices} per (peer, table)             -- small, first
+        local(i)        fused lookup of the replicated tables (prepared plan)
+        serve(i)        fused lookup over the request pieces received for batch i -> one partial row per sub-bag
+        return(i)       all_to_all of the partial rows, split sizes from counts(i)
+        requests(i+1)   all_to_all of the request pieces, split sizes from counts(i+1)  -- the only host wait
+        finish(i)       partial rows added in shard order into [B, dim] per table (emb_unroute_bags)
+
+    Nothing has a capacity that skewed indices could overflow: the payload is sized by the counts."""
     import torch
     import torch.distributed as dist
     import pim_embedding_lookup_amd as pel
@@ -318,22 +361,17 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
     rank, world, dev, backend, stage_cpu = ctx["rank"], ctx["world"], ctx["dev"], ctx["backend"], ctx["stage_cpu"]
 
     rows_list, dim, B0, label = table_set_of(pel, args)
-    if int(getattr(args, "pooling", None) or 1) != 1:
-        raise SystemExit("--shard-mode rows routes one-hot requests; use --shard-mode whole with --pooling")
+    L = max(1, int(getattr(args, "pooling", None) or 1))
+    gen, dist_name = index_generator(pel, args)
     row_b = dim * 4
     B = args.batch or B0
     T = len(rows_list)
+    N = world
     NBATCH = max(3, args.nbatch)
     sharded = [t for t in range(T) if rows_list[t] * row_b > rep_bytes and rows_list[t] >= world]
     local = [t for t in range(T) if t not in sharded]
     K = len(sharded)
     rps = [-(-rows_list[t] // world) for t in sharded]
-    # request-list capacity per (table, source, shard): mean B/world + ~10 sigma + slack, multiple of 4
-    mean = B / world
-    C_ = B if world == 1 else int(mean + 10.0 * np.sqrt(mean) + 64)
-    C_ = min((C_ + 3) // 4 * 4, (B + 3) // 4 * 4)
-    seg = K * C_ * row_b + K * C_ * 4           # bytes exchanged with every peer, both directions
-    idx_off = K * C_ * row_b
 
     eng = pel.EmbeddingEngine(device=dev.index, max_tables=T + K + 1)
     for t in local:
@@ -344,63 +382,58 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
     torch.cuda.empty_cache()
 
     rng = np.random.default_rng(1 + rank)
-    idx_host = [[pel.workloads.uniform_indices(rng, n, B).view(np.int32) for n in rows_list] for _ in range(NBATCH)]
-    off_b = torch.arange(B, dtype=torch.int32, device=dev)
-    off_c = torch.arange(C_, dtype=torch.int32, device=dev)
-    ovf = torch.zeros(1, dtype=torch.int32, device=dev)
-    slots = []
-    for j in range(NBATCH):
-        sl = dict(send=torch.zeros(max(world * seg, 16), dtype=torch.uint8, device=dev),
-                  recv=torch.zeros(max(world * seg, 16), dtype=torch.uint8, device=dev),
-                  perm=torch.zeros(max(K * B, 1), dtype=torch.int32, device=dev),
-                  counts=torch.zeros(max(K * world, 1), dtype=torch.int32, device=dev),
-                  idx_sh=(torch.from_numpy(np.stack([idx_host[j][t] for t in sharded])).to(dev) if K
-                          else torch.zeros(1, dtype=torch.int32, device=dev)),
-                  out_sh=torch.zeros((max(K, 1), B, dim), dtype=torch.float32, device=dev),
-                  idx_local=[torch.from_numpy(idx_host[j][t]).to(dev) for t in local],
-                  out_local=[torch.empty((B, dim), dtype=torch.float32, device=dev) for _ in local])
-        sl["plan_a"] = eng.plan(local, sl["idx_local"], [off_b] * len(local), sl["out_local"]) if local else None
-        slots.append(sl)
-    for j in range(NBATCH):
-        sl, prev = slots[j], slots[(j - 1) % NBATCH]
-        sl["plan_b"] = None
-        if K:   # request lists of batch j arrived with collective(j-1); pooled rows go out with collective(j)
-            ids, ii, oo, uu = [], [], [], []
-            for s in range(world):
-                for k in range(K):
-                    ids.append(T + k)
-                    b0 = s * seg + idx_off + k * C_ * 4
-                    ii.append(prev["recv"][b0:b0 + C_ * 4].view(torch.int32))
-                    oo.append(off_c)
-                    o0 = s * seg + k * C_ * row_b
-                    uu.append(sl["send"][o0:o0 + C_ * row_b].view(torch.float32).view(C_, dim))
-            sl["plan_b"] = eng.plan(ids, ii, oo, uu)
-
+    idx_host = [[gen(rng, n, B * L).view(np.int32) for n in rows_list] for _ in range(NBATCH)]
+    off_b = torch.arange(B, dtype=torch.int32, device=dev) * L
+    sz = eng.route_bags_sizes(max(K, 1), B, max(K, 1) * B * L, N) if K else None
+    work = torch.empty(sz["work"], dtype=torch.uint8, device=dev) if K else None    # scratch of one route call
     stream = torch.cuda.current_stream(dev)
     h = stream.cuda_stream
-    splits = [seg] * world
-    pending = [None]
+    side = torch.cuda.Stream(dev)
     native = native_exchange(pel, args, eng, ctx)
-    seg_off = native.offsets([p_ * seg for p_ in range(world + 1)]) if native is not None else None
+    pad4 = lambda v: (v + 3) & ~3
 
-    def collective(sl):
-        if K == 0:
-            return None
-        if native is not None:
-            native.all_to_all(sl["send"].data_ptr(), seg_off, sl["recv"].data_ptr(), seg_off, h)
+    slots = []
+    for j in range(NBATCH):
+        sl = dict(idx_local=[torch.from_numpy(idx_host[j][t]).to(dev) for t in local],
+                  out_local=[torch.empty((B, dim), dtype=torch.float32, device=dev) for _ in local])
+        sl["plan_a"] = eng.plan(local, sl["idx_local"], [off_b] * len(local), sl["out_local"]) if local else None
+        if K:
+            sl["idx_sh"] = torch.from_numpy(np.stack([idx_host[j][t] for t in sharded])).to(dev)     # [K, B*L]
+            sl["route_spec"] = eng.route_tables([(sl["idx_sh"][k].data_ptr(), None, B * L, L, rps[k]) for k in range(K)])
+            sl["req_send"] = torch.empty(sz["send"] // 4, dtype=torch.int32, device=dev)
+            sl["meta"] = torch.zeros(sz["meta"] // 4, dtype=torch.int32, device=dev)
+            sl["slotmap"] = torch.empty(sz["slots"] // 4, dtype=torch.int32, device=dev)
+            sl["counts_in"] = torch.zeros((N, K, 2), dtype=torch.int32, device=dev)
+            sl["counts_host"] = torch.zeros((2, N, K, 2), dtype=torch.int32).pin_memory()   # [0] sent, [1] received
+            sl["counts_ev"] = torch.cuda.Event()
+            sl["out_sh"] = torch.zeros((K, B, dim), dtype=torch.float32, device=dev)
+            sl["req_recv"] = torch.empty(16, dtype=torch.int32, device=dev)
+            sl["ret_send"] = torch.empty((4, dim), dtype=torch.float32, device=dev)
+            sl["ret_recv"] = torch.empty((4, dim), dtype=torch.float32, device=dev)
+        slots.append(sl)
+
+    def grown(sl, name, n, shape_tail=()):
+        """Grow-only device buffer of at least n leading elements (25 % headroom): sized by the counts, never fixed."""
+        buf = sl[name]
+        if buf.shape[0] < n:
+            sl[name] = buf = torch.empty((n + n // 4 + 16,) + tuple(shape_tail), dtype=buf.dtype, device=dev)
+        return buf
+
+    def exchange(recv, send, out_splits, in_splits):
+        """all_to_all of leading-dimension ranges (RCCL; gloo stages through the host).  Returns a work handle or None."""
+        n_out, n_in = int(sum(out_splits)), int(sum(in_splits))
+        if native is not None:      # stream-ordered on the compute stream
+            esz = send.element_size() * (int(np.prod(send.shape[1:])) if send.dim() > 1 else 1)
+            offs = lambda sp: (C.c_uint64 * (N + 1))(*np.concatenate([[0], np.cumsum(sp)]).astype(np.uint64) * esz)
+            native.all_to_all(send.data_ptr(), offs(in_splits), recv.data_ptr(), offs(out_splits), h)
             return None
         if stage_cpu:
-            r, s_ = torch.empty(sl["recv"].shape, dtype=torch.uint8), sl["send"].cpu()
-            dist.all_to_all_single(r, s_, output_split_sizes=splits, input_split_sizes=splits)
-            sl["recv"].copy_(r)
+            r = torch.empty((n_out,) + tuple(recv.shape[1:]), dtype=recv.dtype)
+            dist.all_to_all_single(r, send[:n_in].cpu(), output_split_sizes=list(out_splits), input_split_sizes=list(in_splits))
+            recv[:n_out].copy_(r)
             return None
-        return dist.all_to_all_single(sl["recv"], sl["send"], async_op=True)   # equal splits: seg bytes per peer
-
-    def unroute(j):      # rows of batch j came back in slots[j].recv
-        if K:
-            sl = slots[j]
-            eng.unroute_rows(sl["recv"].data_ptr(), seg, K, B, dim, C_, sl["perm"].data_ptr(),
-                             sl["out_sh"].data_ptr(), h)
+        return dist.all_to_all_single(recv[:n_out], send[:n_in], output_split_sizes=list(out_splits),
+                                      input_split_sizes=list(in_splits), async_op=True)
 
     prof = {} if os.environ.get("PIMEMB_DIST_PROFILE") == "1" else None
 
@@ -412,27 +445,89 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
         prof[name] = prof.get(name, 0) + time.perf_counter_ns() - t
         return r
 
-    def step(i):
-        j, nxt = i % NBATCH, (i + 1) % NBATCH
-        sl = slots[j]
-        if K:            # route batch i+1: its request lists ride in collective(i)
-            timed("route", eng.route_onehot, slots[nxt]["idx_sh"].data_ptr(), K, B, rps, world, C_,
-                  sl["send"].data_ptr(), seg, idx_off, slots[nxt]["perm"].data_ptr(),
-                  slots[nxt]["counts"].data_ptr(), ovf.data_ptr(), h)
-        if sl["plan_a"] is not None:
-            timed("plan_a", sl["plan_a"].launch, h)
-        if pending[0] is not None:
-            timed("wait", pending[0].wait)
-        timed("unroute", unroute, (i - 1) % NBATCH)   # batch i-1 is complete now
-        if sl["plan_b"] is not None:
-            timed("plan_b", sl["plan_b"].launch, h)
-        pending[0] = timed("all_to_all", collective, sl)
+    def issue_route(sl):
+        """route + counts first: the per-(peer, table) {sub-bags, indices} go out before any payload."""
+        eng.route_bags(sl["route_spec"], B, N, sl["req_send"].data_ptr(), sl["meta"].data_ptr(), sl["slotmap"].data_ptr(),
+                       work.data_ptr(), h)
+        counts_out = sl["meta"][:2 * N * K].view(N, K, 2)
+        sl["counts_work"] = exchange(sl["counts_in"], counts_out, [1] * N, [1] * N)
 
-    def drain(last_i):
-        if pending[0] is not None:
-            pending[0].wait()
-            pending[0] = None
-        unroute(last_i % NBATCH)
+    def issue_requests(sl):
+        """The one host wait of a step: learn the counts, then send the request pieces sized by them."""
+        counts_out = sl["meta"][:2 * N * K].view(N, K, 2)
+        if sl["counts_work"] is not None:
+            with torch.cuda.stream(side):     # off the compute stream: the host waits for route + counts only
+                sl["counts_work"].wait()
+                sl["counts_host"][0].copy_(counts_out, non_blocking=True)
+                sl["counts_host"][1].copy_(sl["counts_in"], non_blocking=True)
+                sl["counts_ev"].record(side)
+            sl["counts_ev"].synchronize()
+        else:
+            sl["counts_host"][0].copy_(counts_out, non_blocking=True)
+            sl["counts_host"][1].copy_(sl["counts_in"], non_blocking=True)
+            stream.synchronize()
+        c = sl["counts_host"].numpy().astype(np.int64)            # [2][peer][table][{n_sub, n_idx}]
+        words = ((c[..., 0] + 3) // 4 * 4 + (c[..., 1] + 3) // 4 * 4).sum(axis=2)     # [2][peer]
+        sl["req_out_words"], sl["req_in_words"] = words[0].tolist(), words[1].tolist()
+        sl["ret_rows_back"] = c[0, :, :, 0].sum(axis=1).tolist()   # partial rows each shard returns to me
+        sl["ret_rows_served"] = c[1, :, :, 0].sum(axis=1).tolist()  # partial rows I return to each source
+        sl["served"] = c[1]
+        recv = grown(sl, "req_recv", int(words[1].sum()))
+        sl["req_work"] = exchange(recv, sl["req_send"], sl["req_in_words"], sl["req_out_words"])
+
+    def serve(sl):
+        """Fused lookup over every request piece received for this batch -> partial rows, laid out per source."""
+        if sl.get("req_work") is not None:
+            sl["req_work"].wait()
+            sl["req_work"] = None
+        c, recv = sl["served"], sl["req_recv"]
+        ret = grown(sl, "ret_send", int(sum(sl["ret_rows_served"])), (dim,))
+        ids, ii, oo, uu = [], [], [], []
+        cur = row = 0
+        for s in range(N):
+            for k in range(K):
+                ns, ni = int(c[s, k, 0]), int(c[s, k, 1])
+                if ns:
+                    ids.append(T + k)
+                    oo.append(recv[cur:cur + ns])
+                    ii.append(recv[cur + pad4(ns):cur + pad4(ns) + ni])
+                    uu.append(ret[row:row + ns])
+                cur += pad4(ns) + pad4(ni)
+                row += ns
+        if ids:
+            eng.lookup_batched(ids, ii, oo, uu, stream=h)
+        back = grown(sl, "ret_recv", int(sum(sl["ret_rows_back"])), (dim,))
+        sl["ret_work"] = exchange(back, ret, sl["ret_rows_back"], sl["ret_rows_served"])
+        return sum(int(c[s, k, 1]) * (row_b + 4) + int(c[s, k, 0]) * (4 + row_b) for s in range(N) for k in range(K))
+
+    def finish(sl):
+        if sl.get("ret_work") is not None:
+            sl["ret_work"].wait()
+            sl["ret_work"] = None
+        eng.unroute_bags(sl["ret_recv"].data_ptr(), sl["meta"].data_ptr(), sl["slotmap"].data_ptr(), K, B, N, dim,
+                         sl["out_sh"].data_ptr(), h)
+
+    def step(i):
+        sl, nxt = slots[i % NBATCH], slots[(i + 1) % NBATCH]
+        if K:
+            timed("route+counts", issue_route, nxt)
+        if sl["plan_a"] is not None:
+            timed("local", sl["plan_a"].launch, h)
+        if K:
+            timed("serve+return", serve, sl)
+            timed("wait counts+requests", issue_requests, nxt)
+            timed("finish", finish, sl)
+
+    def prologue(i):           # batch i's requests on their way before step(i)
+        if K:
+            issue_route(slots[i % NBATCH])
+            issue_requests(slots[i % NBATCH])
+
+    def drain(next_i):         # the requests of the batch after the last one are in flight: let them land
+        sl = slots[next_i % NBATCH]
+        if K and sl.get("req_work") is not None:
+            sl["req_work"].wait()
+            sl["req_work"] = None
         torch.cuda.synchronize()
 
     def outputs(j):
@@ -443,54 +538,89 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
             res[t] = slots[j]["out_sh"][k]
         return res
 
-    # ---- prime one rotation, then verify two consecutive pipelined steps bit-exactly ----------------
+    def verify(i, what):
+        res = outputs(i % NBATCH)
+        for t in range(T):
+            idx = torch.from_numpy(idx_host[i % NBATCH][t]).to(dev)
+            plain = expected_pooled(torch, t, idx, dim, L)
+            want = plain if t in local else expected_row_split(torch, t, idx, dim, L, rps[sharded.index(t)], N)
+            if not torch.equal(res[t], want):
+                raise AssertionError(f"rank {rank}: {what} step {i} table {t} differs from the expected rows")
+            if float((res[t] - plain).abs().max()) > 1e-6:
+                raise AssertionError(f"rank {rank}: {what} step {i} table {t} is more than 1e-6 from the unsharded sum")
+
+    # ---- prime one rotation, then verify two consecutive pipelined steps bit for bit ------------------
+    prologue(0)
     for i in range(NBATCH):
         step(i)
     for i in (NBATCH, NBATCH + 1):
         step(i)
-        drain(i)
-        res = outputs(i % NBATCH)
-        for t in range(T):
-            idx = torch.from_numpy(idx_host[i % NBATCH][t]).to(dev)
-            if not torch.equal(res[t], expected_rows(torch, t, idx, dim) + 0.0):
-                raise AssertionError(f"rank {rank}: step {i} table {t} differs from the expected rows")
-    if int(ovf.item()):
-        raise AssertionError("request-list capacity overflow")
+        torch.cuda.synchronize()
+        verify(i, "pipelined")
     it = NBATCH + 2
 
+    # ---- kernel-only time of this rank's two lookups (replicated tables + served request pieces) ----------
     kernel_us, alg_bytes = 0.0, 0
-    for key in ("plan_a", "plan_b"):
-        if slots[0][key] is None:
+    if slots[0]["plan_a"] is not None:
+        alg_bytes += slots[0]["plan_a"].bytes()[0]
+    probe = slots[it % NBATCH]          # its requests for batch `it` have landed (issued by the last step)
+    if K:
+        if probe.get("req_work") is not None:
+            probe["req_work"].wait()
+            probe["req_work"] = None
+        torch.cuda.synchronize()
+        serve_bytes = [0]
+
+        def serve_only(sl):          # the lookup of serve() without its exchange
+            c, recv, ret = sl["served"], sl["req_recv"], sl["ret_send"]
+            ids, ii, oo, uu = [], [], [], []
+            cur = row = 0
+            for s in range(N):
+                for k in range(K):
+                    ns, ni = int(c[s, k, 0]), int(c[s, k, 1])
+                    if ns:
+                        ids.append(T + k); oo.append(recv[cur:cur + ns])
+                        ii.append(recv[cur + pad4(ns):cur + pad4(ns) + ni]); uu.append(ret[row:row + ns])
+                    cur += pad4(ns) + pad4(ni)
+                    row += ns
+            if ids:
+                eng.lookup_batched(ids, ii, oo, uu, stream=h)
+            serve_bytes[0] = sum(int(c[s, k, 1]) * (row_b + 4) + int(c[s, k, 0]) * (4 + row_b)
+                                 for s in range(N) for k in range(K))
+        grown(probe, "ret_send", int(sum(probe["ret_rows_served"])), (dim,))
+    for key in ("local", "serve"):
+        if (key == "local" and slots[0]["plan_a"] is None) or (key == "serve" and not K):
             continue
-        alg_bytes += slots[0][key].bytes()[0]
-        for i in range(8):
-            slots[i % NBATCH][key].launch(h)
+        fn = (lambda q: slots[q % NBATCH]["plan_a"].launch(h)) if key == "local" else (lambda q: serve_only(probe))
+        for q in range(4):
+            fn(q)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
-        for i in range(64):
-            slots[i % NBATCH][key].launch(h)
+        for q in range(32):
+            fn(q)
         e1.record(stream)
         torch.cuda.synchronize()
-        kernel_us += e0.elapsed_time(e1) * 1000.0 / 64
+        kernel_us += e0.elapsed_time(e1) * 1000.0 / 32
+    if K:
+        alg_bytes += serve_bytes[0]
 
     for _ in range(args.warmup):
         step(it)
         it += 1
-    drain(it - 1)
+    drain(it)
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(it)
         it += 1
-    drain(it - 1)
+    drain(it)
     dist.barrier()
     torch.cuda.synchronize()
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if stage_cpu else dev)
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
     wall = float(el.item())
-    if int(ovf.item()):
-        raise AssertionError("request-list capacity overflow during the timed region")
+    verify(it - 1, "last timed")                     # what the timed loop left behind
     if prof is not None and rank == 0:
         n_calls = args.steps + args.warmup + NBATCH + 2
         print("[dist_bench] host microseconds per step by call:",
@@ -499,6 +629,8 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
     result = None
     if rank == 0:
         ach = alg_bytes / (kernel_us * 1e-6) / 1e9 if kernel_us > 0 else 0.0
+        last = slots[(it - 1) % NBATCH]
+        sent = last["counts_host"][0].numpy().astype(np.int64) if K else np.zeros((N, 1, 2), np.int64)
         result = ({
             "metric": "pooled-lookups/sec + achieved HBM GB/s, 26-table dim-16 Kaggle, 1/2/4/8 GPU",
             "value": world * args.steps * T * B / wall, "unit": "pooled-lookups/s",
@@ -506,25 +638,28 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
             "ms_per_step": wall * 1000.0 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s sharded, dim %d fp32, B=%d bags/table PER RANK, L=1, "
+            "config": {"workload": "%s sharded, dim %d fp32, B=%d bags/table PER RANK, L=%d, %s indices, "
                                    "%d rotating batches; %d tables replicated (<= %d MiB), %d row-range sharded over "
-                                   "%d ranks" % (label, dim, B, NBATCH, len(local), rep_bytes >> 20, K, world),
+                                   "%d ranks" % (label, dim, B, L, dist_name, NBATCH, len(local), rep_bytes >> 20, K, world),
                        "tables": T, "dim": dim, "bags_per_table_per_rank": B, "global_bags_per_table": world * B,
-                       "parallelism": "row-range shards; GPU routing of requests (capacity %d per table/shard); ONE "
-                                      "all_to_all per step carries pooled rows of batch i + request lists of batch "
-                                      "i+1 (%d B per peer each way); backend %s, %s, eager steps" %
-                                      (C_, seg, backend, "collective issued natively to RCCL on the compute stream"
-                                       if native is not None else "torch.distributed.all_to_all_single")},
+                       "pooling": L, "index_dist": dist_name,
+                       "parallelism": "row-range shards; bags cut into per-shard sub-bags on the GPU; counts first "
+                                      "(all_to_all of {sub-bags, indices} per peer and table), then the request pieces "
+                                      "and the partial rows as all_to_all with split sizes from the counts; partial "
+                                      "rows added in shard order; backend %s, %s, eager steps" %
+                                      (backend, "collectives issued natively to RCCL on the compute stream"
+                                       if native is not None else "torch.distributed.all_to_all_single"),
+                       "last_step_request_rows_per_peer": sent[:, :, 0].sum(axis=1).tolist(),
+                       "last_step_request_indices_per_peer": sent[:, :, 1].sum(axis=1).tolist()},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": hbm_peak_gbs, "unit": "GB/s",
                          "frac": ach / hbm_peak_gbs, "traffic": None, "kernel_us": kernel_us,
                          "algorithmic_bytes": alg_bytes,
-                         "note": "rank 0's two lookup launches (replicated tables + served shards), kernel-only"},
+                         "note": "rank 0's two lookup launches (replicated tables + served request pieces), kernel-only"},
         })
     dist.barrier()
     for sl in slots:
-        for p in (sl["plan_a"], sl["plan_b"]):
-            if p is not None:
-                p.destroy()
+        if sl["plan_a"] is not None:
+            sl["plan_a"].destroy()
     if native is not None:
         torch.cuda.synchronize()
         native.close()
@@ -550,7 +685,8 @@ def run_dp(args, hbm_peak_gbs: float, ctx):
     torch.cuda.empty_cache()
     rng = np.random.default_rng(1 + rank)
     off = torch.arange(B, dtype=torch.int32, device=dev) * L
-    idx_host = [[pel.workloads.uniform_indices(rng, n, B * L).view(np.int32) for n in rows_list] for _ in range(NBATCH)]
+    gen, dist_name = index_generator(pel, args)
+    idx_host = [[gen(rng, n, B * L).view(np.int32) for n in rows_list] for _ in range(NBATCH)]
     plans = []
     for j in range(NBATCH):
         plans.append(eng.plan(list(range(T)), [torch.from_numpy(i).to(dev) for i in idx_host[j]], [off] * T))
@@ -597,7 +733,7 @@ def run_dp(args, hbm_peak_gbs: float, ctx):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s, dim %d fp32, B=%d bags/table PER RANK, L=%d, u32 "
-                                   "indices+offsets, uniform indices, %d rotating batches" % (label, dim, B, L, NBATCH),
+                                   "indices+offsets, %s indices, %d rotating batches" % (label, dim, B, L, dist_name, NBATCH),
                        "tables": T, "dim": dim, "bags_per_table_per_rank": B, "global_bags_per_table": world * B,
                        "parallelism": "all %d tables (%.2f GB) replicated on every rank (they fit the per-GPU "
                                       "replication budget); bags data-parallel, no data-path collective"
@@ -638,6 +774,7 @@ def run(args, hbm_peak_gbs: float) -> None:
     ctx = dict(rank=rank, world=world, dev=dev, backend=backend, stage_cpu=backend != "nccl")
 
     rows_list, dim, _, _ = table_set_of(pel, args)
+    TABLE_SCALE.update({t: float(np.float32(2.0 / np.sqrt(n))) for t, n in enumerate(rows_list)})
     total_bytes = sum(rows_list) * dim * 4
     hbm = torch.cuda.get_device_properties(dev).total_memory
     auto = getattr(args, "replicate_mb", None) is None

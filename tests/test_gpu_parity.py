@@ -479,71 +479,6 @@ def test_plan_launch_is_graph_capturable(pel, eng):
     plan.destroy()
 
 
-@pytest.mark.parametrize("mode", ["rows", "whole", "auto", "whole-pooled"])
-def test_distributed_bench_two_ranks_on_one_gpu(mode):
-    """The N > 1 path end to end on the real HIP engine: two processes share cuda:0, collectives over
-    gloo (host-staged), small batch.  dist_bench verifies all 26 tables bit-exactly on every rank
-    (two pipelined steps for the sharded legs) before it prints its JSON line; here we check that line.
-    rows / whole: sharding forced with --replicate-mb 64; auto: the default placement policy
-    (everything replicated, data-parallel) plus the secondary sharded-exchange leg."""
-    import json
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PIMEMB_DIST_BACKEND="gloo")
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
-        env.pop(k, None)
-    pooled = mode == "whole-pooled"       # 5 indices per bag: the exchange carries 5x the index volume
-    mode = "whole" if pooled else mode
-    # no launcher: `python bench.py --gpus 2` starts its two ranks itself (the parent touches no GPU)
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3",
-           "--nbatch", "3", "--batch", "4099"]
-    if mode != "auto":
-        cmd += ["--shard-mode", mode, "--replicate-mb", "64"]
-    if pooled:
-        cmd += ["--pooling", "5"]
-    res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
-    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
-    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
-    d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
-    assert d["roofline"]["bound"] == "hbm" and d["verified"] is True
-    assert d["config"]["backend"] == "gloo" and d["config"]["rccl_ranks"] == 0 and d["config"]["world_size"] == 2
-    assert len([l for l in res.stdout.splitlines() if l.strip()]) == 1      # ONE line on the job's stdout
-    w = d["config"]["workload"]
-    if mode == "rows":
-        assert "5 row-range sharded" in w and "21 tables replicated" in w
-    elif mode == "whole":
-        assert "5 whole" in w and "21 replicated" in w
-        assert d["config"]["pooling"] == (5 if pooled else 1)
-    else:
-        assert "replicated on every rank" in d["config"]["parallelism"]
-        sec = d["sharded_exchange"]
-        assert isinstance(sec, dict) and sec["value"] > 0 and "5 whole" in sec["config"]
-        assert sec["verified"] is True and sec["roofline"]["bound"] == "hbm" and sec["roofline"]["achieved"] > 0
-
-
-def test_distributed_terabyte_shaped_row_shards_two_ranks():
-    """BASELINE configs[3] (Terabyte-shaped tables, dim 128, row-range sharded), rows scaled by 1/256 so
-    that two ranks sharing cuda:0 hold it: dist_bench routes requests on the GPU, exchanges them (gloo
-    here), looks the shards up, un-routes the rows and verifies all 26 tables bit-exactly per rank."""
-    import json
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PIMEMB_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29564",
-           os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "c4", "--rows-scale", str(1 / 256),
-           "--steps", "4", "--warmup", "2", "--nbatch", "3", "--batch", "2051", "--replicate-mb", "8"]
-    res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
-    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
-    d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
-    assert d["n_gpus"] == 2 and d["config"]["dim"] == 128 and d["value"] > 0
-    w = d["config"]["workload"]
-    assert "Terabyte" in w and "row-range sharded over 2 ranks" in w and "5 row-range" in w
-
-
 @pytest.mark.parametrize("dim,dtype", [(4, np.float32), (8, np.float32), (32, np.float32), (64, np.float32),
                                        (128, np.float32), (256, np.float32), (24, np.float32),
                                        (8, np.float16), (128, np.float16), (512, np.float16), (16, np.int32)])

@@ -191,3 +191,101 @@ def test_route_bags_one_index_per_bag_is_exact(pel, eng, oracle):
     torch.cuda.synchronize()
     for k in range(K):
         assert np.array_equal(pooled[k].cpu().numpy(), oracle.c_bag_sum(tabs[k], idxs[k], np.arange(B, dtype=np.uint32)))
+
+
+# ---------------------------------------------------------------------------------------------------
+# bench.py --gpus 2 on ONE GPU: two ranks share cuda:0, collectives over gloo (host-staged)
+# ---------------------------------------------------------------------------------------------------
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench_two_ranks(extra, launcher="self", timeout=600, env_extra=None):
+    """`python bench.py --gpus 2 ...` (self-launching: the parent touches no GPU) or the same under torchrun, as
+    the driver starts it.  Returns (CompletedProcess, parsed JSON line or None)."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, PIMEMB_DIST_BACKEND="gloo", **(env_extra or {}))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    bench = [os.path.join(ROOT, "bench.py"), "--gpus", "2"] + list(extra)
+    if launcher == "self":
+        cmd = [sys.executable] + bench
+    else:
+        env["MASTER_ADDR"] = "127.0.0.1"
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+               "--master-addr", "127.0.0.1", "--master-port", "29564"] + bench
+    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    return res, (json.loads(lines[-1]) if lines else None)
+
+
+@pytest.mark.parametrize("mode", ["rows", "whole", "auto", "whole-pooled", "rows-pooled", "rows-zipf"])
+def test_distributed_bench_two_ranks_on_one_gpu(mode):
+    """The N > 1 path end to end on the real HIP engine, started WITHOUT a launcher.  dist_bench verifies all 26
+    tables bit for bit on every rank (two pipelined steps before timing, the last step after it) before it
+    prints its JSON line; here we check that line.  rows / whole: sharding forced with --replicate-mb 64;
+    auto: the default placement policy (everything replicated, data-parallel) plus the secondary sharded-exchange
+    leg; rows-zipf: Zipf(1.2) indices -- a hot shard -- through the counts-first exchange."""
+    base = ["--steps", "6", "--warmup", "3", "--nbatch", "3", "--batch", "4099"]
+    extra = {"rows": ["--shard-mode", "rows", "--replicate-mb", "64"],
+             "whole": ["--shard-mode", "whole", "--replicate-mb", "64"],
+             "auto": [],
+             "whole-pooled": ["--shard-mode", "whole", "--replicate-mb", "64", "--pooling", "5"],
+             "rows-pooled": ["--shard-mode", "rows", "--replicate-mb", "64", "--pooling", "7"],
+             "rows-zipf": ["--shard-mode", "rows", "--replicate-mb", "64", "--index-dist", "zipf"]}[mode]
+    res, d = _bench_two_ranks(base + extra)
+    assert res.returncode == 0 and d is not None, res.stdout[-2000:] + res.stderr[-4000:]
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["roofline"]["bound"] == "hbm" and d["verified"] is True
+    assert d["config"]["backend"] == "gloo" and d["config"]["rccl_ranks"] == 0 and d["config"]["world_size"] == 2
+    assert len([l for l in res.stdout.splitlines() if l.strip()]) == 1      # ONE line on the job's stdout
+    w = d["config"]["workload"]
+    if mode.startswith("rows"):
+        assert "5 row-range sharded" in w and "21 tables replicated" in w and "counts first" in d["config"]["parallelism"]
+        assert d["config"]["pooling"] == (7 if mode == "rows-pooled" else 1)
+        rows_out = d["config"]["last_step_request_rows_per_peer"]
+        assert len(rows_out) == 2 and sum(rows_out) >= 5 * 4099
+        if mode == "rows-zipf":
+            assert d["config"]["index_dist"] == "zipf" and max(rows_out) > 1.2 * min(rows_out)   # a hot shard
+    elif mode.startswith("whole"):
+        assert "5 whole" in w and "21 replicated" in w
+        assert d["config"]["pooling"] == (5 if mode == "whole-pooled" else 1)
+    else:
+        assert "replicated on every rank" in d["config"]["parallelism"]
+        sec = d["sharded_exchange"]
+        assert isinstance(sec, dict) and sec["value"] > 0 and "5 whole" in sec["config"]
+        assert sec["verified"] is True and sec["roofline"]["bound"] == "hbm" and sec["roofline"]["achieved"] > 0
+
+
+@pytest.mark.parametrize("pooling", [1, 32])
+def test_distributed_terabyte_shaped_row_shards_two_ranks(pooling):
+    """BASELINE configs[3] (Terabyte-shaped tables, dim 128, row-range sharded) at 1/256 of the rows so that two
+    ranks sharing cuda:0 hold it, one and 32 indices per bag, started under torchrun as the driver does.  Every
+    rank compares all 26 tables bit for bit with the shard-ordered sum of partials (and within 1e-6 of the
+    unsharded in-order sum); run twice, the JSON lines must agree on what was exchanged."""
+    extra = ["--workload", "c4", "--rows-scale", str(1 / 256), "--steps", "4", "--warmup", "2", "--nbatch", "3",
+             "--batch", "2051", "--replicate-mb", "8", "--pooling", str(pooling)]
+    res, d = _bench_two_ranks(extra, launcher="torchrun")
+    assert res.returncode == 0 and d is not None, res.stdout[-2000:] + res.stderr[-4000:]
+    assert d["n_gpus"] == 2 and d["config"]["dim"] == 128 and d["value"] > 0 and d["verified"] is True
+    w = d["config"]["workload"]
+    assert "Terabyte" in w and "row-range sharded over 2 ranks" in w and "5 row-range" in w
+    assert d["config"]["pooling"] == pooling
+    idx_out = d["config"]["last_step_request_indices_per_peer"]
+    assert sum(idx_out) == 5 * 2051 * pooling
+    if pooling > 1:
+        res2, d2 = _bench_two_ranks(extra)
+        assert res2.returncode == 0, res2.stderr[-3000:]
+        assert d2["config"]["last_step_request_rows_per_peer"] == d["config"]["last_step_request_rows_per_peer"]
+
+
+def test_exchange_leg_failure_is_a_failed_run():
+    """a hang or failure of the secondary exchange leg must not end with rc 0.  The leg is given a
+    1-second budget here, so its watchdog fires: rank 0 still prints the primary line (with the failure noted),
+    the exit status is non-zero."""
+    res, d = _bench_two_ranks(["--steps", "400", "--warmup", "40", "--nbatch", "3", "--batch", "39292"],
+                              env_extra={"PIMEMB_EXCHANGE_TIMEOUT": "0.05", "PIMEMB_LAUNCH_GRACE": "5"})
+    assert res.returncode != 0
+    assert d is not None and d["value"] > 0 and d["verified"] is False
+    assert "timed out" in d["sharded_exchange"]["failed"]
