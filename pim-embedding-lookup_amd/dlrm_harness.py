@@ -24,9 +24,11 @@ from .engine import EmbeddingEngine
 class EmbeddingBagCollection:
     """emb_l of a DLRM: T tables of dim m in HBM; forward(lS_o, lS_i) -> list of [B, m]."""
 
-    def __init__(self, ln_emb, m_spa: int, device: int = 0, weights=None, seed: int = 0, dtype="f32"):
+    def __init__(self, ln_emb, m_spa: int, device: int = 0, weights=None, seed: int = 0, dtype="f32",
+                 trusted_inputs: bool = False):
         import torch
         self.torch = torch
+        self.trusted_inputs = bool(trusted_inputs)     # False: every apply_emb checks its indices first (IndexError)
         self.device = torch.device("cuda", device)
         self.ln_emb, self.m = [int(n) for n in ln_emb], int(m_spa)
         self.engine = EmbeddingEngine(device=device, max_tables=len(self.ln_emb))
@@ -58,10 +60,21 @@ class EmbeddingBagCollection:
         launch on torch's current stream, no plan and no state kept (every batch brings new tensors)."""
         if len(lS_o) != len(self.ln_emb) or len(lS_i) != len(self.ln_emb):
             raise ValueError("need one (offsets, indices) pair per table")
+        if not self.trusted_inputs:
+            self.validate(lS_o, lS_i)
         if hasattr(lS_i, "dim") and hasattr(lS_o, "dim") and lS_i.dim() == 2 and lS_o.dim() == 2 and lS_i.is_cuda:
             # DLRM stacks fixed-size batches into [T, N] / [T, B] tensors: one [T, B, m] result, unbound
             return list(self.engine.lookup_stacked(self._ids, lS_i, lS_o).unbind(0))
         return self.engine.lookup_batched(self._ids, list(lS_i), list(lS_o))
+
+    def validate(self, lS_o, lS_i) -> None:
+        """emb_validate_inputs over one batch: IndexError on an index >= table rows or broken offsets, as
+        nn.EmbeddingBag raises (the lookup kernels themselves are unchecked, like the reference's DPU program)."""
+        stacked = hasattr(lS_i, "dim") and lS_i.dim() == 2
+        bad = self.engine.validate(self._ids, list(lS_i.unbind(0)) if stacked else list(lS_i),
+                                   list(lS_o.unbind(0)) if stacked else list(lS_o))
+        if bad:
+            raise IndexError(f"{bad} index / offset value(s) out of range (emb_validate_inputs)")
 
     def prepare(self, lS_o, lS_i):
         """For callers that reuse the SAME device tensors every step (static-shape serving, hipGraph
@@ -144,8 +157,9 @@ def main(argv=None):
         else:
             batches.append(random_batch(rng, ebc.ln_emb, B, args.num_indices_per_lookup,
                                         args.num_indices_per_lookup_fixed, dev))
-    for o, i in batches:
+    for o, i in batches:          # checked once here (IndexError on a bad index), unchecked in the timed loops
         ebc.apply_emb(o, i)
+    ebc.trusted_inputs = True
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for b in range(args.num_batches):

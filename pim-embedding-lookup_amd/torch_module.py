@@ -8,7 +8,16 @@ exactly that call to populate_mram / lookup.  Here:
     ebc = FusedEmbeddingBags.from_torch(emb_l)            # all tables, ONE launch per apply_emb
 
 Inference only (the engine has no backward), `mode="sum"` only, no per-sample weights / padding_idx /
-max_norm -- the reference has none of them either."""
+max_norm -- the reference has none of them either.
+
+Input checking.  The C ABI is as unchecked as the reference (an out-of-range index is a wild read there,
+emb_dpu_lookup.c:113); these modules are what user tensors reach first, so by default every forward runs
+emb_validate_inputs on its indices / offsets and raises IndexError like nn.EmbeddingBag does.  That costs one
+small kernel and a device-to-host wait per call; pass `trusted_inputs=True` (constructor or attribute) for the
+unchecked fast path once the producer of the indices is known to be sound.
+
+Checkpoints.  `state_dict()` carries `<prefix>weight` read out of HBM and `load_state_dict` uploads it, so a
+DLRM whose `emb_l[k]` were swapped for these modules saves / loads the same keys and shapes as before."""
 from __future__ import annotations
 
 import threading
@@ -59,13 +68,23 @@ def _bags_from(input, offsets, include_last_offset: bool):
     return input, offsets
 
 
+def _check_inputs(engine: EmbeddingEngine, table_ids, indices, offsets) -> None:
+    """emb_validate_inputs over what a forward is about to look up; IndexError like nn.EmbeddingBag."""
+    bad = engine.validate(table_ids, indices, offsets)
+    if bad:
+        raise IndexError(f"{bad} index / offset value(s) out of range for the embedding table(s) "
+                         f"(checked on the GPU by emb_validate_inputs; trusted_inputs=True skips the check)")
+
+
 class EmbeddingBag(torch.nn.Module):
     """One table.  forward(input, offsets) -> [B, embedding_dim] fp32, like nn.EmbeddingBag(mode="sum")."""
 
     def __init__(self, num_embeddings: int, embedding_dim: int, mode: str = "sum", sparse: bool = False,
                  _weight=None, include_last_offset: bool = False, device: int = 0, engine: EmbeddingEngine | None = None,
-                 table_id: int | None = None, dtype=torch.float32):
+                 table_id: int | None = None, dtype=torch.float32, trusted_inputs: bool = False):
         super().__init__()
+        self.trusted_inputs = bool(trusted_inputs)
+        self._table_dtype = dtype
         if mode != "sum":
             raise NotImplementedError("only mode='sum' (the reference pools by summation, emb_dpu_lookup.c:114)")
         self.num_embeddings, self.embedding_dim = int(num_embeddings), int(embedding_dim)
@@ -102,7 +121,29 @@ class EmbeddingBag(torch.nn.Module):
         if per_sample_weights is not None:
             raise NotImplementedError("per_sample_weights are not part of the reference path")
         idx, off = _bags_from(input, offsets, self.include_last_offset)
-        return self.engine.lookup_batched([self.table_id], [idx.contiguous()], [off.contiguous()])[0]
+        idx, off = idx.contiguous(), off.contiguous()
+        if not self.trusted_inputs:
+            _check_inputs(self.engine, [self.table_id], [idx], [off])
+        return self.engine.lookup_batched([self.table_id], [idx], [off])[0]
+
+    # ---- checkpoints: the same key and shape as nn.EmbeddingBag ("<prefix>weight", [num_embeddings, dim]) ----
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+        destination[prefix + "weight"] = self.weight.detach().clone()
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        key = prefix + "weight"
+        if key not in state_dict:
+            if strict:
+                missing_keys.append(key)
+            return
+        w = state_dict[key]
+        if tuple(w.shape) != (self.num_embeddings, self.embedding_dim):
+            error_msgs.append(f"size mismatch for {key}: copying a param with shape {tuple(w.shape)} from checkpoint, "
+                              f"the shape in current model is ({self.num_embeddings}, {self.embedding_dim}).")
+            return
+        self.engine.load_table(self.table_id, w.detach().to(self._table_dtype).contiguous())
 
     def extra_repr(self) -> str:
         return f"{self.num_embeddings}, {self.embedding_dim}, mode='sum', table_id={self.table_id}, engine=MI355X"
@@ -111,9 +152,11 @@ class EmbeddingBag(torch.nn.Module):
 class FusedEmbeddingBags(torch.nn.Module):
     """All tables of a model: forward(lS_o, lS_i) -> list of [B, m] with ONE fused launch (apply_emb)."""
 
-    def __init__(self, bags):
+    def __init__(self, bags, trusted_inputs: bool | None = None):
         super().__init__()
         self.bags = torch.nn.ModuleList(bags)
+        # unchecked only if every table says so (or the caller does)
+        self.trusted_inputs = all(b.trusted_inputs for b in bags) if trusted_inputs is None else bool(trusted_inputs)
         engines = {id(b.engine) for b in self.bags}
         if len(engines) != 1:
             raise ValueError("all tables of a FusedEmbeddingBags must live in one engine")
@@ -126,12 +169,16 @@ class FusedEmbeddingBags(torch.nn.Module):
 
     def forward(self, lS_o, lS_i):
         if hasattr(lS_i, "dim") and lS_i.dim() == 2 and hasattr(lS_o, "dim") and lS_o.dim() == 2 and lS_i.is_cuda:
+            if not self.trusted_inputs:
+                _check_inputs(self.engine, self._ids, list(lS_i.unbind(0)), list(lS_o.unbind(0)))
             return list(self.engine.lookup_stacked(self._ids, lS_i, lS_o).unbind(0))
         idx, off = [], []
         for b, i, o in zip(self.bags, lS_i, lS_o):
             i1, o1 = _bags_from(i, o, b.include_last_offset)
             idx.append(i1.contiguous())
             off.append(o1.contiguous())
+        if not self.trusted_inputs:
+            _check_inputs(self.engine, self._ids, idx, off)
         return self.engine.lookup_batched(self._ids, idx, off)
 
     apply_emb = forward

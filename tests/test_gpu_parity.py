@@ -1043,3 +1043,99 @@ def test_torch_modules_replace_nn_embeddingbag(pel, oracle):
     for k, m in enumerate(emb_l):
         assert torch.equal(ly[k].cpu(), m(stacked_i[k].cpu(), stacked_o[k].cpu()).detach())
 
+
+
+def test_processed_kaggle_npz_through_the_harness(pel, tmp_path, capsys):
+    """F2 on the GPU: a processed Criteo-Kaggle `.npz` (synthetic, the upstream layout: X_int, X_cat, y, counts)
+    drives the HIP path -- (a) its batches through EmbeddingBagCollection.apply_emb against torch CPU
+    nn.EmbeddingBag on the same checkpoint, bit for bit; (b) the reference's command line
+    `--data-set=kaggle --processed-data-file=... --load-model=...` (README.md:6, upmem/run.sh:117-118) through
+    dlrm_harness.main; (c) an index outside [0, counts[k]) is refused before anything is launched."""
+    import torch
+    from importlib import import_module
+    hz = import_module("pim-embedding-lookup_amd.dlrm_harness")
+    fm = import_module("pim-embedding-lookup_amd.formats")
+    rng = np.random.default_rng(6)
+    counts = np.array([1460, 583, 40_000, 305, 24, 3, 9000, 27], dtype=np.int32)
+    N, m = 700, 16
+    x_cat = np.stack([rng.integers(0, c, size=N) for c in counts], axis=1).astype(np.int32)
+    npz = tmp_path / "kaggleAdDisplayChallenge_processed.npz"
+    np.savez(npz, X_int=rng.integers(0, 9, size=(N, 13)), X_cat=x_cat, y=rng.integers(0, 2, size=N), counts=counts)
+    tabs = [pel.workloads.dlrm_table(rng, int(c), m) for c in counts]
+    ckpt = tmp_path / "model.pt"
+    fm.save_dlrm_embedding_weights(str(ckpt), tabs)
+    data = fm.CriteoKaggleNpz(str(npz))
+    ebc = hz.EmbeddingBagCollection.from_checkpoint(str(ckpt))
+    assert ebc.ln_emb == data.table_rows
+    dev = torch.device("cuda", 0)
+    bags = [torch.nn.EmbeddingBag.from_pretrained(torch.from_numpy(t), mode="sum") for t in tabs]
+    n_batches = 0
+    for lS_o, lS_i in data.batches(128):                          # 5 full batches + a ragged tail of 60
+        ly = ebc.apply_emb([torch.from_numpy(o).to(dev) for o in lS_o], [torch.from_numpy(i).to(dev) for i in lS_i])
+        for k in range(len(counts)):
+            want = bags[k](torch.from_numpy(lS_i[k]), torch.from_numpy(lS_o[k]))
+            assert torch.equal(ly[k].cpu(), want)
+        n_batches += 1
+    assert n_batches == 6
+    ebc.close()
+    rc = hz.main(["--arch-sparse-feature-size=16", "--data-generation=dataset", "--data-set=kaggle",
+                  f"--processed-data-file={npz}", f"--load-model={ckpt}", "--mini-batch-size=128",
+                  "--num-batches=8", "--inference-only", "--print-freq=1024"])
+    out = capsys.readouterr().out
+    assert rc == 0 and "apply_emb: 8 tables, m=16, batch 128" in out and "--print-freq=1024" in out
+    # (c) a corrupted file: index == count
+    bad = x_cat.copy(); bad[5, 2] = counts[2]
+    np.savez(npz, X_cat=bad, counts=counts)
+    with pytest.raises(ValueError):
+        hz.main(["--data-set=kaggle", f"--processed-data-file={npz}", "--mini-batch-size=64", "--num-batches=2",
+                 "--inference-only"])
+
+
+def test_torch_modules_check_inputs_and_carry_state_dict(pel):
+    """(1) an out-of-range index through the default EmbeddingBag.forward raises IndexError like
+    nn.EmbeddingBag instead of reaching the unchecked kernel; trusted_inputs=True is the explicit fast path;
+    (2) state_dict() / load_state_dict() carry `<prefix>weight` with nn.EmbeddingBag's keys and shapes, so a DLRM
+    with swapped emb_l saves and loads the same checkpoint."""
+    import torch
+    from importlib import import_module
+    tm = import_module("pim-embedding-lookup_amd.torch_module")
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    ref = torch.nn.ModuleList([torch.nn.EmbeddingBag(n, 16, mode="sum") for n in (50, 7, 3000)])
+    ours = torch.nn.ModuleList([tm.EmbeddingBag.from_torch(b) for b in ref])
+    idx = torch.tensor([1, 2, 49, 50], dtype=torch.int64)
+    off = torch.tensor([0, 2], dtype=torch.int64)
+    with pytest.raises(IndexError):
+        ref[0](idx, off)                                   # torch CPU refuses index 50 of a 50-row table ...
+    with pytest.raises(IndexError):
+        ours[0](idx.to(dev), off.to(dev))                  # ... and so does the drop-in, before any launch
+    with pytest.raises(IndexError):
+        ours[0](torch.tensor([0, -1], device=dev), torch.tensor([0], device=dev))
+    with pytest.raises(IndexError):
+        ours[0](torch.tensor([0, 1, 2], device=dev), torch.tensor([0, 5], device=dev))        # offset past the end
+    fused = tm.FusedEmbeddingBags(list(ours))
+    assert fused.trusted_inputs is False
+    good_i = [torch.randint(0, b.num_embeddings, (12,), device=dev) for b in ref]
+    good_o = [torch.arange(0, 12, 3, device=dev) for _ in ref]
+    with pytest.raises(IndexError):
+        fused(good_o, [good_i[0], good_i[1] + 7, good_i[2]])
+    ly = fused(good_o, good_i)
+    for k, b in enumerate(ref):
+        assert torch.equal(ly[k].cpu(), b(good_i[k].cpu(), good_o[k].cpu()))
+    ours[2].trusted_inputs = True
+    assert torch.equal(ours[2](good_i[2], good_o[2]).cpu(), ref[2](good_i[2].cpu(), good_o[2].cpu()))
+    # checkpoints
+    sd_ref, sd = ref.state_dict(), ours.state_dict()
+    assert list(sd) == list(sd_ref) == ["0.weight", "1.weight", "2.weight"]
+    for k in sd:
+        assert sd[k].shape == sd_ref[k].shape and torch.equal(sd[k].cpu(), sd_ref[k])
+    new = torch.nn.ModuleList([torch.nn.EmbeddingBag(n, 16, mode="sum") for n in (50, 7, 3000)])
+    ours.load_state_dict(new.state_dict(), strict=True)            # upstream checkpoint -> our modules
+    for k, b in enumerate(new):
+        assert torch.equal(ours[k].weight.cpu(), b.weight.detach())
+        assert torch.equal(ours[k](good_i[k], good_o[k]).cpu(), b(good_i[k].cpu(), good_o[k].cpu()))
+    new2 = torch.nn.ModuleList([torch.nn.EmbeddingBag(n, 16, mode="sum") for n in (50, 7, 3000)])
+    new2.load_state_dict(ours.state_dict(), strict=True)           # our modules -> upstream model
+    assert all(torch.equal(a.weight.detach(), b.weight.detach()) for a, b in zip(new, new2))
+    with pytest.raises(RuntimeError):
+        ours.load_state_dict({"0.weight": torch.zeros(5, 16), "1.weight": sd_ref["1.weight"], "2.weight": sd_ref["2.weight"]})
