@@ -1139,3 +1139,128 @@ def test_torch_modules_check_inputs_and_carry_state_dict(pel):
     assert all(torch.equal(a.weight.detach(), b.weight.detach()) for a, b in zip(new, new2))
     with pytest.raises(RuntimeError):
         ours.load_state_dict({"0.weight": torch.zeros(5, 16), "1.weight": sd_ref["1.weight"], "2.weight": sd_ref["2.weight"]})
+
+
+def test_many_tables_in_one_fused_launch(pel, oracle):
+    """More tables per fused call than any round-1 test launched (26): 80 one-hot tables through the wave-batch
+    kernels and their XCD-aware workgroup map, 72 ragged pooled tables through the lane-group kernel, and a mixed
+    96-descriptor call (three dtypes / dims -> several launch groups), every table against the oracle."""
+    rng = np.random.default_rng(80)
+    e = pel.EmbeddingEngine(device=0, max_tables=128)
+    # (a) 80 tables, one index per bag, sizes from 3 rows to 2M rows, 2111 bags each (168 880 bags: wave-batch + map)
+    sizes = [int(x) for x in np.exp(rng.uniform(np.log(3), np.log(2e6), size=80))]
+    tabs = [pel.workloads.dlrm_table(rng, n, 16) for n in sizes]
+    for t, w in enumerate(tabs):
+        e.load_table(t, w)
+    B = 2111
+    idx = [pel.workloads.uniform_indices(rng, n, B) for n in sizes]
+    off = [np.arange(B, dtype=np.uint32)] * 80
+    outs = e.lookup_batched(list(range(80)), idx, off)
+    kinds = e.stats()["n_launches_by_kind"]
+    assert kinds[0] + kinds[2] >= 1                       # a wave-batch launch
+    for t in range(80):
+        assert np.array_equal(outs[t], oracle.c_bag_sum(tabs[t], idx[t], off[t])), f"one-hot table {t}"
+    # (b) 72 of them with ragged bags (0..24 indices, some empty), device-resident, int64
+    import torch
+    dev = torch.device("cuda", 0)
+    idx2, off2 = [], []
+    for t in range(72):
+        o, n_idx = pel.workloads.ragged_offsets(rng, 301 + t, 24, p_empty=0.2, dtype=np.int64)
+        off2.append(o)
+        idx2.append(rng.integers(0, sizes[t], size=n_idx).astype(np.int64))
+    outs2 = e.lookup_batched(list(range(72)), [torch.from_numpy(i).to(dev) for i in idx2],
+                             [torch.from_numpy(o).to(dev) for o in off2])
+    torch.cuda.synchronize()
+    for t in range(72):
+        assert np.array_equal(outs2[t].cpu().numpy(), oracle.c_bag_sum(tabs[t], idx2[t], off2[t])), f"pooled table {t}"
+    # (c) 96 descriptors of three shapes in ONE call (tables may repeat): fp32 dim 16, fp16 dim 64, fixed-point dim 8
+    h16 = [rng.standard_normal((500 + 37 * k, 64)).astype(np.float16) for k in range(8)]
+    fx = [rng.integers(-2**31, 2**31 - 1, size=(90 + k, 8), dtype=np.int64).astype(np.int32) for k in range(8)]
+    for k in range(8):
+        e.load_table(100 + k, h16[k])
+        e.load_table(110 + k, fx[k])
+    ids, ii, oo, want = [], [], [], []
+    for r in range(96):
+        kind, k = r % 3, (r // 3) % 8
+        tid, tab = [(k, tabs[k]), (100 + k, h16[k]), (110 + k, fx[k])][kind]
+        o, n_idx = pel.workloads.ragged_offsets(rng, 40 + r, 6, p_empty=0.1)
+        i = rng.integers(0, tab.shape[0], size=n_idx).astype(np.uint32)
+        ids.append(tid); ii.append(i); oo.append(o)
+        want.append(oracle.c_lookup_fixed32(tab, i, o) if kind == 2 else oracle.c_bag_sum(tab, i, o))
+    got = e.lookup_batched(ids, ii, oo)
+    for r in range(96):
+        assert np.array_equal(got[r], want[r]), f"descriptor {r}"
+    e.close()
+
+
+def test_full_size_c5_share_properties(pel, oracle):
+    """BASELINE configs[4], one GPU's share at its own shape: 64 tables x 30M rows x dim 64 fp16 (245.8 GB resident),
+    B = 16384 bags per table, pooling 32, Zipf(1.2) on even tables / uniform on odd ones, ONE fused 64-table launch.
+    Size-independent properties (the oracle is only sampled at this size):
+      (1) idempotence: a second launch leaves all 64 outputs unchanged;
+      (2) the hot-row hint (emb_set_hot_rows on the Zipf tables -> LDS-staged kernel) changes no bit;
+      (3) linearity: a table scaled by 2 (exact in fp16) gives exactly 2x the pooled rows;
+      (4) the oracle on 32 sampled bags of every table (rows copied back from HBM);
+      (5) eight tables bag for bag against an in-order torch gather-sum on the GPU, bit for bit."""
+    import torch
+    dev = torch.device("cuda", 0)
+    if torch.cuda.get_device_properties(dev).total_memory < 270e9:
+        pytest.skip("needs the 288 GB of an MI355X")
+    T, n, D, B, L = 64, 30_000_000, 64, 16384, 32
+    e = pel.EmbeddingEngine(device=0, max_tables=T + 2)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    a = float(np.sqrt(1.0 / n))
+    for t in range(T):
+        w = torch.empty((n, D), dtype=torch.float32, device=dev).uniform_(-a, a, generator=g).to(torch.float16)
+        e.load_table(t, w)
+        if t < 2:
+            e.load_table(T + t, w * 2.0)
+        del w
+    torch.cuda.empty_cache()
+    rng = np.random.default_rng(3)
+    idx_h = [(pel.workloads.zipf_indices if t % 2 == 0 else pel.workloads.uniform_indices)(rng, n, B * L) for t in range(T)]
+    idx = [torch.from_numpy(i.view(np.int32)).to(dev) for i in idx_h]
+    off = torch.from_numpy(pel.workloads.fixed_offsets(B, L).view(np.int32)).to(dev)
+    plan = e.plan(list(range(T)), idx, [off] * T)
+    plan.launch()
+    torch.cuda.synchronize()
+    assert e.stats()["n_launches_by_kind"][1] == 1                      # one lane-group launch for all 64 tables
+    first = [o.clone() for o in plan.outputs]
+    plan.launch()
+    torch.cuda.synchronize()
+    for t in range(T):
+        assert torch.equal(plan.outputs[t], first[t]), f"table {t}: second launch differs"
+    # (3) linearity on tables 0 (Zipf) and 1 (uniform)
+    lin = e.lookup_batched([T, T + 1], idx[:2], [off, off])
+    torch.cuda.synchronize()
+    assert torch.equal(lin[0], first[0] * 2.0) and torch.equal(lin[1], first[1] * 2.0)
+    # (4) + (5)
+    for t in range(T):
+        w = e.table_tensor(t)
+        sel = np.unique(rng.integers(0, B, size=32))
+        pos = (sel[:, None] * L + np.arange(L)[None, :]).reshape(-1)
+        idx_s = idx_h[t][pos].astype(np.int64)
+        uniq, inv = np.unique(idx_s, return_inverse=True)
+        small = w[torch.from_numpy(uniq).to(dev)].cpu().numpy()           # fp16 rows
+        want = oracle.c_bag_sum(small, inv.astype(np.int64), np.arange(sel.shape[0], dtype=np.int64) * L)
+        assert np.array_equal(first[t][torch.from_numpy(sel).to(dev)].cpu().numpy(), want), f"table {t} vs oracle"
+        if t % 8 == 0 or t % 8 == 5:
+            rows = w[idx[t].long()].float().view(B, L, D)
+            acc = rows[:, 0, :] + 0.0
+            for j in range(1, L):
+                acc = acc + rows[:, j, :]
+            assert torch.equal(first[t], acc), f"table {t} vs the in-order torch sum"
+            del rows, acc
+    # (2) hot rows on the Zipf tables: same bits through the LDS-staged kernel
+    plan.destroy()
+    for t in range(0, T, 2):
+        e.set_hot_rows(t, pel.workloads.top_rows(idx_h[t], 100))
+    plan = e.plan(list(range(T)), idx, [off] * T)
+    plan.launch()
+    torch.cuda.synchronize()
+    assert e.stats()["n_launches_by_kind"][4] == 1                      # the hot-row kernel ran
+    for t in range(T):
+        assert torch.equal(plan.outputs[t], first[t]), f"table {t}: the hot-row hint changed the result"
+    plan.destroy()
+    e.close()
