@@ -1105,7 +1105,7 @@ def test_torch_modules_check_inputs_and_carry_state_dict(pel):
     ours = torch.nn.ModuleList([tm.EmbeddingBag.from_torch(b) for b in ref])
     idx = torch.tensor([1, 2, 49, 50], dtype=torch.int64)
     off = torch.tensor([0, 2], dtype=torch.int64)
-    with pytest.raises(IndexError):
+    with pytest.raises((IndexError, RuntimeError)):
         ref[0](idx, off)                                   # torch CPU refuses index 50 of a 50-row table ...
     with pytest.raises(IndexError):
         ours[0](idx.to(dev), off.to(dev))                  # ... and so does the drop-in, before any launch
