@@ -1152,17 +1152,22 @@ def test_many_tables_in_one_fused_launch(pel, oracle):
     tabs = [pel.workloads.dlrm_table(rng, n, 16) for n in sizes]
     for t, w in enumerate(tabs):
         e.load_table(t, w)
+    import torch
+    dev = torch.device("cuda", 0)
     B = 2111
     idx = [pel.workloads.uniform_indices(rng, n, B) for n in sizes]
     off = [np.arange(B, dtype=np.uint32)] * 80
-    outs = e.lookup_batched(list(range(80)), idx, off)
+    d_off = torch.arange(B, dtype=torch.int32, device=dev)
+    outs = e.lookup_batched(list(range(80)), [torch.from_numpy(i.view(np.int32)).to(dev) for i in idx], [d_off] * 80)
+    torch.cuda.synchronize()
     kinds = e.stats()["n_launches_by_kind"]
-    assert kinds[0] + kinds[2] >= 1                       # a wave-batch launch
+    assert kinds[0] + kinds[2] == 1 and sum(kinds) == 1   # ONE wave-batch launch over the 80 tables
     for t in range(80):
-        assert np.array_equal(outs[t], oracle.c_bag_sum(tabs[t], idx[t], off[t])), f"one-hot table {t}"
+        assert np.array_equal(outs[t].cpu().numpy(), oracle.c_bag_sum(tabs[t], idx[t], off[t])), f"one-hot table {t}"
+    # the same through host pointers (staged, split into pipelined parts)
+    outs_h = e.lookup_batched(list(range(80)), idx, off)
+    assert all(np.array_equal(outs_h[t], outs[t].cpu().numpy()) for t in range(80))
     # (b) 72 of them with ragged bags (0..24 indices, some empty), device-resident, int64
-    import torch
-    dev = torch.device("cuda", 0)
     idx2, off2 = [], []
     for t in range(72):
         o, n_idx = pel.workloads.ragged_offsets(rng, 301 + t, 24, p_empty=0.2, dtype=np.int64)
