@@ -108,14 +108,71 @@ def make_tables_on_gpu(torch, eng, rows_list, dim, device, seed=0, keep_host=Fal
     return host
 
 
-def measured_traffic(workload: str):
-    """HBM bytes per launch from the committed PMC profile of this very command (profiles/traffic.json),
-    or None when no profile exists for the workload / batch shape being run."""
+L2_PEAK_GBS = 34500.0    # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate
+
+
+def profile_key(args, spec):
+    """Key of this run in profiles/traffic.json, or None when the run is not one of the profiled commands
+    (another batch size / table count / hint changes the traffic)."""
+    if args.batch is not None or args.tables is not None or args.hot_rows or args.streams != 1:
+        return None
+    key = args.workload
+    if args.workload == "c4" and spec["L"] != 1:
+        key += "-l%d" % spec["L"]
+    default_dist = {"c1": "uniform", "c2": "uniform", "c3": "zipf", "c4": "uniform", "c5": "mixed"}[args.workload]
+    if spec["dist"] != default_dist:
+        key += "-" + spec["dist"]
+    return key
+
+
+def measured_traffic(key):
+    """This command's entry of profiles/traffic.json: HBM-side bytes per launch of the dominant kernel from the
+    committed rocprofv3 PMC passes (collected and corrected as MI355X_MICROARCH.md "HBM" prescribes), L2 hit / miss
+    requests per launch.  None when no profile exists for the command being run."""
+    if key is None:
+        return None
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            return json.load(f).get(workload, {}).get("traffic_bytes_per_launch")
+            return json.load(f).get(key)
     except (OSError, ValueError):
         return None
+
+
+def unique_row_bytes(batch, row_bytes):
+    """Compulsory table bytes of one launch: every DISTINCT row of every table once (host-side count).  Read
+    traffic well above this means rows fetched more than once (several private L2s, or evicted and re-read)."""
+    idx, _off = batch
+    return int(sum(np.unique(i).shape[0] for i in idx)) * row_bytes
+
+
+def roofline_object(alg_bytes, kernel_us, entry, uniq_bytes):
+    """HBM roofline of the dominant kernel.  The metric's own config (C2) and every launch whose rows mostly MISS
+    the caches are priced on ALGORITHMIC bytes.  A launch that is mostly served by L2 /
+    Infinity Cache moves far fewer HBM-side bytes than it gathers, so algorithmic bytes / HBM peak would exceed 1
+    and mean nothing: there `achieved` is the MEASURED HBM-side traffic / time, the algorithmic rate is kept as
+    `achieved_algorithmic`, and `l2_frac` prices the L2 requests against the L2's own peak."""
+    t = kernel_us * 1e-6
+    alg = alg_bytes / t / 1e9
+    r = {"bound": "hbm", "achieved": alg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / HBM_PEAK_GBS,
+         "traffic": None, "basis": "algorithmic bytes", "kernel_us": kernel_us, "algorithmic_bytes": alg_bytes,
+         "achieved_algorithmic": alg}
+    if entry:
+        traffic = entry.get("traffic_bytes_per_launch")
+        r["traffic"] = traffic
+        r["traffic_source"] = entry.get("source")
+        if traffic and traffic < 0.75 * alg_bytes:        # cache-served: the counter bytes are the HBM-side load
+            r["achieved"] = traffic / t / 1e9
+            r["frac"] = r["achieved"] / HBM_PEAK_GBS
+            r["basis"] = "measured HBM-side bytes (profiles/traffic.json); algorithmic rate in achieved_algorithmic"
+        if entry.get("tcc_hit") is not None and entry.get("tcc_miss") is not None:
+            req = entry["tcc_hit"] + entry["tcc_miss"]
+            r["l2_hit_rate"] = entry["tcc_hit"] / max(req, 1)
+            r["l2_frac"] = req * 128 / t / 1e9 / L2_PEAK_GBS
+        if uniq_bytes and entry.get("read_bytes"):
+            r["read_over_unique_rows"] = entry["read_bytes"] / uniq_bytes
+    if uniq_bytes:
+        r["unique_row_bytes"] = uniq_bytes
+    return r
 
 
 def workload_spec(pel, args):
@@ -380,12 +437,9 @@ def run_single(args):
                    "prewarm_ms": args.prewarm_ms, "prewarm_launches": n_pre,
                    "launches_by_kind": eng.stats()["n_launches_by_kind"],
                    "parallelism": "single" if len(handles) == 1 else "single GPU, %d streams" % len(handles)},
-        "roofline": {"bound": "hbm", "achieved": alg_bytes / (kernel_us * 1e-6) / 1e9,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": alg_bytes / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                     "traffic": measured_traffic(args.workload) if (args.batch is None and args.index_dist is None
-                                                                    and args.tables is None) else None,
-                     "kernel_us": kernel_us, "algorithmic_bytes": alg_bytes},
+        "roofline": roofline_object(alg_bytes, kernel_us, measured_traffic(profile_key(args, spec)),
+                                    unique_row_bytes(batches[0], dim * (2 if spec.get("dtype") == "f16" else 4))
+                                    if spec["L"] > 1 or spec["dist"] != "uniform" else None),
     }
     if want_cpu:
         result["cpu_baseline"] = cpu_baseline(pel, host_tables, batches[0], args.cpu_seconds)
