@@ -19,9 +19,9 @@ for key in keys:
     src = os.path.join(rnd, f"{key}_pmc_summary.txt")
     c = {}
     for line in open(os.path.join(here, src)):
-        parts = line.split()
-        if len(parts) >= 3 and parts[-1].startswith("mean="):
-            c[parts[0]] = float(parts[-1][5:])
+        parts = line.replace("=", "= ").split()
+        if "mean=" in parts:
+            c[parts[0]] = float(parts[parts.index("mean=") + 1])
     need = ("TCC_EA0_RDREQ_128B_sum", "TCC_EA0_RDREQ_64B_sum", "WRITE_SIZE")
     if any(k not in c for k in need):
         print(f"{key}: counters missing in {src}: {sorted(c)}", file=sys.stderr)
