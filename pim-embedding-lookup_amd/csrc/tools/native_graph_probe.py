@@ -59,8 +59,19 @@ for name, fn, n in (("eager", lambda: [step(s.cuda_stream) for _ in range(8)], 5
             fn()
         torch.cuda.synchronize()
     print("%s: %.1f us per step" % (name, (time.perf_counter() - t0) / n / 8 * 1e6), flush=True)
-# Result on MI355X (RCCL 2.26.6, torch 2.10): capture and replay work and give the right rows
-# (eager 29.2-29.5 us per step, graph 28.0-28.1), but tearing the graph and the communicator down
-# afterwards hung the process twice (graph first or communicator first), so the process leaves without
-# teardown and bench.py keeps its steps eager.
-os._exit(0)
+# Teardown, ONE ordered attempt (round 2): RCCL keeps a reference per captured graph (persistent refs released by
+# a user-object destructor when the graph is destroyed) and ncclCommDestroy waits for them to drop -- so: all work
+# drained, graph exec + graph destroyed FIRST, device drained again, THEN the communicator.  If this still hangs,
+# faulthandler prints the Python frame it hangs in after 40 s and ends the process.
+torch.cuda.synchronize()
+faulthandler.dump_traceback_later(40, exit=True)
+print("teardown: graph reset", flush=True)
+g.reset()
+del g
+torch.cuda.synchronize()
+print("teardown: graph gone, destroying the communicator", flush=True)
+ex.close()
+print("teardown: communicator gone", flush=True)
+plan1.destroy(); plan2.destroy(); eng.close()
+faulthandler.cancel_dump_traceback_later()
+print("teardown complete", flush=True)
