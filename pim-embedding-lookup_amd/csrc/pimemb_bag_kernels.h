@@ -84,12 +84,27 @@ struct BagCfg {
 template <int DT>
 struct RowOps;
 
+// Address space of row / index / pooled-row accesses.  Pointers that come out of a descriptor in memory are generic
+// ("flat"); every buffer this library touches is GPU-visible memory (HBM, or pinned host memory on the zero-copy
+// host path), never LDS or scratch, so they can be accessed as GLOBAL (address space 1): global_load / global_store
+// skip the aperture check, and -- unlike flat accesses -- count on vmcnt alone and return in order, so the compiler
+// may consume the first of several gathers while the others are still in flight.
+#ifndef PIMEMB_GLOBAL_AS
+#define PIMEMB_GLOBAL_AS 0
+#endif
+#if PIMEMB_GLOBAL_AS
+#define PIMEMB_AS __attribute__((address_space(1)))
+#else
+#define PIMEMB_AS
+#endif
+
 template <bool NT>
 __device__ __forceinline__ void store_f32x4(float *dst, f32x4 v) {
+    typedef f32x4 PIMEMB_AS *ptr_t;
     if constexpr (NT)
-        __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(dst));
+        __builtin_nontemporal_store(v, (ptr_t)(reinterpret_cast<f32x4 *>(dst)));
     else
-        *reinterpret_cast<f32x4 *>(dst) = v;
+        *(ptr_t)(reinterpret_cast<f32x4 *>(dst)) = v;
 }
 
 template <>
@@ -145,10 +160,11 @@ struct RowOps<EMB_FIXED32> {
 
 template <bool NT, typename T>
 __device__ __forceinline__ T load_meta(const T *p) {
+    typedef const T PIMEMB_AS *ptr_t;
     if constexpr (NT)
-        return __builtin_nontemporal_load(p);
+        return __builtin_nontemporal_load((ptr_t)p);
     else
-        return *p;
+        return *(ptr_t)p;
 }
 
 // Row id -> row id inside the table.  A 64-bit row id that came from a uint32 index is clamped with
@@ -169,10 +185,11 @@ __device__ __forceinline__ uint64_t clamp_row(uint64_t r, uint64_t last_row) {
 
 template <bool NT>
 __device__ __forceinline__ u32x4 load_row(const char *p) {
+    typedef const u32x4 PIMEMB_AS *ptr_t;
     if constexpr (NT)
-        return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+        return __builtin_nontemporal_load((ptr_t)(reinterpret_cast<const u32x4 *>(p)));
     else
-        return *reinterpret_cast<const u32x4 *>(p);
+        return *(ptr_t)(reinterpret_cast<const u32x4 *>(p));
 }
 
 __device__ __forceinline__ uint32_t shfl_u32(uint32_t v, uint32_t src) {

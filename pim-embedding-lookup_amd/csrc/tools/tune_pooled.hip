@@ -17,6 +17,255 @@
 
 using namespace pimemb;
 
+// =====================================================================================================
+// REJECTED VARIANT, kept here (tuner only) so the measurement can be repeated: "v4 stream".
+// Hypothesis (round 2): the lane-group kernel is bound by outstanding misses per CU -- every bag starts with three
+// dependent round trips (descriptor, bounds, index window) with no row in flight, and its eight gathers drain to
+// zero before the next eight are issued.  v4 makes workgroups persistent over (descriptor, tile) items, prefetches
+// the bounds of item k+2 and the index window and descriptor scalars of item k+1 BEHIND the first eight gathers of
+// item k, and consumes the gathers as a rolling ring (global_load so that vmcnt counts in order: add slot j at
+// vmcnt(7), re-issue it).  Bit-identical to every other kernel.  Measured on MI355X, 16 tables x 4M rows x dim
+// 128, B = 16384, L = 32 (profiles/r02/tunep_stream_kernel_rejected.log): Zipf(1.2) 253-294 us against 222 us for
+// the shipped kernel, uniform 791-825 against 762-768 -- slower in every geometry (G = 1024..8192 workgroups, 4 to 8
+// waves per SIMD, 8 or 16 gathers in flight), and INSENSITIVE to occupancy and ring depth.  So the launch is not
+// short of memory-level parallelism: at 20 TB/s algorithmic the CUs move 32 B/clk each, half of the L1's 64 B/clk,
+// with 61 % of those bytes also crossing the L2->L1 fill path.  The simple kernel already sits on the vector-memory
+// pipe's throughput; what the extra bookkeeping (scalar item arithmetic, carried descriptor state, 72 registers)
+// buys back in latency it loses in issue slots.  Flat vs global address space for the shipped kernels: no
+// difference either (-DPIMEMB_GLOBAL_AS=1: C2 19.5 vs 19.5-19.9 us, pooled 223.4 vs 224.0 us).
+// =====================================================================================================
+namespace pimemb {
+// The same 16-byte row piece through a GLOBAL-address-space pointer (global_load_dwordx4).  Pointers that come out
+// of a descriptor in memory are generic, and the compiler must assume a flat load may return out of order with
+// respect to others: it waits vmcnt(0) before the first use of ANY of them.  Global loads return in order, so a
+// ring of gathers can be consumed oldest-first with vmcnt(N-1) while the younger ones stay in flight.
+typedef const u32x4 __attribute__((address_space(1))) *global_row_ptr;
+template <bool NT, typename T>
+__device__ __forceinline__ T load_meta_global(const T *p) {
+    typedef const T __attribute__((address_space(1))) *gp;
+    if constexpr (NT)
+        return __builtin_nontemporal_load((gp)p);
+    else
+        return *(gp)p;
+}
+template <bool NT>
+__device__ __forceinline__ u32x4 load_row_global(const char *p) {
+    global_row_ptr g = (global_row_ptr)(reinterpret_cast<const u32x4 *>(p));
+    if constexpr (NT)
+        return __builtin_nontemporal_load(g);
+    else
+        return *g;
+}
+
+// ---- v4: persistent lane-group kernel: metadata prefetched two bags ahead, rolling gathers -----------
+// For pooled launches.  The lane-group kernel above starts every bag with three DEPENDENT memory round
+// trips during which the wavefront has no row in flight -- descriptor (scalar), bag bounds, index window --
+// and then drains its eight gathers to zero before it issues the next eight.  Its outstanding misses per CU
+// are therefore waves x duty x rows-in-flight x miss rate, and on cache-served mixes (Zipf: 21 % of the row
+// bytes leave the XCD) that product, not a bandwidth, sets the speed.  Here a workgroup is persistent: it walks
+// work items (descriptor, tile) = blockIdx.x + k * gridDim.x and, while it gathers the rows of item k, the
+// bounds of item k+2 and the index window of item k+1 are already on their way (vector memory returns in
+// order, so by the time the first gather of item k lands, both have).  Inside a bag the gathers ROLL: slot j
+// of the 8-deep ring is added (oldest first, i.e. still in index order from +0 -- same bits as every other
+// kernel) and immediately re-issued for index j+8, so eight rows stay in flight until the bag ends.
+// Register diet (the first version kept three items' descriptor fields and eight lane masks alive and the
+// allocator spilled scalars into AGPRs: 240 registers): a work item is two 32-bit scalars (descriptor, tile)
+// advanced incrementally, descriptor fields are re-read with scalar loads where they are used (they sit in the
+// scalar cache), a lane group's share of an item is three 32-bit values (bag, p, e; bag = ~0: none), and "slot j
+// holds a gather" is recomputed from the window count instead of being carried.  The launch must satisfy
+// n_descs * max_tiles < 2^32, n_bags < 2^32 - 1 and (uint32 indices) n_idx < 2^32 -- the host checks.
+template <typename IdxT, int DT, int LPR, class Cfg>
+__global__ void __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves)
+bag_sum_stream_kernel(const DevDesc *__restrict__ descs, uint32_t chunks, uint32_t n_descs, uint32_t max_tiles) {
+    using Ops = RowOps<DT>;
+    using Pos = typename std::conditional<sizeof(IdxT) == 4, uint32_t, uint64_t>::type;
+    constexpr uint32_t kWaves = Cfg::kBlock / 64;
+    constexpr uint32_t BPW = 64 / LPR;
+    constexpr uint32_t BAGS_PER_TILE = BPW * kWaves;
+    constexpr uint32_t U = (uint32_t)Cfg::kUnroll;
+    constexpr uint32_t IPL = (U + LPR - 1) / LPR;   // indices held per lane
+    constexpr uint32_t W = IPL * LPR;               // index window of a lane group (a multiple of U)
+    constexpr uint32_t kNone = 0xffffffffu;
+
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t sub = lane & (LPR - 1), grp = lane / LPR;
+    const uint32_t row_bytes = chunks * 16u;
+    const uint32_t out_stride = chunks * Ops::kFloatsPerLane;
+    const bool live = sub < chunks;
+    const uint32_t step = gridDim.x;
+    const uint32_t bag_in_tile = wave * BPW + grp;
+
+    auto advance = [&](uint32_t &di, uint32_t &tile) {          // scalar: next work item of this workgroup
+        tile += step;
+        while (tile >= max_tiles && di < n_descs) {
+            tile -= max_tiles;
+            di++;
+        }
+    };
+    // bounds of this lane group's bag in item (di, tile): loads issued here, consumed an iteration later
+    auto open = [&](uint32_t di, uint32_t tile, uint32_t &bag, Pos &p, Pos &e) {
+        bag = kNone;
+        p = e = 0;
+        if (di >= n_descs) return;
+        const DevDesc *dp = descs + di;
+        const uint64_t n_bags = dp->n_bags;
+        const uint32_t b = tile * BAGS_PER_TILE + bag_in_tile;
+        if (tile >= dp->n_tiles || b >= n_bags) return;
+        const uint64_t n_idx = dp->n_idx;
+        const IdxT *__restrict__ offsets = static_cast<const IdxT *>(dp->offsets);
+        uint64_t p64, e64;
+        if (offsets != nullptr) {
+            p64 = (uint64_t)load_meta_global<Cfg::kNtMeta>(offsets + b);
+            e64 = (b + 1 < n_bags) ? (uint64_t)load_meta_global<Cfg::kNtMeta>(offsets + b + 1) : n_idx;
+        } else {
+            p64 = (uint64_t)b * dp->fixed_pooling;
+            e64 = p64 + dp->fixed_pooling;
+        }
+        if (Cfg::kClamp) {
+            if (e64 > n_idx) e64 = n_idx;
+            if (p64 > e64) p64 = e64;
+        }
+        bag = b;
+        p = (Pos)p64;
+        e = (Pos)e64;
+    };
+    // the lane's share of the index window [p, p + W) of descriptor di
+    auto window = [&](uint32_t di, Pos p, Pos e, IdxT (&mine)[IPL]) {
+#pragma unroll
+        for (uint32_t i = 0; i < IPL; i++) mine[i] = 0;
+        if (p >= e) return;                                     // (also: no such item)
+        const IdxT *__restrict__ indices = static_cast<const IdxT *>(descs[di].indices);
+        const uint32_t cnt = (e - p < W) ? (uint32_t)(e - p) : W;
+#pragma unroll
+        for (uint32_t i = 0; i < IPL; i++)
+            if (sub + i * LPR < cnt) mine[i] = load_meta_global<Cfg::kNtMeta>(indices + p + sub + i * LPR);
+    };
+
+    uint32_t di0 = 0, tile0 = blockIdx.x;
+    while (tile0 >= max_tiles && di0 < n_descs) {
+        tile0 -= max_tiles;
+        di0++;
+    }
+    uint32_t di1 = di0, tile1 = tile0;
+    advance(di1, tile1);
+    uint32_t di2 = di1, tile2 = tile1;
+    uint32_t bag0, bag1, bag2;
+    Pos p0, e0, p1, e1, p2, e2;
+    open(di0, tile0, bag0, p0, e0);
+    open(di1, tile1, bag1, p1, e1);
+    IdxT mine[IPL], mine_nxt[IPL];
+    window(di0, p0, e0, mine);
+    // descriptor fields of the CURRENT item live in scalars loaded one item ahead (a scalar load that is waited for
+    // while no gather is in flight is dead time for the whole wavefront)
+    const char *weights0 = nullptr;
+    float *out0 = nullptr;
+    uint64_t last_row0 = 0;
+    if (di0 < n_descs) {
+        weights0 = static_cast<const char *>(descs[di0].weights);
+        out0 = descs[di0].out;
+        last_row0 = descs[di0].nr_rows - 1;
+    }
+
+    while (di0 < n_descs) {                                      // uniform over the workgroup
+        // Every slot of the ring is loaded UNCONDITIONALLY (a conditional store into the loop-carried ring makes the
+        // compiler copy the whole ring at every branch: 254 registers): window positions past the bag's end name
+        // row 0 (their index register is 0), lanes past the row's last piece read piece 0; neither is ever added
+        // or stored.
+        const char *__restrict__ wsub = weights0 + (live ? sub : 0u) * 16u;
+        const uint64_t last_row = last_row0;
+        auto fetch = [&](uint64_t r) -> u32x4 {
+            return load_row_global<Cfg::kNtRow>(wsub + clamp_row<Cfg::kClamp, IdxT>(r, last_row) * row_bytes);
+        };
+        // ---- A. ring prologue of this item's first window: U gathers in flight before anything else is waited for
+        typename Ops::Acc acc = Ops::zero();
+        u32x4 v[U];
+        const uint32_t cnt0 = (e0 - p0 < W) ? (uint32_t)(e0 - p0) : W;     // 0: empty or no bag -> nothing is added
+#pragma unroll
+        for (uint32_t j = 0; j < U; j++)
+            v[j] = fetch(shfl_index<IdxT>(mine[(IPL == 1) ? 0 : j / LPR], grp * LPR + j % LPR));
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- B. prefetch behind the gathers: next item's descriptor scalars and index window (its bounds arrived an
+        //         iteration ago), bounds of the item after it
+        const char *weights1 = weights0;
+        float *out1 = out0;
+        uint64_t last_row1 = last_row0;
+        if (di1 < n_descs) {
+            weights1 = static_cast<const char *>(descs[di1].weights);
+            out1 = descs[di1].out;
+            last_row1 = descs[di1].nr_rows - 1;
+        }
+        window(di1 < n_descs ? di1 : di0, p1, e1, mine_nxt);
+        advance(di2, tile2);
+        open(di2, tile2, bag2, p2, e2);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- C. the rest of the first window, rolling: add the oldest slot, re-issue it
+        uint32_t k0 = U;
+#pragma unroll 1
+        for (; k0 < cnt0; k0 += U) {                            // (kept a loop: unrolled, the scheduler hoists every gather)
+#pragma unroll
+            for (uint32_t j = 0; j < U; j++) {
+                const uint32_t q = k0 + j;
+                const uint64_t r = shfl_index<IdxT>(mine[(IPL == 1) ? 0 : (q / LPR) % IPL], grp * LPR + q % LPR);
+                Ops::add(acc, v[j]);                            // position q - U < cnt: oldest first, index order
+                v[j] = fetch(r);
+                __builtin_amdgcn_sched_barrier(0);              // keep add-then-reissue per slot: the scheduler would
+            }                                                   // otherwise drain all U gathers and re-issue them together
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < U; j++) {
+            typename Ops::Acc with = acc;
+            Ops::add(with, v[j]);
+            acc = (k0 - U + j < cnt0) ? with : acc;
+        }
+        // ---- bags longer than one window (rare): the remaining windows on demand, same ring
+        Pos p = p0 + cnt0;
+        while (p < e0) {                                        // uniform over a lane group
+            const uint32_t cnt = (e0 - p < W) ? (uint32_t)(e0 - p) : W;
+            const IdxT *__restrict__ indices = static_cast<const IdxT *>(descs[di0].indices);
+#pragma unroll
+            for (uint32_t i = 0; i < IPL; i++) {
+                mine[i] = 0;
+                if (sub + i * LPR < cnt) mine[i] = load_meta_global<Cfg::kNtMeta>(indices + p + sub + i * LPR);
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < U; j++)
+                v[j] = fetch(shfl_index<IdxT>(mine[(IPL == 1) ? 0 : j / LPR], grp * LPR + j % LPR));
+            uint32_t k1 = U;
+#pragma unroll 1
+            for (; k1 < cnt; k1 += U) {
+#pragma unroll
+                for (uint32_t j = 0; j < U; j++) {
+                    const uint32_t q = k1 + j;
+                    const uint64_t r = shfl_index<IdxT>(mine[(IPL == 1) ? 0 : (q / LPR) % IPL], grp * LPR + q % LPR);
+                    Ops::add(acc, v[j]);
+                    v[j] = fetch(r);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < U; j++) {
+                typename Ops::Acc with = acc;
+                Ops::add(with, v[j]);
+                acc = (k1 - U + j < cnt) ? with : acc;
+            }
+            p += cnt;
+        }
+        if (bag0 != kNone || Ops::kGroupStore)
+            store_row<Ops, Cfg, LPR>(acc, out0 + (uint64_t)bag0 * out_stride, sub, grp, chunks, bag0 != kNone && live);
+
+        // ---- rotate
+        di0 = di1; tile0 = tile1; bag0 = bag1; p0 = p1; e0 = e1;
+        di1 = di2; tile1 = tile2; bag1 = bag2; p1 = p2; e1 = e2;
+        weights0 = weights1; out0 = out1; last_row0 = last_row1;
+#pragma unroll
+        for (uint32_t i = 0; i < IPL; i++) mine[i] = mine_nxt[i];
+    }
+}
+
+}  // namespace pimemb
+
 #define CK(x)                                                                              \
     do {                                                                                   \
         hipError_t e_ = (x);                                                               \
@@ -93,6 +342,20 @@ Variant make_hot(const char *name, uint32_t hot, uint32_t wgs) {
     return v;
 }
 
+static uint32_t g_stream_wgs = 2048;
+template <class Cfg, int G>
+void do_launch_stream(const DevDesc *d, uint32_t n, uint32_t tiles, const uint32_t *, uint32_t, hipStream_t s) {
+    hipLaunchKernelGGL((bag_sum_stream_kernel<uint32_t, EMB_F32, LPR, Cfg>), dim3(G), dim3(Cfg::kBlock), 0, s, d, (uint32_t)LPR, n, tiles);
+}
+template <class Cfg, int G>
+Variant make_stream(const char *name) {
+    Variant v;
+    v.name = name;
+    v.bags_per_tile = (64u / LPR) * (Cfg::kBlock / 64);
+    v.fn = &do_launch_stream<Cfg, G>;
+    return v;
+}
+
 template <class Cfg, bool WAVEBATCH>
 Variant make_variant(const char *name, bool xcd = false) {
     Variant v;
@@ -156,6 +419,15 @@ int main(int argc, char **argv) {
         vars.push_back(make_variant<BagCfg<64, 32, true, false, 8, 1, 1, false, false, true>, false>("v1 group blk64 U32"));
         vars.push_back(make_variant<BagCfg<128, 16, true, false, 8, 1, 1, false, false, true>, false>("v1 group blk128 U16"));
     }
+    //                        BLOCK U  ntS   ntM  inflight minW
+    vars.push_back(make_stream<BagCfg<256, 8, true, false, 8, 8>, 2048>("v4 stream blk256 U8 minw8 G2048"));
+    vars.push_back(make_stream<BagCfg<256, 8, true, false, 8, 8>, 4096>("v4 stream blk256 U8 minw8 G4096"));
+    vars.push_back(make_stream<BagCfg<256, 8, true, false, 8, 8>, 1024>("v4 stream blk256 U8 minw8 G1024"));
+    vars.push_back(make_stream<BagCfg<256, 8, true, false, 8, 1>, 2048>("v4 stream blk256 U8 minw1 G2048"));
+    vars.push_back(make_stream<BagCfg<256, 16, true, false, 8, 1>, 2048>("v4 stream blk256 U16 minw1 G2048"));
+    vars.push_back(make_stream<BagCfg<256, 16, true, false, 8, 1>, 1280>("v4 stream blk256 U16 minw1 G1280"));
+    vars.push_back(make_stream<BagCfg<64, 8, true, false, 8, 8>, 8192>("v4 stream blk64 U8 minw8 G8192"));
+    if (!getenv("TUNE_ALL")) goto build_done;
     vars.push_back(make_variant<BagCfg<64, 8, true, false, 8, 8, 1, false, true>, true>("v2 wave b1 SHIP (blk64 U8 minw8)"));
     vars.push_back(make_variant<BagCfg<64, 8, true, false, 8, 8, 1, false, true>, true>("v2 wave b1 SHIP XCD", true));
     vars.push_back(make_variant<BagCfg<128, 4, true, false, 8, 8, 2, false, true>, true>("v2 wave b2 SHIP (blk128 U4 minw8)"));
@@ -163,6 +435,7 @@ int main(int argc, char **argv) {
     vars.push_back(make_variant<BagCfg<64, 8, true, false, 16, 4, 1, false, true>, true>("v2 wave b1 inflight16 minw4"));
     vars.push_back(make_variant<BagCfg<64, 8, true, false, 4, 8, 1, false, true>, true>("v2 wave b1 inflight4 minw8"));
 
+build_done:
     // hot sets: the generator maps Zipf rank k of table t to row (k*2654435761 + 12345 + t) % rows
     std::vector<std::vector<void *>> hot_dev(vars.size(), std::vector<void *>(T, nullptr));
     std::vector<std::vector<uint64_t *>> hash_dev(vars.size(), std::vector<uint64_t *>(T, nullptr));
