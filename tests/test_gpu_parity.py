@@ -1269,3 +1269,59 @@ def test_full_size_c5_share_properties(pel, oracle):
         assert torch.equal(plan.outputs[t], first[t]), f"table {t}: the hot-row hint changed the result"
     plan.destroy()
     e.close()
+
+
+def test_full_size_c3_properties(pel, oracle):
+    """BASELINE configs[2] at the size bench.py runs it: 48 tables x 10M rows x dim 128 fp32 (245.8 GB resident; the 64
+    tables as written need 327.7 GB), B = 16384, pooling 32, Zipf(1.2), ONE fused 48-table launch (round 1 only ran one
+    table of this shape).  Idempotence; exact linearity on a x2 copy of table 0; the oracle on 32 sampled bags of every
+    table; six tables bag for bag against an in-order torch gather-sum (bit for bit); bag-halves additivity <= 1e-6."""
+    import torch
+    dev = torch.device("cuda", 0)
+    if torch.cuda.get_device_properties(dev).total_memory < 270e9:
+        pytest.skip("needs the 288 GB of an MI355X")
+    T, n, D, B, L = 48, 10_000_000, 128, 16384, 32
+    e = pel.EmbeddingEngine(device=0, max_tables=T + 1)
+    g = torch.Generator(device=dev)
+    g.manual_seed(2)
+    a = float(np.sqrt(1.0 / n))
+    for t in range(T):
+        w = torch.empty((n, D), dtype=torch.float32, device=dev).uniform_(-a, a, generator=g)
+        e.load_table(t, w)
+        if t == 0:
+            e.load_table(T, w * 2.0)
+        del w
+    torch.cuda.empty_cache()
+    rng = np.random.default_rng(2)
+    idx_h = [pel.workloads.zipf_indices(rng, n, B * L) for _ in range(T)]
+    idx = [torch.from_numpy(i.view(np.int32)).to(dev) for i in idx_h]
+    off = torch.from_numpy(pel.workloads.fixed_offsets(B, L).view(np.int32)).to(dev)
+    plan = e.plan(list(range(T)), idx, [off] * T)
+    plan.launch()
+    torch.cuda.synchronize()
+    assert e.stats()["n_launches_by_kind"][1] == 1
+    first = [o.clone() for o in plan.outputs]
+    plan.launch()
+    torch.cuda.synchronize()
+    assert all(torch.equal(plan.outputs[t], first[t]) for t in range(T))
+    assert torch.equal(e.lookup(T, idx[0], off), first[0] * 2.0)
+    off16 = torch.from_numpy(pel.workloads.fixed_offsets(2 * B, L // 2).view(np.int32)).to(dev)
+    halves = e.lookup(3, idx[3], off16)
+    assert float((halves[0::2] + halves[1::2] - first[3]).abs().max()) <= 1e-6
+    for t in range(T):
+        w = e.table_tensor(t)
+        sel = np.unique(rng.integers(0, B, size=32))
+        pos = (sel[:, None] * L + np.arange(L)[None, :]).reshape(-1)
+        uniq, inv = np.unique(idx_h[t][pos].astype(np.int64), return_inverse=True)
+        small = w[torch.from_numpy(uniq).to(dev)].cpu().numpy()
+        want = oracle.c_bag_sum(small, inv.astype(np.int64), np.arange(sel.shape[0], dtype=np.int64) * L)
+        assert np.array_equal(first[t][torch.from_numpy(sel).to(dev)].cpu().numpy(), want), f"table {t} vs oracle"
+        if t % 8 == 1:
+            rows = w[idx[t].long()].view(B, L, D)
+            acc = rows[:, 0, :] + 0.0
+            for j in range(1, L):
+                acc = acc + rows[:, j, :]
+            assert torch.equal(first[t], acc), f"table {t} vs the in-order torch sum"
+            del rows, acc
+    plan.destroy()
+    e.close()

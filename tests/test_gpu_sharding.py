@@ -365,3 +365,46 @@ def test_sharded_lookup_over_the_engine_backend_two_ranks():
         p.join(timeout=60)
     for rank, status, info in res:
         assert status == "ok", f"rank {rank}:\n{info}"
+
+
+def test_route_bags_limits_many_shards_and_tables(pel, eng):
+    """The router at the edges of its contract: 64 tables in one call, 200 shards (more shards than indices in a bag,
+    most sub-bag lists empty), bag counts that are not a multiple of anything, rows_per_shard that does not divide the
+    table, an out-of-range index (kept inside the last shard's list, never outside the routing buffers).  Checked against
+    the host restatement of the rule."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(64)
+    for K, N, B, L in ((64, 3, 257, 5), (2, 200, 1031, 9)):
+        rows = [int(x) for x in rng.integers(50, 100_000, size=K)]
+        rps = [-(-r // N) for r in rows]
+        idxs = [pel.workloads.uniform_indices(rng, rows[k], B * L) for k in range(K)]
+        idxs[0][7] = rows[0] + 12345                       # out of range: must land in the LAST shard's list
+        sz = eng.route_bags_sizes(K, B, K * B * L, N)
+        u8 = lambda n: torch.zeros(max(n, 16), dtype=torch.uint8, device=dev)
+        send, meta, slots, work = u8(sz["send"]), u8(sz["meta"]), u8(sz["slots"]), u8(sz["work"])
+        guard = torch.full((64,), 0x5A, dtype=torch.uint8, device=dev)
+        d_idx = [torch.from_numpy(i.view(np.int32)).to(dev) for i in idxs]
+        eng.route_bags([(d_idx[k].data_ptr(), None, B * L, L, rps[k]) for k in range(K)], B, N, send.data_ptr(),
+                       meta.data_ptr(), slots.data_ptr(), work.data_ptr())
+        torch.cuda.synchronize()
+        assert bool((guard == 0x5A).all())
+        m = meta.view(torch.int32).cpu().numpy().view(np.uint32)
+        nk = N * K
+        counts, base = m[:2 * nk].reshape(N, K, 2), m[2 * nk:4 * nk].reshape(N, K, 2)
+        piece = m[4 * nk:4 * nk + N + 1]
+        assert counts[:, :, 1].sum() == K * B * L and piece[N] * 4 <= sz["send"]
+        words = send.view(torch.int32).cpu().numpy().view(np.uint32)
+        sl = slots.view(torch.int32).cpu().numpy().view(np.uint32)[:K * N * B].reshape(K, N, B)
+        off = (np.arange(B, dtype=np.int64) * L)
+        for k in range(0, K, max(1, K // 8)):
+            ref = _route_bags_reference(idxs[k], off, B * L, rps[k], N)
+            for d in range(N):
+                ns, ni = int(counts[d, k, 0]), int(counts[d, k, 1])
+                assert (ns, ni) == (ref[d][0].shape[0], ref[d][1].shape[0])
+                b0, b1 = int(base[d, k, 0]), int(base[d, k, 1])
+                assert np.array_equal(words[b0:b0 + ns], ref[d][0]) and np.array_equal(words[b1:b1 + ni], ref[d][1])
+                assert np.array_equal(sl[k, d], ref[d][2])
+        if K == 64:
+            dest_of_bad = np.nonzero(sl[0, :, 7 // L] != 0xffffffff)[0]
+            assert N - 1 in dest_of_bad                     # the out-of-range index went to the last shard
