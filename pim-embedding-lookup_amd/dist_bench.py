@@ -29,7 +29,6 @@ With the auto policy the sharded exchange is still measured in the same run as a
 batch slot."""
 from __future__ import annotations
 
-import ctypes as C
 import json
 import os
 import sys
@@ -357,6 +356,8 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
     import torch
     import torch.distributed as dist
     import pim_embedding_lookup_amd as pel
+    from importlib import import_module
+    sh = import_module("pim-embedding-lookup_amd.sharding")
 
     rank, world, dev, backend, stage_cpu = ctx["rank"], ctx["world"], ctx["dev"], ctx["backend"], ctx["stage_cpu"]
 
@@ -384,13 +385,12 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
     rng = np.random.default_rng(1 + rank)
     idx_host = [[gen(rng, n, B * L).view(np.int32) for n in rows_list] for _ in range(NBATCH)]
     off_b = torch.arange(B, dtype=torch.int32, device=dev) * L
-    sz = eng.route_bags_sizes(max(K, 1), B, max(K, 1) * B * L, N) if K else None
-    work = torch.empty(sz["work"], dtype=torch.uint8, device=dev) if K else None    # scratch of one route call
     stream = torch.cuda.current_stream(dev)
     h = stream.cuda_stream
-    side = torch.cuda.Stream(dev)
     native = native_exchange(pel, args, eng, ctx)
-    pad4 = lambda v: (v + 3) & ~3
+    # the exchange itself is library code (sharding.RowRangeExchange); this leg only pipelines its four phases
+    ex = sh.RowRangeExchange(eng, [T + k for k in range(K)], rps, dim, rank, world, dev, n_slots=NBATCH,
+                             stage_cpu=stage_cpu, native=native) if K else None
 
     slots = []
     for j in range(NBATCH):
@@ -400,40 +400,8 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
         if K:
             sl["idx_sh"] = torch.from_numpy(np.stack([idx_host[j][t] for t in sharded])).to(dev)     # [K, B*L]
             sl["route_spec"] = eng.route_tables([(sl["idx_sh"][k].data_ptr(), None, B * L, L, rps[k]) for k in range(K)])
-            sl["req_send"] = torch.empty(sz["send"] // 4, dtype=torch.int32, device=dev)
-            sl["meta"] = torch.zeros(sz["meta"] // 4, dtype=torch.int32, device=dev)
-            sl["slotmap"] = torch.empty(sz["slots"] // 4, dtype=torch.int32, device=dev)
-            sl["counts_in"] = torch.zeros((N, K, 2), dtype=torch.int32, device=dev)
-            sl["counts_host"] = torch.zeros((2, N, K, 2), dtype=torch.int32).pin_memory()   # [0] sent, [1] received
-            sl["counts_ev"] = torch.cuda.Event()
             sl["out_sh"] = torch.zeros((K, B, dim), dtype=torch.float32, device=dev)
-            sl["req_recv"] = torch.empty(16, dtype=torch.int32, device=dev)
-            sl["ret_send"] = torch.empty((4, dim), dtype=torch.float32, device=dev)
-            sl["ret_recv"] = torch.empty((4, dim), dtype=torch.float32, device=dev)
         slots.append(sl)
-
-    def grown(sl, name, n, shape_tail=()):
-        """Grow-only device buffer of at least n leading elements (25 % headroom): sized by the counts, never fixed."""
-        buf = sl[name]
-        if buf.shape[0] < n:
-            sl[name] = buf = torch.empty((n + n // 4 + 16,) + tuple(shape_tail), dtype=buf.dtype, device=dev)
-        return buf
-
-    def exchange(recv, send, out_splits, in_splits):
-        """all_to_all of leading-dimension ranges (RCCL; gloo stages through the host).  Returns a work handle or None."""
-        n_out, n_in = int(sum(out_splits)), int(sum(in_splits))
-        if native is not None:      # stream-ordered on the compute stream
-            esz = send.element_size() * (int(np.prod(send.shape[1:])) if send.dim() > 1 else 1)
-            offs = lambda sp: (C.c_uint64 * (N + 1))(*np.concatenate([[0], np.cumsum(sp)]).astype(np.uint64) * esz)
-            native.all_to_all(send.data_ptr(), offs(in_splits), recv.data_ptr(), offs(out_splits), h)
-            return None
-        if stage_cpu:
-            r = torch.empty((n_out,) + tuple(recv.shape[1:]), dtype=recv.dtype)
-            dist.all_to_all_single(r, send[:n_in].cpu(), output_split_sizes=list(out_splits), input_split_sizes=list(in_splits))
-            recv[:n_out].copy_(r)
-            return None
-        return dist.all_to_all_single(recv[:n_out], send[:n_in], output_split_sizes=list(out_splits),
-                                      input_split_sizes=list(in_splits), async_op=True)
 
     prof = {} if os.environ.get("PIMEMB_DIST_PROFILE") == "1" else None
 
@@ -445,89 +413,26 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
         prof[name] = prof.get(name, 0) + time.perf_counter_ns() - t
         return r
 
-    def issue_route(sl):
-        """route + counts first: the per-(peer, table) {sub-bags, indices} go out before any payload."""
-        eng.route_bags(sl["route_spec"], B, N, sl["req_send"].data_ptr(), sl["meta"].data_ptr(), sl["slotmap"].data_ptr(),
-                       work.data_ptr(), h)
-        counts_out = sl["meta"][:2 * N * K].view(N, K, 2)
-        sl["counts_work"] = exchange(sl["counts_in"], counts_out, [1] * N, [1] * N)
-
-    def issue_requests(sl):
-        """The one host wait of a step: learn the counts, then send the request pieces sized by them."""
-        counts_out = sl["meta"][:2 * N * K].view(N, K, 2)
-        if sl["counts_work"] is not None:
-            with torch.cuda.stream(side):     # off the compute stream: the host waits for route + counts only
-                sl["counts_work"].wait()
-                sl["counts_host"][0].copy_(counts_out, non_blocking=True)
-                sl["counts_host"][1].copy_(sl["counts_in"], non_blocking=True)
-                sl["counts_ev"].record(side)
-            sl["counts_ev"].synchronize()
-        else:
-            sl["counts_host"][0].copy_(counts_out, non_blocking=True)
-            sl["counts_host"][1].copy_(sl["counts_in"], non_blocking=True)
-            stream.synchronize()
-        c = sl["counts_host"].numpy().astype(np.int64)            # [2][peer][table][{n_sub, n_idx}]
-        words = ((c[..., 0] + 3) // 4 * 4 + (c[..., 1] + 3) // 4 * 4).sum(axis=2)     # [2][peer]
-        sl["req_out_words"], sl["req_in_words"] = words[0].tolist(), words[1].tolist()
-        sl["ret_rows_back"] = c[0, :, :, 0].sum(axis=1).tolist()   # partial rows each shard returns to me
-        sl["ret_rows_served"] = c[1, :, :, 0].sum(axis=1).tolist()  # partial rows I return to each source
-        sl["served"] = c[1]
-        recv = grown(sl, "req_recv", int(words[1].sum()))
-        sl["req_work"] = exchange(recv, sl["req_send"], sl["req_in_words"], sl["req_out_words"])
-
-    def serve(sl):
-        """Fused lookup over every request piece received for this batch -> partial rows, laid out per source."""
-        if sl.get("req_work") is not None:
-            sl["req_work"].wait()
-            sl["req_work"] = None
-        c, recv = sl["served"], sl["req_recv"]
-        ret = grown(sl, "ret_send", int(sum(sl["ret_rows_served"])), (dim,))
-        ids, ii, oo, uu = [], [], [], []
-        cur = row = 0
-        for s in range(N):
-            for k in range(K):
-                ns, ni = int(c[s, k, 0]), int(c[s, k, 1])
-                if ns:
-                    ids.append(T + k)
-                    oo.append(recv[cur:cur + ns])
-                    ii.append(recv[cur + pad4(ns):cur + pad4(ns) + ni])
-                    uu.append(ret[row:row + ns])
-                cur += pad4(ns) + pad4(ni)
-                row += ns
-        if ids:
-            eng.lookup_batched(ids, ii, oo, uu, stream=h)
-        back = grown(sl, "ret_recv", int(sum(sl["ret_rows_back"])), (dim,))
-        sl["ret_work"] = exchange(back, ret, sl["ret_rows_back"], sl["ret_rows_served"])
-        return sum(int(c[s, k, 1]) * (row_b + 4) + int(c[s, k, 0]) * (4 + row_b) for s in range(N) for k in range(K))
-
-    def finish(sl):
-        if sl.get("ret_work") is not None:
-            sl["ret_work"].wait()
-            sl["ret_work"] = None
-        eng.unroute_bags(sl["ret_recv"].data_ptr(), sl["meta"].data_ptr(), sl["slotmap"].data_ptr(), K, B, N, dim,
-                         sl["out_sh"].data_ptr(), h)
-
     def step(i):
-        sl, nxt = slots[i % NBATCH], slots[(i + 1) % NBATCH]
+        j, nxt = i % NBATCH, (i + 1) % NBATCH
+        sl = slots[j]
         if K:
-            timed("route+counts", issue_route, nxt)
+            timed("route+counts", ex.route, nxt, slots[nxt]["route_spec"], B, K * B * L)
         if sl["plan_a"] is not None:
             timed("local", sl["plan_a"].launch, h)
         if K:
-            timed("serve+return", serve, sl)
-            timed("wait counts+requests", issue_requests, nxt)
-            timed("finish", finish, sl)
+            timed("serve+return", ex.serve, j)
+            timed("wait counts+requests", ex.send_requests, nxt)
+            timed("finish", ex.finish, j, sl["out_sh"])
 
     def prologue(i):           # batch i's requests on their way before step(i)
         if K:
-            issue_route(slots[i % NBATCH])
-            issue_requests(slots[i % NBATCH])
+            ex.route(i % NBATCH, slots[i % NBATCH]["route_spec"], B, K * B * L)
+            ex.send_requests(i % NBATCH)
 
     def drain(next_i):         # the requests of the batch after the last one are in flight: let them land
-        sl = slots[next_i % NBATCH]
-        if K and sl.get("req_work") is not None:
-            sl["req_work"].wait()
-            sl["req_work"] = None
+        if K:
+            ex.wait_requests(next_i % NBATCH)
         torch.cuda.synchronize()
 
     def outputs(j):
@@ -563,37 +468,16 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
     kernel_us, alg_bytes = 0.0, 0
     if slots[0]["plan_a"] is not None:
         alg_bytes += slots[0]["plan_a"].bytes()[0]
-    probe = slots[it % NBATCH]          # its requests for batch `it` have landed (issued by the last step)
-    if K:
-        if probe.get("req_work") is not None:
-            probe["req_work"].wait()
-            probe["req_work"] = None
+    if K:                                # requests for batch `it` were issued by the last step: let them land
+        ex.wait_requests(it % NBATCH)
         torch.cuda.synchronize()
-        serve_bytes = [0]
-
-        def serve_only(sl):          # the lookup of serve() without its exchange
-            c, recv, ret = sl["served"], sl["req_recv"], sl["ret_send"]
-            ids, ii, oo, uu = [], [], [], []
-            cur = row = 0
-            for s in range(N):
-                for k in range(K):
-                    ns, ni = int(c[s, k, 0]), int(c[s, k, 1])
-                    if ns:
-                        ids.append(T + k); oo.append(recv[cur:cur + ns])
-                        ii.append(recv[cur + pad4(ns):cur + pad4(ns) + ni]); uu.append(ret[row:row + ns])
-                    cur += pad4(ns) + pad4(ni)
-                    row += ns
-            if ids:
-                eng.lookup_batched(ids, ii, oo, uu, stream=h)
-            serve_bytes[0] = sum(int(c[s, k, 1]) * (row_b + 4) + int(c[s, k, 0]) * (4 + row_b)
-                                 for s in range(N) for k in range(K))
-        grown(probe, "ret_send", int(sum(probe["ret_rows_served"])), (dim,))
+    serve_bytes = 0
     for key in ("local", "serve"):
         if (key == "local" and slots[0]["plan_a"] is None) or (key == "serve" and not K):
             continue
-        fn = (lambda q: slots[q % NBATCH]["plan_a"].launch(h)) if key == "local" else (lambda q: serve_only(probe))
+        fn = (lambda q: slots[q % NBATCH]["plan_a"].launch(h)) if key == "local" else (lambda q: ex.lookup_received(it % NBATCH))
         for q in range(4):
-            fn(q)
+            serve_bytes = fn(q) or serve_bytes
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
         for q in range(32):
@@ -601,8 +485,7 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
         e1.record(stream)
         torch.cuda.synchronize()
         kernel_us += e0.elapsed_time(e1) * 1000.0 / 32
-    if K:
-        alg_bytes += serve_bytes[0]
+    alg_bytes += serve_bytes
 
     for _ in range(args.warmup):
         step(it)
@@ -629,8 +512,7 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
     result = None
     if rank == 0:
         ach = alg_bytes / (kernel_us * 1e-6) / 1e9 if kernel_us > 0 else 0.0
-        last = slots[(it - 1) % NBATCH]
-        sent = last["counts_host"][0].numpy().astype(np.int64) if K else np.zeros((N, 1, 2), np.int64)
+        sent = ex.slots[(it - 1) % NBATCH]["sent"] if K else np.zeros((N, 1, 2), np.int64)
         result = ({
             "metric": "pooled-lookups/sec + achieved HBM GB/s, 26-table dim-16 Kaggle, 1/2/4/8 GPU",
             "value": world * args.steps * T * B / wall, "unit": "pooled-lookups/s",

@@ -134,12 +134,25 @@ class ShardedLookup:
         self.local = plan.replicated_units()              # units every rank holds
         # units I must send requests for, grouped by destination rank, in a fixed global order
         self.send_units = [[u for u in plan.units if u.owner == d] for d in range(self.world)]
+        # Row-split tables over the HIP engine take the GPU router + counts-first exchange (RowRangeExchange); the
+        # host-side routing below then only sees replicated and whole tables.  Other backends (the CPU tests'
+        # stand-in) keep the host-routed path for every table.
+        self.split_tables = [t for t, k in enumerate(plan.kinds) if k == ROW_SPLIT]
+        self._rr = None
+        if self.split_tables and isinstance(backend, EngineBackend) and self.device.type == "cuda":
+            mine = {u.table: u.uid for u in self.served}
+            per = [-(-plan.rows[t] // self.world) for t in self.split_tables]
+            self._rr = RowRangeExchange(backend.engine, [mine[t] for t in self.split_tables], per, plan.dim, rank,
+                                        self.world, self.device, group=group,
+                                        stage_cpu=self.comm_device.type != "cuda")
+            self.send_units = [[u for u in us if plan.kinds[u.table] != ROW_SPLIT] for us in self.send_units]
+            self.served = [u for u in self.served if plan.kinds[u.table] != ROW_SPLIT]
 
     # ---- tables -------------------------------------------------------------------------------
     def load_tables(self, table_rows: Callable[[int, int, int], object]) -> None:
         """table_rows(table, row_lo, row_hi) -> [row_hi-row_lo, dim] rows (torch tensor or numpy);
         only the shards this rank serves are requested."""
-        for u in self.served + self.local:
+        for u in self.plan.owned_units(self.rank) + self.local:
             self.backend.load(u.uid, table_rows(u.table, u.row_lo, u.row_hi))
 
     # ---- one step -----------------------------------------------------------------------------
@@ -183,6 +196,10 @@ class ShardedLookup:
         T = len(self.plan.rows)
         assert len(indices) == T and len(offsets) == T
         idx_dtype = indices[0].dtype
+        rr_out = None
+        if self._rr is not None:     # row-split tables: GPU routing, counts first (uint32 row ids at that boundary)
+            rr_out = self._rr.forward([indices[k].to(t.int32).contiguous() for k in self.split_tables],
+                                      [offsets[k].to(t.int32).contiguous() for k in self.split_tables])
         lens = [self._lens(offsets[i], indices[i].numel()) for i in range(T)]
         n_bags = [int(l.numel()) for l in lens]
 
@@ -242,6 +259,9 @@ class ShardedLookup:
 
         # 4. assemble per table; row-split partials are added in shard (rank) order
         result = [None] * T
+        if rr_out is not None:
+            for j, k in enumerate(self.split_tables):
+                result[k] = rr_out[j]
         for j, u in enumerate(self.local):
             result[u.table] = outs[len(self.served) + j]
         for d in range(self.world):
@@ -252,3 +272,197 @@ class ShardedLookup:
                 cur += nb * D
                 result[u.table] = part if result[u.table] is None else result[u.table] + part
         return result
+
+
+# ------------------------------------------------------------------------------------------------
+class RowRangeExchange:
+    """Pooled lookups over tables split by ROW RANGE across the ranks of a torch.distributed group: routing on the
+    GPU, counts first, payload second (include/pimemb.h: emb_route_bags / emb_unroute_bags; SURVEY.md section 8 row E;
+    the reference sends its lengths before every launch, emb_host.h:280-287).
+
+    One step, four phases (each only enqueues work, except the one host wait in `send_requests`):
+
+        route(slot, spec)      every bag cut into per-shard sub-bags; the per-(peer, table) counts leave FIRST
+        send_requests(slot)    host reads the counts, request pieces travel as all_to_all with split sizes from them
+        serve(slot)            ONE fused engine lookup over every piece received -> one partial row per sub-bag,
+                               returned with split sizes from the same counts
+        finish(slot, out)      partial rows added in shard order from +0 into out[k][b][:]
+
+    `forward` runs them back to back; a pipelined caller (dist_bench.run_rows) interleaves the phases of consecutive
+    batches over several slots.  Nothing has a capacity that skewed indices could overflow.  Shard k of this rank is
+    engine table `shard_table_ids[k]` holding rows [rank*rows_per_shard[k], (rank+1)*rows_per_shard[k])."""
+
+    def __init__(self, engine, shard_table_ids, rows_per_shard, dim: int, rank: int, world: int, device,
+                 n_slots: int = 1, group=None, stage_cpu: bool = False, native=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.engine, self.ids, self.rps = engine, list(shard_table_ids), [int(r) for r in rows_per_shard]
+        self.K, self.N, self.dim, self.rank = len(self.ids), int(world), int(dim), int(rank)
+        self.device, self.group, self.stage_cpu, self.native = torch.device(device), group, stage_cpu, native
+        self.side = torch.cuda.Stream(self.device)
+        self.slots = [dict() for _ in range(n_slots)]
+        self.work = None
+        if self.K == 0 or self.K > 64:
+            raise ValueError("1..64 row-split tables per exchange")
+
+    # ---- buffers ------------------------------------------------------------------------------------
+    def _grown(self, sl, name, n, dtype, tail=()):
+        """Grow-only device buffer of >= n leading elements (25 % headroom): sized by the counts, never fixed."""
+        buf = sl.get(name)
+        if buf is None or buf.shape[0] < n:
+            sl[name] = buf = self.torch.empty((n + n // 4 + 16,) + tuple(tail), dtype=dtype, device=self.device)
+        return buf
+
+    def _prepare(self, sl, n_bags, total_indices):
+        t = self.torch
+        sz = self.engine.route_bags_sizes(self.K, n_bags, total_indices, self.N)
+        self._grown(sl, "req_send", sz["send"] // 4, t.int32)
+        self._grown(sl, "slotmap", sz["slots"] // 4, t.int32)
+        if "meta" not in sl:
+            sl["meta"] = t.zeros(sz["meta"] // 4, dtype=t.int32, device=self.device)
+            sl["counts_in"] = t.zeros((self.N, self.K, 2), dtype=t.int32, device=self.device)
+            sl["counts_host"] = t.zeros((2, self.N, self.K, 2), dtype=t.int32).pin_memory()   # [0] sent, [1] received
+            sl["counts_ev"] = t.cuda.Event()
+        if self.work is None or self.work.numel() < sz["work"]:
+            self.work = t.empty(sz["work"] + sz["work"] // 4, dtype=t.uint8, device=self.device)   # scratch of one route call
+
+    def _exchange(self, recv, send, out_splits, in_splits):
+        """all_to_all of leading-dimension ranges (RCCL; gloo stages through the host).  Work handle or None."""
+        t, dist = self.torch, self.dist
+        n_out, n_in = int(sum(out_splits)), int(sum(in_splits))
+        if self.native is not None:      # stream-ordered on the compute stream (emb_comm_all_to_all)
+            import ctypes as C
+            esz = send.element_size()
+            for d in send.shape[1:]:
+                esz *= int(d)
+            offs = lambda sp: (C.c_uint64 * (self.N + 1))(*([0] + [int(x) * esz for x in _cumsum(sp)]))
+            self.native.all_to_all(send.data_ptr(), offs(in_splits), recv.data_ptr(), offs(out_splits),
+                                   t.cuda.current_stream(self.device).cuda_stream)
+            return None
+        if self.stage_cpu:
+            r = t.empty((n_out,) + tuple(recv.shape[1:]), dtype=recv.dtype)
+            dist.all_to_all_single(r, send[:n_in].cpu(), output_split_sizes=list(out_splits),
+                                   input_split_sizes=list(in_splits), group=self.group)
+            recv[:n_out].copy_(r)
+            return None
+        return dist.all_to_all_single(recv[:n_out], send[:n_in], output_split_sizes=list(out_splits),
+                                      input_split_sizes=list(in_splits), group=self.group, async_op=True)
+
+    # ---- phases -------------------------------------------------------------------------------------
+    def route(self, slot: int, spec, n_bags: int, total_indices: int) -> None:
+        """spec: EmbeddingEngine.route_tables([...]) over this rank's K index arrays (uint32 row ids)."""
+        sl = self.slots[slot]
+        self._prepare(sl, n_bags, total_indices)
+        sl["n_bags"] = n_bags
+        h = self.torch.cuda.current_stream(self.device).cuda_stream
+        self.engine.route_bags(spec, n_bags, self.N, sl["req_send"].data_ptr(), sl["meta"].data_ptr(),
+                               sl["slotmap"].data_ptr(), self.work.data_ptr(), h)
+        counts_out = sl["meta"][:2 * self.N * self.K].view(self.N, self.K, 2)
+        sl["counts_work"] = self._exchange(sl["counts_in"], counts_out, [1] * self.N, [1] * self.N)
+
+    def send_requests(self, slot: int) -> None:
+        """The one host wait of a step: learn the counts, then send the request pieces sized by them."""
+        t, sl = self.torch, self.slots[slot]
+        counts_out = sl["meta"][:2 * self.N * self.K].view(self.N, self.K, 2)
+        if sl.get("counts_work") is not None:
+            with t.cuda.stream(self.side):    # off the compute stream: the host waits for the router + counts only
+                sl["counts_work"].wait()
+                sl["counts_host"][0].copy_(counts_out, non_blocking=True)
+                sl["counts_host"][1].copy_(sl["counts_in"], non_blocking=True)
+                sl["counts_ev"].record(self.side)
+            sl["counts_ev"].synchronize()
+            sl["counts_work"] = None
+        else:
+            sl["counts_host"][0].copy_(counts_out, non_blocking=True)
+            sl["counts_host"][1].copy_(sl["counts_in"], non_blocking=True)
+            t.cuda.current_stream(self.device).synchronize()
+        c = sl["counts_host"].numpy().astype("int64")             # [2][peer][table][{n_sub, n_idx}]
+        words = ((c[..., 0] + 3) // 4 * 4 + (c[..., 1] + 3) // 4 * 4).sum(axis=2)     # [2][peer]
+        sl["req_out_words"], sl["req_in_words"] = words[0].tolist(), words[1].tolist()
+        sl["ret_rows_back"] = c[0, :, :, 0].sum(axis=1).tolist()    # partial rows each shard returns to me
+        sl["ret_rows_served"] = c[1, :, :, 0].sum(axis=1).tolist()  # partial rows I return to each source
+        sl["sent"], sl["served"] = c[0], c[1]
+        recv = self._grown(sl, "req_recv", int(words[1].sum()), t.int32)
+        sl["req_work"] = self._exchange(recv, sl["req_send"], sl["req_in_words"], sl["req_out_words"])
+
+    def lookup_received(self, slot: int) -> int:
+        """The fused lookup over every request piece received for this slot (no exchange).  Returns its algorithmic bytes."""
+        t, sl = self.torch, self.slots[slot]
+        c, recv = sl["served"], sl["req_recv"]
+        ret = self._grown(sl, "ret_send", int(sum(sl["ret_rows_served"])), t.float32, (self.dim,))
+        ids, ii, oo, uu = [], [], [], []
+        cur = row = nbytes = 0
+        row_b = self.dim * 4
+        for s in range(self.N):
+            for k in range(self.K):
+                ns, ni = int(c[s, k, 0]), int(c[s, k, 1])
+                p4 = (ns + 3) // 4 * 4
+                if ns:
+                    ids.append(self.ids[k])
+                    oo.append(recv[cur:cur + ns])
+                    ii.append(recv[cur + p4:cur + p4 + ni])
+                    uu.append(ret[row:row + ns])
+                    nbytes += ni * (row_b + 4) + ns * (4 + row_b)
+                cur += p4 + (ni + 3) // 4 * 4
+                row += ns
+        if ids:
+            self.engine.lookup_batched(ids, ii, oo, uu, stream=t.cuda.current_stream(self.device).cuda_stream)
+        return nbytes
+
+    def serve(self, slot: int) -> int:
+        t, sl = self.torch, self.slots[slot]
+        if sl.get("req_work") is not None:
+            sl["req_work"].wait()
+            sl["req_work"] = None
+        nbytes = self.lookup_received(slot)
+        back = self._grown(sl, "ret_recv", int(sum(sl["ret_rows_back"])), t.float32, (self.dim,))
+        sl["ret_work"] = self._exchange(back, sl["ret_send"], sl["ret_rows_back"], sl["ret_rows_served"])
+        return nbytes
+
+    def finish(self, slot: int, out) -> None:
+        """out: float32 [K, n_bags, dim] on the device."""
+        sl = self.slots[slot]
+        if sl.get("ret_work") is not None:
+            sl["ret_work"].wait()
+            sl["ret_work"] = None
+        self.engine.unroute_bags(sl["ret_recv"].data_ptr(), sl["meta"].data_ptr(), sl["slotmap"].data_ptr(), self.K,
+                                 sl["n_bags"], self.N, self.dim, out.data_ptr(),
+                                 self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def wait_requests(self, slot: int) -> None:
+        sl = self.slots[slot]
+        if sl.get("req_work") is not None:
+            sl["req_work"].wait()
+            sl["req_work"] = None
+
+    # ---- one whole step -----------------------------------------------------------------------------
+    def forward(self, indices, offsets=None, fixed_pooling: int = 0, out=None, slot: int = 0):
+        """indices[k]: this rank's index array of row-split table k (CUDA int32 = uint32 row ids); offsets[k]: bag starts
+        (int32, same bag count for every table) or None with fixed_pooling.  Returns float32 [K, n_bags, dim]."""
+        t = self.torch
+        if offsets is not None:
+            n_bags = int(offsets[0].numel())
+            if any(int(o.numel()) != n_bags for o in offsets):
+                raise ValueError("every row-split table needs the same number of bags in one exchange (one batch)")
+            spec = [(i.data_ptr(), o.data_ptr(), i.numel(), 0, r) for i, o, r in zip(indices, offsets, self.rps)]
+        else:
+            n_bags = int(indices[0].numel()) // int(fixed_pooling)
+            spec = [(i.data_ptr(), None, i.numel(), fixed_pooling, r) for i, r in zip(indices, self.rps)]
+        if out is None:
+            out = t.empty((self.K, n_bags, self.dim), dtype=t.float32, device=self.device)
+        if n_bags == 0:
+            raise ValueError("RowRangeExchange.forward needs at least one bag per rank")
+        self.route(slot, self.engine.route_tables(spec), n_bags, sum(int(i.numel()) for i in indices))
+        self.send_requests(slot)
+        self.serve(slot)
+        self.finish(slot, out)
+        return out
+
+
+def _cumsum(xs):
+    acc, out = 0, []
+    for x in xs:
+        acc += int(x)
+        out.append(acc)
+    return out
