@@ -304,7 +304,7 @@ def run_whole(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
             "roofline": {"bound": "hbm", "achieved": ach, "peak": hbm_peak_gbs, "unit": "GB/s",
                          "frac": ach / hbm_peak_gbs, "traffic": None, "kernel_us": kernel_us,
                          "algorithmic_bytes": alg_bytes,
-                         "note": "rank 0's two local launches (replicated + served tables), kernel-only"},
+                         "basis": "algorithmic bytes (no PMC profile of the N > 1 legs; a pooled launch is partly cache-served and can exceed 1: the same kernels at N = 1 are priced on measured bytes, profiles/traffic.json)", "note": "rank 0's two local launches (replicated + served tables), kernel-only"},
         })
     dist.barrier()
     for sl in slots:
@@ -536,7 +536,7 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
             "roofline": {"bound": "hbm", "achieved": ach, "peak": hbm_peak_gbs, "unit": "GB/s",
                          "frac": ach / hbm_peak_gbs, "traffic": None, "kernel_us": kernel_us,
                          "algorithmic_bytes": alg_bytes,
-                         "note": "rank 0's two lookup launches (replicated tables + served request pieces), kernel-only"},
+                         "basis": "algorithmic bytes (no PMC profile of the N > 1 legs; a pooled launch is partly cache-served and can exceed 1: the same kernels at N = 1 are priced on measured bytes, profiles/traffic.json)", "note": "rank 0's two lookup launches (replicated tables + served request pieces), kernel-only"},
         })
     dist.barrier()
     for sl in slots:
@@ -622,7 +622,7 @@ def run_dp(args, hbm_peak_gbs: float, ctx):
                                       % (T, sum(rows_list) * dim * 4 / 1e9)},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": hbm_peak_gbs, "unit": "GB/s",
                          "frac": ach / hbm_peak_gbs, "traffic": None, "kernel_us": kernel_us,
-                         "algorithmic_bytes": alg_bytes, "note": "rank 0's fused launch, HIP events over the timed region"},
+                         "algorithmic_bytes": alg_bytes, "basis": "algorithmic bytes (no PMC profile of the N > 1 legs; a pooled launch is partly cache-served and can exceed 1: the same kernels at N = 1 are priced on measured bytes, profiles/traffic.json)", "note": "rank 0's fused launch, HIP events over the timed region"},
         }
     for p in plans:
         p.destroy()

@@ -387,6 +387,15 @@ class EmbeddingEngine:
         _l.check(self._L.emb_lookup_batched(self._h, arr_ptr, T, itype, _l.EMB_MEM_DEVICE, stream))
         return out
 
+    def lookup_descs(self, descs: np.ndarray, itype: int = _l.EMB_IDX_U32, stream: int | None = None) -> None:
+        """One fused launch over a numpy array of emb_lookup_desc records (dtype EmbeddingEngine._DESC_DT) holding DEVICE
+        pointers -- for callers that compute their buffer addresses arithmetically (the sharded exchange serves N x K
+        request pieces per step this way).  The caller keeps the buffers alive; nothing is allocated here."""
+        if descs.dtype != self._DESC_DT or not descs.flags["C_CONTIGUOUS"]:
+            raise TypeError("descs must be a contiguous array of EmbeddingEngine._DESC_DT records")
+        _l.check(self._L.emb_lookup_batched(self._h, C.cast(descs.ctypes.data, C.POINTER(_l.EmbLookupDesc)), len(descs),
+                                            itype, _l.EMB_MEM_DEVICE, stream))
+
     def lookup_batched(self, table_ids: Sequence[int], indices: Sequence, offsets: Sequence,
                        outs: Sequence | None = None, fixed_pooling=0, stream: int | None = None):
         """All tables in one fused launch; returns the list of pooled [B_t, D] outputs

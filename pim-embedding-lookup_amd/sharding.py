@@ -387,28 +387,29 @@ class RowRangeExchange:
         sl["req_work"] = self._exchange(recv, sl["req_send"], sl["req_in_words"], sl["req_out_words"])
 
     def lookup_received(self, slot: int) -> int:
-        """The fused lookup over every request piece received for this slot (no exchange).  Returns its algorithmic bytes."""
+        """The fused lookup over every request piece received for this slot (no exchange).  Returns its algorithmic
+        bytes.  The N x K descriptors are laid out arithmetically from the counts (numpy), one C call."""
+        import numpy as np
         t, sl = self.torch, self.slots[slot]
-        c, recv = sl["served"], sl["req_recv"]
+        c, recv = sl["served"], sl["req_recv"]                      # c: int64 [source][table][{n_sub, n_idx}]
         ret = self._grown(sl, "ret_send", int(sum(sl["ret_rows_served"])), t.float32, (self.dim,))
-        ids, ii, oo, uu = [], [], [], []
-        cur = row = nbytes = 0
+        ns, ni = c[:, :, 0].reshape(-1), c[:, :, 1].reshape(-1)
+        p4s, p4i = (ns + 3) // 4 * 4, (ni + 3) // 4 * 4
+        start = np.concatenate([[0], np.cumsum(p4s + p4i)[:-1]])      # word offset of every (source, table) piece
+        row0 = np.concatenate([[0], np.cumsum(ns)[:-1]])
+        live = np.nonzero(ns > 0)[0]
+        if live.size == 0:
+            return 0
         row_b = self.dim * 4
-        for s in range(self.N):
-            for k in range(self.K):
-                ns, ni = int(c[s, k, 0]), int(c[s, k, 1])
-                p4 = (ns + 3) // 4 * 4
-                if ns:
-                    ids.append(self.ids[k])
-                    oo.append(recv[cur:cur + ns])
-                    ii.append(recv[cur + p4:cur + p4 + ni])
-                    uu.append(ret[row:row + ns])
-                    nbytes += ni * (row_b + 4) + ns * (4 + row_b)
-                cur += p4 + (ni + 3) // 4 * 4
-                row += ns
-        if ids:
-            self.engine.lookup_batched(ids, ii, oo, uu, stream=t.cuda.current_stream(self.device).cuda_stream)
-        return nbytes
+        d = np.zeros(live.size, dtype=self.engine._DESC_DT)
+        d["table_id"] = np.asarray(self.ids, dtype=np.uint32)[live % self.K]
+        d["offsets"] = recv.data_ptr() + start[live] * 4
+        d["indices"] = recv.data_ptr() + (start[live] + p4s[live]) * 4
+        d["n_indices"] = ni[live]
+        d["n_bags"] = ns[live]
+        d["pooled"] = ret.data_ptr() + row0[live] * row_b
+        self.engine.lookup_descs(d, stream=t.cuda.current_stream(self.device).cuda_stream)
+        return int((ni[live] * (row_b + 4) + ns[live] * (4 + row_b)).sum())
 
     def serve(self, slot: int) -> int:
         t, sl = self.torch, self.slots[slot]
