@@ -1278,8 +1278,10 @@ int emb_route_bags(emb_engine *e, const emb_route_table *tables, uint32_t n_tabl
     if (n_shards == 0 || n_shards > 255 || n_bags == 0 || n_bags * n_shards > 0x7fffffffull * 256)
         return fail(EMB_ERR_INVALID, "emb_route_bags: n_shards must be 1..255 and n_bags > 0");
     pimemb::RouteBagDesc d[pimemb::kRouteBagMaxTables];
+    uint64_t words = 8ull * n_tables * n_shards + 4;     // word offsets inside `send` are 32-bit
     for (uint32_t k = 0; k < n_tables; k++) {
         const emb_route_table &t = tables[k];
+        words += t.n_indices + std::min<uint64_t>(t.n_indices, n_bags * n_shards);
         if (t.rows_per_shard == 0) return fail(EMB_ERR_INVALID, "emb_route_bags: tables[%u].rows_per_shard is 0", k);
         if (t.n_indices && !t.indices) return fail(EMB_ERR_INVALID, "emb_route_bags: tables[%u].indices is NULL", k);
         if (t.n_indices > 0xffffffffull) return fail(EMB_ERR_UNSUPPORTED, "emb_route_bags: tables[%u]: more than 2^32-1 indices", k);
@@ -1287,6 +1289,9 @@ int emb_route_bags(emb_engine *e, const emb_route_table *tables, uint32_t n_tabl
             return fail(EMB_ERR_INVALID, "emb_route_bags: tables[%u]: fixed_pooling*n_bags != n_indices", k);
         d[k] = pimemb::RouteBagDesc{t.indices, t.offsets, t.n_indices, t.fixed_pooling, t.rows_per_shard};
     }
+    if (words > 0xffffffffull)
+        return fail(EMB_ERR_UNSUPPORTED, "emb_route_bags: %llu request words in one call (limit 2^32-1): route fewer tables per call",
+                    (unsigned long long)words);
     DeviceGuard g(e->device);
     HIP_TRY(pimemb::launch_route_bags(d, n_tables, n_bags, n_shards, static_cast<uint32_t *>(send), meta, slots,
                                       static_cast<uint32_t *>(work), static_cast<hipStream_t>(stream)));

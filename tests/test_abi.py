@@ -53,12 +53,14 @@ def test_struct_layouts(pel):
     assert C.sizeof(pel.lib.EmbConfig) == 12
     assert C.sizeof(pel.lib.EmbStats) == 5 * 8 + 6 * 8 + 5 * 8
     assert C.sizeof(pel.lib.DpuRuntimeTotals) == 48      # six doubles, emb_host.h:41-48
+    assert C.sizeof(pel.lib.EmbRouteTable) == 32 and pel.lib.EmbRouteTable.rows_per_shard.offset == 28
     assert pel.lib.EmbLookupDesc.indices.offset == 8 and pel.lib.EmbLookupDesc.pooled.offset == 40
 
 
 def test_header_compiles_as_c_and_cxx(tmp_path):
     src = tmp_path / "t.c"
-    src.write_text('#include "pimemb.h"\nint main(void){emb_lookup_desc d; (void)d; return sizeof(emb_stats)==128?0:1;}\n')
+    src.write_text('#include "pimemb.h"\nint main(void){emb_lookup_desc d; (void)d; '
+                   'return (sizeof(emb_stats)==128 && sizeof(emb_route_table)==32)?0:1;}\n')
     for cc, std in (("gcc", "-std=c99"), ("g++", "-std=c++11")):
         exe = tmp_path / ("t_" + cc)
         subprocess.check_call([cc, std, "-Wall", "-Werror", "-x", "c" if cc == "gcc" else "c++",
