@@ -82,7 +82,7 @@ def parse_args():
                          "batch to the engine (emb_set_hot_rows: served from LDS) when they cover >= 5 %% of "
                          "that table's accesses; 0 = no hint")
     ap.add_argument("--prewarm-ms", type=float, default=250.0,
-                    help="N=1: untimed device pre-warm before the W warm-up steps (clock ramp of a fresh process); 0 = off")
+                    help="untimed device pre-warm before the W warm-up steps (clock ramp of a fresh process; N=1 and the data-parallel N>1 leg); 0 = off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     return ap.parse_args()

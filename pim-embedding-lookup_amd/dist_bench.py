@@ -269,10 +269,11 @@ def run_whole(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
         step(it)
         it += 1
     drain()
+    local_el = time.perf_counter() - t0     # this rank's K steps are complete (drain synchronises the device)
     dist.barrier()
     torch.cuda.synchronize()
-    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if stage_cpu else dev)
-    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    el = torch.tensor([local_el], dtype=torch.float64, device="cpu" if stage_cpu else dev)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)   # job time = the slowest rank's, all ranks having started together
     wall = float(el.item())
     # what the timed loop left behind: the last step's 26 outputs, bit for bit
     res = outputs(slots[(it - 1) % NBATCH])
@@ -498,9 +499,10 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
         step(it)
         it += 1
     drain(it)
+    local_el = time.perf_counter() - t0     # this rank's K steps are complete (drain synchronises the device)
     dist.barrier()
     torch.cuda.synchronize()
-    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if stage_cpu else dev)
+    el = torch.tensor([local_el], dtype=torch.float64, device="cpu" if stage_cpu else dev)
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
     wall = float(el.item())
     verify(it - 1, "last timed")                     # what the timed loop left behind
@@ -580,6 +582,13 @@ def run_dp(args, hbm_peak_gbs: float, ctx):
         idx = torch.from_numpy(idx_host[0][t]).to(dev)
         if not torch.equal(plans[0].outputs[t], expected_pooled(torch, t, idx, dim, L)):
             raise AssertionError(f"rank {rank}: table {t} differs from the expected rows")
+    # device pre-warm (untimed, before the W warm-up steps), as in the single-GPU run: a fresh process starts with idle clocks
+    prewarm_ms, n_pre, t_pre = float(getattr(args, "prewarm_ms", 250.0) or 0.0), 0, time.perf_counter()
+    while time.perf_counter() - t_pre < prewarm_ms * 1e-3:
+        for _ in range(64):
+            plans[n_pre % NBATCH].launch(h)
+            n_pre += 1
+        torch.cuda.synchronize()
     for i in range(args.warmup):
         plans[i % NBATCH].launch(h)
     torch.cuda.synchronize()
@@ -592,10 +601,11 @@ def run_dp(args, hbm_peak_gbs: float, ctx):
         plans[i % NBATCH].launch(h)
     e1.record(stream)
     torch.cuda.synchronize()
+    local_el = time.perf_counter() - t0     # this rank's K steps are complete
     dist.barrier()
     torch.cuda.synchronize()
-    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if stage_cpu else dev)
-    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    el = torch.tensor([local_el], dtype=torch.float64, device="cpu" if stage_cpu else dev)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)   # job time = the slowest rank's, all ranks having started together
     wall = float(el.item())
     kernel_us = e0.elapsed_time(e1) * 1000.0 / args.steps
     alg_bytes = plans[0].bytes()[0]
@@ -617,6 +627,7 @@ def run_dp(args, hbm_peak_gbs: float, ctx):
             "config": {"workload": "%s, dim %d fp32, B=%d bags/table PER RANK, L=%d, u32 "
                                    "indices+offsets, %s indices, %d rotating batches" % (label, dim, B, L, dist_name, NBATCH),
                        "tables": T, "dim": dim, "bags_per_table_per_rank": B, "global_bags_per_table": world * B,
+                       "prewarm_ms": prewarm_ms, "prewarm_launches": n_pre,
                        "parallelism": "all %d tables (%.2f GB) replicated on every rank (they fit the per-GPU "
                                       "replication budget); bags data-parallel, no data-path collective"
                                       % (T, sum(rows_list) * dim * 4 / 1e9)},
