@@ -665,6 +665,7 @@ def run(args, hbm_peak_gbs: float) -> None:
     dist.init_process_group(backend, rank=rank, world_size=world,
                             **({"device_id": dev} if backend == "nccl" else {}))
     ctx = dict(rank=rank, world=world, dev=dev, backend=backend, stage_cpu=backend != "nccl")
+    dist.barrier()       # the first collective sets the communicator's channels up (milliseconds): not right before a clock starts
 
     rows_list, dim, _, _ = table_set_of(pel, args)
     TABLE_SCALE.update({t: float(np.float32(2.0 / np.sqrt(n))) for t, n in enumerate(rows_list)})
