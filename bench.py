@@ -407,8 +407,9 @@ def run_single(args):
     for x in extra:
         stream.wait_stream(x)
     ev1.record(stream)
-    torch.cuda.synchronize()
+    ev1.synchronize()                        # the event behind the K-th launch has fired: the K steps are complete
     wall = time.perf_counter() - t0
+    torch.cuda.synchronize()                 # (device-wide wait: returns up to a millisecond later once RCCL is loaded)
     dev_ms = ev0.elapsed_time(ev1)
     kernel_us = dev_ms * 1000.0 / args.steps          # avg launch duration on the launch stream
 

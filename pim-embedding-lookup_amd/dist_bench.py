@@ -595,13 +595,21 @@ def run_dp(args, hbm_peak_gbs: float, ctx):
     dist.barrier()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    dbg = [] if os.environ.get("PIMEMB_DIST_PROFILE") == "1" else None
     t0 = time.perf_counter()
     e0.record(stream)
+    if dbg is not None: dbg.append(("e0.record", time.perf_counter() - t0))
     for i in range(args.steps):
         plans[i % NBATCH].launch(h)
+        if dbg is not None and i in (0, 1, args.steps - 1): dbg.append((f"launch {i}", time.perf_counter() - t0))
     e1.record(stream)
+    if dbg is not None: dbg.append(("e1.record", time.perf_counter() - t0))
+    e1.synchronize()
+    local_el = time.perf_counter() - t0     # this rank's K steps are complete (the event after the K-th launch has fired)
     torch.cuda.synchronize()
-    local_el = time.perf_counter() - t0     # this rank's K steps are complete
+    if dbg is not None: dbg.append(("device sync", time.perf_counter() - t0))
+    if dbg is not None and rank == 0:
+        print("[dist_bench] run_dp timed region, seconds since t0:", dbg, "sync", local_el, flush=True)
     dist.barrier()
     torch.cuda.synchronize()
     el = torch.tensor([local_el], dtype=torch.float64, device="cpu" if stage_cpu else dev)
