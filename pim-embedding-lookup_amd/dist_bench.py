@@ -207,11 +207,14 @@ def run_whole(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
             sl["plan_b"].launch(sh_handle)
         pending[0] = collective(sl)
 
+    done_ev = torch.cuda.Event()
+
     def drain():
         if pending[0] is not None:
             pending[0].wait()
             pending[0] = None
-        torch.cuda.synchronize()
+        done_ev.record(stream)       # everything of the loop is ordered before this event on the compute stream
+        done_ev.synchronize()        # (a device-wide synchronize returns up to a millisecond later once RCCL is loaded)
 
     def outputs(sl):
         res = [None] * T
@@ -269,7 +272,7 @@ def run_whole(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
         step(it)
         it += 1
     drain()
-    local_el = time.perf_counter() - t0     # this rank's K steps are complete (drain synchronises the device)
+    local_el = time.perf_counter() - t0     # this rank's K steps are complete (drain waits for the compute stream)
     dist.barrier()
     torch.cuda.synchronize()
     el = torch.tensor([local_el], dtype=torch.float64, device="cpu" if stage_cpu else dev)
@@ -431,10 +434,13 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
             ex.route(i % NBATCH, slots[i % NBATCH]["route_spec"], B, K * B * L)
             ex.send_requests(i % NBATCH)
 
+    done_ev = torch.cuda.Event()
+
     def drain(next_i):         # the requests of the batch after the last one are in flight: let them land
         if K:
             ex.wait_requests(next_i % NBATCH)
-        torch.cuda.synchronize()
+        done_ev.record(stream)       # everything of the loop is ordered before this event on the compute stream
+        done_ev.synchronize()        # (a device-wide synchronize returns up to a millisecond later once RCCL is loaded)
 
     def outputs(j):
         res = [None] * T
@@ -499,7 +505,7 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
         step(it)
         it += 1
     drain(it)
-    local_el = time.perf_counter() - t0     # this rank's K steps are complete (drain synchronises the device)
+    local_el = time.perf_counter() - t0     # this rank's K steps are complete (drain waits for the compute stream)
     dist.barrier()
     torch.cuda.synchronize()
     el = torch.tensor([local_el], dtype=torch.float64, device="cpu" if stage_cpu else dev)
