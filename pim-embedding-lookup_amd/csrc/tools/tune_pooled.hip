@@ -420,13 +420,40 @@ int main(int argc, char **argv) {
         vars.push_back(make_variant<BagCfg<128, 16, true, false, 8, 1, 1, false, false, true>, false>("v1 group blk128 U16"));
     }
     //                        BLOCK U  ntS   ntM  inflight minW
-    vars.push_back(make_stream<BagCfg<256, 8, true, false, 8, 8>, 2048>("v4 stream blk256 U8 minw8 G2048"));
-    vars.push_back(make_stream<BagCfg<256, 8, true, false, 8, 8>, 4096>("v4 stream blk256 U8 minw8 G4096"));
-    vars.push_back(make_stream<BagCfg<256, 8, true, false, 8, 8>, 1024>("v4 stream blk256 U8 minw8 G1024"));
-    vars.push_back(make_stream<BagCfg<256, 8, true, false, 8, 1>, 2048>("v4 stream blk256 U8 minw1 G2048"));
-    vars.push_back(make_stream<BagCfg<256, 16, true, false, 8, 1>, 2048>("v4 stream blk256 U16 minw1 G2048"));
-    vars.push_back(make_stream<BagCfg<256, 16, true, false, 8, 1>, 1280>("v4 stream blk256 U16 minw1 G1280"));
-    vars.push_back(make_stream<BagCfg<64, 8, true, false, 8, 8>, 8192>("v4 stream blk64 U8 minw8 G8192"));
+    if (getenv("TUNE_STREAM")) {   // the rejected persistent / prefetching / rolling-ring variant (see the note at the top)
+        vars.push_back(make_stream<BagCfg<256, 8, true, false, 8, 8>, 2048>("v4 stream blk256 U8 minw8 G2048"));
+        vars.push_back(make_stream<BagCfg<256, 8, true, false, 8, 8>, 4096>("v4 stream blk256 U8 minw8 G4096"));
+        vars.push_back(make_stream<BagCfg<256, 8, true, false, 8, 8>, 1024>("v4 stream blk256 U8 minw8 G1024"));
+        vars.push_back(make_stream<BagCfg<256, 8, true, false, 8, 1>, 2048>("v4 stream blk256 U8 minw1 G2048"));
+        vars.push_back(make_stream<BagCfg<256, 16, true, false, 8, 1>, 2048>("v4 stream blk256 U16 minw1 G2048"));
+        vars.push_back(make_stream<BagCfg<256, 16, true, false, 8, 1>, 1280>("v4 stream blk256 U16 minw1 G1280"));
+        vars.push_back(make_stream<BagCfg<64, 8, true, false, 8, 8>, 8192>("v4 stream blk64 U8 minw8 G8192"));
+    }
+    if (getenv("TUNE_HOT")) {      // LDS hot rows, and cache policy of the rows that MISS the hot set
+        const uint32_t wg = std::max(1u, 8192u / T);
+        //                              BLOCK U  ntS   ntM  inflight minW batches ntRow  spec   idxShuffle
+        vars.push_back(make_variant<BagCfg<256, 8, true, false, 8, 1, 1, true, false, true>, false>("v1 group, ALL rows nt"));
+        vars.push_back(make_hot<BagCfg<1024, 8, true, false, 8, 1, 1, false, false, true>>("v3 hot100 SHIP", 100, wg));
+        vars.push_back(make_hot<BagCfg<1024, 8, true, false, 8, 1, 1, true, false, true>>("v3 hot100, misses nt", 100, wg));
+        vars.push_back(make_hot<BagCfg<1024, 8, true, false, 8, 1, 1, false, false, true>>("v3 hot32", 32, wg));
+        vars.push_back(make_hot<BagCfg<1024, 8, true, false, 8, 1, 1, true, false, true>>("v3 hot32, misses nt", 32, wg));
+        vars.push_back(make_hot<BagCfg<512, 8, true, false, 8, 1, 1, false, false, true>>("v3 hot100 blk512", 100, 2 * wg));
+        vars.push_back(make_hot<BagCfg<512, 8, true, false, 8, 1, 1, true, false, true>>("v3 hot100 blk512, misses nt", 100, 2 * wg));
+    }
+    if (getenv("TUNE_HOT_SWEEP")) {   // how many hot rows, how many persistent workgroups
+        static char names[64][64];
+        int ni = 0;
+        for (uint32_t hot : {8u, 16u, 32u, 64u})
+            for (uint32_t total : {4096u, 8192u, 16384u}) {
+                snprintf(names[ni], 64, "v3 blk1024 hot%u wgs%u", hot, total);
+                vars.push_back(make_hot<BagCfg<1024, 8, true, false, 8, 1, 1, false, false, true>>(names[ni++], hot, std::max(1u, total / T)));
+            }
+        for (uint32_t hot : {16u, 32u})
+            for (uint32_t total : {8192u, 16384u, 32768u}) {
+                snprintf(names[ni], 64, "v3 blk256 hot%u wgs%u", hot, total);
+                vars.push_back(make_hot<BagCfg<256, 8, true, false, 8, 1, 1, false, false, true>>(names[ni++], hot, std::max(1u, total / T)));
+            }
+    }
     if (!getenv("TUNE_ALL")) goto build_done;
     vars.push_back(make_variant<BagCfg<64, 8, true, false, 8, 8, 1, false, true>, true>("v2 wave b1 SHIP (blk64 U8 minw8)"));
     vars.push_back(make_variant<BagCfg<64, 8, true, false, 8, 8, 1, false, true>, true>("v2 wave b1 SHIP XCD", true));
