@@ -70,6 +70,11 @@ typedef struct emb_config {
     uint32_t flags;      /* EMB_FLAG_* */
 } emb_config;
 #define EMB_FLAG_STAGE_TIMING 1u /* host-pointer calls wait after every stage and clock it (see emb_stats) */
+#define EMB_FLAG_CHECK_INPUTS 2u /* emb_lookup / emb_lookup_batched (and lookup()) run emb_validate_inputs on the
+                                    caller's stream first and return EMB_ERR_RANGE instead of launching when an index
+                                    is >= nr_rows or the offsets are broken.  Off by default: the reference never
+                                    checks (emb_dpu_lookup.c:113) and the check costs a kernel and a host wait per
+                                    call.  Prepared plans (emb_plan_launch) are never checked. */
 
 /*
  * One table's share of a batched lookup -- what emb_host.h:234 passes as indices[t], offsets[t],

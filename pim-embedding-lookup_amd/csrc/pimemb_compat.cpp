@@ -118,6 +118,8 @@ struct dpu_set_t *populate_mram(uint32_t table_id, uint64_t nr_rows, uint32_t co
         emb_config cfg{};
         cfg.device = -1;
         cfg.max_tables = g_cfg.nr_tables;
+        const char *chk = getenv("PIMEMB_CHECK_INPUTS");   // the reference interface has no flags argument
+        if (chk && chk[0] && chk[0] != '0') cfg.flags |= EMB_FLAG_CHECK_INPUTS;
         if (emb_create(&cfg, &g_engine) != EMB_OK) {
             fprintf(stderr, "pimemb: populate_mram: %s\n", emb_last_error());
             g_engine = nullptr;

@@ -124,6 +124,7 @@ struct emb_engine {
     double us_copy_in_indices = 0, us_copy_in_lengths = 0, us_launch = 0, us_copy_out = 0,
            us_sync = 0;
     bool stage_timing = false;  // wait + clock after every stage of a host-pointer call
+    bool check_inputs = false;  // EMB_FLAG_CHECK_INPUTS: emb_lookup / emb_lookup_batched validate before they launch
     std::atomic<uint32_t> live_plans{0};
     uint64_t next_generation = 1;
     // stage trace (host-pointer path)
@@ -756,6 +757,7 @@ int emb_create(const emb_config *cfg, emb_engine **out) {
     if (!e) return fail(EMB_ERR_NOMEM, "emb_create: out of host memory");
     e->device = dev;
     e->stage_timing = cfg && (cfg->flags & EMB_FLAG_STAGE_TIMING);
+    e->check_inputs = cfg && (cfg->flags & EMB_FLAG_CHECK_INPUTS);
     {   // transient launches read their descriptors straight from the pinned segment (measured with
         // tools/transient_probe.py: 20.6 vs 22.4 us per C2-shaped call, 5.6 vs 8.7 us at 2048 bags per
         // table); PIMEMB_DESC_MODE=copy stages them into HBM with an in-stream copy instead
@@ -947,6 +949,10 @@ int emb_lookup_batched(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_d
     DeviceGuard g(e->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     e->n_lookup_calls.fetch_add(1, std::memory_order_relaxed);
+    if (e->check_inputs) {   // EMB_FLAG_CHECK_INPUTS: refuse the call instead of gathering a wild row
+        int vrc = validate_on(e, descs, n_descs, itype, space, s, nullptr);
+        if (vrc) return vrc;
+    }
     if (space == EMB_MEM_HOST) return lookup_host(e, descs, n_descs, itype, s);
     Resolved r;
     const double p0 = g_prof.on ? now_us() : 0;
@@ -1071,11 +1077,9 @@ int emb_plan_time(emb_plan *p, void *stream, uint32_t warmup, uint32_t iters, fl
     return EMB_OK;
 }
 
-int emb_validate_inputs(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs,
-                        emb_index_type itype, emb_memspace space, uint64_t *n_bad) {
-    if (!e || !descs) return fail(EMB_ERR_INVALID, "engine or descs is NULL");
-    DeviceGuard g(e->device);
-    hipStream_t s = nullptr;
+// Count out-of-range indices / broken offsets of a batched call on stream `s` (waits for the count).
+static int validate_on(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs, emb_index_type itype,
+                       emb_memspace space, hipStream_t s, uint64_t *n_bad) {
     HostStage hs;
     Resolved r;
     int rc;
@@ -1104,12 +1108,20 @@ int emb_validate_inputs(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_
     if (err == hipSuccess) err = hipMemsetAsync(e->d_bad, 0, sizeof(unsigned long long), s);
     if (err == hipSuccess) err = pimemb::launch_validate(d, (uint32_t)r.descs.size(), itype, e->d_bad, s);
     unsigned long long bad = 0;
-    if (err == hipSuccess) err = hipMemcpy(&bad, e->d_bad, sizeof bad, hipMemcpyDeviceToHost);
+    if (err == hipSuccess) err = hipMemcpyAsync(&bad, e->d_bad, sizeof bad, hipMemcpyDeviceToHost, s);
+    if (err == hipSuccess) err = hipStreamSynchronize(s);
     (void)hipFree(d);
     if (err != hipSuccess) return fail(EMB_ERR_DEVICE, "emb_validate_inputs: %s", hipGetErrorString(err));
     if (n_bad) *n_bad = bad;
     if (bad) return fail(EMB_ERR_RANGE, "%llu out-of-range indices / broken offsets", bad);
     return EMB_OK;
+}
+
+int emb_validate_inputs(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs,
+                        emb_index_type itype, emb_memspace space, uint64_t *n_bad) {
+    if (!e || !descs) return fail(EMB_ERR_INVALID, "engine or descs is NULL");
+    DeviceGuard g(e->device);
+    return validate_on(e, descs, n_descs, itype, space, nullptr, n_bad);
 }
 
 int emb_get_stats(emb_engine *e, emb_stats *out) {

@@ -171,10 +171,12 @@ class NativeExchange:
 class EmbeddingEngine:
     """One engine per GPU: tables resident in HBM, lookups as fused HIP launches."""
 
-    def __init__(self, device: int = -1, max_tables: int = 1024, lib_path: str | None = None):
+    def __init__(self, device: int = -1, max_tables: int = 1024, lib_path: str | None = None,
+                 check_inputs: bool = False):
         # lib_path: another build of libpimemb.so (e.g. the -DPIMEMB_CLAMP_INPUTS=1 flavour)
+        # check_inputs: EMB_FLAG_CHECK_INPUTS -- every plan-less lookup validates its indices / offsets first
         self._L = _l.load(lib_path)
-        cfg = _l.EmbConfig(device, max_tables, 0)
+        cfg = _l.EmbConfig(device, max_tables, _l.EMB_FLAG_CHECK_INPUTS if check_inputs else 0)
         h = C.c_void_p()
         _l.check(self._L.emb_create(C.byref(cfg), C.byref(h)))
         self._h = h.value

@@ -13,6 +13,7 @@ EMB_ERR_INVALID, EMB_ERR_NOMEM, EMB_ERR_DEVICE, EMB_ERR_UNSUPPORTED, EMB_ERR_RAN
 EMB_F32, EMB_F16, EMB_FIXED32 = 0, 1, 2
 EMB_IDX_U32, EMB_IDX_I64 = 0, 1
 EMB_MEM_HOST, EMB_MEM_DEVICE = 0, 1
+EMB_FLAG_STAGE_TIMING, EMB_FLAG_CHECK_INPUTS = 1, 2
 
 
 class EmbConfig(C.Structure):
