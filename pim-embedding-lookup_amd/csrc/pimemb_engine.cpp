@@ -941,6 +941,9 @@ int emb_table_info(emb_engine *e, uint32_t table_id, void **device_rows, uint64_
     return EMB_OK;
 }
 
+static int validate_on(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs, emb_index_type itype,
+                       emb_memspace space, hipStream_t s, uint64_t *n_bad);
+
 int emb_lookup_batched(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs,
                        emb_index_type itype, emb_memspace space, void *stream) {
     if (!e) return fail(EMB_ERR_INVALID, "engine is NULL");
