@@ -1,25 +1,28 @@
 #!/bin/bash
-# Every single-GPU bench line of DESIGN.md section 5 in one go (final-build consolidation).
-# usage: run_all_benches.sh <out.md>      (run from the repository root on a GPU box)
-out=${1:-gpurun_out/summary.md}
-line() { python3 -c '
-import sys, json
-d = json.loads(sys.stdin.read().strip().splitlines()[-1])
-r = d["roofline"]
-print("| %s | %.4f | %.3e | %.0f | %.3f |" % (sys.argv[1], d["ms_per_step"], d["value"], r["achieved"], r["frac"]))' "$1"; }
-{
-echo "| workload (bench.py flags) | ms / step | pooled lookups / s | algorithmic GB/s | frac of 8 TB/s |"
-echo "|---|---|---|---|---|"
-python3 bench.py --no-cpu-baseline 2>/dev/null | line "c2 (default)"
-python3 bench.py --no-cpu-baseline --index-dist zipf 2>/dev/null | line "c2 --index-dist zipf"
-python3 bench.py --no-cpu-baseline --workload c1 2>/dev/null | line "c1 (mini-batch 1)"
-python3 bench.py --no-cpu-baseline --batch 2048 2>/dev/null | line "c2 --batch 2048"
-python3 bench.py --no-cpu-baseline --batch 16384 2>/dev/null | line "c2 --batch 16384"
-python3 bench.py --no-cpu-baseline --workload c3 --steps 100 --warmup 10 2>/dev/null | line "c3 (48 x 10M x 128, L=32, Zipf)"
-python3 bench.py --no-cpu-baseline --workload c3 --steps 100 --warmup 10 --hot-rows 100 2>/dev/null | line "c3 --hot-rows 100"
-python3 bench.py --no-cpu-baseline --workload c3 --steps 50 --warmup 5 --index-dist uniform 2>/dev/null | line "c3 --index-dist uniform"
-python3 bench.py --no-cpu-baseline --workload c4 --steps 300 --warmup 30 2>/dev/null | line "c4 one-rank share, L=1"
-python3 bench.py --no-cpu-baseline --workload c4 --pooling 32 --steps 100 --warmup 10 2>/dev/null | line "c4 one-rank share, L=32"
-python3 bench.py --no-cpu-baseline --workload c5 --steps 100 --warmup 10 2>/dev/null | line "c5 one-GPU share (fp16)"
-} > "$out"
-cat "$out"
+# Every single-GPU bench line of DESIGN.md in one go; JSON lines kept per workload key (profiles/traffic.json keys).
+# usage: run_all_benches.sh <out-dir>      (run from the repository root on a GPU box)
+out=${1:-gpurun_out/benches}
+mkdir -p "$out"
+run() { key=$1; shift; python3 bench.py --no-cpu-baseline "$@" 2>/dev/null | grep '^{' | tail -1 > "$out/bench_$key.json"; }
+run c2
+run c2-zipf --index-dist zipf
+run c1 --workload c1
+run c2-b2048 --batch 2048
+run c3 --workload c3 --steps 100 --warmup 10
+run c3-hot32 --workload c3 --steps 100 --warmup 10 --hot-rows 32
+run c3-uniform --workload c3 --steps 50 --warmup 5 --index-dist uniform
+run c4 --workload c4 --steps 300 --warmup 30
+run c4-l32 --workload c4 --pooling 32 --steps 100 --warmup 10
+run c5 --workload c5 --steps 100 --warmup 10
+python3 - "$out" <<'PY'
+import glob, json, os, sys
+print("| key | ms / step | pooled lookups / s | algorithmic GB/s | roofline.achieved GB/s (basis) | frac | l2_frac | L2 hit | read / unique rows | verified |")
+print("|---|---|---|---|---|---|---|---|---|---|")
+for f in sorted(glob.glob(os.path.join(sys.argv[1], "bench_*.json"))):
+    d = json.load(open(f)); r = d["roofline"]
+    g = lambda k, fmt="%.3f": (fmt % r[k]) if r.get(k) is not None else "—"
+    print("| %s | %.4f | %.3e | %.0f | %.0f (%s) | %.3f | %s | %s | %s | %s |" % (
+        os.path.basename(f)[6:-5], d["ms_per_step"], d["value"], r["achieved_algorithmic"], r["achieved"],
+        "measured bytes" if r["basis"].startswith("measured") else "algorithmic", r["frac"], g("l2_frac"), g("l2_hit_rate"),
+        g("read_over_unique_rows", "%.2f"), d["verified"]))
+PY
