@@ -145,7 +145,7 @@ def unique_row_bytes(batch, row_bytes):
     return int(sum(np.unique(i).shape[0] for i in idx)) * row_bytes
 
 
-def roofline_object(alg_bytes, kernel_us, entry, uniq_bytes):
+def roofline_object(alg_bytes, kernel_us, entry, uniq_bytes, meta_bytes=0):
     """HBM roofline of the dominant kernel.  The metric's own config (C2) and every launch whose rows mostly MISS
     the caches are priced on ALGORITHMIC bytes.  A launch that is mostly served by L2 /
     Infinity Cache moves far fewer HBM-side bytes than it gathers, so algorithmic bytes / HBM peak would exceed 1
@@ -168,10 +168,13 @@ def roofline_object(alg_bytes, kernel_us, entry, uniq_bytes):
             req = entry["tcc_hit"] + entry["tcc_miss"]
             r["l2_hit_rate"] = entry["tcc_hit"] / max(req, 1)
             r["l2_frac"] = req * 128 / t / 1e9 / L2_PEAK_GBS
-        if uniq_bytes and entry.get("read_bytes"):
-            r["read_over_unique_rows"] = entry["read_bytes"] / uniq_bytes
+        if uniq_bytes and entry.get("read_bytes"):     # table bytes read (indices / offsets taken out) per distinct-row byte
+            r["read_over_unique_rows"] = max(entry["read_bytes"] - meta_bytes, 0) / uniq_bytes
     if uniq_bytes:
         r["unique_row_bytes"] = uniq_bytes
+    if not entry and r["frac"] > 1.0:
+        r["basis"] = ("algorithmic bytes; no PMC profile of this exact command in profiles/traffic.json -- a fraction above 1 "
+                      "only says that most rows were served by L2 / Infinity Cache, it is not an HBM utilisation")
     return r
 
 
@@ -440,7 +443,8 @@ def run_single(args):
                    "parallelism": "single" if len(handles) == 1 else "single GPU, %d streams" % len(handles)},
         "roofline": roofline_object(alg_bytes, kernel_us, measured_traffic(profile_key(args, spec)),
                                     unique_row_bytes(batches[0], dim * (2 if spec.get("dtype") == "f16" else 4))
-                                    if spec["L"] > 1 or spec["dist"] != "uniform" else None),
+                                    if spec["L"] > 1 or spec["dist"] != "uniform" else None,
+                                    meta_bytes=4 * (n_idx + n_bags)),
     }
     if want_cpu:
         result["cpu_baseline"] = cpu_baseline(pel, host_tables, batches[0], args.cpu_seconds)
