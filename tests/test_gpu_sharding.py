@@ -408,3 +408,23 @@ def test_route_bags_limits_many_shards_and_tables(pel, eng):
         if K == 64:
             dest_of_bad = np.nonzero(sl[0, :, 7 // L] != 0xffffffff)[0]
             assert N - 1 in dest_of_bad                     # the out-of-range index went to the last shard
+
+
+def test_distributed_row_shards_four_ranks_pooled_zipf():
+    """More than two ranks (four processes on cuda:0, gloo): row ranges that do not divide the tables evenly, pooled
+    bags, Zipf indices (a hot shard) -- the counts-first exchange with N = 4."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, PIMEMB_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--shard-mode", "rows", "--replicate-mb", "64",
+           "--index-dist", "zipf", "--pooling", "3", "--batch", "2003", "--steps", "3", "--warmup", "1", "--nbatch", "3"]
+    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 4 and d["verified"] is True and d["config"]["world_size"] == 4
+    rows_out = d["config"]["last_step_request_rows_per_peer"]
+    assert len(rows_out) == 4 and max(rows_out) > 1.2 * min(rows_out)
+    assert sum(d["config"]["last_step_request_indices_per_peer"]) == 5 * 2003 * 3
