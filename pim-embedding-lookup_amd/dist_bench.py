@@ -610,7 +610,8 @@ def run_dp(args, hbm_peak_gbs: float, ctx):
         if dbg is not None and i in (0, 1, args.steps - 1): dbg.append((f"launch {i}", time.perf_counter() - t0))
     e1.record(stream)
     if dbg is not None: dbg.append(("e1.record", time.perf_counter() - t0))
-    e1.synchronize()
+    while not e1.query():                   # polled: a blocking wait is woken ~20 us late
+        pass
     local_el = time.perf_counter() - t0     # this rank's K steps are complete (the event after the K-th launch has fired)
     torch.cuda.synchronize()
     if dbg is not None: dbg.append(("device sync", time.perf_counter() - t0))
