@@ -673,7 +673,12 @@ def run(args, hbm_peak_gbs: float) -> None:
     world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     backend = os.environ.get("PIMEMB_DIST_BACKEND", "nccl")
-    dev = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
+    n_dev = torch.cuda.device_count()
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if backend == "nccl" and n_dev < local_world:
+        raise SystemExit(f"bench.py --gpus {world}: {local_world} ranks on this node but {n_dev} GPU(s) visible -- RCCL needs one GPU "
+                         "per rank (PIMEMB_DIST_BACKEND=gloo rehearses the N > 1 code with several ranks on one GPU)")
+    dev = torch.device("cuda", local_rank % max(n_dev, 1))
     torch.cuda.set_device(dev)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
