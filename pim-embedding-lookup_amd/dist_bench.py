@@ -354,7 +354,8 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
         serve(i)        fused lookup over the request pieces received for batch i -> one partial row per sub-bag
         return(i)       all_to_all of the partial rows, split sizes from counts(i)
         requests(i+1)   all_to_all of the request pieces, split sizes from counts(i+1)  -- the only host wait
-        finish(i)       partial rows added in shard order into [B, dim] per table (emb_unroute_bags)
+        finish(i)       partial rows added in shard order into [B, dim] per table (emb_unroute_bags) -- enqueued one step
+                        later, in front of serve(i+1), so the compute stream never waits out return(i)
 
     Nothing has a capacity that skewed indices could overflow: the payload is sized by the counts."""
     import torch
@@ -417,7 +418,17 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
         prof[name] = prof.get(name, 0) + time.perf_counter_ns() - t
         return r
 
+    unfinished = [None]        # slot whose partial rows are on their way back (its un-routing is the next step's job)
+
+    def finish_pending():
+        if unfinished[0] is not None:
+            timed("finish", ex.finish, unfinished[0], slots[unfinished[0]]["out_sh"])
+            unfinished[0] = None
+
     def step(i):
+        """One pipelined step.  On the compute stream: route(i+1), local(i), finish(i-1), serve(i) -- the partial rows of
+        batch i-1 have had a whole step to come back, so un-routing them never stalls the stream behind a collective
+        (with finish(i) right behind serve(i) every step waited out one all_to_all: +25 % per step)."""
         j, nxt = i % NBATCH, (i + 1) % NBATCH
         sl = slots[j]
         if K:
@@ -425,9 +436,10 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
         if sl["plan_a"] is not None:
             timed("local", sl["plan_a"].launch, h)
         if K:
+            finish_pending()
             timed("serve+return", ex.serve, j)
             timed("wait counts+requests", ex.send_requests, nxt)
-            timed("finish", ex.finish, j, sl["out_sh"])
+            unfinished[0] = j
 
     def prologue(i):           # batch i's requests on their way before step(i)
         if K:
@@ -436,8 +448,9 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
 
     done_ev = torch.cuda.Event()
 
-    def drain(next_i):         # the requests of the batch after the last one are in flight: let them land
+    def drain(next_i):         # un-route the last batch; the requests of the batch after it are in flight: let them land
         if K:
+            finish_pending()
             ex.wait_requests(next_i % NBATCH)
         done_ev.record(stream)       # everything of the loop is ordered before this event on the compute stream
         done_ev.synchronize()        # (a device-wide synchronize returns up to a millisecond later once RCCL is loaded)
@@ -467,7 +480,7 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
         step(i)
     for i in (NBATCH, NBATCH + 1):
         step(i)
-        torch.cuda.synchronize()
+        drain(i + 1)
         verify(i, "pipelined")
     it = NBATCH + 2
 
