@@ -348,8 +348,8 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
     """Big tables split by ROW RANGE over all ranks, any number of indices per bag.  Counts first, payload second
     (the reference sends its lengths before every launch, emb_host.h:280-287):
 
-        route(i+1)      GPU: every bag of a row-split table cut into per-shard sub-bags (emb_route_bags)
-        counts(i+1)     all_to_all of {sub-bags, indices} per (peer, table)             -- small, first
+        route(i+2)      GPU: every bag of a row-split table cut into per-shard sub-bags (emb_route_bags)
+        counts(i+2)     all_to_all of {sub-bags, indices} per (peer, table)             -- small, first, two batches ahead
         local(i)        fused lookup of the replicated tables (prepared plan)
         serve(i)        fused lookup over the request pieces received for batch i -> one partial row per sub-bag
         return(i)       all_to_all of the partial rows, split sizes from counts(i)
@@ -373,7 +373,7 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
     B = args.batch or B0
     T = len(rows_list)
     N = world
-    NBATCH = max(3, args.nbatch)
+    NBATCH = max(4, args.nbatch)            # slots: the router runs two batches ahead of the un-router
     sharded = [t for t in range(T) if rows_list[t] * row_b > rep_bytes and rows_list[t] >= world]
     local = [t for t in range(T) if t not in sharded]
     K = len(sharded)
@@ -426,13 +426,16 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
             unfinished[0] = None
 
     def step(i):
-        """One pipelined step.  On the compute stream: route(i+1), local(i), finish(i-1), serve(i) -- the partial rows of
-        batch i-1 have had a whole step to come back, so un-routing them never stalls the stream behind a collective
-        (with finish(i) right behind serve(i) every step waited out one all_to_all: +25 % per step)."""
-        j, nxt = i % NBATCH, (i + 1) % NBATCH
+        """One pipelined step.  On the compute stream: route(i+2), local(i), finish(i-1), serve(i).
+          * the router runs TWO batches ahead: the counts the host needs for batch i+1 were sent a whole step ago, so its
+            one wait per step (send_requests) returns at once and the host stays a step ahead of the GPU -- routed one
+            batch ahead, every enqueue behind that wait reached an idle queue (~100 us of gaps per 250-us step);
+          * the partial rows of batch i-1 have had a whole step to come back, so un-routing them never stalls the stream
+            behind a collective."""
+        j, nxt, nxt2 = i % NBATCH, (i + 1) % NBATCH, (i + 2) % NBATCH
         sl = slots[j]
         if K:
-            timed("route+counts", ex.route, nxt, slots[nxt]["route_spec"], B, K * B * L)
+            timed("route+counts", ex.route, nxt2, slots[nxt2]["route_spec"], B, K * B * L)
         if sl["plan_a"] is not None:
             timed("local", sl["plan_a"].launch, h)
         if K:
@@ -441,10 +444,11 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
             timed("wait counts+requests", ex.send_requests, nxt)
             unfinished[0] = j
 
-    def prologue(i):           # batch i's requests on their way before step(i)
+    def prologue(i):           # before step(i): batch i's requests on their way, batch i+1 routed and its counts sent
         if K:
             ex.route(i % NBATCH, slots[i % NBATCH]["route_spec"], B, K * B * L)
             ex.send_requests(i % NBATCH)
+            ex.route((i + 1) % NBATCH, slots[(i + 1) % NBATCH]["route_spec"], B, K * B * L)
 
     done_ev = torch.cuda.Event()
 
