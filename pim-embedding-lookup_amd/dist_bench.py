@@ -428,8 +428,9 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
     def step(i):
         """One pipelined step.  On the compute stream: route(i+2), local(i), finish(i-1), serve(i).
           * the router runs TWO batches ahead: the counts the host needs for batch i+1 were sent a whole step ago, so its
-            one wait per step (send_requests) returns at once and the host stays a step ahead of the GPU -- routed one
-            batch ahead, every enqueue behind that wait reached an idle queue (~100 us of gaps per 250-us step);
+            one wait per step (send_requests) does not depend on how far the slowest peer has got in THIS step.  (With one
+            rank it changes nothing -- 246 vs 262 us per step at the C4 shape, inside the noise: there the step is the
+            sum of its kernels, all in one hardware queue, the 50-us self-copy of the return collective included.)
           * the partial rows of batch i-1 have had a whole step to come back, so un-routing them never stalls the stream
             behind a collective."""
         j, nxt, nxt2 = i % NBATCH, (i + 1) % NBATCH, (i + 2) % NBATCH
