@@ -1,6 +1,6 @@
 """Soak: minutes of randomised lookups -- every path (host / device / plan / checked engine / bag router + partial-sum
 un-router emulating N shards in one process), every result compared with the CPU oracle -- watching HBM and host memory.
-    python soak_probe_r2.py [seconds]"""
+    python tests/soak_r2.py [seconds]     (lives under tests/: it uses the oracle as its checker)"""
 import os
 import resource
 import sys
@@ -8,7 +8,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..", ".."))
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import pim_embedding_lookup_amd as pel  # noqa: E402
