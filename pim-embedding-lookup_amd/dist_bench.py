@@ -38,6 +38,7 @@ import numpy as np
 
 
 TABLE_SCALE: dict[int, float] = {}     # table id -> 2/sqrt(rows): DLRM's U(-sqrt(1/n), sqrt(1/n)) range, set by run()
+TABLE_F16 = [False]                    # run(): the table set is stored as fp16 (c5); expected values round the same way
 
 
 def table_values(torch, t: int, row_lo: int, row_hi: int, dim: int, device):
@@ -52,14 +53,15 @@ def table_values(torch, t: int, row_lo: int, row_hi: int, dim: int, device):
         e = torch.arange(lo * dim, hi * dim, dtype=torch.int64, device=device)
         h = (e * 2654435761 + (t + 1) * 40503) % 2147483647
         out[lo - row_lo:hi - row_lo] = ((h.to(torch.float32) / 2147483647.0 - 0.5) * scale).reshape(hi - lo, dim)
-    return out
+    return out.to(torch.float16) if TABLE_F16[0] else out
 
 
 def expected_rows(torch, t: int, idx, dim: int):
     """Rows idx of table t recomputed from the formula (fp32, same ops as table_values)."""
     e = idx.to(torch.int64)[:, None] * dim + torch.arange(dim, dtype=torch.int64, device=idx.device)[None, :]
     h = (e * 2654435761 + (t + 1) * 40503) % 2147483647
-    return (h.to(torch.float32) / 2147483647.0 - 0.5) * TABLE_SCALE.get(t, 1.0)
+    v = (h.to(torch.float32) / 2147483647.0 - 0.5) * TABLE_SCALE.get(t, 1.0)
+    return v.to(torch.float16).to(torch.float32) if TABLE_F16[0] else v     # fp16 rows, fp32 accumulate
 
 
 def expected_pooled(torch, t: int, idx, dim: int, L: int):
@@ -91,8 +93,8 @@ def native_exchange(pel, args, eng, ctx):
 def table_set_of(pel, args):
     """rows, dim, default batch, label of the table set the N > 1 legs run (--workload c2 | c4)."""
     name = getattr(args, "workload", "c2")
-    if name not in ("c2", "c4"):
-        raise SystemExit("bench.py --gpus N > 1 runs --workload c2 or c4 (c3/c5 are single-GPU lines)")
+    if name not in ("c2", "c4", "c5"):
+        raise SystemExit("bench.py --gpus N > 1 runs --workload c2, c4 or c5 (c3 is a single-GPU line)")
     return pel.workloads.table_set(name, float(getattr(args, "rows_scale", 1.0) or 1.0))
 
 
@@ -107,11 +109,11 @@ def run_whole(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
 
     rows_list, dim, B0, label = table_set_of(pel, args)
     B = args.batch or B0
-    L = max(1, int(getattr(args, "pooling", None) or 1))      # indices per bag (fixed pooling)
+    L = pooling_of(pel, args)               # indices per bag (fixed pooling)
     Bp = (B * L + 3) // 4 * 4               # index slots per (table, rank): keeps every piece 16-B aligned
     T = len(rows_list)
     NBATCH = max(2, args.nbatch)
-    plan = sh.plan_shards(rows_list, dim, 4, world, replicate_bytes=rep_bytes, split_bytes=1 << 62)
+    plan = sh.plan_shards(rows_list, dim, 2 if TABLE_F16[0] else 4, world, replicate_bytes=rep_bytes, split_bytes=1 << 62)
     served = plan.owned_units(rank)
     local = plan.replicated_units()
     send_units = [[u for u in plan.units if u.owner == d] for d in range(world)]
@@ -144,7 +146,7 @@ def run_whole(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
     rng = np.random.default_rng(1 + rank)
     gen, dist_name = index_generator(pel, args)
     off_dev = torch.arange(B, dtype=torch.int32, device=dev) * L
-    idx_host = [[gen(rng, n, B * L).view(np.int32) for n in rows_list] for _ in range(NBATCH)]
+    idx_host = [[gen(rng, n, B * L, t).view(np.int32) for t, n in enumerate(rows_list)] for _ in range(NBATCH)]
     slots = []
     for j in range(NBATCH):
         send = torch.zeros(max(int(in_off[-1]), 16), dtype=torch.uint8, device=dev)
@@ -294,9 +296,9 @@ def run_whole(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall * 1000.0 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s sharded, dim %d fp32, B=%d bags/table PER RANK, "
-                                   "L=%d, %s indices, %d rotating batches; %s" % (label, dim, B, L, dist_name, NBATCH, plan.describe()),
+            "dtype": "f16" if TABLE_F16[0] else "f32", "data": "synthetic",
+            "config": {"workload": "%s sharded, dim %d %s, B=%d bags/table PER RANK, "
+                                   "L=%d, %s indices, %d rotating batches; %s" % (label, dim, "fp16" if TABLE_F16[0] else "fp32", B, L, dist_name, NBATCH, plan.describe()),
                        "tables": T, "dim": dim, "bags_per_table_per_rank": B, "global_bags_per_table": world * B,
                        "pooling": L,
                        "parallelism": "tables sharded by id (replicate <= %d MiB); one all_to_all per step carries "
@@ -340,8 +342,21 @@ def expected_row_split(torch, t: int, idx, dim: int, L: int, rps: int, n_shards:
 
 
 def index_generator(pel, args):
-    dist_name = getattr(args, "index_dist", None) or "uniform"
-    return (pel.workloads.zipf_indices if dist_name == "zipf" else pel.workloads.uniform_indices), dist_name
+    """gen(rng, n_rows, count, table=t) and the distribution's name: uniform, zipf, or the table set's default
+    ("mixed": Zipf(1.2) on even tables, uniform on odd ones)."""
+    extras = pel.workloads.TABLE_SET_EXTRAS[getattr(args, "workload", "c2")]
+    dist_name = getattr(args, "index_dist", None) or extras["dist"]
+
+    def gen(rng, n, count, table=0):
+        zipf = dist_name == "zipf" or (dist_name == "mixed" and table % 2 == 0)
+        return (pel.workloads.zipf_indices if zipf else pel.workloads.uniform_indices)(rng, n, count)
+
+    return gen, dist_name
+
+
+def pooling_of(pel, args) -> int:
+    extras = pel.workloads.TABLE_SET_EXTRAS[getattr(args, "workload", "c2")]
+    return max(1, int(getattr(args, "pooling", None) or extras["pooling"]))
 
 
 def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
@@ -367,14 +382,14 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
     rank, world, dev, backend, stage_cpu = ctx["rank"], ctx["world"], ctx["dev"], ctx["backend"], ctx["stage_cpu"]
 
     rows_list, dim, B0, label = table_set_of(pel, args)
-    L = max(1, int(getattr(args, "pooling", None) or 1))
+    L = pooling_of(pel, args)
     gen, dist_name = index_generator(pel, args)
     row_b = dim * 4
     B = args.batch or B0
     T = len(rows_list)
     N = world
     NBATCH = max(4, args.nbatch)            # slots: the router runs two batches ahead of the un-router
-    sharded = [t for t in range(T) if rows_list[t] * row_b > rep_bytes and rows_list[t] >= world]
+    sharded = [t for t in range(T) if rows_list[t] * dim * (2 if TABLE_F16[0] else 4) > rep_bytes and rows_list[t] >= world]
     local = [t for t in range(T) if t not in sharded]
     K = len(sharded)
     rps = [-(-rows_list[t] // world) for t in sharded]
@@ -388,7 +403,7 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
     torch.cuda.empty_cache()
 
     rng = np.random.default_rng(1 + rank)
-    idx_host = [[gen(rng, n, B * L).view(np.int32) for n in rows_list] for _ in range(NBATCH)]
+    idx_host = [[gen(rng, n, B * L, t).view(np.int32) for t, n in enumerate(rows_list)] for _ in range(NBATCH)]
     off_b = torch.arange(B, dtype=torch.int32, device=dev) * L
     stream = torch.cuda.current_stream(dev)
     h = stream.cuda_stream
@@ -545,10 +560,10 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall * 1000.0 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s sharded, dim %d fp32, B=%d bags/table PER RANK, L=%d, %s indices, "
+            "dtype": "f16" if TABLE_F16[0] else "f32", "data": "synthetic",
+            "config": {"workload": "%s sharded, dim %d %s, B=%d bags/table PER RANK, L=%d, %s indices, "
                                    "%d rotating batches; %d tables replicated (<= %d MiB), %d row-range sharded over "
-                                   "%d ranks" % (label, dim, B, L, dist_name, NBATCH, len(local), rep_bytes >> 20, K, world),
+                                   "%d ranks" % (label, dim, "fp16" if TABLE_F16[0] else "fp32", B, L, dist_name, NBATCH, len(local), rep_bytes >> 20, K, world),
                        "tables": T, "dim": dim, "bags_per_table_per_rank": B, "global_bags_per_table": world * B,
                        "pooling": L, "index_dist": dist_name,
                        "parallelism": "row-range shards; bags cut into per-shard sub-bags on the GPU; counts first "
@@ -584,7 +599,7 @@ def run_dp(args, hbm_peak_gbs: float, ctx):
     rank, world, dev, stage_cpu = ctx["rank"], ctx["world"], ctx["dev"], ctx["stage_cpu"]
     rows_list, dim, B0, label = table_set_of(pel, args)
     B = args.batch or B0
-    L = max(1, int(getattr(args, "pooling", None) or 1))
+    L = pooling_of(pel, args)
     T = len(rows_list)
     NBATCH = max(2, args.nbatch)
     eng = pel.EmbeddingEngine(device=dev.index, max_tables=T)
@@ -594,7 +609,7 @@ def run_dp(args, hbm_peak_gbs: float, ctx):
     rng = np.random.default_rng(1 + rank)
     off = torch.arange(B, dtype=torch.int32, device=dev) * L
     gen, dist_name = index_generator(pel, args)
-    idx_host = [[gen(rng, n, B * L).view(np.int32) for n in rows_list] for _ in range(NBATCH)]
+    idx_host = [[gen(rng, n, B * L, t).view(np.int32) for t, n in enumerate(rows_list)] for _ in range(NBATCH)]
     plans = []
     for j in range(NBATCH):
         plans.append(eng.plan(list(range(T)), [torch.from_numpy(i).to(dev) for i in idx_host[j]], [off] * T))
@@ -656,14 +671,14 @@ def run_dp(args, hbm_peak_gbs: float, ctx):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall * 1000.0 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s, dim %d fp32, B=%d bags/table PER RANK, L=%d, u32 "
-                                   "indices+offsets, %s indices, %d rotating batches" % (label, dim, B, L, dist_name, NBATCH),
+            "dtype": "f16" if TABLE_F16[0] else "f32", "data": "synthetic",
+            "config": {"workload": "%s, dim %d %s, B=%d bags/table PER RANK, L=%d, u32 "
+                                   "indices+offsets, %s indices, %d rotating batches" % (label, dim, "fp16" if TABLE_F16[0] else "fp32", B, L, dist_name, NBATCH),
                        "tables": T, "dim": dim, "bags_per_table_per_rank": B, "global_bags_per_table": world * B,
                        "prewarm_ms": prewarm_ms, "prewarm_launches": n_pre,
                        "parallelism": "all %d tables (%.2f GB) replicated on every rank (they fit the per-GPU "
                                       "replication budget); bags data-parallel, no data-path collective"
-                                      % (T, sum(rows_list) * dim * 4 / 1e9)},
+                                      % (T, sum(rows_list) * dim * (2 if TABLE_F16[0] else 4) / 1e9)},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": hbm_peak_gbs, "unit": "GB/s",
                          "frac": ach / hbm_peak_gbs, "traffic": None, "kernel_us": kernel_us,
                          "algorithmic_bytes": alg_bytes, "basis": "algorithmic bytes (no PMC profile of the N > 1 legs; a pooled launch is partly cache-served and can exceed 1: the same kernels at N = 1 are priced on measured bytes, profiles/traffic.json)", "note": "rank 0's fused launch, HIP events over the timed region"},
@@ -707,7 +722,8 @@ def run(args, hbm_peak_gbs: float) -> None:
 
     rows_list, dim, _, _ = table_set_of(pel, args)
     TABLE_SCALE.update({t: float(np.float32(2.0 / np.sqrt(n))) for t, n in enumerate(rows_list)})
-    total_bytes = sum(rows_list) * dim * 4
+    TABLE_F16[0] = pel.workloads.TABLE_SET_EXTRAS[getattr(args, "workload", "c2")]["dtype"] == "f16"
+    total_bytes = sum(rows_list) * dim * (2 if TABLE_F16[0] else 4)
     hbm = torch.cuda.get_device_properties(dev).total_memory
     auto = getattr(args, "replicate_mb", None) is None
     mode = getattr(args, "shard_mode", None) or ("rows" if getattr(args, "workload", "c2") == "c4" else "whole")

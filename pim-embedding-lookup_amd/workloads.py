@@ -77,12 +77,22 @@ def table_set(name: str, rows_scale: float = 1.0):
     be rehearsed on fewer GPUs."""
     if name == "c4":
         rows, dim, batch, label = TERABYTE_ROWS, TERABYTE_DIM, TERABYTE_BATCH, "C4: 26 Criteo-Terabyte-shaped tables"
+    elif name == "c5":
+        # BASELINE configs[4]: 512 tables x 50M rows x dim 64 fp16 = 3.28 TB does not fit 8 x 288 GB; rows scaled to 30M
+        # (1.97 TB, 246 GB per GPU at 8), as the single-GPU `--workload c5` share does (64 of these tables)
+        rows, dim, batch, label = [30_000_000] * 512, 64, 16384, "C5: 512 tables x 30M rows (50M as written does not fit), fp16"
     else:
         rows, dim, batch, label = KAGGLE_ROWS, KAGGLE_DIM, KAGGLE_BATCH, "C2: 26 Criteo-Kaggle tables"
     if rows_scale != 1.0:
         rows = [max(1, int(n * rows_scale)) for n in rows]
         label += " (rows x %g)" % rows_scale
     return list(rows), dim, batch, label
+
+
+# per table set: table dtype, default indices per bag, default index distribution ("mixed" = Zipf(1.2) on even tables,
+# uniform on odd ones -- configs[4]'s "mixed hot/cold")
+TABLE_SET_EXTRAS = {"c2": dict(dtype="f32", pooling=1, dist="uniform"), "c4": dict(dtype="f32", pooling=1, dist="uniform"),
+                    "c5": dict(dtype="f16", pooling=32, dist="mixed")}
 
 
 def top_rows(indices: np.ndarray, k: int, min_share: float = 0.0) -> np.ndarray:

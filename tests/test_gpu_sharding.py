@@ -428,3 +428,17 @@ def test_distributed_row_shards_four_ranks_pooled_zipf():
     rows_out = d["config"]["last_step_request_rows_per_peer"]
     assert len(rows_out) == 4 and max(rows_out) > 1.2 * min(rows_out)
     assert sum(d["config"]["last_step_request_indices_per_peer"]) == 5 * 2003 * 3
+
+
+def test_distributed_c5_shape_whole_table_shards_two_ranks():
+    """BASELINE configs[4] in its multi-GPU form at a size two ranks on one GPU hold: 512 fp16 tables of dim 64 (rows scaled
+    to 30M/4096), pooling 32, Zipf on even / uniform on odd tables, tables placed WHOLE on owner ranks (table-id sharding),
+    the pipelined all_to_all of indices in / pooled rows out; every rank compares all 512 tables bit for bit with the
+    in-order fp32 sum of the fp16 rows."""
+    res, d = _bench_two_ranks(["--workload", "c5", "--rows-scale", str(1 / 4096), "--replicate-mb", "0", "--batch", "257",
+                               "--steps", "3", "--warmup", "1", "--nbatch", "2"], timeout=900)
+    assert res.returncode == 0 and d is not None, res.stdout[-2000:] + res.stderr[-4000:]
+    assert d["n_gpus"] == 2 and d["dtype"] == "f16" and d["verified"] is True and d["value"] > 0
+    c = d["config"]
+    assert c["tables"] == 512 and c["dim"] == 64 and c["pooling"] == 32
+    assert "512 whole" in c["workload"] and "fp16" in c["workload"] and "mixed indices" in c["workload"]
