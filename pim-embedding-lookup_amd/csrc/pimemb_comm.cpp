@@ -131,11 +131,19 @@ int emb_comm_all_to_all(emb_comm *c, const void *send, const uint64_t *send_off,
     int prev = -1;
     (void)hipGetDevice(&prev);
     if (prev != c->device) (void)hipSetDevice(c->device);
+    // One send / receive moves at most kChunk bytes: RCCL 2.26.6 (the one torch 2.10 bundles) delivers only the first half
+    // of a transfer above 1 GiB (tools/a2a_size_probe.py: intact up to 1.0 GiB, corrupt from 1.1 GiB, any element type).
+    // Both ends of a pair know the pair's size, so both cut it into the same pieces; pieces to one peer match in order.
+    constexpr uint64_t kChunk = 512ull << 20;
     ncclResult_t rc = r->GroupStart();
     for (int p = 0; rc == 0 && p < c->world; p++) {
         const uint64_t ns = send_off[p + 1] - send_off[p], nr = recv_off[p + 1] - recv_off[p];
-        if (ns) rc = r->Send(static_cast<const char *>(send) + send_off[p], ns, kNcclUint8, p, c->comm, s);
-        if (rc == 0 && nr) rc = r->Recv(static_cast<char *>(recv) + recv_off[p], nr, kNcclUint8, p, c->comm, s);
+        for (uint64_t o = 0; rc == 0 && o < ns; o += kChunk)
+            rc = r->Send(static_cast<const char *>(send) + send_off[p] + o, ns - o < kChunk ? ns - o : kChunk, kNcclUint8, p,
+                         c->comm, s);
+        for (uint64_t o = 0; rc == 0 && o < nr; o += kChunk)
+            rc = r->Recv(static_cast<char *>(recv) + recv_off[p] + o, nr - o < kChunk ? nr - o : kChunk, kNcclUint8, p,
+                         c->comm, s);
     }
     ncclResult_t rc2 = r->GroupEnd();
     if (prev >= 0 && prev != c->device) (void)hipSetDevice(prev);

@@ -136,6 +136,9 @@ def run_whole(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
     out_split = [n_send[s] * B * row_b + K * Bp * 4 for s in range(world)]
     in_off = np.concatenate([[0], np.cumsum(in_split)]).astype(np.int64)
     out_off = np.concatenate([[0], np.cumsum(out_split)]).astype(np.int64)
+    # the largest piece any rank sends any peer, from the plan every rank holds (so all ranks agree on the rounds)
+    owned = [sum(1 for u in plan.units if u.owner == r) for r in range(world)]
+    a2a_rounds = sh.rounds_for(max(owned[r] * B * row_b + owned[d] * Bp * 4 for r in range(world) for d in range(world)))
 
     def f32_view(buf, byte_off, n_rows):
         return buf[byte_off:byte_off + n_rows * row_b].view(torch.float32).view(n_rows, dim)
@@ -196,8 +199,7 @@ def run_whole(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
             dist.all_to_all_single(r, s_, output_split_sizes=out_split, input_split_sizes=in_split)
             sl["recv"].copy_(r)
             return None
-        return dist.all_to_all_single(sl["recv"], sl["send"], output_split_sizes=out_split,
-                                      input_split_sizes=in_split, async_op=True)
+        return sh.all_to_all_rounds(dist, sl["recv"], sl["send"], out_split, in_split, a2a_rounds)
 
     def step(i):
         sl = slots[i % NBATCH]

@@ -185,6 +185,8 @@ class ShardedLookup:
             recv_counts = [int(x) for x in r.cpu().tolist()]
         send = t.cat([p.reshape(-1).to(dtype) for p in send_parts]).to(self.comm_device)
         recv = t.empty(int(sum(recv_counts)), dtype=dtype, device=self.comm_device)
+        if self.comm_device.type == "cuda":
+            check_piece_sizes(list(recv_counts) + counts, send.element_size(), "ShardedLookup")
         dist.all_to_all_single(recv, send, output_split_sizes=list(recv_counts),
                                input_split_sizes=counts, group=self.group)
         return list(recv.split(list(recv_counts))), recv_counts
@@ -346,6 +348,10 @@ class RowRangeExchange:
                                    input_split_sizes=list(in_splits), group=self.group)
             recv[:n_out].copy_(r)
             return None
+        item = send.element_size()
+        for dd in send.shape[1:]:
+            item *= int(dd)
+        check_piece_sizes(list(out_splits) + list(in_splits), item, "RowRangeExchange")
         return dist.all_to_all_single(recv[:n_out], send[:n_in], output_split_sizes=list(out_splits),
                                       input_split_sizes=list(in_splits), group=self.group, async_op=True)
 
@@ -459,6 +465,54 @@ class RowRangeExchange:
         self.serve(slot)
         self.finish(slot, out)
         return out
+
+
+# RCCL 2.26.6 (bundled with torch 2.10) delivers only the first half of a single send / receive above 1 GiB
+# (csrc/tools/a2a_size_probe.py: intact at 1.0 GiB, corrupt from 1.1 GiB, whatever the element type).  The native exchange
+# (emb_comm_all_to_all) cuts every pair's transfer into 512-MiB pieces itself; through torch.distributed a piece above the
+# limit is refused here (both ends of the pair see it), or -- where every rank can compute the same number of rounds from
+# static shapes -- moved in several rounds (all_to_all_rounds).
+A2A_MAX_PIECE_BYTES = 1 << 30
+A2A_ROUND_BYTES = 512 << 20
+
+
+def check_piece_sizes(splits, bytes_per_item: int, what: str = "all_to_all") -> None:
+    worst = max((int(x) for x in splits), default=0) * int(bytes_per_item)
+    if worst > A2A_MAX_PIECE_BYTES:
+        raise RuntimeError(f"{what}: a {worst / 2**30:.2f}-GiB piece for one peer -- RCCL 2.26 corrupts single transfers above "
+                           "1 GiB; use the native exchange (emb_comm_all_to_all cuts them), more ranks or a smaller batch")
+
+
+def rounds_for(max_piece_bytes: int) -> int:
+    """Rounds all_to_all_rounds needs so that no piece of a round exceeds A2A_ROUND_BYTES.  Every rank must arrive at the
+    SAME number: compute it from shapes all ranks share, never from one rank's own counts."""
+    return max(1, -(-int(max_piece_bytes) // A2A_ROUND_BYTES))
+
+
+class _Works:
+    def __init__(self, works):
+        self.works = [w for w in works if w is not None]
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+
+
+def all_to_all_rounds(dist, recv, send, out_splits, in_splits, rounds: int, group=None):
+    """all_to_all over leading-dimension ranges of 1-D uint8 tensors in `rounds` rounds: round r moves bytes
+    [r*A2A_ROUND_BYTES, (r+1)*A2A_ROUND_BYTES) of every pair's piece.  rounds == 1 is one all_to_all_single."""
+    if rounds <= 1:
+        check_piece_sizes(list(out_splits) + list(in_splits), send.element_size(), "all_to_all_single")
+        return dist.all_to_all_single(recv, send, output_split_sizes=list(out_splits), input_split_sizes=list(in_splits),
+                                      group=group, async_op=True)
+    in_off, out_off = [0] + _cumsum(in_splits), [0] + _cumsum(out_splits)
+    step = A2A_ROUND_BYTES // send.element_size()
+    works = []
+    for r in range(rounds):
+        ins = [send[in_off[p] + min(r * step, n):in_off[p] + min((r + 1) * step, n)] for p, n in enumerate(in_splits)]
+        outs = [recv[out_off[p] + min(r * step, n):out_off[p] + min((r + 1) * step, n)] for p, n in enumerate(out_splits)]
+        works.append(dist.all_to_all(outs, ins, group=group, async_op=True))
+    return _Works(works)
 
 
 def _cumsum(xs):
