@@ -442,3 +442,45 @@ def test_distributed_c5_shape_whole_table_shards_two_ranks():
     c = d["config"]
     assert c["tables"] == 512 and c["dim"] == 64 and c["pooling"] == 32
     assert "512 whole" in c["workload"] and "fp16" in c["workload"] and "mixed indices" in c["workload"]
+
+
+def test_all_to_all_rounds_and_the_piece_size_guard():
+    """sharding.all_to_all_rounds over RCCL (one rank, self exchange) with the round size forced down to 1 MiB: a 5.5-MiB
+    payload moved in 6 rounds arrives intact; check_piece_sizes refuses a piece above 1 GiB (RCCL 2.26 would deliver half of
+    it: csrc/tools/a2a_size_probe.py) before anything is sent."""
+    import subprocess
+    import sys
+    import textwrap
+    script = textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, %r)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29613")
+        import torch, torch.distributed as dist
+        from importlib import import_module
+        import pim_embedding_lookup_amd
+        sh = import_module("pim-embedding-lookup_amd.sharding")
+        dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        sh.A2A_ROUND_BYTES = 1 << 20
+        n = (5 << 20) + (1 << 19) + 13
+        src = torch.randint(0, 256, (n,), dtype=torch.uint8, device=dev)
+        dst = torch.zeros_like(src)
+        assert sh.rounds_for(n) == 6
+        sh.all_to_all_rounds(dist, dst, src, [n], [n], sh.rounds_for(n)).wait()
+        torch.cuda.synchronize()
+        assert torch.equal(dst, src)
+        dst.zero_()
+        sh.all_to_all_rounds(dist, dst, src, [n], [n], 1).wait()
+        torch.cuda.synchronize()
+        assert torch.equal(dst, src)
+        try:
+            sh.check_piece_sizes([3, (1 << 30) // 4 + 1], 4, "test")
+            raise SystemExit("oversize piece accepted")
+        except RuntimeError as e:
+            assert "1 GiB" in str(e)
+        sh.check_piece_sizes([(1 << 30) // 4], 4, "test")
+        dist.destroy_process_group()
+        print("rounds ok")
+    """ % ROOT)
+    res = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "rounds ok" in res.stdout, res.stdout[-1000:] + res.stderr[-3000:]
