@@ -547,6 +547,13 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
     wall = float(el.item())
     verify(it - 1, "last timed")                     # what the timed loop left behind
+    digest = None
+    if rank == 0 and K:                              # bits of rank 0's row-split outputs of that step: two runs must agree
+        import hashlib
+        hsh = hashlib.sha1()
+        for k in range(K):
+            hsh.update(slots[(it - 1) % NBATCH]["out_sh"][k][:4096].contiguous().cpu().numpy().tobytes())
+        digest = hsh.hexdigest()
     if prof is not None and rank == 0:
         n_calls = args.steps + args.warmup + NBATCH + 2
         print("[dist_bench] host microseconds per step by call:",
@@ -574,6 +581,7 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
                                       "rows added in shard order; backend %s, %s, eager steps" %
                                       (backend, "collectives issued natively to RCCL on the compute stream"
                                        if native is not None else "torch.distributed.all_to_all_single"),
+                       "last_step_outputs_sha1": digest,
                        "last_step_request_rows_per_peer": sent[:, :, 0].sum(axis=1).tolist(),
                        "last_step_request_indices_per_peer": sent[:, :, 1].sum(axis=1).tolist()},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": hbm_peak_gbs, "unit": "GB/s",

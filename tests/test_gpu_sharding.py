@@ -278,6 +278,8 @@ def test_distributed_terabyte_shaped_row_shards_two_ranks(pooling):
         res2, d2 = _bench_two_ranks(extra)
         assert res2.returncode == 0, res2.stderr[-3000:]
         assert d2["config"]["last_step_request_rows_per_peer"] == d["config"]["last_step_request_rows_per_peer"]
+        # bit-identical between two runs (and between the two launchers): the same digest of rank 0's row-split outputs
+        assert d2["config"]["last_step_outputs_sha1"] == d["config"]["last_step_outputs_sha1"] is not None
 
 
 def test_exchange_leg_failure_is_a_failed_run():
