@@ -436,10 +436,20 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
         return r
 
     unfinished = [None]        # slot whose partial rows are on their way back (its un-routing is the next step's job)
+    # the router and its counts exchange depend on nothing of the step they are issued in: they run on their own stream,
+    # ordered behind the last reader of the slot they fill (the un-router of NBATCH batches ago)
+    route_stream = torch.cuda.Stream(dev) if (K and os.environ.get("PIMEMB_ROUTE_STREAM", "1") != "0" and native is None) else None
+    slot_free = [torch.cuda.Event() for _ in range(NBATCH)]
+
+    def route_into(slot):
+        if route_stream is not None:
+            route_stream.wait_event(slot_free[slot])
+        ex.route(slot, slots[slot]["route_spec"], B, K * B * L, stream=route_stream)
 
     def finish_pending():
         if unfinished[0] is not None:
             timed("finish", ex.finish, unfinished[0], slots[unfinished[0]]["out_sh"])
+            slot_free[unfinished[0]].record(stream)
             unfinished[0] = None
 
     def step(i):
@@ -453,7 +463,7 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
         j, nxt, nxt2 = i % NBATCH, (i + 1) % NBATCH, (i + 2) % NBATCH
         sl = slots[j]
         if K:
-            timed("route+counts", ex.route, nxt2, slots[nxt2]["route_spec"], B, K * B * L)
+            timed("route+counts", route_into, nxt2)
         if sl["plan_a"] is not None:
             timed("local", sl["plan_a"].launch, h)
         if K:
@@ -464,9 +474,9 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
 
     def prologue(i):           # before step(i): batch i's requests on their way, batch i+1 routed and its counts sent
         if K:
-            ex.route(i % NBATCH, slots[i % NBATCH]["route_spec"], B, K * B * L)
+            route_into(i % NBATCH)
             ex.send_requests(i % NBATCH)
-            ex.route((i + 1) % NBATCH, slots[(i + 1) % NBATCH]["route_spec"], B, K * B * L)
+            route_into((i + 1) % NBATCH)
 
     done_ev = torch.cuda.Event()
 

@@ -356,16 +356,30 @@ class RowRangeExchange:
                                       input_split_sizes=list(in_splits), group=self.group, async_op=True)
 
     # ---- phases -------------------------------------------------------------------------------------
-    def route(self, slot: int, spec, n_bags: int, total_indices: int) -> None:
-        """spec: EmbeddingEngine.route_tables([...]) over this rank's K index arrays (uint32 row ids)."""
-        sl = self.slots[slot]
+    def route(self, slot: int, spec, n_bags: int, total_indices: int, stream=None) -> None:
+        """spec: EmbeddingEngine.route_tables([...]) over this rank's K index arrays (uint32 row ids).
+        stream: a torch.cuda.Stream to run the router and the counts exchange on (they depend on nothing of the current
+        step, so a pipelined caller lets them overlap the lookups); the caller orders it behind the slot's last reader.
+        Buffers are always allocated on the CURRENT stream."""
+        t, sl = self.torch, self.slots[slot]
         self._prepare(sl, n_bags, total_indices)
         sl["n_bags"] = n_bags
-        h = self.torch.cuda.current_stream(self.device).cuda_stream
-        self.engine.route_bags(spec, n_bags, self.N, sl["req_send"].data_ptr(), sl["meta"].data_ptr(),
-                               sl["slotmap"].data_ptr(), self.work.data_ptr(), h)
-        counts_out = sl["meta"][:2 * self.N * self.K].view(self.N, self.K, 2)
-        sl["counts_work"] = self._exchange(sl["counts_in"], counts_out, [1] * self.N, [1] * self.N)
+
+        def enqueue():
+            h = t.cuda.current_stream(self.device).cuda_stream
+            self.engine.route_bags(spec, n_bags, self.N, sl["req_send"].data_ptr(), sl["meta"].data_ptr(),
+                                   sl["slotmap"].data_ptr(), self.work.data_ptr(), h)
+            counts_out = sl["meta"][:2 * self.N * self.K].view(self.N, self.K, 2)
+            sl["counts_work"] = self._exchange(sl["counts_in"], counts_out, [1] * self.N, [1] * self.N)
+
+        sl["routed_ev"] = None
+        if stream is None:
+            enqueue()
+        else:
+            with t.cuda.stream(stream):
+                enqueue()
+                sl["routed_ev"] = t.cuda.Event()
+                sl["routed_ev"].record(stream)
 
     def send_requests(self, slot: int) -> None:
         """The one host wait of a step: learn the counts, then send the request pieces sized by them."""
@@ -380,6 +394,8 @@ class RowRangeExchange:
             sl["counts_ev"].synchronize()
             sl["counts_work"] = None
         else:
+            if sl.get("routed_ev") is not None:     # the router ran on another stream (no collective handle to wait on)
+                t.cuda.current_stream(self.device).wait_event(sl["routed_ev"])
             sl["counts_host"][0].copy_(counts_out, non_blocking=True)
             sl["counts_host"][1].copy_(sl["counts_in"], non_blocking=True)
             t.cuda.current_stream(self.device).synchronize()
