@@ -342,7 +342,6 @@ Variant make_hot(const char *name, uint32_t hot, uint32_t wgs) {
     return v;
 }
 
-static uint32_t g_stream_wgs = 2048;
 template <class Cfg, int G>
 void do_launch_stream(const DevDesc *d, uint32_t n, uint32_t tiles, const uint32_t *, uint32_t, hipStream_t s) {
     hipLaunchKernelGGL((bag_sum_stream_kernel<uint32_t, EMB_F32, LPR, Cfg>), dim3(G), dim3(Cfg::kBlock), 0, s, d, (uint32_t)LPR, n, tiles);
