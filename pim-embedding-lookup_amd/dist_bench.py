@@ -545,10 +545,14 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
     drain(it)
     dist.barrier()
     torch.cuda.synchronize()
+    check_every = int(os.environ.get("PIMEMB_VERIFY_EVERY", "0"))   # soak mode: verify inside the loop (times mean nothing then)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for n in range(args.steps):
         step(it)
         it += 1
+        if check_every and (n + 1) % check_every == 0:
+            drain(it)
+            verify(it - 1, "soak")
     drain(it)
     local_el = time.perf_counter() - t0     # this rank's K steps are complete (drain waits for the compute stream)
     dist.barrier()
