@@ -522,12 +522,26 @@ unroute_bags_kernel(const float *__restrict__ recv, const uint32_t *__restrict__
     if (b >= n_bags) return;
     const uint32_t *ret_row0 = meta + 4 * n_shards * n_tables + n_shards + 1;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (uint32_t d = 0; d < n_shards; d++) {
-        const uint32_t slot = slots[((uint64_t)k * n_shards + d) * n_bags + b];
-        if (slot != kNoSlot) {
-            const uint64_t row = (uint64_t)ret_row0[d * n_tables + k] + slot;
-            acc += *(reinterpret_cast<const f32x4 *>(recv) + row * pieces + piece);
+    // eight shards at a time: their slot words are fetched together, then the partial rows that exist, then the adds in
+    // shard order (a slot -> row -> add chain per shard paid up to 2 x n_shards dependent round trips per bag: 37 -> 23 us
+    // at one index per bag, 8 tables x 16384 bags x 8 shards)
+    for (uint32_t d0 = 0; d0 < n_shards; d0 += 8) {
+        uint32_t slot[8];
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++)
+            slot[j] = (d0 + j < n_shards) ? slots[((uint64_t)k * n_shards + d0 + j) * n_bags + b] : kNoSlot;
+        f32x4 v[8];
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) {
+            v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (slot[j] != kNoSlot) {
+                const uint64_t row = (uint64_t)ret_row0[(d0 + j) * n_tables + k] + slot[j];
+                v[j] = *(reinterpret_cast<const f32x4 *>(recv) + row * pieces + piece);
+            }
         }
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++)
+            if (slot[j] != kNoSlot) acc += v[j];
     }
     __builtin_nontemporal_store(acc, reinterpret_cast<f32x4 *>(pooled + ((uint64_t)k * n_bags + b) * dim) + piece);
 }
