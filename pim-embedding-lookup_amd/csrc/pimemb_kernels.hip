@@ -345,6 +345,15 @@ route_bags_count_kernel(RouteBagParams rp, uint64_t n_bags, uint32_t n_shards, u
     bag_bounds(t, b, n_bags, &p, &e);
     shard_range(t.rows_per_shard, d, n_shards, &lo, &hi);
     uint32_t c = 0;
+    for (; p < e && (p & 3u); p++) {                       // up to the next 16-byte boundary of the index array
+        const uint64_t r = t.indices[p];
+        c += (r >= lo && r < hi) ? 1u : 0u;
+    }
+    for (; p + 4 <= e; p += 4) {                           // four indices per load
+        const u32x4_a4 r4 = *reinterpret_cast<const u32x4_a4 *>(t.indices + p);   // (4-byte aligned type: the caller's array may start anywhere)
+#pragma unroll
+        for (int q = 0; q < 4; q++) c += ((uint64_t)r4[q] >= lo && (uint64_t)r4[q] < hi) ? 1u : 0u;
+    }
     for (; p < e; p++) {
         const uint64_t r = t.indices[p];
         c += (r >= lo && r < hi) ? 1u : 0u;
@@ -503,6 +512,16 @@ route_bags_place_kernel(RouteBagParams rp, uint64_t n_bags, uint32_t n_shards, u
     uint64_t p, e, lo, hi;
     bag_bounds(t, b, n_bags, &p, &e);
     shard_range(t.rows_per_shard, d, n_shards, &lo, &hi);
+    for (; p < e && (p & 3u); p++) {
+        const uint64_t r = t.indices[p];
+        if (r >= lo && r < hi) list[pos++] = (uint32_t)(r - lo);
+    }
+    for (; p + 4 <= e; p += 4) {                           // four indices per load, kept in bag order
+        const u32x4_a4 r4 = *reinterpret_cast<const u32x4_a4 *>(t.indices + p);   // (4-byte aligned type: the caller's array may start anywhere)
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if ((uint64_t)r4[q] >= lo && (uint64_t)r4[q] < hi) list[pos++] = (uint32_t)((uint64_t)r4[q] - lo);
+    }
     for (; p < e; p++) {
         const uint64_t r = t.indices[p];
         if (r >= lo && r < hi) list[pos++] = (uint32_t)(r - lo);
