@@ -386,7 +386,11 @@ def test_route_bags_limits_many_shards_and_tables(pel, eng):
         u8 = lambda n: torch.zeros(max(n, 16), dtype=torch.uint8, device=dev)
         send, meta, slots, work = u8(sz["send"]), u8(sz["meta"]), u8(sz["slots"]), u8(sz["work"])
         guard = torch.full((64,), 0x5A, dtype=torch.uint8, device=dev)
-        d_idx = [torch.from_numpy(i.view(np.int32)).to(dev) for i in idxs]
+        # index arrays that start 4, 8, 12 bytes off a 16-byte boundary (views into a larger tensor): the router's four-
+        # indices-per-load passes must not assume alignment
+        d_idx = [torch.cat([torch.zeros(1 + k % 3, dtype=torch.int32, device=dev),
+                            torch.from_numpy(i.view(np.int32)).to(dev)])[1 + k % 3:] for k, i in enumerate(idxs)]
+        assert d_idx[0].data_ptr() % 16 == 4
         eng.route_bags([(d_idx[k].data_ptr(), None, B * L, L, rps[k]) for k in range(K)], B, N, send.data_ptr(),
                        meta.data_ptr(), slots.data_ptr(), work.data_ptr())
         torch.cuda.synchronize()
