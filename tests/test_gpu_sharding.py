@@ -37,30 +37,27 @@ def _route_bags_reference(idx, off, n_idx, rps, N):
     return out
 
 
-@pytest.mark.parametrize("dim,ragged", [(16, True), (128, False), (64, True)])
-def test_route_bags_row_range_shards_pooled(pel, eng, oracle, dim, ragged):
-    """Pooled lookups over row-split tables in ONE process: emb_route_bags cuts every bag into per-shard sub-bags
-    (counts, layout, request pieces), every 'shard' serves its piece with the ordinary fused lookup, and
-    emb_unroute_bags adds the partial rows in shard order.  Checked: the counts / slots / request lists against a
-    host restatement of the routing rule; the result bit for bit against 'partials in shard order' built from the
-    oracle, and within 1e-6 of the oracle's unsharded sum; bit-identical on a second run."""
+def _router_case(pel, eng, oracle, rng, rows, N, B, dim, ragged, max_len=40, zipf_first=True):
+    """One router / un-router round trip in ONE process: emb_route_bags cuts every bag into per-shard sub-bags, every
+    'shard' serves its piece with the ordinary fused lookup, emb_unroute_bags adds the partial rows in shard order.
+    Checks counts / offsets / lists / slots against the host restatement of the routing rule, the result bit for bit
+    against 'oracle partial sums in shard order' and within 1e-6 of the oracle's unsharded sum.  Returns the pooled rows."""
     import torch
     dev = torch.device("cuda", 0)
-    rng = np.random.default_rng(dim)
-    K, N, B = 3, 4, 3001
-    rows = [100_003, 5_000, 40_001]
+    K = len(rows)
     rps = [-(-r // N) for r in rows]
     tabs = [pel.workloads.dlrm_table(rng, r, dim) for r in rows]
     idxs, offs = [], []
     for k in range(K):
         if ragged:
-            off, n_idx = pel.workloads.ragged_offsets(rng, B, 40, p_empty=0.15)
+            off, n_idx = pel.workloads.ragged_offsets(rng, B, max_len, p_empty=0.15) if max_len else (np.zeros(B, np.uint32), 0)
         else:
             off, n_idx = pel.workloads.fixed_offsets(B, 32), 32 * B
-        gen = pel.workloads.zipf_indices if k == 0 else pel.workloads.uniform_indices
+        gen = pel.workloads.zipf_indices if (k == 0 and zipf_first) else pel.workloads.uniform_indices
         idxs.append(gen(rng, rows[k], n_idx))
         offs.append(off)
-    # shard tables: engine table id 60 + k*N + d holds rows [d*rps, (d+1)*rps) of table k
+    # shard tables: engine table id 60 + k*N + d holds rows [d*rps, (d+1)*rps) of table k (a one-row stand-in where the
+    # range is empty: rows that do not divide, fewer rows than shards)
     for k in range(K):
         for d in range(N):
             lo, hi = min(d * rps[k], rows[k]), min((d + 1) * rps[k], rows[k])
@@ -69,7 +66,8 @@ def test_route_bags_row_range_shards_pooled(pel, eng, oracle, dim, ragged):
     sz = eng.route_bags_sizes(K, B, total, N)
     u8 = lambda n: torch.zeros(max(n, 16), dtype=torch.uint8, device=dev)
     send, meta, slots, work = u8(sz["send"]), u8(sz["meta"]), u8(sz["slots"]), u8(sz["work"])
-    d_idx = [torch.from_numpy(i.view(np.int32)).to(dev) for i in idxs]
+    d_idx = [torch.from_numpy(np.ascontiguousarray(i).view(np.int32)).to(dev) if i.shape[0] else
+             torch.zeros(1, dtype=torch.int32, device=dev) for i in idxs]
     d_off = [torch.from_numpy(o.view(np.int32)).to(dev) for o in offs]
     spec = [(d_idx[k].data_ptr(), d_off[k].data_ptr() if ragged else None, idxs[k].shape[0], 0 if ragged else 32, rps[k])
             for k in range(K)]
@@ -106,7 +104,7 @@ def test_route_bags_row_range_shards_pooled(pel, eng, oracle, dim, ragged):
             if ids:
                 eng.lookup_batched(ids, ii, oo, outs)
             rets.append(ret[:n_rows])
-        recv = torch.cat(rets)
+        recv = torch.cat(rets) if sum(r.shape[0] for r in rets) else torch.zeros((1, dim), device=dev)
         pooled = torch.full((K, B, dim), float("nan"), device=dev)
         eng.unroute_bags(recv.data_ptr(), meta.data_ptr(), slots.data_ptr(), K, B, N, dim, pooled.data_ptr())
         torch.cuda.synchronize()
@@ -116,11 +114,12 @@ def test_route_bags_row_range_shards_pooled(pel, eng, oracle, dim, ragged):
     words = send.view(torch.int32).cpu().numpy().view(np.uint32)
     sl = slots.view(torch.int32).cpu().numpy().view(np.uint32)[:K * N * B].reshape(K, N, B)
     pad4 = lambda v: (v + 3) & ~3
+    refs = [_route_bags_reference(idxs[k], offs[k].astype(np.int64), idxs[k].shape[0], rps[k], N) for k in range(K)]
     cursor, row = 0, 0
     for d in range(N):
         assert piece[d] == cursor
         for k in range(K):
-            ref = _route_bags_reference(idxs[k], offs[k].astype(np.int64), idxs[k].shape[0], rps[k], N)[d]
+            ref = refs[k][d]
             ns, ni = int(counts[d, k, 0]), int(counts[d, k, 1])
             assert (ns, ni) == (ref[0].shape[0], ref[1].shape[0])
             assert base[d, k, 0] == cursor and base[d, k, 1] == cursor + pad4(ns) and row0[d, k] == row
@@ -132,10 +131,9 @@ def test_route_bags_row_range_shards_pooled(pel, eng, oracle, dim, ragged):
     assert piece[N] == cursor and cursor * 4 <= sz["send"]
     # expected: partial sums per shard (oracle, in index order), added in shard order from +0
     for k in range(K):
-        ref = _route_bags_reference(idxs[k], offs[k].astype(np.int64), idxs[k].shape[0], rps[k], N)
         want = np.zeros((B, dim), np.float32)
         for d in range(N):
-            sub_off, lst, slot = ref[d]
+            sub_off, lst, slot = refs[k][d]
             if sub_off.shape[0] == 0:
                 continue
             lo, hi = min(d * rps[k], rows[k]), min((d + 1) * rps[k], rows[k])
@@ -145,8 +143,32 @@ def test_route_bags_row_range_shards_pooled(pel, eng, oracle, dim, ragged):
         assert np.array_equal(pooled[k], want), f"table {k}: not the shard-ordered sum of partials"
         full = oracle.c_bag_sum(tabs[k], idxs[k], offs[k])
         assert float(np.abs(pooled[k] - full).max()) <= 1e-6
-    again = run_once()[-1]
-    assert np.array_equal(again, pooled)                   # deterministic: same bits on a second run
+    return pooled, run_once
+
+
+@pytest.mark.parametrize("dim,ragged", [(16, True), (128, False), (64, True)])
+def test_route_bags_row_range_shards_pooled(pel, eng, oracle, dim, ragged):
+    """Pooled lookups over row-split tables in ONE process (see _router_case): three tables, four shards, ragged bags
+    with empty ones / 32 indices per bag, Zipf and uniform indices; bit-identical on a second run."""
+    rng = np.random.default_rng(dim)
+    pooled, run_once = _router_case(pel, eng, oracle, rng, [100_003, 5_000, 40_001], 4, 3001, dim, ragged)
+    assert np.array_equal(run_once()[-1], pooled)          # deterministic: same bits on a second run
+
+
+def test_route_bags_hypothesis_shapes(pel, eng, oracle):
+    """Property test over shapes (hypothesis, seeded): 1..4 tables of 1..5000 rows -- fewer rows than shards included --
+    over 1..17 shards, 1..300 bags of 0..9 indices (all-empty launches included), dims 4 / 16 / 64."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+
+    @settings(max_examples=30, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(seed=st.integers(0, 2**31 - 1), k=st.integers(1, 4), n=st.integers(1, 17), b=st.integers(1, 300),
+           dim=st.sampled_from([4, 16, 64]), max_len=st.integers(0, 9), small=st.booleans())
+    def case(seed, k, n, b, dim, max_len, small):
+        rng = np.random.default_rng(seed)
+        rows = [int(x) for x in rng.integers(1, 12 if small else 5000, size=k)]
+        _router_case(pel, eng, oracle, rng, rows, n, b, dim, True, max_len=max_len, zipf_first=False)
+
+    case()
 
 
 def test_route_bags_one_index_per_bag_is_exact(pel, eng, oracle):
