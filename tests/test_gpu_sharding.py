@@ -142,7 +142,8 @@ def _router_case(pel, eng, oracle, rng, rows, N, B, dim, ragged, max_len=40, zip
             want[has] = want[has] + part[slot[has]]
         assert np.array_equal(pooled[k], want), f"table {k}: not the shard-ordered sum of partials"
         full = oracle.c_bag_sum(tabs[k], idxs[k], offs[k])
-        assert float(np.abs(pooled[k] - full).max()) <= 1e-6
+        # 1e-6 (load_generator.c:58) at DLRM scale; tables of a handful of rows have entries near 1, so scale with them
+        assert float(np.abs(pooled[k] - full).max()) <= 1e-6 * max(1.0, float(np.abs(full).max(initial=0.0)))
     return pooled, run_once
 
 
