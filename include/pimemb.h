@@ -237,33 +237,8 @@ int emb_synchronize(emb_engine *e, void *stream);
 int emb_device_of(emb_engine *e, int32_t *device);
 
 /* ------------------------------------------------------------------------------------------ */
-/* multi-GPU routing helpers for ROW-RANGE sharded tables, one index per bag                    */
-/* (the Criteo shape; counterpart of the reference's index broadcast / result gather over       */
-/*  per-column DPUs, emb_host.h:258-270, 312-321, for row-range shards over GPUs)                */
-/* ------------------------------------------------------------------------------------------ */
-/* All pointers are DEVICE pointers; both calls only enqueue work on `stream`.
- *
- * emb_route_onehot: `indices` holds n_tables x n_bags uint32 row ids (table-major).  Table k is
- * split over n_shards ranks in ranges of rows_per_shard[k] rows.  Every index goes to shard
- * d = idx / rows_per_shard[k] as the LOCAL row idx - d*rows_per_shard[k], appended to that shard's
- * request list: send_base + d*dest_stride_bytes + idx_offset_bytes is a uint32[n_tables][capacity]
- * array; list slots are handed out with wavefront-aggregated atomics on counts[k*n_shards + d]
- * (zeroed by this call, on `stream`).  perm[k*n_bags + b] = (d << 24) | slot remembers where
- * bag b's pooled row will come back.  A list that would exceed `capacity` sets *overflow to 1 (the
- * step's result is then incomplete -- size capacity with headroom, check the flag). */
-int emb_route_onehot(emb_engine *e, const uint32_t *indices, uint32_t n_tables, uint64_t n_bags,
-                     const uint32_t *rows_per_shard /* host array [n_tables] */, uint32_t n_shards,
-                     uint32_t capacity, void *send_base, uint64_t dest_stride_bytes,
-                     uint64_t idx_offset_bytes, uint32_t *perm, uint32_t *counts, uint32_t *overflow,
-                     void *stream);
-/* emb_unroute_rows: pooled[k][b][:] = the row that came back for bag b: recv_base +
- * d*src_stride_bytes is a float[n_tables][capacity][dim] array written by shard d. */
-int emb_unroute_rows(emb_engine *e, const void *recv_base, uint64_t src_stride_bytes, uint32_t n_tables,
-                     uint64_t n_bags, uint32_t dim, uint32_t capacity, const uint32_t *perm,
-                     float *pooled /* [n_tables][n_bags][dim] */, void *stream);
-
-/* ------------------------------------------------------------------------------------------ */
-/* row-range shards, VARIABLE-LENGTH bags (pooled lookups): counts first, payload second          */
+/* multi-GPU routing for ROW-RANGE sharded tables, any number of indices per bag:                  */
+/* counts first, payload second                                                                   */
 /* ------------------------------------------------------------------------------------------ */
 /* The bag loop being sharded is upmem/src/dpu/emb_dpu_lookup.c:106-116; the reference tells its devices the
  * lengths before every launch (emb_host.h:280-287) -- here the lengths are computed on the GPU and are the
@@ -276,16 +251,28 @@ int emb_unroute_rows(emb_engine *e, const void *recv_base, uint64_t src_stride_b
  * bit-identical to an unsharded lookup when a bag lives in one shard (one index per bag), within fp32
  * re-association (<= 1e-6 on DLRM-scale tables) otherwise.
  *
- * emb_route_bags enqueues four small kernels on `stream` and fills (all DEVICE memory, sizes from
+ * emb_route_bags enqueues a few small kernels on `stream` and fills (all DEVICE memory, sizes from
  * emb_route_bags_sizes; K = n_tables, N = n_shards, pad4(x) = x rounded up to a multiple of 4):
- *   meta  uint32 words:  counts[N][K][2] = {n_sub, n_idx} of the request to shard d for table k  <- send to d first
- *                        base  [N][K][2] = word offsets in `send` of that request's offsets / indices arrays
- *                        piece [N+1]     = word offset of destination d's piece (piece[N] = words in all)
- *                        ret_row0[N][K]  = first partial row of (d, k) in the returned rows (see below)
+ *   meta  uint32 words:  counts[N][K+1][2]: entry [d][k], k < K = {n_sub, n_idx} of the request to shard d for table k;
+ *                                           entry [d][K] = {peak request words, peak partial rows}: the largest piece
+ *                                           this rank sends to / expects back from any ONE peer (the same pair in every
+ *                                           d).  counts[d] is the message for peer d and goes out FIRST; from the K+1
+ *                                           entries it receives from every peer a rank sizes the payload AND learns the
+ *                                           job-wide largest piece, so all ranks agree on how many rounds a transfer
+ *                                           that is too large for one collective takes (sharding.py)
+ *                        base  [N][K][2]  = word offsets in `send` of that request's offsets / indices arrays
+ *                        piece [N+1]      = word offset of destination d's piece (piece[N] = words in all)
+ *                        ret_row0[N][K]   = first partial row of (d, k) in the returned rows (see below)
+ *                        mode             = how `slots` is encoded: 0 bags, 1 one index per bag
  *   send  uint32 words:  for d: for k: offsets[pad4(n_sub)] then local row ids[pad4(n_idx)]  (every array
  *                        16-byte aligned; the host derives the split sizes from `counts` with the same rule)
- *   slots uint32[K][N][n_bags]: slot of bag b's sub-bag in (d, k)'s request, 0xffffffff = none (kept by the
- *                        source for emb_unroute_bags; valid until the next emb_route_bags into the same buffer)
+ *   slots (opaque; kept by the source for emb_unroute_bags, valid until the next emb_route_bags into the same
+ *                        buffers).  mode 0: uint32[K][N][n_bags], slot of bag b's sub-bag in (d, k)'s request,
+ *                        0xffffffff = none.  mode 1: uint32[K][n_bags], (d << 24) | slot.
+ * One index per bag (every table: offsets == NULL, fixed_pooling == 1; n_shards <= 64, n_bags < 2^24 -- the Criteo
+ * shape, emb_host.h:258-263 pushes one index list per table) takes a fast path with the same request format and the
+ * same slot order: each index is read once (ballot ranks inside 1024-bag blocks, block prefixes, no atomics) and
+ * the un-router reads one slot word and one row per bag instead of n_shards slot words.
  * The serving rank runs emb_lookup_batched over the received pieces (n_bags = n_sub, n_indices = n_idx, device
  * pointers) and returns, per source, the partial rows of k = 0 .. K-1 back to back (float[n_sub][dim], no
  * padding).  emb_unroute_bags then reads `recv` = the returned rows of shard 0, shard 1, ... back to back

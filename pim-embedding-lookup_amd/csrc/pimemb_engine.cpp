@@ -1236,41 +1236,6 @@ int emb_device_of(emb_engine *e, int32_t *device) {
     return EMB_OK;
 }
 
-int emb_route_onehot(emb_engine *e, const uint32_t *indices, uint32_t n_tables, uint64_t n_bags,
-                     const uint32_t *rows_per_shard, uint32_t n_shards, uint32_t capacity, void *send_base,
-                     uint64_t dest_stride_bytes, uint64_t idx_offset_bytes, uint32_t *perm, uint32_t *counts,
-                     uint32_t *overflow, void *stream) {
-    if (!e || !indices || !rows_per_shard || !send_base || !perm || !counts || !overflow)
-        return fail(EMB_ERR_INVALID, "emb_route_onehot: NULL argument");
-    if (n_tables > 64) return fail(EMB_ERR_UNSUPPORTED, "emb_route_onehot: more than 64 tables per call");
-    if (n_shards == 0 || n_shards > 255 || capacity == 0 || capacity >= (1u << 24))
-        return fail(EMB_ERR_INVALID, "emb_route_onehot: n_shards must be 1..255 and capacity 1..2^24-1");
-    if (idx_offset_bytes % 4 || dest_stride_bytes % 4) return fail(EMB_ERR_INVALID, "emb_route_onehot: unaligned layout");
-    pimemb::RouteParams rp{};
-    for (uint32_t k = 0; k < n_tables; k++) {
-        if (rows_per_shard[k] == 0) return fail(EMB_ERR_INVALID, "emb_route_onehot: rows_per_shard[%u] is 0", k);
-        rp.rows_per_shard[k] = rows_per_shard[k];
-    }
-    DeviceGuard g(e->device);
-    HIP_TRY(hipMemsetAsync(counts, 0, sizeof(uint32_t) * n_tables * n_shards, static_cast<hipStream_t>(stream)));
-    HIP_TRY(pimemb::launch_route_onehot(indices, n_tables, n_bags, rp, n_shards, capacity,
-                                        static_cast<char *>(send_base), dest_stride_bytes, idx_offset_bytes, perm,
-                                        counts, overflow, static_cast<hipStream_t>(stream)));
-    return EMB_OK;
-}
-
-int emb_unroute_rows(emb_engine *e, const void *recv_base, uint64_t src_stride_bytes, uint32_t n_tables,
-                     uint64_t n_bags, uint32_t dim, uint32_t capacity, const uint32_t *perm, float *pooled,
-                     void *stream) {
-    if (!e || !recv_base || !perm || !pooled) return fail(EMB_ERR_INVALID, "emb_unroute_rows: NULL argument");
-    if (dim == 0 || dim % 4 || src_stride_bytes % 16)
-        return fail(EMB_ERR_UNSUPPORTED, "emb_unroute_rows: dim must be a multiple of 4 and strides 16-byte aligned");
-    DeviceGuard g(e->device);
-    HIP_TRY(pimemb::launch_unroute_rows(static_cast<const char *>(recv_base), src_stride_bytes, n_tables, n_bags, dim,
-                                        capacity, perm, pooled, static_cast<hipStream_t>(stream)));
-    return EMB_OK;
-}
-
 int emb_route_bags_sizes(uint32_t n_tables, uint64_t n_bags, uint64_t total_indices, uint32_t n_shards,
                          uint64_t *send_bytes, uint64_t *meta_bytes, uint64_t *slots_bytes, uint64_t *work_bytes) {
     if (n_tables == 0 || n_tables > pimemb::kRouteBagMaxTables || n_shards == 0 || n_shards > 255)
@@ -1279,7 +1244,7 @@ int emb_route_bags_sizes(uint32_t n_tables, uint64_t n_bags, uint64_t total_indi
     // every index once, at most min(indices, bags x shards) sub-bag offsets, < 4 padding words per array
     const uint64_t sub_max = std::min<uint64_t>(total_indices, n_bags * nk);
     if (send_bytes) *send_bytes = (total_indices + sub_max + 8 * nk + 4) * 4;
-    if (meta_bytes) *meta_bytes = (5 * nk + n_shards + 1 + 3) / 4 * 16;
+    if (meta_bytes) *meta_bytes = ((uint64_t)pimemb::route_bags_meta_words(n_tables, n_shards) + 3) / 4 * 16;
     if (slots_bytes) *slots_bytes = (nk * n_bags + 3) / 4 * 16;
     if (work_bytes) *work_bytes = (nk * n_bags + 3) / 4 * 16;
     return EMB_OK;

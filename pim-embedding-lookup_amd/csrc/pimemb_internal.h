@@ -60,20 +60,9 @@ hipError_t launch_scatter_column(int32_t *table, const int32_t *column, uint64_t
 hipError_t launch_validate(const DevDesc *d_descs, uint32_t n_descs, emb_index_type itype,
                            unsigned long long *d_bad, hipStream_t stream);
 
-// Row-range routing of one-hot requests (multi-GPU; see pimemb.h).  rows_per_shard: up to 64 tables.
-struct RouteParams {
-    uint32_t rows_per_shard[64];
-};
-hipError_t launch_route_onehot(const uint32_t *indices, uint32_t n_tables, uint64_t n_bags,
-                               const RouteParams &rp, uint32_t n_shards, uint32_t capacity, char *send_base,
-                               uint64_t dest_stride_bytes, uint64_t idx_offset_bytes, uint32_t *perm,
-                               uint32_t *counts, uint32_t *overflow, hipStream_t stream);
-hipError_t launch_unroute_rows(const char *recv_base, uint64_t src_stride_bytes, uint32_t n_tables,
-                               uint64_t n_bags, uint32_t dim, uint32_t capacity, const uint32_t *perm,
-                               float *pooled, hipStream_t stream);
-
 // Row-range routing of variable-length bags (pooled lookups over row-split tables; see pimemb.h,
-// emb_route_bags).  All pointers are device pointers; the four kernels are enqueued on `stream`.
+// emb_route_bags).  All pointers are device pointers; the kernels (four; three on the one-index-per-bag fast path)
+// are enqueued on `stream`.
 constexpr uint32_t kRouteBagMaxTables = 64;
 struct RouteBagDesc {
     const uint32_t *indices;
@@ -84,6 +73,7 @@ struct RouteBagDesc {
 };
 hipError_t launch_route_bags(const RouteBagDesc *tables, uint32_t n_tables, uint64_t n_bags, uint32_t n_shards,
                              uint32_t *send, uint32_t *meta, uint32_t *slots, uint32_t *work, hipStream_t stream);
+uint32_t route_bags_meta_words(uint32_t n_tables, uint32_t n_shards);   // uint32 words of `meta`
 hipError_t launch_unroute_bags(const float *recv, const uint32_t *meta, const uint32_t *slots, uint32_t n_tables,
                                uint64_t n_bags, uint32_t n_shards, uint32_t dim, float *pooled, hipStream_t stream);
 

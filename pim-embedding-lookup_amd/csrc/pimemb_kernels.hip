@@ -1,5 +1,7 @@
 // pimemb_kernels.hip -- instantiates the bag kernels of pimemb_bag_kernels.h for the library and
 // holds the two small helper kernels (column scatter, input validation).  gfx950 only.
+#include <cstdlib>
+
 #include "pimemb_internal.h"
 
 namespace pimemb {
@@ -204,88 +206,6 @@ validate_kernel(const DevDesc *__restrict__ descs, unsigned long long *__restric
     if (local) atomicAdd(bad, local);
 }
 
-// ---- multi-GPU routing of one-hot requests to row-range shards --------------------------------
-// One request = one (table, bag).  Slots in a shard's request list are handed out per WORKGROUP of
-// 1024 requests: every wavefront counts its lanes per shard with ballots, the counts meet in LDS,
-// and ONE returning atomicAdd per (workgroup, shard) reserves the range.  Returning device-scope
-// atomics on one address retire at only ~20 per microsecond on this chip, so their number -- not
-// the arithmetic -- sets the kernel time: 39 per counter for B = 39292 instead of 614 with
-// per-wavefront aggregation (measured 37 us -> see profiles).
-constexpr int kRouteBlock = 1024;
-constexpr int kRouteWaves = kRouteBlock / 64;
-constexpr int kRouteMaxShards = 255;
-
-__global__ void __launch_bounds__(kRouteBlock)
-route_onehot_kernel(const uint32_t *__restrict__ indices, uint64_t n_bags, RouteParams rp, uint32_t n_shards,
-                    uint32_t capacity, char *__restrict__ send_base, uint64_t dest_stride_bytes,
-                    uint64_t idx_offset_bytes, uint32_t *__restrict__ perm, uint32_t *__restrict__ counts,
-                    uint32_t *__restrict__ overflow) {
-    __shared__ uint32_t wcnt[kRouteWaves][kRouteMaxShards + 1];  // per wavefront / shard, then exclusive prefix
-    __shared__ uint32_t bbase[kRouteMaxShards + 1];              // first slot of this workgroup per shard
-    const uint32_t k = blockIdx.y;
-    const uint64_t b = (uint64_t)blockIdx.x * kRouteBlock + threadIdx.x;
-    const bool live = b < n_bags;
-    const uint32_t rps = rp.rows_per_shard[k];
-    uint32_t idx = 0, dest = 0;
-    if (live) {
-        idx = indices[(uint64_t)k * n_bags + b];
-        dest = idx / rps;
-        if (dest >= n_shards) dest = n_shards - 1;       // out-of-range index: keep memory accesses in bounds
-    }
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t rank_in_wave = 0;
-    for (uint32_t d = 0; d < n_shards; d++) {            // wave-uniform trip count
-        const unsigned long long m = __ballot(live && dest == d);
-        if (lane == 0) wcnt[wave][d] = (uint32_t)__popcll(m);
-        if (live && dest == d) rank_in_wave = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    }
-    __syncthreads();
-    if (threadIdx.x < n_shards) {
-        const uint32_t d = threadIdx.x;
-        uint32_t total = 0;
-        for (uint32_t w = 0; w < kRouteWaves; w++) {      // counts -> exclusive prefix over wavefronts
-            const uint32_t c = wcnt[w][d];
-            wcnt[w][d] = total;
-            total += c;
-        }
-        bbase[d] = total ? atomicAdd(&counts[k * n_shards + d], total) : 0u;
-    }
-    __syncthreads();
-    if (!live) return;
-    const uint32_t slot = bbase[dest] + wcnt[wave][dest] + rank_in_wave;
-    if (slot >= capacity) {
-        *overflow = 1u;                                   // benign race: every writer stores 1
-        perm[(uint64_t)k * n_bags + b] = 0xffffffffu;
-        return;
-    }
-    uint32_t *list = reinterpret_cast<uint32_t *>(send_base + dest * dest_stride_bytes + idx_offset_bytes) +
-                     (uint64_t)k * capacity;
-    list[slot] = idx - dest * rps;
-    perm[(uint64_t)k * n_bags + b] = (dest << 24) | slot;
-}
-
-__global__ void __launch_bounds__(kBlock)
-unroute_rows_kernel(const char *__restrict__ recv_base, uint64_t src_stride_bytes, uint64_t n_bags, uint32_t dim,
-                    uint32_t capacity, const uint32_t *__restrict__ perm, float *__restrict__ pooled) {
-    // dim/4 lanes per row, 16 bytes each
-    const uint32_t k = blockIdx.y, n_tables = gridDim.y;
-    const uint32_t pieces = dim / 4;
-    const uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    const uint64_t b = gid / pieces;
-    const uint32_t piece = (uint32_t)(gid % pieces);
-    if (b >= n_bags) return;
-    const uint32_t p = perm[(uint64_t)k * n_bags + b];
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (p != 0xffffffffu) {
-        const uint32_t d = p >> 24, slot = p & 0xffffffu;
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(recv_base + d * src_stride_bytes) +
-                           ((uint64_t)k * capacity + slot) * pieces + piece;
-        v = *src;
-    }
-    __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(pooled + ((uint64_t)k * n_bags + b) * dim) + piece);
-    (void)n_tables;
-}
-
 // ---- multi-GPU routing of variable-length BAGS to row-range shards -------------------------------
 // A bag of a row-split table is cut into one SUB-BAG per shard that owns some of its rows; the shard
 // returns one partial pooled row per sub-bag and the bag's owner adds the partials in shard order
@@ -302,6 +222,27 @@ unroute_rows_kernel(const char *__restrict__ recv_base, uint64_t src_stride_byte
 // of L1/L2; at B = 16384 x 32 indices x 8 tables x 8 shards that is 134 MB of cache reads, a few us.
 constexpr uint32_t kNoSlot = 0xffffffffu;
 constexpr int kScanBlock = 1024;
+
+// Word offsets of the sections of `meta` (pimemb.h, emb_route_bags).  The counts message of destination d is
+// counts[d][0 .. K] -- K table entries {n_sub, n_idx} and one trailing entry {peak request words, peak partial rows}
+// that is the same for every d: the largest piece this rank sends / expects back from any ONE peer, so that every
+// rank can derive the same number of transfer rounds from the counts it receives (sharding.py).
+struct MetaLayout {
+    uint32_t base, piece, row0, mode, words;
+};
+__host__ __device__ __forceinline__ MetaLayout meta_layout(uint32_t n_shards, uint32_t n_tables) {
+    MetaLayout m;
+    m.base = 2 * n_shards * (n_tables + 1);
+    m.piece = m.base + 2 * n_shards * n_tables;
+    m.row0 = m.piece + n_shards + 1;
+    m.mode = m.row0 + n_shards * n_tables;
+    m.words = m.mode + 1;
+    return m;
+}
+__host__ __device__ __forceinline__ uint32_t counts_at(uint32_t d, uint32_t k, uint32_t n_tables) {
+    return (d * (n_tables + 1) + k) * 2;
+}
+constexpr uint32_t kModeBags = 0, kModeOneHot = 1;   // meta[mode]: how `slots` is encoded (see unroute_bags_kernel)
 
 struct RouteBagTable {
     const uint32_t *indices;
@@ -438,30 +379,32 @@ route_bags_scan_kernel(uint64_t n_bags, uint32_t n_tables, uint32_t *__restrict_
         carry_idx += s_idx[kScanBlock - 1];
     }
     if (threadIdx.x == 0) {
-        counts[((uint64_t)d * n_tables + k) * 2 + 0] = carry_sub;
-        counts[((uint64_t)d * n_tables + k) * 2 + 1] = carry_idx;
+        counts[counts_at(d, k, n_tables) + 0] = carry_sub;
+        counts[counts_at(d, k, n_tables) + 1] = carry_idx;
     }
 }
 
 __host__ __device__ __forceinline__ uint32_t pad4(uint32_t v) { return (v + 3u) & ~3u; }
 
-// meta words: counts[N][K][2] | base[N][K][2] | piece[N+1] | ret_row0[N][K]   (see pimemb.h, emb_route_bags).
+// meta words: counts[N][K+1][2] | base[N][K][2] | piece[N+1] | ret_row0[N][K] | mode   (see pimemb.h, emb_route_bags).
 // Exclusive prefix over the N*K (shard, table) entries, kBlock entries per pass: every thread loads its entry's
 // counts (in parallel -- one lane walking the list paid a dependent load per entry: 11 us for 64 entries), an LDS scan
-// gives the word / row offsets, a carry links the passes.
-__global__ void __launch_bounds__(kBlock)
-route_bags_layout_kernel(uint32_t n_shards, uint32_t n_tables, uint32_t *__restrict__ meta) {
-    __shared__ uint32_t s_w[kBlock], s_r[kBlock];
+// gives the word / row offsets, a carry links the passes.  Then the peaks: the largest request piece (words) and the
+// largest number of partial rows exchanged with any one peer, copied into every destination's counts message.
+__device__ __forceinline__ void layout_meta(uint32_t n_shards, uint32_t n_tables, uint32_t *__restrict__ meta, uint32_t mode) {
+    __shared__ uint32_t s_w[kBlock], s_r[kBlock], s_peak[2];
     const uint32_t nk = n_shards * n_tables;
-    const uint32_t *counts = meta;
-    uint32_t *base = meta + 2 * nk, *piece = meta + 4 * nk, *ret_row0 = meta + 4 * nk + n_shards + 1;
+    const MetaLayout ml = meta_layout(n_shards, n_tables);
+    uint32_t *counts = meta;
+    uint32_t *base = meta + ml.base, *piece = meta + ml.piece, *ret_row0 = meta + ml.row0;
     uint32_t carry_w = 0, carry_r = 0;
+    if (threadIdx.x < 2) s_peak[threadIdx.x] = 0;
     for (uint32_t e0 = 0; e0 < nk; e0 += kBlock) {
         const uint32_t e = e0 + threadIdx.x;
         uint32_t n_sub = 0, n_idx = 0;
         if (e < nk) {
-            n_sub = counts[2 * e];
-            n_idx = counts[2 * e + 1];
+            n_sub = counts[counts_at(e / n_tables, e % n_tables, n_tables)];
+            n_idx = counts[counts_at(e / n_tables, e % n_tables, n_tables) + 1];
         }
         const uint32_t words = pad4(n_sub) + pad4(n_idx);
         __syncthreads();
@@ -489,7 +432,27 @@ route_bags_layout_kernel(uint32_t n_shards, uint32_t n_tables, uint32_t *__restr
         carry_w += s_w[kBlock - 1];
         carry_r += s_r[kBlock - 1];
     }
-    if (threadIdx.x == 0) piece[n_shards] = carry_w;
+    if (threadIdx.x == 0) {
+        piece[n_shards] = carry_w;
+        meta[ml.mode] = mode;
+    }
+    __syncthreads();                                     // piece[] and ret_row0[] of this workgroup are visible
+    for (uint32_t d = threadIdx.x; d < n_shards; d += kBlock) {
+        const uint32_t words = piece[d + 1] - piece[d];
+        const uint32_t rows = (d + 1 < n_shards ? ret_row0[(d + 1) * n_tables] : carry_r) - ret_row0[d * n_tables];
+        atomicMax(&s_peak[0], words);
+        atomicMax(&s_peak[1], rows);
+    }
+    __syncthreads();
+    for (uint32_t d = threadIdx.x; d < n_shards; d += kBlock) {
+        counts[counts_at(d, n_tables, n_tables)] = s_peak[0];
+        counts[counts_at(d, n_tables, n_tables) + 1] = s_peak[1];
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+route_bags_layout_kernel(uint32_t n_shards, uint32_t n_tables, uint32_t *__restrict__ meta) {
+    layout_meta(n_shards, n_tables, meta, kModeBags);
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -505,7 +468,7 @@ route_bags_place_kernel(RouteBagParams rp, uint64_t n_bags, uint32_t n_shards, u
     const uint32_t slot = slots[at];
     if (slot == kNoSlot) return;
     const RouteBagTable &t = rp.t[k];
-    const uint32_t *base = meta + 2 * n_shards * n_tables + 2 * (d * n_tables + k);
+    const uint32_t *base = meta + meta_layout(n_shards, n_tables).base + 2 * (d * n_tables + k);
     uint32_t pos = work[at];
     send[base[0] + slot] = pos;                       // the sub-bag's start in the shard's index list (bag-start offsets)
     uint32_t *list = send + base[1];
@@ -528,8 +491,97 @@ route_bags_place_kernel(RouteBagParams rp, uint64_t n_bags, uint32_t n_shards, u
     }
 }
 
+// ---- one index per bag (the Criteo shape): every bag lives in exactly ONE shard --------------------------------
+// Same request format, same slot order (a bag's slot = the number of earlier bags of its table that go to the same
+// shard), same counts-first rule -- but each index is read once instead of n_shards times, and a bag costs one slot
+// word instead of n_shards:
+//   count : one thread per bag; dest = idx / rows_per_shard; the bag's rank among the bags of its 1024-bag block that
+//           share its destination comes from wavefront ballots + an LDS prefix over the 16 wavefronts (no atomics);
+//           per-(block, shard) totals go to `work`, (dest, rank in block) to `slots`;
+//   layout: ONE workgroup turns the block totals into exclusive prefixes, the per-(shard, table) totals into the
+//           counts message and the request layout (layout_meta);
+//   place : one thread per bag writes its request (offset entry = slot: sub-bag s starts at index s; local row id)
+//           and replaces its slot word by (dest << 24) | slot.
+// Eligible when every table has fixed_pooling == 1 and no offsets array, n_shards <= 64 and n_bags < 2^24.
+constexpr int kOneHotBlock = 1024;
+constexpr uint32_t kOneHotMaxShards = 64;
+
+__global__ void __launch_bounds__(kOneHotBlock)
+route_onehot_count_kernel(RouteBagParams rp, uint64_t n_bags, uint32_t n_shards, uint32_t n_blocks,
+                          uint32_t *__restrict__ packed, uint32_t *__restrict__ blockcnt) {
+    __shared__ uint32_t wcnt[kOneHotBlock / 64][kOneHotMaxShards];   // per wavefront / shard, then exclusive prefix
+    const uint32_t k = blockIdx.y, blk = blockIdx.x;
+    const uint64_t b = (uint64_t)blk * kOneHotBlock + threadIdx.x;
+    const bool live = b < n_bags;
+    const RouteBagTable &t = rp.t[k];
+    uint32_t dest = 0;
+    if (live) {
+        dest = t.indices[b] / t.rows_per_shard;
+        if (dest >= n_shards) dest = n_shards - 1;       // an out-of-range index goes to the last shard (as shard_range does)
+    }
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t rank = 0;
+    for (uint32_t d = 0; d < n_shards; d++) {            // wave-uniform trip count
+        const unsigned long long m = __ballot(live && dest == d);
+        if (lane == 0) wcnt[wave][d] = (uint32_t)__popcll(m);
+        if (live && dest == d) rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    }
+    __syncthreads();
+    if (threadIdx.x < n_shards) {
+        const uint32_t d = threadIdx.x;
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < kOneHotBlock / 64; w++) {
+            const uint32_t c = wcnt[w][d];
+            wcnt[w][d] = total;
+            total += c;
+        }
+        blockcnt[((uint64_t)k * n_blocks + blk) * n_shards + d] = total;
+    }
+    __syncthreads();
+    if (live) packed[(uint64_t)k * n_bags + b] = (dest << 24) | (wcnt[wave][dest] + rank);
+}
+
+__global__ void __launch_bounds__(kBlock)
+route_onehot_layout_kernel(uint32_t n_shards, uint32_t n_tables, uint32_t n_blocks, uint32_t *__restrict__ blockcnt,
+                           uint32_t *__restrict__ meta) {
+    const uint32_t nk = n_shards * n_tables;
+    for (uint32_t e = threadIdx.x; e < nk; e += kBlock) {      // block totals -> exclusive prefix; the sum is the count
+        const uint32_t d = e / n_tables, k = e % n_tables;
+        uint32_t run = 0;
+        for (uint32_t blk = 0; blk < n_blocks; blk++) {
+            uint32_t *p = blockcnt + ((uint64_t)k * n_blocks + blk) * n_shards + d;
+            const uint32_t c = *p;
+            *p = run;
+            run += c;
+        }
+        meta[counts_at(d, k, n_tables)] = run;                   // one index per sub-bag: n_sub == n_idx
+        meta[counts_at(d, k, n_tables) + 1] = run;
+    }
+    __syncthreads();
+    layout_meta(n_shards, n_tables, meta, kModeOneHot);
+}
+
+__global__ void __launch_bounds__(kOneHotBlock)
+route_onehot_place_kernel(RouteBagParams rp, uint64_t n_bags, uint32_t n_shards, uint32_t n_tables, uint32_t n_blocks,
+                          uint32_t *__restrict__ packed, const uint32_t *__restrict__ blockcnt,
+                          const uint32_t *__restrict__ meta, uint32_t *__restrict__ send) {
+    const uint32_t k = blockIdx.y, blk = blockIdx.x;
+    const uint64_t b = (uint64_t)blk * kOneHotBlock + threadIdx.x;
+    if (b >= n_bags) return;
+    const RouteBagTable &t = rp.t[k];
+    const uint32_t pk = packed[(uint64_t)k * n_bags + b];
+    const uint32_t dest = pk >> 24;
+    const uint32_t slot = blockcnt[((uint64_t)k * n_blocks + blk) * n_shards + dest] + (pk & 0xffffffu);
+    const uint32_t *base = meta + meta_layout(n_shards, n_tables).base + 2 * (dest * n_tables + k);
+    send[base[0] + slot] = slot;                                          // sub-bag `slot` starts at index `slot`
+    send[base[1] + slot] = t.indices[b] - dest * t.rows_per_shard;       // local row id
+    packed[(uint64_t)k * n_bags + b] = (dest << 24) | slot;
+}
+
 // pooled[k][b][:] = sum over the shards d = 0 .. N-1 that served a sub-bag of bag b, IN THAT ORDER, of the partial
 // row that came back: deterministic, and exact for bags that live in one shard (one-hot lookups).
+// `slots` as emb_route_bags left it: meta[mode] == kModeBags: uint32[K][N][n_bags], slot of bag b's sub-bag in
+// (d, k)'s request or kNoSlot; kModeOneHot: uint32[K][n_bags], (dest << 24) | slot -- one word and one row per bag.
 __global__ void __launch_bounds__(kBlock)
 unroute_bags_kernel(const float *__restrict__ recv, const uint32_t *__restrict__ meta, const uint32_t *__restrict__ slots,
                     uint64_t n_bags, uint32_t n_shards, uint32_t dim, float *__restrict__ pooled) {
@@ -539,8 +591,16 @@ unroute_bags_kernel(const float *__restrict__ recv, const uint32_t *__restrict__
     const uint64_t b = gid / pieces;
     const uint32_t piece = (uint32_t)(gid % pieces);
     if (b >= n_bags) return;
-    const uint32_t *ret_row0 = meta + 4 * n_shards * n_tables + n_shards + 1;
+    const MetaLayout ml = meta_layout(n_shards, n_tables);
+    const uint32_t *ret_row0 = meta + ml.row0;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (meta[ml.mode] == kModeOneHot) {
+        const uint32_t pk = slots[(uint64_t)k * n_bags + b];
+        const uint64_t row = (uint64_t)ret_row0[(pk >> 24) * n_tables + k] + (pk & 0xffffffu);
+        acc += *(reinterpret_cast<const f32x4 *>(recv) + row * pieces + piece);
+        __builtin_nontemporal_store(acc, reinterpret_cast<f32x4 *>(pooled + ((uint64_t)k * n_bags + b) * dim) + piece);
+        return;
+    }
     // eight shards at a time: their slot words are fetched together, then the partial rows that exist, then the adds in
     // shard order (a slot -> row -> add chain per shard paid up to 2 x n_shards dependent round trips per bag: 37 -> 23 us
     // at one index per bag, 8 tables x 16384 bags x 8 shards)
@@ -567,6 +627,14 @@ unroute_bags_kernel(const float *__restrict__ recv, const uint32_t *__restrict__
 
 }  // namespace
 
+bool route_bags_is_onehot(const RouteBagDesc *tables, uint32_t n_tables, uint64_t n_bags, uint32_t n_shards) {
+    static const bool off = getenv("PIMEMB_ROUTE_ONEHOT") && getenv("PIMEMB_ROUTE_ONEHOT")[0] == '0';   // A/B switch (tools/route_probe.py, tests)
+    if (off || n_shards > kOneHotMaxShards || n_bags >= (1ull << 24)) return false;
+    for (uint32_t k = 0; k < n_tables; k++)
+        if (tables[k].offsets != nullptr || tables[k].fixed_pooling != 1 || tables[k].n_indices != n_bags) return false;
+    return true;
+}
+
 hipError_t launch_route_bags(const RouteBagDesc *tables, uint32_t n_tables, uint64_t n_bags, uint32_t n_shards,
                              uint32_t *send, uint32_t *meta, uint32_t *slots, uint32_t *work, hipStream_t stream) {
     if (n_tables == 0 || n_bags == 0 || n_tables > kRouteBagMaxTables) return hipErrorInvalidValue;
@@ -574,6 +642,17 @@ hipError_t launch_route_bags(const RouteBagDesc *tables, uint32_t n_tables, uint
     for (uint32_t k = 0; k < n_tables; k++)
         rp.t[k] = RouteBagTable{tables[k].indices, tables[k].offsets, tables[k].n_indices, tables[k].fixed_pooling,
                                 tables[k].rows_per_shard};
+    if (route_bags_is_onehot(tables, n_tables, n_bags, n_shards)) {
+        const uint32_t n_blocks = (uint32_t)((n_bags + kOneHotBlock - 1) / kOneHotBlock);
+        const dim3 grid(n_blocks, n_tables, 1);
+        hipLaunchKernelGGL(route_onehot_count_kernel, grid, dim3(kOneHotBlock), 0, stream, rp, n_bags, n_shards, n_blocks,
+                           slots, work);
+        hipLaunchKernelGGL(route_onehot_layout_kernel, dim3(1), dim3(kBlock), 0, stream, n_shards, n_tables, n_blocks, work,
+                           meta);
+        hipLaunchKernelGGL(route_onehot_place_kernel, grid, dim3(kOneHotBlock), 0, stream, rp, n_bags, n_shards, n_tables,
+                           n_blocks, slots, work, meta, send);
+        return hipGetLastError();
+    }
     const uint64_t threads = n_bags * n_shards;
     const dim3 grid((uint32_t)((threads + kBlock - 1) / kBlock), n_tables, 1);
     hipLaunchKernelGGL(route_bags_count_kernel, grid, dim3(kBlock), 0, stream, rp, n_bags, n_shards, work);
@@ -585,34 +664,14 @@ hipError_t launch_route_bags(const RouteBagDesc *tables, uint32_t n_tables, uint
     return hipGetLastError();
 }
 
+uint32_t route_bags_meta_words(uint32_t n_tables, uint32_t n_shards) { return meta_layout(n_shards, n_tables).words; }
+
 hipError_t launch_unroute_bags(const float *recv, const uint32_t *meta, const uint32_t *slots, uint32_t n_tables,
                                uint64_t n_bags, uint32_t n_shards, uint32_t dim, float *pooled, hipStream_t stream) {
     if (n_tables == 0 || n_bags == 0) return hipSuccess;
     const uint64_t threads = n_bags * (dim / 4);
     const dim3 grid((uint32_t)((threads + kBlock - 1) / kBlock), n_tables, 1);
     hipLaunchKernelGGL(unroute_bags_kernel, grid, dim3(kBlock), 0, stream, recv, meta, slots, n_bags, n_shards, dim, pooled);
-    return hipGetLastError();
-}
-
-hipError_t launch_route_onehot(const uint32_t *indices, uint32_t n_tables, uint64_t n_bags,
-                               const RouteParams &rp, uint32_t n_shards, uint32_t capacity, char *send_base,
-                               uint64_t dest_stride_bytes, uint64_t idx_offset_bytes, uint32_t *perm,
-                               uint32_t *counts, uint32_t *overflow, hipStream_t stream) {
-    if (n_tables == 0 || n_bags == 0) return hipSuccess;
-    dim3 grid((uint32_t)((n_bags + kRouteBlock - 1) / kRouteBlock), n_tables, 1);
-    hipLaunchKernelGGL(route_onehot_kernel, grid, dim3(kRouteBlock), 0, stream, indices, n_bags, rp, n_shards, capacity,
-                       send_base, dest_stride_bytes, idx_offset_bytes, perm, counts, overflow);
-    return hipGetLastError();
-}
-
-hipError_t launch_unroute_rows(const char *recv_base, uint64_t src_stride_bytes, uint32_t n_tables,
-                               uint64_t n_bags, uint32_t dim, uint32_t capacity, const uint32_t *perm,
-                               float *pooled, hipStream_t stream) {
-    if (n_tables == 0 || n_bags == 0) return hipSuccess;
-    const uint64_t threads = n_bags * (dim / 4);
-    dim3 grid((uint32_t)((threads + kBlock - 1) / kBlock), n_tables, 1);
-    hipLaunchKernelGGL(unroute_rows_kernel, grid, dim3(kBlock), 0, stream, recv_base, src_stride_bytes, n_bags, dim,
-                       capacity, perm, pooled);
     return hipGetLastError();
 }
 

@@ -41,6 +41,58 @@ TABLE_SCALE: dict[int, float] = {}     # table id -> 2/sqrt(rows): DLRM's U(-sqr
 TABLE_F16 = [False]                    # run(): the table set is stored as fp16 (c5); expected values round the same way
 
 
+XGMI_EGRESS_GBS = 7 * 153.0     # MI355X_MICROARCH.md / SURVEY.md section 8 row E: 7 xGMI links x ~153 GB/s per GPU
+
+
+def step_fractions(alg_bytes_per_rank: int, bytes_out_per_rank: int, ms_per_step: float, hbm_peak_gbs: float) -> dict:
+    """Step-level yardsticks of a sharded leg: what the whole step -- routing, collectives, un-routing
+    included -- achieves against the two bounds it can hit.  alg_bytes_per_rank: the lookup's algorithmic bytes for this
+    rank's own bags (SURVEY.md section 8 row D, as if the tables were local: the exchange is overhead, not payload);
+    bytes_out_per_rank: bytes this rank hands to OTHER ranks per step (requests + returned rows + counts)."""
+    t = ms_per_step * 1e-3
+    out = {"step_algorithmic_bytes_per_rank": int(alg_bytes_per_rank), "bytes_out_per_rank_per_step": int(bytes_out_per_rank)}
+    if t > 0:
+        out["step_GBps"] = alg_bytes_per_rank / t / 1e9
+        out["step_frac"] = out["step_GBps"] / hbm_peak_gbs
+        out["xgmi_GBps"] = bytes_out_per_rank / t / 1e9
+        out["xgmi_frac"] = out["xgmi_GBps"] / XGMI_EGRESS_GBS
+        out["xgmi_peak_GBps"] = XGMI_EGRESS_GBS
+    return out
+
+
+def lookup_bytes(T: int, B: int, L: int, dim: int, elem: int) -> int:
+    """Algorithmic bytes of one rank's step: T tables x B bags x (L rows + L u32 indices + one u32 offset + one fp32 row)."""
+    return T * B * (L * (dim * elem + 4) + 4 + dim * 4)
+
+
+def job_times(torch, dist, t0: float, t_event: float, stage_cpu: bool, dev):
+    """Both closing brackets of a timed region, MAX over ranks (N = 1 and N > 1 on the same clocks).
+    t_event: perf_counter when the event behind this rank's K-th step had fired (polled / waited on the compute stream);
+    the device-wide torch.cuda.synchronize() -- the contract's bracket -- is taken here, inside the second clock.
+    Returns (event seconds, sync seconds)."""
+    import time as _t
+    torch.cuda.synchronize()
+    t_sync = _t.perf_counter()
+    dist.barrier()
+    torch.cuda.synchronize()
+    el = torch.tensor([t_event - t0, t_sync - t0], dtype=torch.float64, device="cpu" if stage_cpu else dev)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)   # job time = the slowest rank's, all ranks having started together
+    return float(el[0].item()), float(el[1].item())
+
+
+def clock_fields(wall_event: float, wall_sync: float, steps: int, units: float) -> dict:
+    """ms_per_step / value on the primary clock plus both clocks spelled out.  Primary: `sync`, the contract's bracket
+    (the clock stops after the device-wide torch.cuda.synchronize()), as on bench.py's N = 1 line, so that the per-N
+    values a SCALE record compares sit on ONE clock.  `event` stops when the event behind the K-th step has fired: the
+    difference is the runtime's synchronize latency (24 us of a 0.42-ms region with RCCL loaded and one rank, round 3;
+    round 2 once saw 0.8 ms), not the path's -- PIMEMB_CLOCK=event makes it the primary one."""
+    primary = os.environ.get("PIMEMB_CLOCK", "sync")
+    wall = wall_sync if primary == "sync" else wall_event
+    return {"value": units / wall, "ms_per_step": wall * 1000.0 / steps, "clock": primary,
+            "ms_per_step_event": wall_event * 1000.0 / steps, "ms_per_step_sync": wall_sync * 1000.0 / steps,
+            "value_event": units / wall_event, "value_sync": units / wall_sync}
+
+
 def table_values(torch, t: int, row_lo: int, row_hi: int, dim: int, device):
     """Deterministic table contents any rank can recompute: W_t[r][c] from a hash of (t, r, c), in DLRM's
     U(-sqrt(1/n), sqrt(1/n)) range (the scale the 1e-6 tolerance of load_generator.c:58 is meant for).
@@ -262,7 +314,7 @@ def run_whole(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
 
     # NOTE: steps are enqueued eagerly.  The engine's launches are hipGraph-capturable (tests/
     # test_gpu_parity.py::test_plan_launch_is_graph_capturable), but capturing RCCL's all_to_all with
-    # this torch 2.10 / RCCL 2.26 build segfaults in capture_end (csrc/tools/graph_probe.py), so the
+    # this torch 2.10 / RCCL 2.26 build segfaults in capture_end (tools/graph_probe.py), so the
     # collective keeps the step out of a graph.
     it = n_primed
     for _ in range(args.warmup):
@@ -276,12 +328,7 @@ def run_whole(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
         step(it)
         it += 1
     drain()
-    local_el = time.perf_counter() - t0     # this rank's K steps are complete (drain waits for the compute stream)
-    dist.barrier()
-    torch.cuda.synchronize()
-    el = torch.tensor([local_el], dtype=torch.float64, device="cpu" if stage_cpu else dev)
-    dist.all_reduce(el, op=dist.ReduceOp.MAX)   # job time = the slowest rank's, all ranks having started together
-    wall = float(el.item())
+    wall_ev, wall_sync = job_times(torch, dist, t0, time.perf_counter(), stage_cpu, dev)   # drain waited for this rank's K-th step
     # what the timed loop left behind: the last step's 26 outputs, bit for bit
     res = outputs(slots[(it - 1) % NBATCH])
     for t in range(T):
@@ -292,11 +339,13 @@ def run_whole(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
     result = None
     if rank == 0:
         ach = alg_bytes / (kernel_us * 1e-6) / 1e9 if kernel_us > 0 else 0.0
+        clk = clock_fields(wall_ev, wall_sync, args.steps, world * args.steps * T * B)
+        bytes_out = int(sum(in_split[d] for d in range(world) if d != rank))
+        fr = step_fractions(lookup_bytes(T, B, L, dim, 2 if TABLE_F16[0] else 4), bytes_out, clk["ms_per_step"], hbm_peak_gbs)
         result = ({
             "metric": "pooled-lookups/sec + achieved HBM GB/s, 26-table dim-16 Kaggle, 1/2/4/8 GPU",
-            "value": world * args.steps * T * B / wall, "unit": "pooled-lookups/s",
+            "unit": "pooled-lookups/s", **clk,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": wall * 1000.0 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16" if TABLE_F16[0] else "f32", "data": "synthetic",
             "config": {"workload": "%s sharded, dim %d %s, B=%d bags/table PER RANK, "
@@ -308,11 +357,14 @@ def run_whole(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
                                       "backend %s, %s, eager steps" %
                                       (rep_bytes >> 20, int(in_off[-1]), int(out_off[-1]), backend,
                                        "collective issued natively to RCCL on the compute stream" if native is not None
-                                       else "torch.distributed.all_to_all_single")},
+                                       else "torch.distributed.all_to_all_single"),
+                       "exchange": {"mode": "whole", "value": clk["value"], "ms_per_step": clk["ms_per_step"], "verified": True,
+                                    "bytes_out_per_rank_per_step": bytes_out}},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": hbm_peak_gbs, "unit": "GB/s",
                          "frac": ach / hbm_peak_gbs, "traffic": None, "kernel_us": kernel_us,
                          "algorithmic_bytes": alg_bytes,
-                         "basis": "algorithmic bytes (no PMC profile of the N > 1 legs; a pooled launch is partly cache-served and can exceed 1: the same kernels at N = 1 are priced on measured bytes, profiles/traffic.json)", "note": "rank 0's two local launches (replicated + served tables), kernel-only"},
+                         "basis": "algorithmic bytes (no PMC profile of the N > 1 legs; a pooled launch is partly cache-served and can exceed 1: the same kernels at N = 1 are priced on measured bytes, profiles/traffic.json)", "note": "rank 0's two local launches (replicated + served tables), kernel-only; the whole step (collective included) against HBM and xGMI: roofline.exchange",
+                         "exchange": fr},
         })
     dist.barrier()
     for sl in slots:
@@ -359,6 +411,36 @@ def index_generator(pel, args):
 def pooling_of(pel, args) -> int:
     extras = pel.workloads.TABLE_SET_EXTRAS[getattr(args, "workload", "c2")]
     return max(1, int(getattr(args, "pooling", None) or extras["pooling"]))
+
+
+def dump_row_split(torch, eng, args, gen, rank, world, dev, rows_list, sharded, rps, T, B, L, dim, NBATCH, last, idx_host, slots):
+    """PIMEMB_DUMP_ROWSPLIT=<prefix>: leave what a TEST needs to put the oracle behind the sharded path (nothing under the
+    package may import it).  Every rank writes <prefix>.rank<r>.npz with, per row-split table, the rows of ITS shard that
+    rank 0's bags of the last timed step name -- read back from the engine's table in HBM -- and rank 0 adds its index
+    arrays (global row ids) and the pooled rows the exchange returned.  Other ranks regenerate rank 0's indices from its seed."""
+    prefix = os.environ.get("PIMEMB_DUMP_ROWSPLIT")
+    if not prefix or not sharded:
+        return
+    if rank == 0:
+        idx0 = idx_host[last]
+    else:
+        rng0 = np.random.default_rng(1 + 0)
+        idx0 = [[gen(rng0, n, B * L, t).view(np.int32) for t, n in enumerate(rows_list)] for _ in range(NBATCH)][last]
+    rec = {"tables": np.asarray(sharded), "pooling": np.asarray(L), "bags": np.asarray(B), "dim": np.asarray(dim),
+           "rows_per_shard": np.asarray(rps), "world": np.asarray(world)}
+    for k, t in enumerate(sharded):
+        ids = np.unique(idx0[t].view(np.uint32).astype(np.int64))
+        lo = rank * rps[k]
+        hi = rows_list[t] if rank == world - 1 else min(lo + rps[k], rows_list[t])
+        mine = ids[(ids >= lo) & (ids < hi)]
+        w = eng.table_tensor(T + k)
+        rec["ids_%d" % t] = mine
+        rec["rows_%d" % t] = (w[torch.from_numpy(mine - lo).to(dev)].float().cpu().numpy() if mine.size
+                              else np.zeros((0, dim), np.float32))
+        if rank == 0:
+            rec["idx_%d" % t] = idx0[t].view(np.uint32)
+            rec["out_%d" % t] = slots[last]["out_sh"][k].cpu().numpy()
+    np.savez("%s.rank%d.npz" % (prefix, rank), **rec)
 
 
 def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
@@ -506,10 +588,15 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
             if float((res[t] - plain).abs().max()) > 1e-6:
                 raise AssertionError(f"rank {rank}: {what} step {i} table {t} is more than 1e-6 from the unsharded sum")
 
-    # ---- prime one rotation, then verify two consecutive pipelined steps bit for bit ------------------
+    # ---- the first rotation, fully pipelined (every slot's buffers are used for the first time here: ADVICE r2 --
+    #      an un-ordered first use shows up in these steps and in no later one), checked afterwards from the slots' own
+    #      output buffers; then two consecutive pipelined steps, each checked on its own -------------------------------
     prologue(0)
     for i in range(NBATCH):
         step(i)
+    drain(NBATCH)
+    for i in range(NBATCH):
+        verify(i, "first rotation")
     for i in (NBATCH, NBATCH + 1):
         step(i)
         drain(i + 1)
@@ -554,13 +641,10 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
             drain(it)
             verify(it - 1, "soak")
     drain(it)
-    local_el = time.perf_counter() - t0     # this rank's K steps are complete (drain waits for the compute stream)
-    dist.barrier()
-    torch.cuda.synchronize()
-    el = torch.tensor([local_el], dtype=torch.float64, device="cpu" if stage_cpu else dev)
-    dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    wall = float(el.item())
+    wall_ev, wall_sync = job_times(torch, dist, t0, time.perf_counter(), stage_cpu, dev)   # drain waited for this rank's K-th step
     verify(it - 1, "last timed")                     # what the timed loop left behind
+    dump_row_split(torch, eng, args, gen, rank, world, dev, rows_list, sharded, rps, T, B, L, dim, NBATCH, (it - 1) % NBATCH,
+                   idx_host, slots)
     digest = None
     if rank == 0 and K:                              # bits of rank 0's row-split outputs of that step: two runs must agree
         import hashlib
@@ -577,11 +661,17 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
     if rank == 0:
         ach = alg_bytes / (kernel_us * 1e-6) / 1e9 if kernel_us > 0 else 0.0
         sent = ex.slots[(it - 1) % NBATCH]["sent"] if K else np.zeros((N, 1, 2), np.int64)
+        clk = clock_fields(wall_ev, wall_sync, args.steps, world * args.steps * T * B)
+        bytes_out = 0
+        if K:        # what rank 0 handed to OTHER ranks in the last step: counts message, request pieces, returned partial rows
+            last = ex.slots[(it - 1) % NBATCH]
+            bytes_out = sum(8 * (K + 1) + 4 * int(last["req_out_words"][d]) + row_b * int(last["ret_rows_served"][d])
+                            for d in range(N) if d != rank)
+        fr = step_fractions(lookup_bytes(T, B, L, dim, 2 if TABLE_F16[0] else 4), bytes_out, clk["ms_per_step"], hbm_peak_gbs)
         result = ({
             "metric": "pooled-lookups/sec + achieved HBM GB/s, 26-table dim-16 Kaggle, 1/2/4/8 GPU",
-            "value": world * args.steps * T * B / wall, "unit": "pooled-lookups/s",
+            "unit": "pooled-lookups/s", **clk,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": wall * 1000.0 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16" if TABLE_F16[0] else "f32", "data": "synthetic",
             "config": {"workload": "%s sharded, dim %d %s, B=%d bags/table PER RANK, L=%d, %s indices, "
@@ -597,11 +687,14 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
                                        if native is not None else "torch.distributed.all_to_all_single"),
                        "last_step_outputs_sha1": digest,
                        "last_step_request_rows_per_peer": sent[:, :, 0].sum(axis=1).tolist(),
-                       "last_step_request_indices_per_peer": sent[:, :, 1].sum(axis=1).tolist()},
+                       "last_step_request_indices_per_peer": sent[:, :, 1].sum(axis=1).tolist(),
+                       "exchange": {"mode": "rows", "value": clk["value"], "ms_per_step": clk["ms_per_step"], "verified": True,
+                                    "bytes_out_per_rank_per_step": bytes_out}},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": hbm_peak_gbs, "unit": "GB/s",
                          "frac": ach / hbm_peak_gbs, "traffic": None, "kernel_us": kernel_us,
                          "algorithmic_bytes": alg_bytes,
-                         "basis": "algorithmic bytes (no PMC profile of the N > 1 legs; a pooled launch is partly cache-served and can exceed 1: the same kernels at N = 1 are priced on measured bytes, profiles/traffic.json)", "note": "rank 0's two lookup launches (replicated tables + served request pieces), kernel-only"},
+                         "basis": "algorithmic bytes (no PMC profile of the N > 1 legs; a pooled launch is partly cache-served and can exceed 1: the same kernels at N = 1 are priced on measured bytes, profiles/traffic.json)", "note": "rank 0's two lookup launches (replicated tables + served request pieces), kernel-only; the whole step (routing, three collectives, un-routing) against HBM and xGMI: roofline.exchange",
+                         "exchange": fr},
         })
     dist.barrier()
     for sl in slots:
@@ -669,16 +762,11 @@ def run_dp(args, hbm_peak_gbs: float, ctx):
     if dbg is not None: dbg.append(("e1.record", time.perf_counter() - t0))
     while not e1.query():                   # polled: a blocking wait is woken ~20 us late
         pass
-    local_el = time.perf_counter() - t0     # this rank's K steps are complete (the event after the K-th launch has fired)
-    torch.cuda.synchronize()
-    if dbg is not None: dbg.append(("device sync", time.perf_counter() - t0))
+    t_event = time.perf_counter()           # this rank's K steps are complete (the event after the K-th launch has fired)
+    wall_ev, wall_sync = job_times(torch, dist, t0, t_event, stage_cpu, dev)
     if dbg is not None and rank == 0:
-        print("[dist_bench] run_dp timed region, seconds since t0:", dbg, "sync", local_el, flush=True)
-    dist.barrier()
-    torch.cuda.synchronize()
-    el = torch.tensor([local_el], dtype=torch.float64, device="cpu" if stage_cpu else dev)
-    dist.all_reduce(el, op=dist.ReduceOp.MAX)   # job time = the slowest rank's, all ranks having started together
-    wall = float(el.item())
+        print("[dist_bench] run_dp timed region, seconds since t0:", dbg, "event", t_event - t0, "job event / sync",
+              wall_ev, wall_sync, flush=True)
     kernel_us = e0.elapsed_time(e1) * 1000.0 / args.steps
     alg_bytes = plans[0].bytes()[0]
     last = (args.steps - 1) % NBATCH if args.steps > 0 else 0
@@ -689,11 +777,11 @@ def run_dp(args, hbm_peak_gbs: float, ctx):
     result = None
     if rank == 0:
         ach = alg_bytes / (kernel_us * 1e-6) / 1e9
+        clk = clock_fields(wall_ev, wall_sync, args.steps, world * args.steps * T * B)
         result = {
             "metric": "pooled-lookups/sec + achieved HBM GB/s, 26-table dim-16 Kaggle, 1/2/4/8 GPU",
-            "value": world * args.steps * T * B / wall, "unit": "pooled-lookups/s",
+            "unit": "pooled-lookups/s", **clk,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": wall * 1000.0 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16" if TABLE_F16[0] else "f32", "data": "synthetic",
             "config": {"workload": "%s, dim %d %s, B=%d bags/table PER RANK, L=%d, u32 "
@@ -773,6 +861,7 @@ def run(args, hbm_peak_gbs: float) -> None:
         wait for this rank in a collective are ended by the launcher (bench.py's self-launch / torchrun)."""
         if rank == 0 and state.get("primary") is not None:
             state["primary"]["sharded_exchange"] = {"failed": note}
+            state["primary"]["config"]["exchange"] = {"failed": note, "verified": False}
             state["primary"]["verified"] = False
             emit(finish(state["primary"]))
         sys.stdout.flush()
@@ -800,9 +889,15 @@ def run(args, hbm_peak_gbs: float) -> None:
                 die(4, f"{type(ex).__name__}: {ex}")
             state["dog"].cancel()
             if rank == 0:
-                result["sharded_exchange"] = {k: sec[k] for k in ("value", "unit", "ms_per_step", "steps", "roofline")}
+                result["sharded_exchange"] = {k: sec[k] for k in ("value", "unit", "ms_per_step", "ms_per_step_event",
+                                                                  "ms_per_step_sync", "clock", "steps", "roofline")}
                 result["sharded_exchange"]["verified"] = True
                 result["sharded_exchange"]["config"] = sec["config"]["workload"] + "; " + sec["config"]["parallelism"]
+                # the same numbers inside the two objects a SCALE record keeps (config / roofline): the all-to-all leg's
+                # value is the xGMI curve north_star asks for, next to the replica curve in `value`
+                result["config"]["exchange"] = dict(sec["config"]["exchange"], steps=sec["steps"],
+                                                    what="secondary leg of the same run: " + sec["config"]["workload"])
+                result["roofline"]["exchange"] = sec["roofline"]["exchange"]
     else:
         rep_mb = 64 if auto else int(args.replicate_mb)
         result = shard_leg(args, hbm_peak_gbs, ctx, rep_mb << 20)

@@ -183,7 +183,6 @@ class EmbeddingEngine:
         self._tables: dict[int, tuple[int, int, int]] = {}  # id -> (nr_rows, dim, dtype)
         self._desc_bufs: dict[int, tuple] = {}              # n descriptors -> (packed buffer, typed pointer)
         self._stacked: dict[tuple, tuple] = {}              # table ids -> descriptor array of lookup_stacked
-        self._rps_cache: dict = {}
 
     # ---- tables (populate_mram's job, emb_host.h:136) ------------------------------------------
     def load_table(self, table_id: int, rows, dtype: int | None = None) -> None:
@@ -435,23 +434,6 @@ class EmbeddingEngine:
         if rc not in (_l.EMB_OK, _l.EMB_ERR_RANGE):
             _l.check(rc)
         return bad.value
-
-    # ---- multi-GPU routing helpers (row-range shards, one index per bag) ---------------------------
-    def route_onehot(self, indices_ptr: int, n_tables: int, n_bags: int, rows_per_shard, n_shards: int,
-                     capacity: int, send_base: int, dest_stride_bytes: int, idx_offset_bytes: int,
-                     perm_ptr: int, counts_ptr: int, overflow_ptr: int, stream: int | None = None) -> None:
-        key = tuple(int(x) for x in rows_per_shard)
-        rps = self._rps_cache.get(key)
-        if rps is None:
-            rps = self._rps_cache[key] = (C.c_uint32 * n_tables)(*key)
-        _l.check(self._L.emb_route_onehot(self._h, indices_ptr, n_tables, n_bags, rps, n_shards, capacity,
-                                          send_base, dest_stride_bytes, idx_offset_bytes, perm_ptr, counts_ptr,
-                                          overflow_ptr, stream))
-
-    def unroute_rows(self, recv_base: int, src_stride_bytes: int, n_tables: int, n_bags: int, dim: int,
-                     capacity: int, perm_ptr: int, pooled_ptr: int, stream: int | None = None) -> None:
-        _l.check(self._L.emb_unroute_rows(self._h, recv_base, src_stride_bytes, n_tables, n_bags, dim, capacity,
-                                          perm_ptr, pooled_ptr, stream))
 
     # ---- multi-GPU routing helpers (row-range shards, variable-length bags: counts first) ---------------
     def route_bags_sizes(self, n_tables: int, n_bags: int, total_indices: int, n_shards: int) -> dict:

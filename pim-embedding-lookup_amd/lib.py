@@ -91,9 +91,6 @@ SIGNATURES = {
     "emb_memset_device": (C.c_int, [_vp, _vp, C.c_int, _sz]),
     "emb_synchronize": (C.c_int, [_vp, _vp]),
     "emb_device_of": (C.c_int, [_vp, C.POINTER(_i32)]),
-    "emb_route_onehot": (C.c_int, [_vp, _vp, _u32, _u64, C.POINTER(_u32), _u32, _u32, _vp, _u64, _u64, _vp, _vp,
-                                   _vp, _vp]),
-    "emb_unroute_rows": (C.c_int, [_vp, _vp, _u64, _u32, _u64, _u32, _u32, _vp, _vp, _vp]),
     "emb_route_bags_sizes": (C.c_int, [_u32, _u64, _u64, _u32, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64),
                                        C.POINTER(_u64)]),
     "emb_route_bags": (C.c_int, [_vp, C.POINTER(EmbRouteTable), _u32, _u64, _u32, _vp, _vp, _vp, _vp, _vp]),

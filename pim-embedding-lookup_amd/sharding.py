@@ -123,12 +123,14 @@ class ShardedLookup:
     initialised (backend nccl = RCCL on GPUs; gloo for CPU tests).  comm_device: where collective
     buffers live ('cuda:N' for RCCL; 'cpu' stages through host for gloo)."""
 
-    def __init__(self, plan: ShardPlan, rank: int, backend, device, comm_device=None, group=None):
+    def __init__(self, plan: ShardPlan, rank: int, backend, device, comm_device=None, group=None,
+                 trusted_inputs: bool = False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.plan, self.rank, self.world = plan, rank, plan.world
         self.backend, self.device, self.group = backend, torch.device(device), group
+        self.trusted_inputs = trusted_inputs       # False: row ids of row-split tables are range-checked before they are narrowed
         self.comm_device = torch.device(comm_device) if comm_device is not None else self.device
         self.served = plan.owned_units(rank)              # units whose rows live here (sharded)
         self.local = plan.replicated_units()              # units every rank holds
@@ -172,24 +174,45 @@ class ShardedLookup:
         new_lens = t.bincount(bag_of[keep], minlength=lens.numel()).to(lens.dtype)
         return idx[keep] - u.row_lo, new_lens
 
-    def _a2a(self, send_parts, dtype, recv_counts=None):
-        """all_to_all of one 1-D tensor per destination.  recv_counts=None: element counts are
-        exchanged first (alltoallv); otherwise they are known from the plan.  Returns the list of
-        received pieces, one per source rank."""
+    def _a2a(self, send_parts, dtype, recv_counts=None, small: bool = False):
+        """all_to_all of one 1-D tensor per destination.  recv_counts=None: element counts are exchanged first
+        (alltoallv); otherwise they are known from the plan.  Returns the list of received pieces, one per source rank.
+        Over RCCL the transfer takes as many rounds as the JOB's largest piece needs: every rank sends its own largest
+        count next to each count (or, with known counts, joins a MAX all_reduce), so all ranks arrive at the same number
+        and nobody is left waiting in a collective.  small: the payload is a few words by construction (no agreement)."""
         t, dist = self.torch, self.dist
         counts = [int(p.numel()) for p in send_parts]
+        on_gpu = self.comm_device.type == "cuda"
+        worst = max(counts, default=0)
         if recv_counts is None:
-            c = t.tensor(counts, dtype=t.int64, device=self.comm_device)
-            r = t.empty(self.world, dtype=t.int64, device=self.comm_device)
+            c = t.tensor([[n, worst] for n in counts], dtype=t.int64, device=self.comm_device)
+            r = t.empty((self.world, 2), dtype=t.int64, device=self.comm_device)
             dist.all_to_all_single(r, c, group=self.group)
-            recv_counts = [int(x) for x in r.cpu().tolist()]
+            r = r.cpu()
+            recv_counts = [int(x) for x in r[:, 0].tolist()]
+            worst = int(r[:, 1].max())
+        elif on_gpu and not small:
+            w = t.tensor([max(worst, max(recv_counts, default=0))], dtype=t.int64, device=self.comm_device)
+            dist.all_reduce(w, op=dist.ReduceOp.MAX, group=self.group)
+            worst = int(w.item())
         send = t.cat([p.reshape(-1).to(dtype) for p in send_parts]).to(self.comm_device)
         recv = t.empty(int(sum(recv_counts)), dtype=dtype, device=self.comm_device)
-        if self.comm_device.type == "cuda":
-            check_piece_sizes(list(recv_counts) + counts, send.element_size(), "ShardedLookup")
-        dist.all_to_all_single(recv, send, output_split_sizes=list(recv_counts),
-                               input_split_sizes=counts, group=self.group)
+        if on_gpu:
+            all_to_all_rounds(dist, recv, send, list(recv_counts), counts, rounds_for(worst * send.element_size()),
+                              group=self.group).wait()
+        else:            # gloo: no piece-size limit (and no list all_to_all)
+            dist.all_to_all_single(recv, send, output_split_sizes=list(recv_counts), input_split_sizes=counts,
+                                   group=self.group)
         return list(recv.split(list(recv_counts))), recv_counts
+
+    def _bad_inputs(self, indices) -> bool:
+        """Row ids of the row-split tables are narrowed to uint32 for the GPU router: a negative or >= nr_rows id must
+        not wrap silently (nn.EmbeddingBag raises IndexError).  One device-side min / max per table, one host read."""
+        t = self.torch
+        lo = [indices[k].min() if indices[k].numel() else indices[k].new_zeros(()) for k in self.split_tables]
+        hi = [indices[k].max() - self.plan.rows[k] if indices[k].numel() else indices[k].new_full((), -1) for k in self.split_tables]
+        flags = t.stack([t.stack(lo).min() < 0, t.stack(hi).max() >= 0])
+        return bool(flags.any().item())
 
     def forward(self, indices: Sequence, offsets: Sequence):
         """indices[t], offsets[t]: this rank's bags for table t (torch int64/int32 tensors on
@@ -198,10 +221,7 @@ class ShardedLookup:
         T = len(self.plan.rows)
         assert len(indices) == T and len(offsets) == T
         idx_dtype = indices[0].dtype
-        rr_out = None
-        if self._rr is not None:     # row-split tables: GPU routing, counts first (uint32 row ids at that boundary)
-            rr_out = self._rr.forward([indices[k].to(t.int32).contiguous() for k in self.split_tables],
-                                      [offsets[k].to(t.int32).contiguous() for k in self.split_tables])
+        bad = int(self._rr is not None and not self.trusted_inputs and self._bad_inputs(indices))
         lens = [self._lens(offsets[i], indices[i].numel()) for i in range(T)]
         n_bags = [int(l.numel()) for l in lens]
 
@@ -214,10 +234,17 @@ class ShardedLookup:
                 meta.append(t.tensor([l_u.numel(), i_u.numel()], dtype=t.int64))
                 ls.append(l_u.to(t.int64))
                 ix.append(i_u)
-            send_meta.append(t.cat(meta) if meta else t.empty(0, dtype=t.int64))
+            send_meta.append(t.cat(meta + [t.tensor([bad], dtype=t.int64)]))     # last word: "my inputs are out of range"
             send_lens.append(t.cat(ls) if ls else t.empty(0, dtype=t.int64))
             send_idx.append(t.cat(ix) if ix else t.empty(0, dtype=idx_dtype))
-        meta_in, _ = self._a2a(send_meta, t.int64, recv_counts=[2 * len(self.served)] * self.world)
+        meta_in, _ = self._a2a(send_meta, t.int64, recv_counts=[2 * len(self.served) + 1] * self.world, small=True)
+        culprits = [s for s in range(self.world) if int(meta_in[s][-1])]
+        if culprits:         # every rank learns it from the same message and raises together: nobody hangs in a collective
+            raise IndexError(f"ShardedLookup: rank(s) {culprits} passed row ids outside [0, nr_rows) of a row-split table")
+        rr_out = None
+        if self._rr is not None:     # row-split tables: GPU routing, counts first (uint32 row ids at that boundary)
+            rr_out = self._rr.forward([indices[k].to(t.int32).contiguous() for k in self.split_tables],
+                                      [offsets[k].to(t.int32).contiguous() for k in self.split_tables])
         lens_in, _ = self._a2a(send_lens, t.int64)
         idx_in, _ = self._a2a(send_idx, idx_dtype)
 
@@ -305,35 +332,53 @@ class RowRangeExchange:
         self.side = torch.cuda.Stream(self.device)
         self.slots = [dict() for _ in range(n_slots)]
         self.work = None
+        self._streams = {}          # every stream the exchange's buffers have been used on (cuda_stream handle -> Stream)
         if self.K == 0 or self.K > 64:
             raise ValueError("1..64 row-split tables per exchange")
 
     # ---- buffers ------------------------------------------------------------------------------------
+    def _retire(self, buf):
+        """A buffer about to be dropped may still be read or written by work queued on ANY stream the exchange uses
+        (router stream, compute stream, the host-copy side stream): tell the caching allocator, so the block is not
+        handed out again before that work has run."""
+        if buf is not None and buf.is_cuda:
+            for st in self._streams.values():
+                buf.record_stream(st)
+
+    def _use_stream(self, stream):
+        self._streams.setdefault(stream.cuda_stream, stream)
+
     def _grown(self, sl, name, n, dtype, tail=()):
         """Grow-only device buffer of >= n leading elements (25 % headroom): sized by the counts, never fixed."""
         buf = sl.get(name)
         if buf is None or buf.shape[0] < n:
+            self._retire(buf)
             sl[name] = buf = self.torch.empty((n + n // 4 + 16,) + tuple(tail), dtype=dtype, device=self.device)
         return buf
 
     def _prepare(self, sl, n_bags, total_indices):
+        """Buffers of one route call.  Runs on the stream the router runs on (see route): the zero fills of a slot's
+        first use are then ordered before the router kernels and the counts exchange that write the same words."""
         t = self.torch
-        sz = self.engine.route_bags_sizes(self.K, n_bags, total_indices, self.N)
+        sz = self.engine.route_bags_sizes(self.K, max(n_bags, 1), total_indices, self.N)
         self._grown(sl, "req_send", sz["send"] // 4, t.int32)
         self._grown(sl, "slotmap", sz["slots"] // 4, t.int32)
         if "meta" not in sl:
             sl["meta"] = t.zeros(sz["meta"] // 4, dtype=t.int32, device=self.device)
-            sl["counts_in"] = t.zeros((self.N, self.K, 2), dtype=t.int32, device=self.device)
-            sl["counts_host"] = t.zeros((2, self.N, self.K, 2), dtype=t.int32).pin_memory()   # [0] sent, [1] received
+            sl["counts_in"] = t.zeros((self.N, self.K + 1, 2), dtype=t.int32, device=self.device)
+            sl["counts_host"] = t.zeros((2, self.N, self.K + 1, 2), dtype=t.int32).pin_memory()   # [0] sent, [1] received
             sl["counts_ev"] = t.cuda.Event()
         if self.work is None or self.work.numel() < sz["work"]:
+            self._retire(self.work)
             self.work = t.empty(sz["work"] + sz["work"] // 4, dtype=t.uint8, device=self.device)   # scratch of one route call
 
-    def _exchange(self, recv, send, out_splits, in_splits):
-        """all_to_all of leading-dimension ranges (RCCL; gloo stages through the host).  Work handle or None."""
+    def _exchange(self, recv, send, out_splits, in_splits, rounds: int = 1):
+        """all_to_all of leading-dimension ranges (RCCL; gloo stages through the host).  Work handle or None.
+        rounds: how many transfers the largest piece of the JOB needs (every rank passes the same number: it comes from
+        the peaks in the counts messages, see send_requests)."""
         t, dist = self.torch, self.dist
         n_out, n_in = int(sum(out_splits)), int(sum(in_splits))
-        if self.native is not None:      # stream-ordered on the compute stream (emb_comm_all_to_all)
+        if self.native is not None:      # stream-ordered on the compute stream (emb_comm_all_to_all cuts large pieces itself)
             import ctypes as C
             esz = send.element_size()
             for d in send.shape[1:]:
@@ -348,28 +393,32 @@ class RowRangeExchange:
                                    input_split_sizes=list(in_splits), group=self.group)
             recv[:n_out].copy_(r)
             return None
-        item = send.element_size()
-        for dd in send.shape[1:]:
-            item *= int(dd)
-        check_piece_sizes(list(out_splits) + list(in_splits), item, "RowRangeExchange")
-        return dist.all_to_all_single(recv[:n_out], send[:n_in], output_split_sizes=list(out_splits),
-                                      input_split_sizes=list(in_splits), group=self.group, async_op=True)
+        return all_to_all_rounds(dist, recv[:n_out], send[:n_in], out_splits, in_splits, rounds, group=self.group)
 
     # ---- phases -------------------------------------------------------------------------------------
     def route(self, slot: int, spec, n_bags: int, total_indices: int, stream=None) -> None:
         """spec: EmbeddingEngine.route_tables([...]) over this rank's K index arrays (uint32 row ids).
         stream: a torch.cuda.Stream to run the router and the counts exchange on (they depend on nothing of the current
         step, so a pipelined caller lets them overlap the lookups); the caller orders it behind the slot's last reader.
-        Buffers are always allocated on the CURRENT stream."""
+        The slot's buffers are allocated AND zero-filled on that stream, so their first use is ordered too; a buffer
+        that is outgrown is retired with record_stream on every stream the exchange has used.
+        n_bags == 0 (a rank with an empty batch) is a valid participant: it sends zero counts and still serves."""
         t, sl = self.torch, self.slots[slot]
-        self._prepare(sl, n_bags, total_indices)
+        run_on = stream if stream is not None else t.cuda.current_stream(self.device)
+        self._use_stream(t.cuda.current_stream(self.device))
+        self._use_stream(run_on)
+        self._use_stream(self.side)
         sl["n_bags"] = n_bags
 
         def enqueue():
+            self._prepare(sl, n_bags, total_indices)
             h = t.cuda.current_stream(self.device).cuda_stream
-            self.engine.route_bags(spec, n_bags, self.N, sl["req_send"].data_ptr(), sl["meta"].data_ptr(),
-                                   sl["slotmap"].data_ptr(), self.work.data_ptr(), h)
-            counts_out = sl["meta"][:2 * self.N * self.K].view(self.N, self.K, 2)
+            if n_bags:
+                self.engine.route_bags(spec, n_bags, self.N, sl["req_send"].data_ptr(), sl["meta"].data_ptr(),
+                                       sl["slotmap"].data_ptr(), self.work.data_ptr(), h)
+            else:
+                sl["meta"].zero_()           # nothing to ask for: all counts (and peaks) zero
+            counts_out = sl["meta"][:2 * self.N * (self.K + 1)].view(self.N, self.K + 1, 2)
             sl["counts_work"] = self._exchange(sl["counts_in"], counts_out, [1] * self.N, [1] * self.N)
 
         sl["routed_ev"] = None
@@ -384,7 +433,8 @@ class RowRangeExchange:
     def send_requests(self, slot: int) -> None:
         """The one host wait of a step: learn the counts, then send the request pieces sized by them."""
         t, sl = self.torch, self.slots[slot]
-        counts_out = sl["meta"][:2 * self.N * self.K].view(self.N, self.K, 2)
+        K = self.K
+        counts_out = sl["meta"][:2 * self.N * (K + 1)].view(self.N, K + 1, 2)
         if sl.get("counts_work") is not None:
             with t.cuda.stream(self.side):    # off the compute stream: the host waits for the router + counts only
                 sl["counts_work"].wait()
@@ -399,14 +449,20 @@ class RowRangeExchange:
             sl["counts_host"][0].copy_(counts_out, non_blocking=True)
             sl["counts_host"][1].copy_(sl["counts_in"], non_blocking=True)
             t.cuda.current_stream(self.device).synchronize()
-        c = sl["counts_host"].numpy().astype("int64")             # [2][peer][table][{n_sub, n_idx}]
+        full = sl["counts_host"].numpy().view("uint32").astype("int64")   # [2][peer][table | peaks][2] (uint32 on the device)
+        c = full[:, :, :K, :]                                               # [2][peer][table][{n_sub, n_idx}]
         words = ((c[..., 0] + 3) // 4 * 4 + (c[..., 1] + 3) // 4 * 4).sum(axis=2)     # [2][peer]
         sl["req_out_words"], sl["req_in_words"] = words[0].tolist(), words[1].tolist()
         sl["ret_rows_back"] = c[0, :, :, 0].sum(axis=1).tolist()    # partial rows each shard returns to me
         sl["ret_rows_served"] = c[1, :, :, 0].sum(axis=1).tolist()  # partial rows I return to each source
         sl["sent"], sl["served"] = c[0], c[1]
+        # every rank put its largest piece in every counts message, so the maximum over the messages received (my own
+        # included) is the JOB's largest piece: the same number of rounds on every rank, nobody left in a collective
+        peaks = full[1, :, K, :].max(axis=0)
+        sl["req_rounds"] = rounds_for(int(peaks[0]) * 4)
+        sl["ret_rounds"] = rounds_for(int(peaks[1]) * self.dim * 4)
         recv = self._grown(sl, "req_recv", int(words[1].sum()), t.int32)
-        sl["req_work"] = self._exchange(recv, sl["req_send"], sl["req_in_words"], sl["req_out_words"])
+        sl["req_work"] = self._exchange(recv, sl["req_send"], sl["req_in_words"], sl["req_out_words"], sl["req_rounds"])
 
     def lookup_received(self, slot: int) -> int:
         """The fused lookup over every request piece received for this slot (no exchange).  Returns its algorithmic
@@ -440,7 +496,7 @@ class RowRangeExchange:
             sl["req_work"] = None
         nbytes = self.lookup_received(slot)
         back = self._grown(sl, "ret_recv", int(sum(sl["ret_rows_back"])), t.float32, (self.dim,))
-        sl["ret_work"] = self._exchange(back, sl["ret_send"], sl["ret_rows_back"], sl["ret_rows_served"])
+        sl["ret_work"] = self._exchange(back, sl["ret_send"], sl["ret_rows_back"], sl["ret_rows_served"], sl["ret_rounds"])
         return nbytes
 
     def finish(self, slot: int, out) -> None:
@@ -449,6 +505,8 @@ class RowRangeExchange:
         if sl.get("ret_work") is not None:
             sl["ret_work"].wait()
             sl["ret_work"] = None
+        if not sl["n_bags"]:
+            return
         self.engine.unroute_bags(sl["ret_recv"].data_ptr(), sl["meta"].data_ptr(), sl["slotmap"].data_ptr(), self.K,
                                  sl["n_bags"], self.N, self.dim, out.data_ptr(),
                                  self.torch.cuda.current_stream(self.device).cuda_stream)
@@ -474,8 +532,6 @@ class RowRangeExchange:
             spec = [(i.data_ptr(), None, i.numel(), fixed_pooling, r) for i, r in zip(indices, self.rps)]
         if out is None:
             out = t.empty((self.K, n_bags, self.dim), dtype=t.float32, device=self.device)
-        if n_bags == 0:
-            raise ValueError("RowRangeExchange.forward needs at least one bag per rank")
         self.route(slot, self.engine.route_tables(spec), n_bags, sum(int(i.numel()) for i in indices))
         self.send_requests(slot)
         self.serve(slot)
@@ -484,10 +540,12 @@ class RowRangeExchange:
 
 
 # RCCL 2.26.6 (bundled with torch 2.10) delivers only the first half of a single send / receive above 1 GiB
-# (csrc/tools/a2a_size_probe.py: intact at 1.0 GiB, corrupt from 1.1 GiB, whatever the element type).  The native exchange
-# (emb_comm_all_to_all) cuts every pair's transfer into 512-MiB pieces itself; through torch.distributed a piece above the
-# limit is refused here (both ends of the pair see it), or -- where every rank can compute the same number of rounds from
-# static shapes -- moved in several rounds (all_to_all_rounds).
+# (tools/a2a_size_probe.py: intact at 1.0 GiB, corrupt from 1.1 GiB, whatever the element type).  The native exchange
+# (emb_comm_all_to_all) cuts every pair's transfer into 512-MiB pieces itself; through torch.distributed a large piece is
+# moved in several rounds (all_to_all_rounds).  The number of rounds is a JOB-wide decision -- every rank must enter the
+# same collectives -- so it is derived from a number all ranks share: static shapes (dist_bench.run_whole), or the largest
+# piece of the job, which every rank learns from the counts messages (RowRangeExchange: the peaks entry of emb_route_bags'
+# counts; ShardedLookup._a2a: a second word next to every count).  check_piece_sizes is the last line of defence.
 A2A_MAX_PIECE_BYTES = 1 << 30
 A2A_ROUND_BYTES = 512 << 20
 
@@ -514,15 +572,24 @@ class _Works:
             w.wait()
 
 
+def _item_bytes(x) -> int:
+    n = x.element_size()
+    for d in x.shape[1:]:
+        n *= int(d)
+    return n
+
+
 def all_to_all_rounds(dist, recv, send, out_splits, in_splits, rounds: int, group=None):
-    """all_to_all over leading-dimension ranges of 1-D uint8 tensors in `rounds` rounds: round r moves bytes
-    [r*A2A_ROUND_BYTES, (r+1)*A2A_ROUND_BYTES) of every pair's piece.  rounds == 1 is one all_to_all_single."""
+    """all_to_all over leading-dimension ranges (splits count leading-dimension items) in `rounds` rounds: round r moves
+    bytes [r*A2A_ROUND_BYTES, (r+1)*A2A_ROUND_BYTES) of every pair's piece.  rounds == 1 is one all_to_all_single.  Every
+    rank of the group must pass the SAME `rounds` (rounds_for of a number all ranks share)."""
+    item = _item_bytes(send)
     if rounds <= 1:
-        check_piece_sizes(list(out_splits) + list(in_splits), send.element_size(), "all_to_all_single")
+        check_piece_sizes(list(out_splits) + list(in_splits), item, "all_to_all_single")
         return dist.all_to_all_single(recv, send, output_split_sizes=list(out_splits), input_split_sizes=list(in_splits),
                                       group=group, async_op=True)
     in_off, out_off = [0] + _cumsum(in_splits), [0] + _cumsum(out_splits)
-    step = A2A_ROUND_BYTES // send.element_size()
+    step = max(1, A2A_ROUND_BYTES // item)
     works = []
     for r in range(rounds):
         ins = [send[in_off[p] + min(r * step, n):in_off[p] + min((r + 1) * step, n)] for p, n in enumerate(in_splits)]

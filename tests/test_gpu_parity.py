@@ -535,53 +535,6 @@ def test_random_shapes_host_path(pel, eng, oracle):
         assert np.array_equal(got, want), f"case {case}: dim {dim} {dtype} rows {rows} bags {n_bags}"
 
 
-def test_route_unroute_row_range_shards(pel, eng):
-    """Multi-GPU routing helpers in one process: requests routed to N row-range shards, each shard's
-    answer emulated with a torch gather, rows brought back by the permutation -> W[idx] exactly."""
-    import torch
-    dev = torch.device("cuda", 0)
-    g = torch.Generator(device=dev); g.manual_seed(5)
-    K, B, D, N = 3, 10_000, 16, 8
-    rows = [1_000_003, 50_000, 777_777]
-    rps = [-(-r // N) for r in rows]
-    C_ = int(B / N * 1.3) // 4 * 4 + 64
-    W = [torch.randn(r, D, device=dev, generator=g) for r in rows]
-    idx = torch.stack([torch.randint(0, r, (B,), device=dev, generator=g, dtype=torch.int64) for r in rows]).to(torch.int32)
-    seg = K * C_ * D * 4 + K * C_ * 4
-    send = torch.zeros(N * seg, dtype=torch.uint8, device=dev)
-    recv = torch.zeros(N * seg, dtype=torch.uint8, device=dev)
-    perm = torch.zeros(K * B, dtype=torch.int32, device=dev)
-    counts = torch.full((K * N,), 12345, dtype=torch.int32, device=dev)      # the call zeroes them itself
-    ovf = torch.zeros(1, dtype=torch.int32, device=dev)
-    eng.route_onehot(idx.data_ptr(), K, B, rps, N, C_, send.data_ptr(), seg, K * C_ * D * 4,
-                     perm.data_ptr(), counts.data_ptr(), ovf.data_ptr())
-    torch.cuda.synchronize()
-    assert int(ovf.item()) == 0
-    cnt = counts.view(K, N).cpu().numpy()
-    assert (cnt.sum(axis=1) == B).all()
-    for k in range(K):
-        want = np.bincount((idx[k].cpu().numpy().astype(np.int64) // rps[k]), minlength=N)
-        assert np.array_equal(cnt[k], want)
-    # every shard "serves" its request list: recv[d] out region [K][C][D] = W_k[d*rps + local]
-    for d in range(N):
-        lists = send[d * seg + K * C_ * D * 4:(d + 1) * seg].view(torch.int32).view(K, C_).long()
-        out = recv[d * seg:d * seg + K * C_ * D * 4].view(torch.float32).view(K, C_, D)
-        for k in range(K):
-            n = int(cnt[k, d])
-            assert n == 0 or int(lists[k, :n].max()) < rps[k]
-            out[k, :n] = W[k][lists[k, :n] + d * rps[k]]
-    pooled = torch.full((K, B, D), float("nan"), device=dev)
-    eng.unroute_rows(recv.data_ptr(), seg, K, B, D, C_, perm.data_ptr(), pooled.data_ptr())
-    torch.cuda.synchronize()
-    for k in range(K):
-        assert torch.equal(pooled[k], W[k][idx[k].long()])
-    # capacity too small -> overflow flag, nothing written out of bounds
-    eng.route_onehot(idx.data_ptr(), K, B, rps, N, 64, send.data_ptr(), seg, K * C_ * D * 4,
-                     perm.data_ptr(), counts.data_ptr(), ovf.data_ptr())
-    torch.cuda.synchronize()
-    assert int(ovf.item()) == 1
-
-
 @pytest.mark.parametrize("dim,dtype", [(16, np.float32), (128, np.float32), (64, np.float16), (4, np.float32)])
 def test_two_batch_wave_kernel_very_big_launch(pel, eng, oracle, dim, dtype):
     """>= 524288 one-hot-ish bags: the two-batches-per-wavefront kernel, fast path and general rounds."""
@@ -1323,6 +1276,79 @@ def test_full_size_c3_properties(pel, oracle):
                 acc = acc + rows[:, j, :]
             assert torch.equal(first[t], acc), f"table {t} vs the in-order torch sum"
             del rows, acc
+    plan.destroy()
+    e.close()
+
+
+@pytest.mark.parametrize("L", [1, 32])
+def test_full_size_c4_share_properties(pel, oracle, L):
+    """BASELINE configs[3] at the size one of its 8 ranks runs (`bench.py --workload c4 [--pooling 32]`): the 1/8 row
+    shards of the 8 Terabyte-shaped tables above 64 MiB + the 18 small tables whole, 56.6 GB, dim 128 fp32, B = 16384
+    bags per table, uniform indices, one and 32 indices per bag, ONE fused 26-table launch each (wave-batch kernel for
+    L = 1, lane-group kernel for L = 32).  The loop being sharded is emb_dpu_lookup.c:106-116.
+      (1) idempotence: a second launch leaves all 26 outputs unchanged;
+      (2) linearity: x2 copies of a row shard and of a small table give exactly 2x the pooled rows;
+      (3) the oracle on 32 sampled bags of EVERY table (rows copied back from HBM): bit for bit;
+      (4) four row shards and two small tables bag for bag against the in-order torch gather-sum: bit for bit."""
+    import torch
+    dev = torch.device("cuda", 0)
+    if torch.cuda.get_device_properties(dev).total_memory < 100e9:
+        pytest.skip("needs 60 GB of HBM for the tables")
+    D, B = pel.workloads.TERABYTE_DIM, pel.workloads.TERABYTE_BATCH
+    full = pel.workloads.TERABYTE_ROWS
+    split = [n * D * 4 > (64 << 20) for n in full]
+    rows = [(-(-n // 8) if s else n) for n, s in zip(full, split)]
+    assert sum(split) == 8 and D == 128 and B == 16384 and 56e9 < sum(rows) * D * 4 < 57.5e9
+    T = len(rows)
+    big = max(range(T), key=lambda t: rows[t])
+    small = min((t for t in range(T) if not split[t]), key=lambda t: -rows[t])
+    e = pel.EmbeddingEngine(device=0, max_tables=T + 2)
+    g = torch.Generator(device=dev)
+    g.manual_seed(4)
+    for t, n in enumerate(rows):
+        a = float(np.sqrt(1.0 / full[t]))
+        w = torch.empty((n, D), dtype=torch.float32, device=dev).uniform_(-a, a, generator=g)
+        e.load_table(t, w)
+        if t == big:
+            e.load_table(T, w * 2.0)
+        if t == small:
+            e.load_table(T + 1, w * 2.0)
+        del w
+    torch.cuda.empty_cache()
+    rng = np.random.default_rng(40 + L)
+    idx_h = [pel.workloads.uniform_indices(rng, n, B * L) for n in rows]
+    idx = [torch.from_numpy(i.view(np.int32)).to(dev) for i in idx_h]
+    off = torch.from_numpy(pel.workloads.fixed_offsets(B, L).view(np.int32)).to(dev)
+    plan = e.plan(list(range(T)), idx, [off] * T)
+    plan.launch()
+    torch.cuda.synchronize()
+    kinds = e.stats()["n_launches_by_kind"]
+    assert sum(kinds) == 1 and kinds[0 if L == 1 else 1] == 1           # ONE launch: wave-batch (one-hot) / lane-group (pooled)
+    first = [o.clone() for o in plan.outputs]
+    plan.launch()
+    torch.cuda.synchronize()
+    assert all(torch.equal(plan.outputs[t], first[t]) for t in range(T))
+    lin = e.lookup_batched([T, T + 1], [idx[big], idx[small]], [off, off])
+    torch.cuda.synchronize()
+    assert torch.equal(lin[0], first[big] * 2.0) and torch.equal(lin[1], first[small] * 2.0)
+    exact = [t for t in range(T) if split[t]][::2] + [small, min(range(T), key=lambda t: rows[t])]
+    for t in range(T):
+        w = e.table_tensor(t)
+        sel = np.unique(rng.integers(0, B, size=32))
+        pos = (sel[:, None] * L + np.arange(L)[None, :]).reshape(-1)
+        uniq, inv = np.unique(idx_h[t][pos].astype(np.int64), return_inverse=True)
+        rows_s = w[torch.from_numpy(uniq).to(dev)].cpu().numpy()
+        want = oracle.c_bag_sum(rows_s, inv.astype(np.int64), np.arange(sel.shape[0], dtype=np.int64) * L)
+        assert np.array_equal(first[t][torch.from_numpy(sel).to(dev)].cpu().numpy(), want), f"table {t} vs oracle"
+        if t in exact:
+            r = w[idx[t].long()].view(B, L, D)
+            acc = r[:, 0, :] + 0.0
+            for j in range(1, L):
+                acc = acc + r[:, j, :]
+            assert torch.equal(first[t], acc), f"table {t} vs the in-order torch sum"
+            del r, acc
+    nb, ni = plan.bytes()[1:]
+    assert (nb, ni) == (T * B, T * B * L)
     plan.destroy()
     e.close()
 

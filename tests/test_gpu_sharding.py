@@ -16,6 +16,30 @@ def eng(pel):
     e.close()
 
 
+def _meta_views(m, N, K):
+    """Sections of emb_route_bags' meta words (include/pimemb.h): counts[N][K+1][2] (entry K = peaks), base[N][K][2],
+    piece[N+1], ret_row0[N][K], mode."""
+    nk = N * K
+    c = m[:2 * N * (K + 1)].reshape(N, K + 1, 2)
+    o = 2 * N * (K + 1)
+    base = m[o:o + 2 * nk].reshape(N, K, 2)
+    piece = m[o + 2 * nk:o + 2 * nk + N + 1]
+    row0 = m[o + 2 * nk + N + 1:o + 3 * nk + N + 1].reshape(N, K)
+    mode = int(m[o + 3 * nk + N + 1])
+    return c[:, :K, :], c[:, K, :], base, piece, row0, mode
+
+
+def _slots_view(slots_words, mode, K, N, B):
+    """`slots` in the general encoding [K][N][B] whatever mode the router used (mode 1 packs (dest << 24) | slot per bag)."""
+    if mode == 0:
+        return slots_words[:K * N * B].reshape(K, N, B)
+    pk = slots_words[:K * B].reshape(K, B)
+    out = np.full((K, N, B), 0xffffffff, dtype=np.uint32)
+    for k in range(K):
+        out[k, pk[k] >> 24, np.arange(B)] = pk[k] & 0xffffff
+    return out
+
+
 def _route_bags_reference(idx, off, n_idx, rps, N):
     """Host restatement of the routing rule (tests only): per shard d the sub-bag lists in bag order."""
     B = off.shape[0]
@@ -37,7 +61,7 @@ def _route_bags_reference(idx, off, n_idx, rps, N):
     return out
 
 
-def _router_case(pel, eng, oracle, rng, rows, N, B, dim, ragged, max_len=40, zipf_first=True):
+def _router_case(pel, eng, oracle, rng, rows, N, B, dim, ragged, max_len=40, zipf_first=True, onehot=False):
     """One router / un-router round trip in ONE process: emb_route_bags cuts every bag into per-shard sub-bags, every
     'shard' serves its piece with the ordinary fused lookup, emb_unroute_bags adds the partial rows in shard order.
     Checks counts / offsets / lists / slots against the host restatement of the routing rule, the result bit for bit
@@ -45,6 +69,7 @@ def _router_case(pel, eng, oracle, rng, rows, N, B, dim, ragged, max_len=40, zip
     import torch
     dev = torch.device("cuda", 0)
     K = len(rows)
+    L_fixed = 1 if onehot else 32           # onehot: fixed pooling 1, no offsets array -> the router's one-index-per-bag path
     rps = [-(-r // N) for r in rows]
     tabs = [pel.workloads.dlrm_table(rng, r, dim) for r in rows]
     idxs, offs = [], []
@@ -52,7 +77,7 @@ def _router_case(pel, eng, oracle, rng, rows, N, B, dim, ragged, max_len=40, zip
         if ragged:
             off, n_idx = pel.workloads.ragged_offsets(rng, B, max_len, p_empty=0.15) if max_len else (np.zeros(B, np.uint32), 0)
         else:
-            off, n_idx = pel.workloads.fixed_offsets(B, 32), 32 * B
+            off, n_idx = pel.workloads.fixed_offsets(B, L_fixed), L_fixed * B
         gen = pel.workloads.zipf_indices if (k == 0 and zipf_first) else pel.workloads.uniform_indices
         idxs.append(gen(rng, rows[k], n_idx))
         offs.append(off)
@@ -69,18 +94,14 @@ def _router_case(pel, eng, oracle, rng, rows, N, B, dim, ragged, max_len=40, zip
     d_idx = [torch.from_numpy(np.ascontiguousarray(i).view(np.int32)).to(dev) if i.shape[0] else
              torch.zeros(1, dtype=torch.int32, device=dev) for i in idxs]
     d_off = [torch.from_numpy(o.view(np.int32)).to(dev) for o in offs]
-    spec = [(d_idx[k].data_ptr(), d_off[k].data_ptr() if ragged else None, idxs[k].shape[0], 0 if ragged else 32, rps[k])
+    spec = [(d_idx[k].data_ptr(), d_off[k].data_ptr() if ragged else None, idxs[k].shape[0], 0 if ragged else L_fixed, rps[k])
             for k in range(K)]
 
     def run_once():
         eng.route_bags(spec, B, N, send.data_ptr(), meta.data_ptr(), slots.data_ptr(), work.data_ptr())
         torch.cuda.synchronize()
         m = meta.view(torch.int32).cpu().numpy().view(np.uint32)
-        nk = N * K
-        counts = m[:2 * nk].reshape(N, K, 2)
-        base = m[2 * nk:4 * nk].reshape(N, K, 2)
-        piece = m[4 * nk:4 * nk + N + 1]
-        row0 = m[4 * nk + N + 1:5 * nk + N + 1].reshape(N, K)
+        counts, peaks, base, piece, row0, mode = _meta_views(m, N, K)
         words = send.view(torch.int32)
         # every shard serves its piece: one fused lookup per shard over the K request lists
         rets = []
@@ -108,11 +129,12 @@ def _router_case(pel, eng, oracle, rng, rows, N, B, dim, ragged, max_len=40, zip
         pooled = torch.full((K, B, dim), float("nan"), device=dev)
         eng.unroute_bags(recv.data_ptr(), meta.data_ptr(), slots.data_ptr(), K, B, N, dim, pooled.data_ptr())
         torch.cuda.synchronize()
-        return counts.copy(), base.copy(), piece.copy(), row0.copy(), pooled.cpu().numpy()
+        return counts.copy(), peaks.copy(), base.copy(), piece.copy(), row0.copy(), mode, pooled.cpu().numpy()
 
-    counts, base, piece, row0, pooled = run_once()
+    counts, peaks, base, piece, row0, mode, pooled = run_once()
+    assert mode == (1 if onehot else 0)
     words = send.view(torch.int32).cpu().numpy().view(np.uint32)
-    sl = slots.view(torch.int32).cpu().numpy().view(np.uint32)[:K * N * B].reshape(K, N, B)
+    sl = _slots_view(slots.view(torch.int32).cpu().numpy().view(np.uint32), mode, K, N, B)
     pad4 = lambda v: (v + 3) & ~3
     refs = [_route_bags_reference(idxs[k], offs[k].astype(np.int64), idxs[k].shape[0], rps[k], N) for k in range(K)]
     cursor, row = 0, 0
@@ -129,6 +151,8 @@ def _router_case(pel, eng, oracle, rng, rows, N, B, dim, ragged, max_len=40, zip
             cursor += pad4(ns) + pad4(ni)
             row += ns
     assert piece[N] == cursor and cursor * 4 <= sz["send"]
+    # the peaks entry of every destination's counts message: my largest request piece (words) / most partial rows from one peer
+    assert (peaks[:, 0] == np.diff(piece.astype(np.int64)).max()).all() and (peaks[:, 1] == counts[:, :, 0].sum(axis=1).max()).all()
     # expected: partial sums per shard (oracle, in index order), added in shard order from +0
     for k in range(K):
         want = np.zeros((B, dim), np.float32)
@@ -156,6 +180,18 @@ def test_route_bags_row_range_shards_pooled(pel, eng, oracle, dim, ragged):
     assert np.array_equal(run_once()[-1], pooled)          # deterministic: same bits on a second run
 
 
+@pytest.mark.parametrize("dim,N,B", [(16, 8, 39_292), (128, 8, 5_000), (64, 3, 1025), (4, 64, 777), (32, 1, 100)])
+def test_route_bags_one_index_per_bag_fast_path(pel, eng, oracle, dim, N, B):
+    """The router's one-index-per-bag path (fixed pooling 1, no offsets: the Criteo shape) against the same host
+    restatement as the general path -- same counts, offsets, lists, slot order, peaks -- through ballot ranks in 1024-bag
+    blocks instead of per-(bag, shard) threads; bag counts that are / are not multiples of 1024, 1 / 3 / 8 / 64 shards,
+    a Zipf table (a hot shard).  The un-routed rows equal the unsharded oracle bit for bit; twice the same bits."""
+    rng = np.random.default_rng(dim * 1000 + N)
+    rows = [100_003, 64, 40_001] if N <= 8 else [100_003, 7_000]
+    pooled, run_once = _router_case(pel, eng, oracle, rng, rows, N, B, dim, False, onehot=True)
+    assert np.array_equal(run_once()[-1], pooled)
+
+
 def test_route_bags_hypothesis_shapes(pel, eng, oracle):
     """Property test over shapes (hypothesis, seeded): 1..4 tables of 1..5000 rows -- fewer rows than shards included --
     over 1..17 shards, 1..300 bags of 0..9 indices (all-empty launches included), dims 4 / 16 / 64."""
@@ -163,11 +199,11 @@ def test_route_bags_hypothesis_shapes(pel, eng, oracle):
 
     @settings(max_examples=30, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
     @given(seed=st.integers(0, 2**31 - 1), k=st.integers(1, 4), n=st.integers(1, 17), b=st.integers(1, 300),
-           dim=st.sampled_from([4, 16, 64]), max_len=st.integers(0, 9), small=st.booleans())
-    def case(seed, k, n, b, dim, max_len, small):
+           dim=st.sampled_from([4, 16, 64]), max_len=st.integers(0, 9), small=st.booleans(), onehot=st.booleans())
+    def case(seed, k, n, b, dim, max_len, small, onehot):
         rng = np.random.default_rng(seed)
         rows = [int(x) for x in rng.integers(1, 12 if small else 5000, size=k)]
-        _router_case(pel, eng, oracle, rng, rows, n, b, dim, True, max_len=max_len, zipf_first=False)
+        _router_case(pel, eng, oracle, rng, rows, n, b, dim, not onehot, max_len=max_len, zipf_first=False, onehot=onehot)
 
     case()
 
@@ -197,9 +233,9 @@ def test_route_bags_one_index_per_bag_is_exact(pel, eng, oracle):
     eng.route_bags(spec, B, N, send.data_ptr(), meta.data_ptr(), slots.data_ptr(), work.data_ptr())
     torch.cuda.synchronize()
     m = meta.view(torch.int32).cpu().numpy().view(np.uint32)
-    nk = N * K
-    counts, base = m[:2 * nk].reshape(N, K, 2), m[2 * nk:4 * nk].reshape(N, K, 2)
-    assert counts[:, :, 0].sum() == K * B and np.array_equal(counts[:, :, 0], counts[:, :, 1])
+    counts, peaks, base, _piece, _row0, mode = _meta_views(m, N, K)
+    assert mode == 1 and counts[:, :, 0].sum() == K * B and np.array_equal(counts[:, :, 0], counts[:, :, 1])
+    assert counts[0, 0, 0] > 0.9 * B and peaks[0, 1] == counts[:, :, 0].sum(axis=1).max()     # the hot shard sets the peak
     words = send.view(torch.int32)
     rets = []
     for d in range(N):
@@ -279,18 +315,58 @@ def test_distributed_bench_two_ranks_on_one_gpu(mode):
         sec = d["sharded_exchange"]
         assert isinstance(sec, dict) and sec["value"] > 0 and "5 whole" in sec["config"]
         assert sec["verified"] is True and sec["roofline"]["bound"] == "hbm" and sec["roofline"]["achieved"] > 0
+        # the same leg inside the objects a SCALE record keeps
+        cx, rx = d["config"]["exchange"], d["roofline"]["exchange"]
+        assert cx["mode"] == "whole" and cx["verified"] is True and cx["value"] == sec["value"]
+        assert cx["bytes_out_per_rank_per_step"] > 0 and 0 < rx["step_frac"] < 1 and rx["xgmi_GBps"] > 0
+
+
+def _check_row_split_dump_with_oracle(oracle, prefix, world, pooling):
+    """The oracle behind the sharded path: dist_bench left (PIMEMB_DUMP_ROWSPLIT), per rank, the rows of its shard that
+    rank 0's last timed step names -- read back from the engine's tables in HBM -- and, from rank 0, the index arrays and
+    the pooled rows the exchange returned.  Rebuild each row-split table's touched rows from the per-rank pieces and let
+    oracle.c_bag_sum pool them: exact for one index per bag, <= 1e-6 (load_generator.c:58) when partial sums were
+    re-associated across shards."""
+    dumps = [np.load("%s.rank%d.npz" % (prefix, r)) for r in range(world)]
+    d0 = dumps[0]
+    B, L, dim = int(d0["bags"]), int(d0["pooling"]), int(d0["dim"])
+    assert L == pooling and int(d0["world"]) == world and len(d0["tables"]) > 0
+    off = np.arange(B, dtype=np.int64) * L
+    worst = 0.0
+    for t in d0["tables"]:
+        ids = np.concatenate([d["ids_%d" % t] for d in dumps])
+        rows = np.concatenate([d["rows_%d" % t] for d in dumps])
+        idx = d0["idx_%d" % t].astype(np.int64)
+        assert np.array_equal(ids, np.unique(idx)), f"table {t}: the shards together do not hold every touched row once"
+        want = oracle.c_bag_sum(rows, np.searchsorted(ids, idx), off)
+        got = d0["out_%d" % t]
+        assert got.shape == want.shape == (B, dim)
+        if L == 1:
+            assert np.array_equal(got, want), f"table {t}: sharded one-hot lookup differs from the oracle"
+        else:
+            worst = max(worst, float(np.abs(got - want).max()))
+            assert worst <= 1e-6, f"table {t}: {worst} from the oracle's in-order sum"
+    return worst
 
 
 @pytest.mark.parametrize("pooling", [1, 32])
-def test_distributed_terabyte_shaped_row_shards_two_ranks(pooling):
+def test_distributed_terabyte_shaped_row_shards_two_ranks(pooling, oracle, tmp_path):
     """BASELINE configs[3] (Terabyte-shaped tables, dim 128, row-range sharded) at 1/256 of the rows so that two
     ranks sharing cuda:0 hold it, one and 32 indices per bag, started under torchrun as the driver does.  Every
     rank compares all 26 tables bit for bit with the shard-ordered sum of partials (and within 1e-6 of the
-    unsharded in-order sum); run twice, the JSON lines must agree on what was exchanged."""
+    unsharded in-order sum); run twice, the JSON lines must agree on what was exchanged.  The ORACLE checks the
+    row-split tables of rank 0's last timed step from a dump of (rows touched in HBM on both ranks, indices, outputs)."""
     extra = ["--workload", "c4", "--rows-scale", str(1 / 256), "--steps", "4", "--warmup", "2", "--nbatch", "3",
              "--batch", "2051", "--replicate-mb", "8", "--pooling", str(pooling)]
-    res, d = _bench_two_ranks(extra, launcher="torchrun")
+    prefix = str(tmp_path / "rowsplit")
+    res, d = _bench_two_ranks(extra, launcher="torchrun", env_extra={"PIMEMB_DUMP_ROWSPLIT": prefix})
     assert res.returncode == 0 and d is not None, res.stdout[-2000:] + res.stderr[-4000:]
+    _check_row_split_dump_with_oracle(oracle, prefix, 2, pooling)
+    assert d["config"]["exchange"]["mode"] == "rows" and d["config"]["exchange"]["verified"] is True
+    assert d["config"]["exchange"]["bytes_out_per_rank_per_step"] > 5 * 2051 * pooling * 4 // 3
+    ex = d["roofline"]["exchange"]
+    assert 0 < ex["step_frac"] < 1 and 0 < ex["xgmi_frac"] and ex["xgmi_peak_GBps"] == 7 * 153.0
+    assert d["clock"] in ("event", "sync") and d["ms_per_step_sync"] >= d["ms_per_step_event"] > 0
     assert d["n_gpus"] == 2 and d["config"]["dim"] == 128 and d["value"] > 0 and d["verified"] is True
     w = d["config"]["workload"]
     assert "Terabyte" in w and "row-range sharded over 2 ranks" in w and "5 row-range" in w
@@ -313,7 +389,7 @@ def test_exchange_leg_failure_is_a_failed_run():
                               env_extra={"PIMEMB_EXCHANGE_TIMEOUT": "0.05", "PIMEMB_LAUNCH_GRACE": "5"})
     assert res.returncode != 0
     assert d is not None and d["value"] > 0 and d["verified"] is False
-    assert "timed out" in d["sharded_exchange"]["failed"]
+    assert "timed out" in d["sharded_exchange"]["failed"] and d["config"]["exchange"]["verified"] is False
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -419,12 +495,10 @@ def test_route_bags_limits_many_shards_and_tables(pel, eng):
         torch.cuda.synchronize()
         assert bool((guard == 0x5A).all())
         m = meta.view(torch.int32).cpu().numpy().view(np.uint32)
-        nk = N * K
-        counts, base = m[:2 * nk].reshape(N, K, 2), m[2 * nk:4 * nk].reshape(N, K, 2)
-        piece = m[4 * nk:4 * nk + N + 1]
+        counts, _peaks, base, piece, _row0, mode = _meta_views(m, N, K)
         assert counts[:, :, 1].sum() == K * B * L and piece[N] * 4 <= sz["send"]
         words = send.view(torch.int32).cpu().numpy().view(np.uint32)
-        sl = slots.view(torch.int32).cpu().numpy().view(np.uint32)[:K * N * B].reshape(K, N, B)
+        sl = _slots_view(slots.view(torch.int32).cpu().numpy().view(np.uint32), mode, K, N, B)
         off = (np.arange(B, dtype=np.int64) * L)
         for k in range(0, K, max(1, K // 8)):
             ref = _route_bags_reference(idxs[k], off, B * L, rps[k], N)
@@ -473,10 +547,40 @@ def test_distributed_c5_shape_whole_table_shards_two_ranks():
     assert "512 whole" in c["workload"] and "fp16" in c["workload"] and "mixed indices" in c["workload"]
 
 
+def test_driver_command_shape_five_ranks_on_one_gpu():
+    """`python3 bench.py --gpus N --steps 20 --warmup 5` -- the shape of the driver's SCALE command: default flags, so
+    B = 39 292 bags per table per rank, the data-parallel leg AND the sharded-exchange leg under its 180-s watchdog --
+    rehearsed with gloo ranks sharing the one GPU.  N = 5, not 8: a GPU box admits six processes on its card and this
+    pytest process is one of them (the N = 8 run is the driver's, on an 8-GPU node).  One stdout line, rc 0, the exchange
+    leg's numbers inside config / roofline (the two objects a SCALE record keeps), and well inside the driver's time limit."""
+    import json
+    import subprocess
+    import sys
+    import time
+    env = dict(os.environ, PIMEMB_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.time()
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "5", "--steps", "20", "--warmup", "5"],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    wall = time.time() - t0
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    c = d["config"]
+    assert d["n_gpus"] == 5 and c["world_size"] == 5 and c["backend"] == "gloo" and c["bags_per_table_per_rank"] == 39292
+    assert d["steps"] == 20 and d["warmup"] == 5 and d["verified"] is True and d["scaling"] == "weak"
+    assert c["exchange"]["verified"] is True and c["exchange"]["value"] > 0 and c["exchange"]["bytes_out_per_rank_per_step"] > 0
+    assert d["roofline"]["exchange"]["step_frac"] > 0 and d["roofline"]["exchange"]["xgmi_frac"] > 0
+    assert d["ms_per_step_sync"] >= d["ms_per_step_event"] > 0
+    assert wall < 300, f"{wall:.0f} s for the rehearsal: too close to the driver's limit"
+
+
 def test_all_to_all_rounds_and_the_piece_size_guard():
     """sharding.all_to_all_rounds over RCCL (one rank, self exchange) with the round size forced down to 1 MiB: a 5.5-MiB
     payload moved in 6 rounds arrives intact; check_piece_sizes refuses a piece above 1 GiB (RCCL 2.26 would deliver half of
-    it: csrc/tools/a2a_size_probe.py) before anything is sent."""
+    it: tools/a2a_size_probe.py) before anything is sent."""
     import subprocess
     import sys
     import textwrap

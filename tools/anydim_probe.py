@@ -1,7 +1,7 @@
 """Device time of the element-per-thread kernel (rows that are not 16-byte multiples): 26 Kaggle-sized
 fp32 tables, B = 39292, one and eight indices per bag."""
 import os, sys
-sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..", "..")))
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 import numpy as np, torch
 import pim_embedding_lookup_amd as pel
 dev = torch.device("cuda", 0)

@@ -1,7 +1,7 @@
 """Where the host time of one counts-first exchange step goes (RowRangeExchange, ONE RCCL rank, C2's five big tables):
 microseconds per step, then a cProfile of 300 steps."""
 import os, sys, time, cProfile, pstats
-sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..", "..")))
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 os.environ.setdefault("MASTER_ADDR","127.0.0.1"); os.environ.setdefault("MASTER_PORT","29591")
 import numpy as np, torch, torch.distributed as dist
 import pim_embedding_lookup_amd as pel

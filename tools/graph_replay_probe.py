@@ -1,6 +1,6 @@
 """Developer probe: eager plan launches vs one hipGraph holding 8 of them, small batches (launch-bound)."""
 import os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 import numpy as np, torch
 import pim_embedding_lookup_amd as pel
 dev = torch.device("cuda", 0)

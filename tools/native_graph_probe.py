@@ -6,7 +6,7 @@ import sys
 import time
 
 faulthandler.enable()
-sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..", "..")))
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 import torch  # noqa: E402
 import pim_embedding_lookup_amd as pel  # noqa: E402
 

@@ -10,8 +10,8 @@
 #include <string>
 #include <vector>
 
-#include "../pimemb_bag_kernels.h"
-#include "../pimemb_xcd_map.h"
+#include "pimemb_bag_kernels.h"
+#include "pimemb_xcd_map.h"
 
 using namespace pimemb;
 

@@ -11,9 +11,9 @@
 #include <string>
 #include <vector>
 
-#include "../pimemb_bag_kernels.h"
-#include "../pimemb_xcd_map.h"
-#include "../pimemb_hot_rows.h"
+#include "pimemb_bag_kernels.h"
+#include "pimemb_xcd_map.h"
+#include "pimemb_hot_rows.h"
 
 using namespace pimemb;
 
