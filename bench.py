@@ -83,6 +83,8 @@ def parse_args():
                          "that table's accesses; 0 = no hint")
     ap.add_argument("--prewarm-ms", type=float, default=250.0,
                     help="untimed device pre-warm before the W warm-up steps (clock ramp of a fresh process; N=1 and the data-parallel N>1 leg); 0 = off")
+    ap.add_argument("--graph", action="store_true",
+                    help="N=1: capture the K timed launches in one hipGraph and replay it (tried in round 3: see DESIGN.md section 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     return ap.parse_args()
@@ -109,12 +111,14 @@ def make_tables_on_gpu(torch, eng, rows_list, dim, device, seed=0, keep_host=Fal
 
 
 L2_PEAK_GBS = 34500.0    # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate
+PROFILED_NBATCH = 8      # the --nbatch every entry of profiles/traffic.json was collected with
 
 
 def profile_key(args, spec):
     """Key of this run in profiles/traffic.json, or None when the run is not one of the profiled commands
     (another batch size / table count / hint changes the traffic)."""
-    if args.batch is not None or args.tables is not None or args.hot_rows or args.streams != 1:
+    if args.batch is not None or args.tables is not None or args.hot_rows or args.streams != 1 \
+            or getattr(args, "nbatch", PROFILED_NBATCH) != PROFILED_NBATCH:     # (another rotation length = another index reuse)
         return None
     key = args.workload
     if args.workload == "c4" and spec["L"] != 1:
@@ -146,11 +150,12 @@ def unique_row_bytes(batch, row_bytes):
 
 
 def roofline_object(alg_bytes, kernel_us, entry, uniq_bytes, meta_bytes=0):
-    """HBM roofline of the dominant kernel.  The metric's own config (C2) and every launch whose rows mostly MISS
-    the caches are priced on ALGORITHMIC bytes.  A launch that is mostly served by L2 /
-    Infinity Cache moves far fewer HBM-side bytes than it gathers, so algorithmic bytes / HBM peak would exceed 1
-    and mean nothing: there `achieved` is the MEASURED HBM-side traffic / time, the algorithmic rate is kept as
-    `achieved_algorithmic`, and `l2_frac` prices the L2 requests against the L2's own peak."""
+    """HBM roofline of the dominant kernel, ONE basis on every line: `achieved` / `frac` = ALGORITHMIC bytes per launch
+    (cache hits still count) / the launch's duration / the 8 TB/s peak.  A launch that is
+    mostly served by L2 / Infinity Cache gathers more than the HBM delivers, so its `frac` can exceed 1: `cache_served`
+    says so, and the MEASURED HBM-side rate (committed rocprofv3 PMC passes of the same command, profiles/traffic.json)
+    is reported next to it as `achieved_measured` / `frac_measured`, with `l2_frac` pricing the L2 requests against
+    the L2's own peak."""
     t = kernel_us * 1e-6
     alg = alg_bytes / t / 1e9
     r = {"bound": "hbm", "achieved": alg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / HBM_PEAK_GBS,
@@ -160,10 +165,10 @@ def roofline_object(alg_bytes, kernel_us, entry, uniq_bytes, meta_bytes=0):
         traffic = entry.get("traffic_bytes_per_launch")
         r["traffic"] = traffic
         r["traffic_source"] = entry.get("source")
-        if traffic and traffic < 0.75 * alg_bytes:        # cache-served: the counter bytes are the HBM-side load
-            r["achieved"] = traffic / t / 1e9
-            r["frac"] = r["achieved"] / HBM_PEAK_GBS
-            r["basis"] = "measured HBM-side bytes (profiles/traffic.json); algorithmic rate in achieved_algorithmic"
+        if traffic:
+            r["achieved_measured"] = traffic / t / 1e9      # committed profile's bytes / THIS run's launch time
+            r["frac_measured"] = r["achieved_measured"] / HBM_PEAK_GBS
+            r["cache_served"] = bool(traffic < 0.75 * alg_bytes)
         if entry.get("tcc_hit") is not None and entry.get("tcc_miss") is not None:
             req = entry["tcc_hit"] + entry["tcc_miss"]
             r["l2_hit_rate"] = entry["tcc_hit"] / max(req, 1)
@@ -172,9 +177,10 @@ def roofline_object(alg_bytes, kernel_us, entry, uniq_bytes, meta_bytes=0):
             r["read_over_unique_rows"] = max(entry["read_bytes"] - meta_bytes, 0) / uniq_bytes
     if uniq_bytes:
         r["unique_row_bytes"] = uniq_bytes
-    if not entry and r["frac"] > 1.0:
-        r["basis"] = ("algorithmic bytes; no PMC profile of this exact command in profiles/traffic.json -- a fraction above 1 "
-                      "only says that most rows were served by L2 / Infinity Cache, it is not an HBM utilisation")
+    if r["frac"] > 1.0:
+        r["basis"] = ("algorithmic bytes; above 1 because most rows were served by L2 / Infinity Cache -- not an HBM "
+                      "utilisation" + ("; the HBM-side rate is frac_measured" if r.get("frac_measured") is not None else
+                                       "; no PMC profile of this exact command in profiles/traffic.json"))
     return r
 
 
@@ -386,12 +392,43 @@ def run_single(args):
     alg_bytes, n_bags, n_idx = plans[0].bytes()
 
     stream = torch.cuda.current_stream(dev)
+    if args.graph:                       # graph capture needs a non-default stream; everything below runs on it
+        stream = torch.cuda.Stream(dev)
+        torch.cuda.set_stream(stream)
     sh = stream.cuda_stream
     extra = [torch.cuda.Stream(dev) for _ in range(max(args.streams, 1) - 1)]
     handles = [sh] + [x.cuda_stream for x in extra]
-    # Device pre-warm (untimed, before the W warm-up steps): a fresh process starts with idle clocks, and the
-    # driver's default run is W=5 / K=20 (0.5 ms in all).  ~0.25 s of the same launches brings the chip to the
-    # state a serving loop is in; the W warm-up steps and the EXACTLY K timed steps follow unchanged.
+
+    def timed_region(replay=None):
+        """W untimed warm-up steps, then EXACTLY K timed steps between two device-wide synchronizes.  Returns
+        (sync-clock seconds, event-clock seconds, HIP-event ms over the K launches).  replay: a captured graph holding
+        the K launches (one graph launch instead of K kernel enqueues)."""
+        for i in range(args.warmup):
+            plans[i % len(plans)].launch(handles[i % len(handles)])
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        if replay is not None:
+            replay.replay()
+        else:
+            for i in range(args.steps):
+                plans[i % len(plans)].launch(handles[i % len(handles)])
+        for x in extra:
+            stream.wait_stream(x)
+        ev1.record(stream)
+        while not ev1.query():               # the event clock: the K-th launch has retired (polled)
+            pass
+        t_event = time.perf_counter() - t0
+        torch.cuda.synchronize()             # the contract's closing bracket, inside the primary clock
+        t_sync = time.perf_counter() - t0
+        return t_sync, t_event, ev0.elapsed_time(ev1)
+
+    # The same W / K shape on the chip as a fresh process finds it (idle clocks), reported next to the headline number:
+    # the driver's default run is W = 5 / K = 20, 0.5 ms in all.
+    cold_sync, _cold_event, cold_ms = timed_region() if args.prewarm_ms > 0 else (None, None, None)
+    # Device pre-warm (untimed, before the W warm-up steps): ~0.25 s of the same launches brings the chip to the state a
+    # serving loop is in; the W warm-up steps and the EXACTLY K timed steps follow unchanged.
     t_pre = time.perf_counter()
     n_pre = 0
     while time.perf_counter() - t_pre < args.prewarm_ms * 1e-3:
@@ -399,20 +436,16 @@ def run_single(args):
             plans[n_pre % len(plans)].launch(sh)
             n_pre += 1
         torch.cuda.synchronize()
-    for i in range(args.warmup):
-        plans[i % len(plans)].launch(handles[i % len(handles)])
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for i in range(args.steps):
-        plans[i % len(plans)].launch(handles[i % len(handles)])
-    for x in extra:
-        stream.wait_stream(x)
-    ev1.record(stream)
-    torch.cuda.synchronize()                 # the contract's closing bracket, inside the clock (N = 1: no RCCL in the
-    wall = time.perf_counter() - t0          # process, the call returns as the K-th launch retires)
-    dev_ms = ev0.elapsed_time(ev1)
+    graph = None
+    if args.graph:                       # the K launches of the timed region captured once, replayed as ONE graph launch
+        graph = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=stream):
+            for i in range(args.steps):
+                plans[i % len(plans)].launch(torch.cuda.current_stream(dev).cuda_stream)
+        graph.replay()
+        torch.cuda.synchronize()
+    wall, wall_event, dev_ms = timed_region(graph)
     kernel_us = dev_ms * 1000.0 / args.steps          # avg launch duration on the launch stream
 
     # what was just timed, checked outside the timed region: every bag of the last batch (all tables) bit for bit
@@ -429,6 +462,10 @@ def run_single(args):
         "unit": "pooled-lookups/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall * 1000.0 / args.steps,
+        # both closing brackets, as on the N > 1 lines: `sync` (primary, the contract's: the clock stops after the
+        # device-wide synchronize) and `event` (the event behind the K-th launch has fired)
+        "clock": "sync", "ms_per_step_sync": wall * 1000.0 / args.steps, "ms_per_step_event": wall_event * 1000.0 / args.steps,
+        "value_sync": args.steps * n_bags / wall, "value_event": args.steps * n_bags / wall_event,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": spec.get("dtype", "f32"), "data": "synthetic",
         "verified": True,
@@ -438,6 +475,11 @@ def run_single(args):
                    "tables": T, "dim": dim, "bags_per_table": B, "pooling": spec["L"],
                    "table_bytes": eng.stats()["table_bytes"], "hot_rows_hint": args.hot_rows,
                    "prewarm_ms": args.prewarm_ms, "prewarm_launches": n_pre,
+                   # the same W warm-up + K timed steps BEFORE the pre-warm (a fresh process, idle clocks): us per step on
+                   # the sync clock / per launch by HIP events
+                   "timed_without_prewarm_us": None if cold_sync is None else cold_sync * 1e6 / args.steps,
+                   "kernel_without_prewarm_us": None if cold_ms is None else cold_ms * 1000.0 / args.steps,
+                   "launch_mode": "one hipGraph holding the K launches" if args.graph else "K eager kernel enqueues",
                    "launches_by_kind": eng.stats()["n_launches_by_kind"],
                    "parallelism": "single" if len(handles) == 1 else "single GPU, %d streams" % len(handles)},
         "roofline": roofline_object(alg_bytes, kernel_us, measured_traffic(profile_key(args, spec)),

@@ -200,6 +200,16 @@ int emb_plan_time(emb_plan *p, void *stream, uint32_t warmup, uint32_t iters, fl
  * DEVICE or HOST buffers; returns EMB_ERR_RANGE if *n_bad > 0. */
 int emb_validate_inputs(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs,
                         emb_index_type itype, emb_memspace space, uint64_t *n_bad);
+/* The same on a stream of the caller's (emb_validate_inputs uses the default stream): the check is ordered behind
+ * whatever produced the indices on `stream`.  One small kernel and one event wait; no allocation, no device-wide
+ * synchronize. */
+int emb_validate_inputs_on(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs,
+                           emb_index_type itype, emb_memspace space, void *stream, uint64_t *n_bad);
+/* emb_lookup_batched that checks first, whatever the engine's flags say: the descriptors are resolved once, validated
+ * on `stream`, and launched only if clean -- otherwise EMB_ERR_RANGE, *n_bad (may be NULL) = the number of offending
+ * values, nothing launched.  What nn.EmbeddingBag-shaped layers call for tensors they do not trust (IndexError). */
+int emb_lookup_batched_checked(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs,
+                               emb_index_type itype, emb_memspace space, void *stream, uint64_t *n_bad);
 
 int emb_get_stats(emb_engine *e, emb_stats *out);
 int emb_reset_stats(emb_engine *e);

@@ -116,7 +116,7 @@ struct emb_engine {
     size_t h_stage_cap = 0;
     char *d_stage = nullptr;
     size_t d_stage_cap = 0;
-    unsigned long long *d_bad = nullptr;
+    hipEvent_t val_ev = nullptr;   // "the validation kernel of this call is done" (validate_resolved, under mu)
     // stats
     std::atomic<uint64_t> n_lookup_calls{0}, n_kernel_launches{0}, n_bags{0}, n_indices{0};
     std::atomic<uint64_t> n_by_kind[5] = {};
@@ -767,12 +767,6 @@ int emb_create(const emb_config *cfg, emb_engine **out) {
     }
     uint32_t max_tables = (cfg && cfg->max_tables) ? cfg->max_tables : 1024;
     e->tables.resize(max_tables);
-    DeviceGuard g(dev);
-    hipError_t err = hipMalloc((void **)&e->d_bad, sizeof(unsigned long long));
-    if (err != hipSuccess) {
-        delete e;
-        return fail(EMB_ERR_DEVICE, "emb_create: hipMalloc failed: %s", hipGetErrorString(err));
-    }
     *out = e;
     return EMB_OK;
 }
@@ -804,7 +798,7 @@ int emb_destroy(emb_engine *e) {
         if (ev) (void)hipEventDestroy(ev);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
     if (e->d_stage) (void)hipFree(e->d_stage);
-    if (e->d_bad) (void)hipFree(e->d_bad);
+    if (e->val_ev) (void)hipEventDestroy(e->val_ev);
     delete e;
     return EMB_OK;
 }
@@ -943,30 +937,48 @@ int emb_table_info(emb_engine *e, uint32_t table_id, void **device_rows, uint64_
 
 static int validate_on(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs, emb_index_type itype,
                        emb_memspace space, hipStream_t s, uint64_t *n_bad);
+static int validate_resolved(emb_engine *e, const Resolved &r, emb_index_type itype, hipStream_t s, uint64_t *n_bad);
 
-int emb_lookup_batched(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs,
-                       emb_index_type itype, emb_memspace space, void *stream) {
+static int lookup_batched_impl(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs, emb_index_type itype,
+                               emb_memspace space, void *stream, bool check, uint64_t *n_bad) {
+    if (n_bad) *n_bad = 0;
     if (!e) return fail(EMB_ERR_INVALID, "engine is NULL");
     if (n_descs == 0) return EMB_OK;
     if (!descs) return fail(EMB_ERR_INVALID, "descs is NULL");
     DeviceGuard g(e->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     e->n_lookup_calls.fetch_add(1, std::memory_order_relaxed);
-    if (e->check_inputs) {   // EMB_FLAG_CHECK_INPUTS: refuse the call instead of gathering a wild row
-        int vrc = validate_on(e, descs, n_descs, itype, space, s, nullptr);
-        if (vrc) return vrc;
+    if (space == EMB_MEM_HOST) {
+        if (check) {         // refuse the call instead of gathering a wild row
+            int vrc = validate_on(e, descs, n_descs, itype, space, s, n_bad);
+            if (vrc) return vrc;
+        }
+        return lookup_host(e, descs, n_descs, itype, s);
     }
-    if (space == EMB_MEM_HOST) return lookup_host(e, descs, n_descs, itype, s);
     Resolved r;
     const double p0 = g_prof.on ? now_us() : 0;
     int rc = resolve(e, descs, n_descs, itype, nullptr, nullptr, nullptr, &r, /*cache_maps=*/true);
     if (rc) return rc;
     if (g_prof.on) g_prof.resolve += now_us() - p0;
+    if (check) {             // the descriptors are resolved ONCE: validated first, launched if clean
+        rc = validate_resolved(e, r, itype, s, n_bad);
+        if (rc) return rc;
+    }
     rc = launch_resolved(e, r, itype, s);
     if (rc) return rc;
     e->n_bags.fetch_add(r.n_bags, std::memory_order_relaxed);
     e->n_indices.fetch_add(r.n_indices, std::memory_order_relaxed);
     return EMB_OK;
+}
+
+int emb_lookup_batched(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs,
+                       emb_index_type itype, emb_memspace space, void *stream) {
+    return lookup_batched_impl(e, descs, n_descs, itype, space, stream, e && e->check_inputs, nullptr);
+}
+
+int emb_lookup_batched_checked(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs,
+                               emb_index_type itype, emb_memspace space, void *stream, uint64_t *n_bad) {
+    return lookup_batched_impl(e, descs, n_descs, itype, space, stream, true, n_bad);
 }
 
 int emb_lookup(emb_engine *e, uint32_t table_id, const void *indices, uint64_t n_indices,
@@ -1080,7 +1092,37 @@ int emb_plan_time(emb_plan *p, void *stream, uint32_t warmup, uint32_t iters, fl
     return EMB_OK;
 }
 
-// Count out-of-range indices / broken offsets of a batched call on stream `s` (waits for the count).
+// Count out-of-range indices / broken offsets over the resolved descriptors of a call (device-resident buffers) on
+// stream `s`, and wait for the count.  No allocation and no device-wide synchronize on this path: the descriptors and
+// the 8-byte counter take a piece of the launch-image ring (pinned, device-visible: the kernel reads the descriptors
+// from it and adds to the counter with system-scope atomics -- only threads that FOUND something write at all), and the
+// host waits for one event of its own, polling it first (a blocking wait is woken ~20 us late).
+static int validate_resolved(emb_engine *e, const Resolved &r, emb_index_type itype, hipStream_t s, uint64_t *n_bad) {
+    if (n_bad) *n_bad = 0;
+    if (r.descs.empty()) return EMB_OK;
+    std::lock_guard<std::mutex> lk(e->mu);
+    const size_t dbytes = (sizeof(DevDesc) * r.descs.size() + 127) / 128 * 128;
+    char *h = nullptr, *d = nullptr;
+    int rc = take_image_space(e, dbytes + 128, s, &h, &d);
+    if (rc) return rc;
+    memcpy(h, r.descs.data(), sizeof(DevDesc) * r.descs.size());
+    volatile unsigned long long *count = reinterpret_cast<volatile unsigned long long *>(h + dbytes);
+    *count = 0;
+    if (!e->val_ev) HIP_TRY(hipEventCreateWithFlags(&e->val_ev, hipEventDisableTiming));
+    HIP_TRY(pimemb::launch_validate(reinterpret_cast<const DevDesc *>(h), (uint32_t)r.descs.size(), itype,
+                                    const_cast<unsigned long long *>(count), s));
+    HIP_TRY(hipEventRecord(e->val_ev, s));
+    hipError_t q = hipErrorNotReady;
+    for (int spin = 0; spin < 4000 && q == hipErrorNotReady; spin++) q = hipEventQuery(e->val_ev);
+    if (q == hipErrorNotReady) q = hipEventSynchronize(e->val_ev);
+    if (q != hipSuccess) return fail(EMB_ERR_DEVICE, "emb_validate_inputs: %s", hipGetErrorString(q));
+    const unsigned long long bad = *count;
+    if (n_bad) *n_bad = bad;
+    if (bad) return fail(EMB_ERR_RANGE, "%llu out-of-range indices / broken offsets", bad);
+    return EMB_OK;
+}
+
+// The same for a batched call as the caller describes it; host buffers are staged into HBM first.
 static int validate_on(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs, emb_index_type itype,
                        emb_memspace space, hipStream_t s, uint64_t *n_bad) {
     HostStage hs;
@@ -1088,43 +1130,33 @@ static int validate_on(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_d
     int rc;
     std::unique_lock<std::mutex> host_lk(e->host_mu, std::defer_lock);
     if (space == EMB_MEM_HOST) host_lk.lock();
-    std::unique_lock<std::mutex> lk(e->mu);
+    std::vector<emb_lookup_desc> tmp(descs, descs + n_descs);
+    for (uint32_t i = 0; i < n_descs; i++)
+        if (!tmp[i].pooled) tmp[i].pooled = (float *)16;   // pooled pointers are not touched by validation
     if (space == EMB_MEM_HOST) {
-        rc = stage_host_inputs(e, descs, n_descs, itype, s, &hs, false);
+        {
+            std::lock_guard<std::mutex> lk(e->mu);
+            rc = stage_host_inputs(e, descs, n_descs, itype, s, &hs, false);
+        }
         if (rc) return rc;
-        // pooled pointers are not touched by validation; pass the user's through
-        std::vector<float *> outs(n_descs);
-        for (uint32_t i = 0; i < n_descs; i++) outs[i] = descs[i].pooled ? descs[i].pooled : (float *)16;
-        std::vector<emb_lookup_desc> tmp(descs, descs + n_descs);
-        for (uint32_t i = 0; i < n_descs; i++) tmp[i].pooled = outs[i];
         rc = resolve(e, tmp.data(), n_descs, itype, &hs.d_indices, &hs.d_offsets, nullptr, &r);
     } else {
-        std::vector<emb_lookup_desc> tmp(descs, descs + n_descs);
-        for (uint32_t i = 0; i < n_descs; i++)
-            if (!tmp[i].pooled) tmp[i].pooled = (float *)16;
         rc = resolve(e, tmp.data(), n_descs, itype, nullptr, nullptr, nullptr, &r);
     }
     if (rc) return rc;
-    DevDesc *d = nullptr;
-    HIP_TRY(hipMalloc((void **)&d, sizeof(DevDesc) * r.descs.size()));
-    hipError_t err = hipMemcpy(d, r.descs.data(), sizeof(DevDesc) * r.descs.size(), hipMemcpyHostToDevice);
-    if (err == hipSuccess) err = hipMemsetAsync(e->d_bad, 0, sizeof(unsigned long long), s);
-    if (err == hipSuccess) err = pimemb::launch_validate(d, (uint32_t)r.descs.size(), itype, e->d_bad, s);
-    unsigned long long bad = 0;
-    if (err == hipSuccess) err = hipMemcpyAsync(&bad, e->d_bad, sizeof bad, hipMemcpyDeviceToHost, s);
-    if (err == hipSuccess) err = hipStreamSynchronize(s);
-    (void)hipFree(d);
-    if (err != hipSuccess) return fail(EMB_ERR_DEVICE, "emb_validate_inputs: %s", hipGetErrorString(err));
-    if (n_bad) *n_bad = bad;
-    if (bad) return fail(EMB_ERR_RANGE, "%llu out-of-range indices / broken offsets", bad);
-    return EMB_OK;
+    return validate_resolved(e, r, itype, s, n_bad);
 }
 
 int emb_validate_inputs(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs,
                         emb_index_type itype, emb_memspace space, uint64_t *n_bad) {
+    return emb_validate_inputs_on(e, descs, n_descs, itype, space, nullptr, n_bad);
+}
+
+int emb_validate_inputs_on(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs, emb_index_type itype,
+                           emb_memspace space, void *stream, uint64_t *n_bad) {
     if (!e || !descs) return fail(EMB_ERR_INVALID, "engine or descs is NULL");
     DeviceGuard g(e->device);
-    return validate_on(e, descs, n_descs, itype, space, nullptr, n_bad);
+    return validate_on(e, descs, n_descs, itype, space, static_cast<hipStream_t>(stream), n_bad);
 }
 
 int emb_get_stats(emb_engine *e, emb_stats *out) {

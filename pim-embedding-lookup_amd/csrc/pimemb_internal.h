@@ -56,7 +56,8 @@ hipError_t launch_bag_sum_hot(const DevDesc *d_descs, uint32_t n_descs, uint32_t
 hipError_t launch_scatter_column(int32_t *table, const int32_t *column, uint64_t nr_rows,
                                  uint32_t dim, uint32_t col, hipStream_t stream);
 
-// Count out-of-range indices and broken offsets (debug check).  *d_bad must be zeroed by the caller.
+// Count out-of-range indices and broken offsets.  *d_bad (device-visible, pinned host memory is fine: system-scope
+// atomics) must be zeroed by the caller.
 hipError_t launch_validate(const DevDesc *d_descs, uint32_t n_descs, emb_index_type itype,
                            unsigned long long *d_bad, hipStream_t stream);
 

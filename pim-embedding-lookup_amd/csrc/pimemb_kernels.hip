@@ -203,7 +203,9 @@ validate_kernel(const DevDesc *__restrict__ descs, unsigned long long *__restric
     } else if (blockIdx.x == 0 && threadIdx.x == 0) {
         if ((uint64_t)dp->fixed_pooling * n_bags != n_idx) local++;
     }
-    if (local) atomicAdd(bad, local);
+    // `bad` lives in pinned host memory (the caller reads it after the kernel's event): system-scope atomic, and only
+    // threads that found something touch it at all
+    if (local) __hip_atomic_fetch_add(bad, local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---- multi-GPU routing of variable-length BAGS to row-range shards -------------------------------

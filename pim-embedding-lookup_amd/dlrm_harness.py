@@ -60,12 +60,11 @@ class EmbeddingBagCollection:
         launch on torch's current stream, no plan and no state kept (every batch brings new tensors)."""
         if len(lS_o) != len(self.ln_emb) or len(lS_i) != len(self.ln_emb):
             raise ValueError("need one (offsets, indices) pair per table")
-        if not self.trusted_inputs:
-            self.validate(lS_o, lS_i)
+        check = not self.trusted_inputs      # validated and looked up in ONE engine call; nothing is launched on bad input
         if hasattr(lS_i, "dim") and hasattr(lS_o, "dim") and lS_i.dim() == 2 and lS_o.dim() == 2 and lS_i.is_cuda:
             # DLRM stacks fixed-size batches into [T, N] / [T, B] tensors: one [T, B, m] result, unbound
-            return list(self.engine.lookup_stacked(self._ids, lS_i, lS_o).unbind(0))
-        return self.engine.lookup_batched(self._ids, list(lS_i), list(lS_o))
+            return list(self.engine.lookup_stacked(self._ids, lS_i, lS_o, check=check).unbind(0))
+        return self.engine.lookup_batched(self._ids, list(lS_i), list(lS_o), check=check)
 
     def validate(self, lS_o, lS_i) -> None:
         """emb_validate_inputs over one batch: IndexError on an index >= table rows or broken offsets, as

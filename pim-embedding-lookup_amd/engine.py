@@ -183,6 +183,15 @@ class EmbeddingEngine:
         self._tables: dict[int, tuple[int, int, int]] = {}  # id -> (nr_rows, dim, dtype)
         self._desc_bufs: dict[int, tuple] = {}              # n descriptors -> (packed buffer, typed pointer)
         self._stacked: dict[tuple, tuple] = {}              # table ids -> descriptor array of lookup_stacked
+        # plan cache of per-table-list calls (lookup_batched over fresh lists of torch CUDA tensors, as an apply_emb loop
+        # makes them): call signature -> prepared plan.  See _lookup_batched_cuda.
+        self._plan_cache: dict[tuple, list] = {}            # key -> [Plan, last use]
+        self._plan_seen: dict[tuple, int] = {}              # key -> sightings before a plan is worth building
+        self._plan_clock = 0
+        self._plan_evictions = 0
+        self.plan_cache_size = 16                           # 0 switches the cache off
+        self._same_dim: dict[tuple, int] = {}               # table ids -> their common dim (0: dims differ)
+        self.plan_cache_hits = 0
 
     # ---- tables (populate_mram's job, emb_host.h:136) ------------------------------------------
     def load_table(self, table_id: int, rows, dtype: int | None = None) -> None:
@@ -206,10 +215,12 @@ class EmbeddingEngine:
             raise ValueError("table must be 2-D [nr_rows, dim]")
         _l.check(self._L.emb_load_table(self._h, table_id, shape[0], shape[1], dt, ptr, space))
         self._tables[table_id] = (shape[0], shape[1], dt)
+        self._same_dim.clear()
 
     def alloc_table(self, table_id: int, nr_rows: int, dim: int, dtype: int) -> None:
         _l.check(self._L.emb_alloc_table(self._h, table_id, nr_rows, dim, dtype))
         self._tables[table_id] = (nr_rows, dim, dtype)
+        self._same_dim.clear()
 
     def load_table_column(self, table_id: int, col: int, column: np.ndarray) -> None:
         column = np.ascontiguousarray(column, dtype=np.int32)
@@ -292,12 +303,27 @@ class EmbeddingEngine:
 
     _DESC = struct.Struct("<IIQQQQQ")    # emb_lookup_desc: table_id, fixed_pooling, indices, offsets, n_indices, n_bags, pooled
 
-    def _lookup_batched_cuda(self, table_ids, indices, offsets, outs, stream):
+    def _drop_plans(self) -> None:
+        for plan, _ in self._plan_cache.values():
+            plan.destroy()
+        self._plan_cache.clear()
+        self._plan_seen.clear()
+
+    def _lookup_batched_cuda(self, table_ids, indices, offsets, outs, stream, check=False):
         """Fast path of lookup_batched for torch CUDA tensors with explicit offsets -- what an
         `apply_emb` loop hands over, fresh tensors every batch.  Same C call as the general path, but
         the descriptors are packed without per-buffer helper objects and the outputs of tables that
         share a dim come from ONE allocation (views).  Returns None if the arguments do not qualify.
-        26 tables: ~150 us -> ~40 us of Python per call."""
+        26 tables: ~150 us -> ~40 us of Python per call.
+
+        Plan cache.  A training / serving loop hands over NEW tensor objects every batch, but torch's caching
+        allocator gives them the addresses of the previous batch's, so the call is byte for byte the one made before:
+        same tables, same buffer addresses, same lengths.  Its signature -- table ids, data_ptr / len / dtype of every
+        index and offset tensor, the output addresses -- is looked up in a small cache; the second sighting builds a
+        prepared plan (emb_plan_create), later ones are ONE emb_plan_launch: no per-table Python, no descriptor
+        resolution.  A plan holds addresses, never values: new indices in the same buffers are read by the launch.
+        Reloaded tables make the plan stale (emb_plan_launch refuses it; the entry is dropped); a miss is the ordinary
+        transient call.  Checked calls (check=True) always take the transient path."""
         import torch
         n = len(table_ids)
         i0 = indices[0]
@@ -310,6 +336,41 @@ class EmbeddingEngine:
             itype = _l.EMB_IDX_U32
         else:
             return None
+        if stream is None:
+            stream = torch.cuda.current_stream(dev).cuda_stream
+        key = one_buffer = None
+        if self.plan_cache_size and not check:
+            try:
+                ptr = torch.Tensor.data_ptr
+                ids_t = tuple(table_ids)
+                nbs = tuple(map(len, offsets))
+                if outs is None:       # fresh outputs: ONE allocation when every table has the same dim (else no caching)
+                    d0 = self._same_dim.get(ids_t)
+                    if d0 is None:
+                        ds = {tables[t][1] for t in table_ids}
+                        d0 = self._same_dim[ids_t] = ds.pop() if len(ds) == 1 else 0
+                    if d0:
+                        one_buffer = torch.empty((sum(nbs), d0), dtype=torch.float32, device=dev)
+                        out_key = one_buffer.data_ptr()
+                else:
+                    out_key = tuple(map(ptr, outs))
+                if outs is not None or one_buffer is not None:
+                    # (dtypes: the first tensor's stands for its list -- the engine refuses mixed lists on the ordinary path)
+                    key = (ids_t, tuple(map(ptr, indices)), tuple(map(ptr, offsets)), tuple(map(len, indices)), nbs,
+                           dt, offsets[0].dtype, dev.index, out_key)
+            except (TypeError, KeyError):      # not all 1-D torch tensors / a table that is not loaded: the general path sorts it out
+                key = None
+        if key is not None:
+            ent = self._plan_cache.get(key)
+            if ent is not None:
+                plan = ent[0]
+                if self._L.emb_plan_launch(plan._p, stream) == _l.EMB_OK:
+                    self._plan_clock += 1
+                    ent[1] = self._plan_clock
+                    self.plan_cache_hits += 1
+                    return list(one_buffer.split(nbs)) if outs is None else list(outs)
+                plan.destroy()                 # stale (a table was reloaded): forget it, make the ordinary call
+                del self._plan_cache[key]
         slot = self._desc_bufs.get(n)
         if slot is None:
             raw = C.create_string_buffer(self._DESC.size * n)
@@ -319,13 +380,16 @@ class EmbeddingEngine:
         nbs, dims = [], []
         for t, ia, oa in zip(table_ids, indices, offsets):
             if type(ia) is not torch.Tensor or type(oa) is not torch.Tensor or ia.dtype is not dt or oa.dtype is not dt \
-                    or ia.device != dev or oa.device != dev or not ia.is_contiguous() or not oa.is_contiguous():
+                    or ia.device != dev or oa.device != dev or not ia.is_contiguous() or not oa.is_contiguous() \
+                    or ia.dim() != 1 or oa.dim() != 1:
                 return None
             nbs.append(oa.numel())
             dims.append(tables[t][1])        # KeyError: table not loaded
         if outs is None:
             d0 = dims[0]
-            if all(d == d0 for d in dims):   # one allocation, one view per table
+            if one_buffer is not None:       # allocated for the cache key above
+                outs = one_buffer.split(nbs)
+            elif all(d == d0 for d in dims):   # one allocation, one view per table
                 outs = torch.empty((sum(nbs), d0), dtype=torch.float32, device=dev).split(nbs)
             else:
                 outs = [torch.empty((b, d), dtype=torch.float32, device=dev) for b, d in zip(nbs, dims)]
@@ -338,15 +402,52 @@ class EmbeddingEngine:
         for t, ia, oa, b, o in zip(table_ids, indices, offsets, nbs, outs):
             pack(buf, off, t, 0, ia.data_ptr(), oa.data_ptr(), ia.numel(), b, o.data_ptr())
             off += size
-        if stream is None:
-            stream = torch.cuda.current_stream(dev).cuda_stream
+        if check:
+            bad = C.c_uint64()
+            rc = self._L.emb_lookup_batched_checked(self._h, buf_ptr, n, itype, _l.EMB_MEM_DEVICE, stream, C.byref(bad))
+            if rc == _l.EMB_ERR_RANGE:
+                raise IndexError(f"{bad.value} index / offset value(s) out of range for the embedding table(s) "
+                                 "(checked on the GPU before anything was launched)")
+            _l.check(rc)
+            return list(outs)
         _l.check(self._L.emb_lookup_batched(self._h, buf_ptr, n, itype, _l.EMB_MEM_DEVICE, stream))
+        if key is not None:
+            self._remember_call(key, buf_ptr, n, itype)
         return list(outs)
+
+    def _remember_call(self, key, desc_ptr, n, itype) -> None:
+        """Second sighting of a call signature: build its plan.  The cache holds plan_cache_size plans; the least recently
+        used one goes when it is full, and a caller whose signatures keep changing (64 evictions) switches the cache
+        off -- destroying a plan waits for the device."""
+        if key in self._plan_cache:
+            return
+        seen = self._plan_seen.get(key, 0) + 1
+        if seen < 2:
+            if len(self._plan_seen) > 4 * max(self.plan_cache_size, 1):
+                self._plan_seen.clear()
+            self._plan_seen[key] = seen
+            return
+        self._plan_seen.pop(key, None)
+        if len(self._plan_cache) >= self.plan_cache_size:
+            victim = min(self._plan_cache, key=lambda k: self._plan_cache[k][1])
+            self._plan_cache.pop(victim)[0].destroy()
+            self._plan_evictions += 1
+            if self._plan_evictions >= 64:
+                self._drop_plans()
+                self.plan_cache_size = 0
+                return
+        p = C.c_void_p()
+        if self._L.emb_plan_create(self._h, desc_ptr, n, itype, C.byref(p)) != _l.EMB_OK:
+            return
+        plan = Plan(self, p.value, None, None)
+        self._plan_clock += 1
+        self._plan_cache[key] = [plan, self._plan_clock]
 
     _DESC_DT = np.dtype([("table_id", "<u4"), ("fixed_pooling", "<u4"), ("indices", "<u8"), ("offsets", "<u8"),
                          ("n_indices", "<u8"), ("n_bags", "<u8"), ("pooled", "<u8")])
 
-    def lookup_stacked(self, table_ids: Sequence[int], indices, offsets, out=None, stream: int | None = None):
+    def lookup_stacked(self, table_ids: Sequence[int], indices, offsets, out=None, stream: int | None = None,
+                       check: bool = False):
         """The stacked form DLRM uses for fixed-size batches: `indices` [T, N] and `offsets` [T, B] as two
         2-D torch CUDA tensors (row t belongs to table_ids[t]; all tables share one dim).  Returns ONE
         [T, B, dim] fp32 tensor (out[t] is table t's pooled rows).  The per-table pointers are computed
@@ -385,6 +486,14 @@ class EmbeddingEngine:
         arr["n_bags"] = B
         if stream is None:
             stream = torch.cuda.current_stream(indices.device).cuda_stream
+        if check:
+            bad = C.c_uint64()
+            rc = self._L.emb_lookup_batched_checked(self._h, arr_ptr, T, itype, _l.EMB_MEM_DEVICE, stream, C.byref(bad))
+            if rc == _l.EMB_ERR_RANGE:
+                raise IndexError(f"{bad.value} index / offset value(s) out of range for the embedding table(s) "
+                                 "(checked on the GPU before anything was launched)")
+            _l.check(rc)
+            return out
         _l.check(self._L.emb_lookup_batched(self._h, arr_ptr, T, itype, _l.EMB_MEM_DEVICE, stream))
         return out
 
@@ -398,24 +507,33 @@ class EmbeddingEngine:
                                             itype, _l.EMB_MEM_DEVICE, stream))
 
     def lookup_batched(self, table_ids: Sequence[int], indices: Sequence, offsets: Sequence,
-                       outs: Sequence | None = None, fixed_pooling=0, stream: int | None = None):
+                       outs: Sequence | None = None, fixed_pooling=0, stream: int | None = None, check: bool = False):
         """All tables in one fused launch; returns the list of pooled [B_t, D] outputs
-        (the `apply_emb` contract: one [B, D] per table)."""
+        (the `apply_emb` contract: one [B, D] per table).  check=True: indices / offsets are validated on the GPU
+        first (emb_lookup_batched_checked) and IndexError is raised, like nn.EmbeddingBag, before anything is launched."""
         if not fixed_pooling and len(table_ids) and _is_torch(indices[0]):
-            res = self._lookup_batched_cuda(table_ids, indices, offsets, outs, stream)
+            res = self._lookup_batched_cuda(table_ids, indices, offsets, outs, stream, check)
             if res is not None:
                 return res
         arr, n, itype, space, results, _keep = self._descs(table_ids, indices, offsets, outs, fixed_pooling)
         if stream is None and space == _l.EMB_MEM_DEVICE:
             stream = _current_stream_for(*indices)
+        if check:
+            bad = C.c_uint64()
+            rc = self._L.emb_lookup_batched_checked(self._h, arr, n, itype, space, stream, C.byref(bad))
+            if rc == _l.EMB_ERR_RANGE:
+                raise IndexError(f"{bad.value} index / offset value(s) out of range for the embedding table(s) "
+                                 "(checked on the GPU before anything was launched)")
+            _l.check(rc)
+            return results
         _l.check(self._L.emb_lookup_batched(self._h, arr, n, itype, space, stream))
         return results
 
     def lookup(self, table_id: int, indices, offsets, out=None, fixed_pooling: int = 0,
-               stream: int | None = None):
+               stream: int | None = None, check: bool = False):
         """lookup(table_id, offsets, indices) -> pooled_rows for one table."""
         return self.lookup_batched([table_id], [indices], [offsets], None if out is None else [out],
-                                   fixed_pooling, stream)[0]
+                                   fixed_pooling, stream, check)[0]
 
     def plan(self, table_ids, indices, offsets, outs=None, fixed_pooling=0) -> Plan:
         arr, n, itype, space, results, keep = self._descs(table_ids, indices, offsets, outs, fixed_pooling)
@@ -430,7 +548,8 @@ class EmbeddingEngine:
         arr, n, itype, space, _r, _k = self._descs(table_ids, indices, offsets, None, fixed_pooling,
                                                    want_outputs=False)
         bad = C.c_uint64()
-        rc = self._L.emb_validate_inputs(self._h, arr, n, itype, space, C.byref(bad))
+        stream = _current_stream_for(*indices) if space == _l.EMB_MEM_DEVICE else None   # behind the indices' producer
+        rc = self._L.emb_validate_inputs_on(self._h, arr, n, itype, space, stream, C.byref(bad))
         if rc not in (_l.EMB_OK, _l.EMB_ERR_RANGE):
             _l.check(rc)
         return bad.value
@@ -484,6 +603,7 @@ class EmbeddingEngine:
 
     def close(self) -> None:
         if self._h:
+            self._drop_plans()                       # the plan cache's own plans
             _l.check(self._L.emb_destroy(self._h))   # raises while plans are alive
             self._h = None
 

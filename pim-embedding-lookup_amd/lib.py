@@ -79,6 +79,10 @@ SIGNATURES = {
     "emb_plan_time": (C.c_int, [_vp, _vp, _u32, _u32, C.POINTER(C.c_float)]),
     "emb_validate_inputs": (C.c_int, [_vp, C.POINTER(EmbLookupDesc), _u32, C.c_int, C.c_int,
                                       C.POINTER(_u64)]),
+    "emb_validate_inputs_on": (C.c_int, [_vp, C.POINTER(EmbLookupDesc), _u32, C.c_int, C.c_int, _vp,
+                                         C.POINTER(_u64)]),
+    "emb_lookup_batched_checked": (C.c_int, [_vp, C.POINTER(EmbLookupDesc), _u32, C.c_int, C.c_int, _vp,
+                                             C.POINTER(_u64)]),
     "emb_get_stats": (C.c_int, [_vp, C.POINTER(EmbStats)]),
     "emb_reset_stats": (C.c_int, [_vp]),
     "emb_set_stage_timing": (C.c_int, [_vp, C.c_int]),

@@ -11,10 +11,11 @@ Inference only (the engine has no backward), `mode="sum"` only, no per-sample we
 max_norm -- the reference has none of them either.
 
 Input checking.  The C ABI is as unchecked as the reference (an out-of-range index is a wild read there,
-emb_dpu_lookup.c:113); these modules are what user tensors reach first, so by default every forward runs
-emb_validate_inputs on its indices / offsets and raises IndexError like nn.EmbeddingBag does.  That costs one
-small kernel and a device-to-host wait per call; pass `trusted_inputs=True` (constructor or attribute) for the
-unchecked fast path once the producer of the indices is known to be sound.
+emb_dpu_lookup.c:113); these modules are what user tensors reach first, so by default every forward goes through
+emb_lookup_batched_checked: indices / offsets are validated on the GPU first and IndexError is raised, like
+nn.EmbeddingBag does, before anything is launched.  That costs one small kernel and one event wait per call (no
+allocation, no device-wide synchronize); pass `trusted_inputs=True` (constructor or attribute) for the unchecked
+fast path once the producer of the indices is known to be sound.
 
 Checkpoints.  `state_dict()` carries `<prefix>weight` read out of HBM and `load_state_dict` uploads it, so a
 DLRM whose `emb_l[k]` were swapped for these modules saves / loads the same keys and shapes as before."""
@@ -68,14 +69,6 @@ def _bags_from(input, offsets, include_last_offset: bool):
     return input, offsets
 
 
-def _check_inputs(engine: EmbeddingEngine, table_ids, indices, offsets) -> None:
-    """emb_validate_inputs over what a forward is about to look up; IndexError like nn.EmbeddingBag."""
-    bad = engine.validate(table_ids, indices, offsets)
-    if bad:
-        raise IndexError(f"{bad} index / offset value(s) out of range for the embedding table(s) "
-                         f"(checked on the GPU by emb_validate_inputs; trusted_inputs=True skips the check)")
-
-
 class EmbeddingBag(torch.nn.Module):
     """One table.  forward(input, offsets) -> [B, embedding_dim] fp32, like nn.EmbeddingBag(mode="sum")."""
 
@@ -92,6 +85,7 @@ class EmbeddingBag(torch.nn.Module):
         self.engine = engine if engine is not None else default_engine(device)
         self.device_index = self.engine.device
         self.table_id = table_id if table_id is not None else _new_table_id(self.device_index)
+        self._id_list = [self.table_id]
         dev = torch.device("cuda", self.device_index)
         if _weight is None:      # nn.EmbeddingBag's default init is N(0, 1)
             _weight = torch.randn((self.num_embeddings, self.embedding_dim), device=dev)
@@ -122,9 +116,7 @@ class EmbeddingBag(torch.nn.Module):
             raise NotImplementedError("per_sample_weights are not part of the reference path")
         idx, off = _bags_from(input, offsets, self.include_last_offset)
         idx, off = idx.contiguous(), off.contiguous()
-        if not self.trusted_inputs:
-            _check_inputs(self.engine, [self.table_id], [idx], [off])
-        return self.engine.lookup_batched([self.table_id], [idx], [off])[0]
+        return self.engine.lookup_batched(self._id_list, [idx], [off], check=not self.trusted_inputs)[0]
 
     # ---- checkpoints: the same key and shape as nn.EmbeddingBag ("<prefix>weight", [num_embeddings, dim]) ----
     def _save_to_state_dict(self, destination, prefix, keep_vars):
@@ -168,18 +160,15 @@ class FusedEmbeddingBags(torch.nn.Module):
         return cls([EmbeddingBag.from_torch(m, **kw) for m in emb_l])
 
     def forward(self, lS_o, lS_i):
+        check = not self.trusted_inputs
         if hasattr(lS_i, "dim") and lS_i.dim() == 2 and hasattr(lS_o, "dim") and lS_o.dim() == 2 and lS_i.is_cuda:
-            if not self.trusted_inputs:
-                _check_inputs(self.engine, self._ids, list(lS_i.unbind(0)), list(lS_o.unbind(0)))
-            return list(self.engine.lookup_stacked(self._ids, lS_i, lS_o).unbind(0))
+            return list(self.engine.lookup_stacked(self._ids, lS_i, lS_o, check=check).unbind(0))
         idx, off = [], []
         for b, i, o in zip(self.bags, lS_i, lS_o):
             i1, o1 = _bags_from(i, o, b.include_last_offset)
             idx.append(i1.contiguous())
             off.append(o1.contiguous())
-        if not self.trusted_inputs:
-            _check_inputs(self.engine, self._ids, idx, off)
-        return self.engine.lookup_batched(self._ids, idx, off)
+        return self.engine.lookup_batched(self._ids, idx, off, check=check)
 
     apply_emb = forward
 

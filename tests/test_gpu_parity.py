@@ -1353,6 +1353,113 @@ def test_full_size_c4_share_properties(pel, oracle, L):
     e.close()
 
 
+def test_plan_cache_of_per_table_list_calls(pel, oracle):
+    """lookup_batched over per-table LISTS of torch tensors, as an apply_emb loop calls it: new list and tensor objects
+    every batch, the same addresses underneath.  From the third identical call on it is one emb_plan_launch of a cached
+    plan -- and must behave exactly like the ordinary call: new index VALUES in the same buffers are picked up, a reloaded
+    table is picked up (the stale plan is refused and dropped), other lengths / addresses / dtypes are other calls, caller
+    outputs are written in place, and plan_cache_size = 0 switches it off.  Always against the oracle, bit for bit."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(77)
+    rows, D, B = [5000, 33, 70_000], 16, 700
+    e = pel.EmbeddingEngine(device=0, max_tables=4)
+    tabs = [pel.workloads.dlrm_table(rng, n, D) for n in rows]
+    for t, w in enumerate(tabs):
+        e.load_table(t, w)
+    L = [3, 1, 5]
+    idx = [torch.from_numpy(rng.integers(0, n, size=B * l)).to(dev) for n, l in zip(rows, L)]
+    off = [torch.arange(0, B * l, l, dtype=torch.int64, device=dev) for l in L]
+
+    def call(outs=None, ii=None, oo=None):
+        ii, oo = ii or idx, oo or off
+        return e.lookup_batched([0, 1, 2], [x.view(-1) for x in ii], [x.view(-1) for x in oo], outs)   # fresh objects
+
+    def want(ii=None, oo=None):
+        ii, oo = ii or idx, oo or off
+        return [oracle.c_bag_sum(tabs[t], ii[t].cpu().numpy(), oo[t].cpu().numpy()) for t in range(3)]
+
+    def same(got, ref):
+        return all(np.array_equal(g.cpu().numpy(), r) for g, r in zip(got, ref))
+
+    for _ in range(4):
+        assert same(call(), want())
+    assert e.plan_cache_hits >= 1 and len(e._plan_cache) == 1
+    hits = e.plan_cache_hits
+    for x, n in zip(idx, rows):                      # new index values, same buffers: the cached plan reads them
+        x.copy_(torch.from_numpy(rng.integers(0, n, size=x.numel())).to(dev))
+    assert same(call(), want()) and e.plan_cache_hits == hits + 1
+    tabs[1] = pel.workloads.dlrm_table(rng, rows[1], D)          # reloaded table, same shape: same allocation, plan still valid
+    e.load_table(1, tabs[1])
+    assert same(call(), want())
+    tabs[1] = pel.workloads.dlrm_table(rng, 90, D)               # other shape: re-allocated, the plan is stale -> dropped
+    e.load_table(1, tabs[1])
+    idx[1].copy_(torch.from_numpy(rng.integers(0, 90, size=idx[1].numel())).to(dev))
+    hits = e.plan_cache_hits
+    assert same(call(), want()) and e.plan_cache_hits == hits and len(e._plan_cache) == 0
+    for _ in range(3):
+        assert same(call(), want())
+    assert len(e._plan_cache) == 1
+    # shorter inputs in the same buffers: another signature, the ordinary call
+    ii = [x[:x.numel() // 2] for x in idx]
+    oo = [x[:x.numel() // 2] for x in off]
+    assert same(call(ii=ii, oo=oo), want(ii, oo))
+    # int32 copies: other addresses and another index width
+    i32, o32 = [x.to(torch.int32) for x in idx], [x.to(torch.int32) for x in off]
+    for _ in range(3):
+        assert same(call(ii=i32, oo=o32), want())
+    # caller-provided outputs are part of the signature and are written in place
+    outs = [torch.full((B, D), 7.0, device=dev) for _ in range(3)]
+    for _ in range(4):
+        for o in outs:
+            o.fill_(7.0)
+        res = call(outs=outs)
+        assert all(r.data_ptr() == o.data_ptr() for r, o in zip(res, outs)) and same(outs, want())
+    # a live result keeps its memory: the next call gets another address (a miss) and must not overwrite it
+    keep = call()
+    ref = [k.clone() for k in keep]
+    idx[0].copy_(torch.from_numpy(rng.integers(0, rows[0], size=idx[0].numel())).to(dev))
+    assert same(call(), want()) and all(torch.equal(k, r) for k, r in zip(keep, ref))
+    # checked calls never use the cache, and refuse bad input whatever is cached
+    idx[2][5] = rows[2]
+    with pytest.raises(IndexError):
+        e.lookup_batched([0, 1, 2], idx, off, check=True)
+    idx[2][5] = 0
+    assert same(e.lookup_batched([0, 1, 2], idx, off, check=True), want())
+    e.plan_cache_size = 0
+    hits = e.plan_cache_hits
+    for _ in range(3):
+        assert same(call(), want())
+    assert e.plan_cache_hits == hits
+    e.close()                                        # destroys the cached plans first (emb_destroy refuses live plans)
+
+
+def test_checked_lookup_is_ordered_on_the_callers_stream(pel, oracle):
+    """emb_lookup_batched_checked / emb_validate_inputs_on run on the stream they are given: indices produced on a side
+    stream just before the call are what gets checked (round 2 validated on the default stream whatever the caller's)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(5)
+    e = pel.EmbeddingEngine(device=0, max_tables=2)
+    tab = pel.workloads.dlrm_table(rng, 1000, 32)
+    e.load_table(0, tab)
+    side = torch.cuda.Stream(dev)
+    big = torch.zeros(1 << 24, device=dev)
+    idx = torch.full((4096,), 5000, dtype=torch.int64, device=dev)          # out of range until the side stream fixes it
+    off = torch.arange(0, 4096, 4, dtype=torch.int64, device=dev)
+    good = torch.from_numpy(rng.integers(0, 1000, size=4096)).to(dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for _ in range(20):
+            big.add_(1.0)                        # keep the side stream busy, then produce the indices on it
+        idx.copy_(good)
+        out = e.lookup_batched([0], [idx], [off], check=True)[0]
+        assert e.validate([0], [idx], [off]) == 0
+    side.synchronize()
+    assert np.array_equal(out.cpu().numpy(), oracle.c_bag_sum(tab, good.cpu().numpy(), off.cpu().numpy()))
+    e.close()
+
+
 def test_checked_engine_refuses_bad_indices(pel, oracle):
     """EMB_FLAG_CHECK_INPUTS (emb_config.flags; PIMEMB_CHECK_INPUTS=1 for the engine behind populate_mram / lookup): a
     plan-less lookup with an out-of-range index or broken offsets returns EMB_ERR_RANGE and launches nothing -- host and
