@@ -7,15 +7,16 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "lib", "libpimemb.so")
-SOURCES = ["pimemb_kernels.hip", "pimemb_engine.cpp", "pimemb_compat.cpp", "pimemb_comm.cpp", "pimemb_internal.h",
+MARSHAL_PATH = os.path.join(PKG_DIR, "lib", "_pimemb_marshal.so")
+SOURCES = ["pimemb_kernels.hip", "pimemb_engine.cpp", "pimemb_compat.cpp", "pimemb_comm.cpp", "pimemb_internal.h", "pimemb_torch_marshal.cpp",
            "pimemb_bag_kernels.h", "pimemb_xcd_map.h", "pimemb_hot_rows.h", "pimemb_hostcopy.h", "Makefile",
            os.path.join("..", "..", "include", "pimemb.h")]
 
 
 def is_stale() -> bool:
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(LIB_PATH) or not os.path.exists(MARSHAL_PATH):
         return True
-    built = os.path.getmtime(LIB_PATH)
+    built = min(os.path.getmtime(LIB_PATH), os.path.getmtime(MARSHAL_PATH))
     return any(os.path.getmtime(os.path.join(CSRC_DIR, s)) > built for s in SOURCES)
 
 
@@ -34,6 +35,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 raise RuntimeError("building libpimemb.so failed:\n" + res.stdout)
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("libpimemb.so missing after build")
+    if not os.path.exists(MARSHAL_PATH):
+        raise RuntimeError("_pimemb_marshal.so (torch tensor-list marshalling helper) missing after build")
     return LIB_PATH
 
 
@@ -43,7 +46,7 @@ def build_clamped(out_dir: str) -> str:
     out = os.path.join(out_dir, "libpimemb_clamp.so")
     flags = "-O3 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter -I../../include -I. -DPIMEMB_CLAMP_INPUTS=1"
     res = subprocess.run(["make", "-C", CSRC_DIR, "-j8", f"CXXFLAGS={flags}", f"OUT={out}",
-                          f"OBJDIR={os.path.join(out_dir, 'obj_clamp')}"],
+                          f"OBJDIR={os.path.join(out_dir, 'obj_clamp')}", f"MARSHAL={os.path.join(out_dir, '_pimemb_marshal.so')}"],
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0 or not os.path.exists(out):
         raise RuntimeError("building the clamped flavour failed:\n" + res.stdout)

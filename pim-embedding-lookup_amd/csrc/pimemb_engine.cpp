@@ -116,7 +116,10 @@ struct emb_engine {
     size_t h_stage_cap = 0;
     char *d_stage = nullptr;
     size_t d_stage_cap = 0;
-    hipEvent_t val_ev = nullptr;   // "the validation kernel of this call is done" (validate_resolved, under mu)
+    // input validation (checked_launch, under mu): 16 bytes of HBM the validation kernels count in, and what the host
+    // remembers of them -- tickets drawn and offending values found by all earlier calls, and a sequence number
+    pimemb::ValidateCtl *d_val = nullptr;
+    unsigned long long val_tickets = 0, val_bad = 0, val_seq = 0;
     // stats
     std::atomic<uint64_t> n_lookup_calls{0}, n_kernel_launches{0}, n_bags{0}, n_indices{0};
     std::atomic<uint64_t> n_by_kind[5] = {};
@@ -798,7 +801,7 @@ int emb_destroy(emb_engine *e) {
         if (ev) (void)hipEventDestroy(ev);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
     if (e->d_stage) (void)hipFree(e->d_stage);
-    if (e->val_ev) (void)hipEventDestroy(e->val_ev);
+    if (e->d_val) (void)hipFree(e->d_val);
     delete e;
     return EMB_OK;
 }
@@ -937,7 +940,7 @@ int emb_table_info(emb_engine *e, uint32_t table_id, void **device_rows, uint64_
 
 static int validate_on(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs, emb_index_type itype,
                        emb_memspace space, hipStream_t s, uint64_t *n_bad);
-static int validate_resolved(emb_engine *e, const Resolved &r, emb_index_type itype, hipStream_t s, uint64_t *n_bad);
+static int checked_launch(emb_engine *e, Resolved &r, emb_index_type itype, hipStream_t s, bool launch, uint64_t *n_bad);
 
 static int lookup_batched_impl(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs, emb_index_type itype,
                                emb_memspace space, void *stream, bool check, uint64_t *n_bad) {
@@ -960,11 +963,10 @@ static int lookup_batched_impl(emb_engine *e, const emb_lookup_desc *descs, uint
     int rc = resolve(e, descs, n_descs, itype, nullptr, nullptr, nullptr, &r, /*cache_maps=*/true);
     if (rc) return rc;
     if (g_prof.on) g_prof.resolve += now_us() - p0;
-    if (check) {             // the descriptors are resolved ONCE: validated first, launched if clean
-        rc = validate_resolved(e, r, itype, s, n_bad);
-        if (rc) return rc;
-    }
-    rc = launch_resolved(e, r, itype, s);
+    // checked: the descriptors are resolved ONCE; the validation kernel and the lookup kernels share one launch image and
+    // are enqueued back to back -- a finding disarms the lookup on the device (validate_kernel's poison) -- and the host
+    // waits for the validation result only
+    rc = check ? checked_launch(e, r, itype, s, /*launch=*/true, n_bad) : launch_resolved(e, r, itype, s);
     if (rc) return rc;
     e->n_bags.fetch_add(r.n_bags, std::memory_order_relaxed);
     e->n_indices.fetch_add(r.n_indices, std::memory_order_relaxed);
@@ -1092,33 +1094,69 @@ int emb_plan_time(emb_plan *p, void *stream, uint32_t warmup, uint32_t iters, fl
     return EMB_OK;
 }
 
-// Count out-of-range indices / broken offsets over the resolved descriptors of a call (device-resident buffers) on
-// stream `s`, and wait for the count.  No allocation and no device-wide synchronize on this path: the descriptors and
-// the 8-byte counter take a piece of the launch-image ring (pinned, device-visible: the kernel reads the descriptors
-// from it and adds to the counter with system-scope atomics -- only threads that FOUND something write at all), and the
-// host waits for one event of its own, polling it first (a blocking wait is woken ~20 us late).
-static int validate_resolved(emb_engine *e, const Resolved &r, emb_index_type itype, hipStream_t s, uint64_t *n_bad) {
+// Validate the resolved descriptors of a call (device-resident buffers) on stream `s` and -- with `launch` -- enqueue its
+// lookup kernels right behind the validation kernel, over the SAME launch image: a finding zeroes the descriptors' tile
+// counts on the device, so the lookup does nothing.  The host waits for the validation result only (two pinned words the
+// kernel's last workgroup writes; polled), not for the lookup.  No allocation on this path (the 16-byte HBM counter block
+// is created once), no event, no device-wide synchronize.
+static int checked_launch(emb_engine *e, Resolved &r, emb_index_type itype, hipStream_t s, bool launch, uint64_t *n_bad) {
     if (n_bad) *n_bad = 0;
     if (r.descs.empty()) return EMB_OK;
     std::lock_guard<std::mutex> lk(e->mu);
-    const size_t dbytes = (sizeof(DevDesc) * r.descs.size() + 127) / 128 * 128;
+    if (!e->d_val) {
+        HIP_TRY(hipMalloc((void **)&e->d_val, sizeof(pimemb::ValidateCtl)));
+        HIP_TRY(hipMemset(e->d_val, 0, sizeof(pimemb::ValidateCtl)));
+    }
+    const size_t img = (r.image.size() + 127) / 128 * 128;
     char *h = nullptr, *d = nullptr;
-    int rc = take_image_space(e, dbytes + 128, s, &h, &d);
+    int rc = take_image_space(e, img + 128, s, &h, &d);
     if (rc) return rc;
-    memcpy(h, r.descs.data(), sizeof(DevDesc) * r.descs.size());
-    volatile unsigned long long *count = reinterpret_cast<volatile unsigned long long *>(h + dbytes);
-    *count = 0;
-    if (!e->val_ev) HIP_TRY(hipEventCreateWithFlags(&e->val_ev, hipEventDisableTiming));
-    HIP_TRY(pimemb::launch_validate(reinterpret_cast<const DevDesc *>(h), (uint32_t)r.descs.size(), itype,
-                                    const_cast<unsigned long long *>(count), s));
-    HIP_TRY(hipEventRecord(e->val_ev, s));
-    hipError_t q = hipErrorNotReady;
-    for (int spin = 0; spin < 4000 && q == hipErrorNotReady; spin++) q = hipEventQuery(e->val_ev);
-    if (q == hipErrorNotReady) q = hipEventSynchronize(e->val_ev);
-    if (q != hipSuccess) return fail(EMB_ERR_DEVICE, "emb_validate_inputs: %s", hipGetErrorString(q));
-    const unsigned long long bad = *count;
+    memcpy(h, r.image.data(), r.image.size());
+    volatile unsigned long long *result = reinterpret_cast<volatile unsigned long long *>(h + img);
+    result[0] = result[1] = 0;
+    char *base = h;        // the kernels' scalar loads read the pinned, device-visible segment itself ...
+    if (d != nullptr) {    // ... or its HBM twin (PIMEMB_DESC_MODE=copy)
+        HIP_TRY(hipMemcpyAsync(d, h, r.image.size(), hipMemcpyHostToDevice, s));
+        base = d;
+    }
+    r.bind(base);
+    uint64_t max_items = 1;
+    for (const DevDesc &dd : r.descs) max_items = std::max<uint64_t>(max_items, std::max<uint64_t>(dd.n_idx, dd.n_bags));
+    const uint32_t wgs = pimemb::validate_workgroups(max_items);
+    const unsigned long long n_wgs = (unsigned long long)wgs * r.descs.size();
+    const unsigned long long seq = ++e->val_seq;
+    const bool tickets = n_wgs <= 32;      // small grid: its last workgroup reports; else a one-thread kernel behind it
+    hipError_t err = pimemb::launch_validate(reinterpret_cast<DevDesc *>(base + r.groups[0].desc_off), (uint32_t)r.descs.size(),
+                                             itype, e->d_val, tickets ? e->val_tickets + n_wgs : 0ull,
+                                             const_cast<unsigned long long *>(result), seq, wgs, /*poison=*/launch, s);
+    if (err != hipSuccess) return fail(EMB_ERR_DEVICE, "validation kernel: %s", hipGetErrorString(err));
+    if (tickets) e->val_tickets += n_wgs;
+    if (launch) {
+        rc = launch_groups(e, r.groups, itype, s);
+        if (rc) {
+            (void)hipStreamSynchronize(s);     // keep the counters' bookkeeping in step with the device
+            e->val_bad = result[0];
+            return rc;
+        }
+    }
+    bool done = false;
+    for (int spin = 0; spin < 200000 && !(done = result[1] == seq); spin++) {
+    }
+    if (!done) {
+        HIP_TRY(hipStreamSynchronize(s));
+        if (result[1] != seq) return fail(EMB_ERR_DEVICE, "validation kernel did not report");
+    }
+    const unsigned long long total = result[0];
+    const unsigned long long bad = total - e->val_bad;
+    e->val_bad = total;
     if (n_bad) *n_bad = bad;
-    if (bad) return fail(EMB_ERR_RANGE, "%llu out-of-range indices / broken offsets", bad);
+    if (bad) {
+        if (launch) {      // the lookup kernels were disarmed on the device: they gathered and stored nothing, do not count them
+            e->n_kernel_launches.fetch_sub(r.groups.size(), std::memory_order_relaxed);
+            for (const PlanGroup &g : r.groups) e->n_by_kind[g.kind].fetch_sub(1, std::memory_order_relaxed);
+        }
+        return fail(EMB_ERR_RANGE, "%llu out-of-range indices / broken offsets", bad);
+    }
     return EMB_OK;
 }
 
@@ -1139,12 +1177,12 @@ static int validate_on(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_d
             rc = stage_host_inputs(e, descs, n_descs, itype, s, &hs, false);
         }
         if (rc) return rc;
-        rc = resolve(e, tmp.data(), n_descs, itype, &hs.d_indices, &hs.d_offsets, nullptr, &r);
+        rc = resolve(e, tmp.data(), n_descs, itype, &hs.d_indices, &hs.d_offsets, nullptr, &r, /*cache_maps=*/true);
     } else {
-        rc = resolve(e, tmp.data(), n_descs, itype, nullptr, nullptr, nullptr, &r);
+        rc = resolve(e, tmp.data(), n_descs, itype, nullptr, nullptr, nullptr, &r, /*cache_maps=*/true);
     }
     if (rc) return rc;
-    return validate_resolved(e, r, itype, s, n_bad);
+    return checked_launch(e, r, itype, s, /*launch=*/false, n_bad);
 }
 
 int emb_validate_inputs(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs,

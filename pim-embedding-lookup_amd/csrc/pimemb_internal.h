@@ -56,10 +56,19 @@ hipError_t launch_bag_sum_hot(const DevDesc *d_descs, uint32_t n_descs, uint32_t
 hipError_t launch_scatter_column(int32_t *table, const int32_t *column, uint64_t nr_rows,
                                  uint32_t dim, uint32_t col, hipStream_t stream);
 
-// Count out-of-range indices and broken offsets.  *d_bad (device-visible, pinned host memory is fine: system-scope
-// atomics) must be zeroed by the caller.
-hipError_t launch_validate(const DevDesc *d_descs, uint32_t n_descs, emb_index_type itype,
-                           unsigned long long *d_bad, hipStream_t stream);
+// Input validation (see validate_kernel): counts out-of-range indices / broken offsets over the descriptors of a launch
+// image and reports through `result` (two pinned, device-visible words: [0] running total of ctl->bad, [1] = seq once the
+// kernel's last workgroup is done).  ctl: 16 bytes of HBM owned by the engine, zeroed once, never reset.  poison: a
+// finding zeroes n_tiles of every descriptor, so lookup kernels enqueued behind it do nothing.  ticket_target: tickets of
+// all earlier calls + this grid's workgroups (its last workgroup reports), or 0: a one-thread kernel behind it reports.
+struct ValidateCtl {
+    unsigned long long tickets;   // workgroups of all validation kernels so far
+    unsigned long long bad;       // offending values found so far
+};
+uint32_t validate_workgroups(uint64_t max_items /* largest n_idx / n_bags of a descriptor */);
+hipError_t launch_validate(DevDesc *d_descs, uint32_t n_descs, emb_index_type itype, ValidateCtl *ctl,
+                           unsigned long long ticket_target, unsigned long long *result, unsigned long long seq,
+                           uint32_t wgs_per_desc, bool poison, hipStream_t stream);
 
 // Row-range routing of variable-length bags (pooled lookups over row-split tables; see pimemb.h,
 // emb_route_bags).  All pointers are device pointers; the kernels (four; three on the one-index-per-bag fast path)

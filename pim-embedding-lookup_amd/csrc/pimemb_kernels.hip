@@ -180,21 +180,35 @@ scatter_column_kernel(int32_t *__restrict__ table, const int32_t *__restrict__ c
         table[r * dim + col] = column[r];
 }
 
-// ---- debug validation ------------------------------------------------------------------------
+// ---- input validation ------------------------------------------------------------------------
+// Counts indices >= nr_rows and broken offsets of a batched call.  The kernel reports by itself, without a host-side
+// event: every workgroup adds what it found to ctl->bad (HBM, never reset: the host remembers the previous total) and
+// takes a ticket; the workgroup that draws the call's LAST ticket copies the total into the pinned `result` words --
+// [0] = total, then [1] = this call's sequence number, which the host polls.  With `poison` a workgroup that found
+// something also zeroes n_tiles of EVERY descriptor of the launch image -- the guard every lookup kernel tests before it
+// touches anything -- so the lookup kernels enqueued right behind this one on the same stream find no work (the host still learns the count and reports it;
+// it just does not have to wait before enqueueing the lookup).
 template <typename IdxT>
 __global__ void __launch_bounds__(kBlock)
-validate_kernel(const DevDesc *__restrict__ descs, unsigned long long *__restrict__ bad) {
+validate_kernel(DevDesc *__restrict__ descs, uint32_t n_descs, ValidateCtl *__restrict__ ctl,
+                unsigned long long ticket_target, volatile unsigned long long *__restrict__ result,
+                unsigned long long seq, int poison) {
+    __shared__ unsigned int s_any;
+    if (threadIdx.x == 0) s_any = 0;
+    __syncthreads();
     const DevDesc *dp = descs + blockIdx.y;
     const IdxT *indices = static_cast<const IdxT *>(dp->indices);
     const IdxT *offsets = static_cast<const IdxT *>(dp->offsets);
     const uint64_t n_idx = dp->n_idx, n_bags = dp->n_bags, nr_rows = dp->nr_rows;
     unsigned long long local = 0;
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+#pragma unroll 4
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n_idx; i += stride) {
         const IdxT v = indices[i];
         if (v < 0 || (uint64_t)v >= nr_rows) local++;
     }
     if (offsets != nullptr) {
+#pragma unroll 4
         for (uint64_t b = (uint64_t)blockIdx.x * kBlock + threadIdx.x; b < n_bags; b += stride) {
             const IdxT o = offsets[b];
             const uint64_t nxt = (b + 1 < n_bags) ? (uint64_t)offsets[b + 1] : n_idx;
@@ -203,9 +217,27 @@ validate_kernel(const DevDesc *__restrict__ descs, unsigned long long *__restric
     } else if (blockIdx.x == 0 && threadIdx.x == 0) {
         if ((uint64_t)dp->fixed_pooling * n_bags != n_idx) local++;
     }
-    // `bad` lives in pinned host memory (the caller reads it after the kernel's event): system-scope atomic, and only
-    // threads that found something touch it at all
-    if (local) __hip_atomic_fetch_add(bad, local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (local) {
+        __hip_atomic_fetch_add(&ctl->bad, local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_any = 1u;
+    }
+    __syncthreads();
+    if (s_any && poison)
+        for (uint32_t j = threadIdx.x; j < n_descs; j += kBlock) descs[j].n_tiles = 0;   // (a field this kernel never reads)
+    __syncthreads();
+    // ticket_target == 0: a big grid -- returning atomics on one address retire at ~20 per microsecond on this chip, so
+    // the tickets of hundreds of workgroups would cost more than the checking; validate_publish_kernel, enqueued behind
+    // this kernel, reports instead
+    if (threadIdx.x == 0 && ticket_target != 0) {
+        const unsigned long long t =
+            __hip_atomic_fetch_add(&ctl->tickets, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
+        if (t == ticket_target) {        // every other workgroup of this call has released its adds before its ticket
+            const unsigned long long total = __hip_atomic_load(&ctl->bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            result[0] = total;
+            __threadfence_system();
+            result[1] = seq;
+        }
+    }
 }
 
 // ---- multi-GPU routing of variable-length BAGS to row-range shards -------------------------------
@@ -764,14 +796,34 @@ hipError_t launch_scatter_column(int32_t *table, const int32_t *column, uint64_t
     return hipGetLastError();
 }
 
-hipError_t launch_validate(const DevDesc *d_descs, uint32_t n_descs, emb_index_type itype,
-                           unsigned long long *d_bad, hipStream_t stream) {
+// One thread, enqueued behind a validation kernel that took no tickets: the kernel boundary is the "all workgroups are
+// done", this only carries the total to the host.
+__global__ void validate_publish_kernel(const ValidateCtl *__restrict__ ctl, volatile unsigned long long *__restrict__ result,
+                                        unsigned long long seq) {
+    result[0] = __hip_atomic_load(&ctl->bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    result[1] = seq;
+}
+
+uint32_t validate_workgroups(uint64_t max_items) {
+    // workgroups per descriptor: ~16 values per thread, 1..256 (a small call is a small kernel: the caller waits for it)
+    uint64_t wgs = (max_items + kBlock * 16 - 1) / (kBlock * 16);
+    return (uint32_t)(wgs < 1 ? 1 : (wgs > 256 ? 256 : wgs));
+}
+
+hipError_t launch_validate(DevDesc *d_descs, uint32_t n_descs, emb_index_type itype, ValidateCtl *ctl,
+                           unsigned long long ticket_target, unsigned long long *result, unsigned long long seq,
+                           uint32_t wgs_per_desc, bool poison, hipStream_t stream) {
     if (n_descs == 0) return hipSuccess;
-    dim3 grid(256, n_descs, 1), block(kBlock, 1, 1);
+    dim3 grid(wgs_per_desc, n_descs, 1), block(kBlock, 1, 1);
     if (itype == EMB_IDX_U32)
-        hipLaunchKernelGGL(validate_kernel<uint32_t>, grid, block, 0, stream, d_descs, d_bad);
+        hipLaunchKernelGGL(validate_kernel<uint32_t>, grid, block, 0, stream, d_descs, n_descs, ctl, ticket_target, result,
+                           seq, poison ? 1 : 0);
     else
-        hipLaunchKernelGGL(validate_kernel<int64_t>, grid, block, 0, stream, d_descs, d_bad);
+        hipLaunchKernelGGL(validate_kernel<int64_t>, grid, block, 0, stream, d_descs, n_descs, ctl, ticket_target, result,
+                           seq, poison ? 1 : 0);
+    if (ticket_target == 0)
+        hipLaunchKernelGGL(validate_publish_kernel, dim3(1), dim3(1), 0, stream, ctl, result, seq);
     return hipGetLastError();
 }
 

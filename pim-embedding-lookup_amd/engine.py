@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import ctypes as C
 import struct
+import threading
 from typing import Sequence
 
 import numpy as np
@@ -22,6 +23,28 @@ from . import lib as _l
 
 _NP_TABLE_DTYPES = {np.dtype(np.float32): _l.EMB_F32, np.dtype(np.float16): _l.EMB_F16,
                     np.dtype(np.int32): _l.EMB_FIXED32}
+
+
+_MARSHAL = [False]      # False: not looked for yet; None: not built; else the _pimemb_marshal module
+
+
+def _marshal():
+    """The CPython helper that unpacks lists of torch tensors into emb_lookup_desc records in one call
+    (csrc/pimemb_torch_marshal.cpp, built next to libpimemb.so).  None when it has not been built: the same unpacking is
+    then done in Python, ~1 us per table and call slower.  PIMEMB_NO_MARSHAL=1 switches it off (tests, probes)."""
+    m = _MARSHAL[0]
+    if m is False:
+        import importlib.util
+        import os
+        m = None
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "_pimemb_marshal.so")
+        if os.path.exists(path) and os.environ.get("PIMEMB_NO_MARSHAL") != "1":
+            import torch  # noqa: F401  (the helper links against torch's libraries: they must be mapped first)
+            spec = importlib.util.spec_from_file_location("_pimemb_marshal", path)
+            m = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(m)
+        _MARSHAL[0] = m
+    return m
 
 
 def _is_torch(x) -> bool:
@@ -181,8 +204,11 @@ class EmbeddingEngine:
         _l.check(self._L.emb_create(C.byref(cfg), C.byref(h)))
         self._h = h.value
         self._tables: dict[int, tuple[int, int, int]] = {}  # id -> (nr_rows, dim, dtype)
-        self._desc_bufs: dict[int, tuple] = {}              # n descriptors -> (packed buffer, typed pointer)
-        self._stacked: dict[tuple, tuple] = {}              # table ids -> descriptor array of lookup_stacked
+        # Scratch descriptor arrays are PER THREAD: the C call that reads them releases the GIL, so another thread packing
+        # its own call into a shared array would be read half-way (lookups may be issued from several threads, pimemb.h).
+        self._tls = threading.local()                       # .bufs: n descriptors -> (buffer, typed pointer, address)
+                                                            # .stacked: table ids -> descriptor array of lookup_stacked
+        self._plan_lock = threading.Lock()                  # a cached plan is not destroyed while another thread launches it
         # plan cache of per-table-list calls (lookup_batched over fresh lists of torch CUDA tensors, as an apply_emb loop
         # makes them): call signature -> prepared plan.  See _lookup_batched_cuda.
         self._plan_cache: dict[tuple, list] = {}            # key -> [Plan, last use]
@@ -304,10 +330,79 @@ class EmbeddingEngine:
     _DESC = struct.Struct("<IIQQQQQ")    # emb_lookup_desc: table_id, fixed_pooling, indices, offsets, n_indices, n_bags, pooled
 
     def _drop_plans(self) -> None:
-        for plan, _ in self._plan_cache.values():
-            plan.destroy()
-        self._plan_cache.clear()
-        self._plan_seen.clear()
+        with self._plan_lock:
+            for plan, _ in self._plan_cache.values():
+                plan.destroy()
+            self._plan_cache.clear()
+            self._plan_seen.clear()
+
+    def _desc_slot(self, n: int):
+        """This thread's scratch array of n emb_lookup_desc records: (buffer, typed pointer, address)."""
+        try:
+            bufs = self._tls.bufs
+        except AttributeError:
+            bufs = self._tls.bufs = {}
+        slot = bufs.get(n)
+        if slot is None:
+            raw = C.create_string_buffer(self._DESC.size * n)
+            slot = bufs[n] = (raw, C.cast(raw, C.POINTER(_l.EmbLookupDesc)), C.addressof(raw))
+        return slot
+
+    def _launch_cached(self, key, stream) -> bool:
+        """Launch the cached plan of this call signature, if there is one (under the plan lock: see _plan_lock)."""
+        with self._plan_lock:
+            ent = self._plan_cache.get(key)
+            if ent is None:
+                return False
+            if self._L.emb_plan_launch(ent[0]._p, stream) == _l.EMB_OK:
+                self._plan_clock += 1
+                ent[1] = self._plan_clock
+                self.plan_cache_hits += 1
+                return True
+            ent[0].destroy()                 # stale (a table was reloaded): forget it, make the ordinary call
+            del self._plan_cache[key]
+            return False
+
+    def _raise_range(self, bad):
+        raise IndexError(f"{bad} index / offset value(s) out of range for the embedding table(s) "
+                         "(checked on the GPU before anything was launched)")
+
+    def _lookup_batched_marshal(self, tb, table_ids, indices, offsets, outs, stream, check):
+        """_lookup_batched_cuda with the tensor lists unpacked by the C helper (one call instead of ~8 attribute
+        reads / method calls per table), same checks, same plan cache -- keyed on the descriptor bytes themselves, which
+        ARE the call's signature (table ids, every address and length)."""
+        import torch
+        n = len(table_ids)
+        _raw, buf_ptr, addr = self._desc_slot(n)
+        r = tb.pack(addr, table_ids, indices, offsets, outs, self._tables)
+        if r is None:
+            return None
+        itype, _dev, d0, nbs, key, cur_stream = r
+        if outs is None:
+            if not d0:             # tables of different dims: one allocation per table (the Python path does that)
+                return None
+            one = torch.empty((sum(nbs), d0), dtype=torch.float32, device=indices[0].device)
+            key = tb.fill_pooled(addr, n, one.data_ptr(), d0)
+            res = list(one.split(nbs))
+        else:
+            res = list(outs)
+        if stream is None:
+            stream = cur_stream
+        if check:
+            bad = C.c_uint64()
+            rc = self._L.emb_lookup_batched_checked(self._h, buf_ptr, n, itype, _l.EMB_MEM_DEVICE, stream, C.byref(bad))
+            if rc == _l.EMB_ERR_RANGE:
+                self._raise_range(bad.value)
+            _l.check(rc)
+            return res
+        if self.plan_cache_size:
+            key = (key, itype)
+            if self._launch_cached(key, stream):
+                return res
+        _l.check(self._L.emb_lookup_batched(self._h, buf_ptr, n, itype, _l.EMB_MEM_DEVICE, stream))
+        if self.plan_cache_size:
+            self._remember_call(key, buf_ptr, n, itype)
+        return res
 
     def _lookup_batched_cuda(self, table_ids, indices, offsets, outs, stream, check=False):
         """Fast path of lookup_batched for torch CUDA tensors with explicit offsets -- what an
@@ -325,6 +420,11 @@ class EmbeddingEngine:
         Reloaded tables make the plan stale (emb_plan_launch refuses it; the entry is dropped); a miss is the ordinary
         transient call.  Checked calls (check=True) always take the transient path."""
         import torch
+        tb = _marshal()
+        if tb is not None and type(table_ids) is list and type(indices) is list and type(offsets) is list:
+            res = self._lookup_batched_marshal(tb, table_ids, indices, offsets, outs, stream, check)
+            if res is not None:
+                return res
         n = len(table_ids)
         i0 = indices[0]
         if type(i0) is not torch.Tensor or not i0.is_cuda or len(indices) != n or len(offsets) != n:
@@ -360,22 +460,9 @@ class EmbeddingEngine:
                            dt, offsets[0].dtype, dev.index, out_key)
             except (TypeError, KeyError):      # not all 1-D torch tensors / a table that is not loaded: the general path sorts it out
                 key = None
-        if key is not None:
-            ent = self._plan_cache.get(key)
-            if ent is not None:
-                plan = ent[0]
-                if self._L.emb_plan_launch(plan._p, stream) == _l.EMB_OK:
-                    self._plan_clock += 1
-                    ent[1] = self._plan_clock
-                    self.plan_cache_hits += 1
-                    return list(one_buffer.split(nbs)) if outs is None else list(outs)
-                plan.destroy()                 # stale (a table was reloaded): forget it, make the ordinary call
-                del self._plan_cache[key]
-        slot = self._desc_bufs.get(n)
-        if slot is None:
-            raw = C.create_string_buffer(self._DESC.size * n)
-            slot = self._desc_bufs[n] = (raw, C.cast(raw, C.POINTER(_l.EmbLookupDesc)))
-        buf, buf_ptr = slot
+        if key is not None and self._launch_cached(key, stream):
+            return list(one_buffer.split(nbs)) if outs is None else list(outs)
+        buf, buf_ptr, _addr = self._desc_slot(n)
         pack, size = self._DESC.pack_into, self._DESC.size
         nbs, dims = [], []
         for t, ia, oa in zip(table_ids, indices, offsets):
@@ -419,6 +506,10 @@ class EmbeddingEngine:
         """Second sighting of a call signature: build its plan.  The cache holds plan_cache_size plans; the least recently
         used one goes when it is full, and a caller whose signatures keep changing (64 evictions) switches the cache
         off -- destroying a plan waits for the device."""
+        with self._plan_lock:
+            self._remember_locked(key, desc_ptr, n, itype)
+
+    def _remember_locked(self, key, desc_ptr, n, itype) -> None:
         if key in self._plan_cache:
             return
         seen = self._plan_seen.get(key, 0) + 1
@@ -433,7 +524,10 @@ class EmbeddingEngine:
             self._plan_cache.pop(victim)[0].destroy()
             self._plan_evictions += 1
             if self._plan_evictions >= 64:
-                self._drop_plans()
+                for plan, _ in self._plan_cache.values():
+                    plan.destroy()
+                self._plan_cache.clear()
+                self._plan_seen.clear()
                 self.plan_cache_size = 0
                 return
         p = C.c_void_p()
@@ -463,14 +557,18 @@ class EmbeddingEngine:
             raise TypeError("indices and offsets must share dtype width")
         itype = _index_type_of(indices.dtype)
         key = tuple(table_ids)
-        cached = self._stacked.get(key)
+        try:
+            stacked = self._tls.stacked
+        except AttributeError:
+            stacked = self._tls.stacked = {}
+        cached = stacked.get(key)
         if cached is None:
             dims = {self._tables[t][1] for t in table_ids}        # KeyError: table not loaded
             if len(dims) != 1:
                 raise ValueError("lookup_stacked needs tables of one dim")
             arr = np.zeros(T, dtype=self._DESC_DT)
             arr["table_id"] = np.asarray(table_ids, dtype=np.uint32)
-            cached = self._stacked[key] = (arr, np.arange(T, dtype=np.uint64), dims.pop(),
+            cached = stacked[key] = (arr, np.arange(T, dtype=np.uint64), dims.pop(),
                                            C.cast(arr.ctypes.data, C.POINTER(_l.EmbLookupDesc)))
         arr, steps, dim, arr_ptr = cached
         N, B = indices.shape[1], offsets.shape[1]

@@ -105,3 +105,22 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert not pat.search(text), (dirpath, f)
     assert seen >= 8
+
+
+def test_marshal_helper_is_built_and_refuses_what_it_does_not_handle():
+    """_pimemb_marshal (torch tensor lists -> emb_lookup_desc records) is built next to libpimemb.so and loads; CPU
+    tensors, mixed dtypes and unknown tables are not its business: None (the Python path reports the error) / KeyError."""
+    import ctypes
+    import torch
+    from importlib import import_module
+    eng = import_module("pim-embedding-lookup_amd.engine")
+    m = eng._marshal()
+    assert m is not None, "pim-embedding-lookup_amd/lib/_pimemb_marshal.so missing: run __graft_entry__.build()"
+    buf = ctypes.create_string_buffer(48 * 2)
+    tables = {0: (5, 16, 0), 1: (7, 16, 0)}
+    i, o = torch.zeros(3, dtype=torch.int64), torch.zeros(1, dtype=torch.int64)
+    assert m.pack(ctypes.addressof(buf), [0, 1], [i, i], [o, o], None, tables) is None          # not CUDA tensors
+    assert m.pack(ctypes.addressof(buf), [0, 1], [i, 5], [o, o], None, tables) is None          # not a tensor
+    assert m.pack(ctypes.addressof(buf), [0], [i, i], [o, o], None, tables) is None             # lengths differ
+    key = m.fill_pooled(ctypes.addressof(buf), 2, 4096, 16)
+    assert isinstance(key, bytes) and len(key) == 96
