@@ -612,6 +612,99 @@ route_onehot_place_kernel(RouteBagParams rp, uint64_t n_bags, uint32_t n_shards,
     packed[(uint64_t)k * n_bags + b] = (dest << 24) | slot;
 }
 
+// Layout and placement in ONE kernel (shapes with n_shards * n_tables <= 1024 entries and <= 16 block totals per
+// thread -- every BASELINE shape): each workgroup re-derives, from the block totals of the count kernel, what it needs --
+// the totals of every (shard, table) entry (LDS adds), the prefix over the entries (request layout), the totals of the
+// blocks of its own table before it -- and places its 1024 bags; workgroup (0, 0) also writes `meta`.  The totals are a
+// few KB out of L2, so the redundancy costs ~1 us per workgroup, all of them in parallel, and saves a launch and the
+// one-workgroup kernel in the middle (11.8 -> 8 us for the router at the C4 shape).
+constexpr uint32_t kFusedMaxEntries = 1024;
+
+__global__ void __launch_bounds__(kOneHotBlock)
+route_onehot_place_fused_kernel(RouteBagParams rp, uint64_t n_bags, uint32_t n_shards, uint32_t n_tables, uint32_t n_blocks,
+                                uint32_t *__restrict__ packed, const uint32_t *__restrict__ blockcnt,
+                                uint32_t *__restrict__ meta, uint32_t *__restrict__ send) {
+    __shared__ uint32_t s_tot[kFusedMaxEntries], s_w[kFusedMaxEntries], s_r[kFusedMaxEntries];
+    __shared__ uint32_t s_before[kOneHotMaxShards], s_peak[2];
+    const uint32_t k = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
+    const uint32_t nk = n_shards * n_tables;
+    if (tid < nk) s_tot[tid] = 0;
+    if (tid < n_shards) s_before[tid] = 0;
+    if (tid < 2) s_peak[tid] = 0;
+    __syncthreads();
+    const uint32_t per_table = n_blocks * n_shards, n_words = n_tables * per_table;
+    for (uint32_t w = tid; w < n_words; w += kOneHotBlock) {          // blockcnt[(k' * n_blocks + b') * n_shards + d]
+        const uint32_t kk = w / per_table, rem = w - kk * per_table, bb = rem / n_shards, d = rem - bb * n_shards;
+        const uint32_t c = blockcnt[w];
+        if (c) {
+            atomicAdd(&s_tot[d * n_tables + kk], c);
+            if (kk == k && bb < blk) atomicAdd(&s_before[d], c);
+        }
+    }
+    __syncthreads();
+    // inclusive scan over the entries e = d * K + k' (the order of the request layout) of words and partial rows
+    uint32_t n = 0, words = 0;
+    if (tid < nk) {
+        n = s_tot[tid];
+        words = 2u * pad4(n);                   // offsets[pad4(n)] + row ids[pad4(n)]: one index per sub-bag
+    }
+    s_w[tid] = words;
+    s_r[tid] = n;
+    __syncthreads();
+    for (uint32_t step = 1; step < nk; step <<= 1) {
+        uint32_t a = 0, c = 0;
+        if (tid >= step) {
+            a = s_w[tid - step];
+            c = s_r[tid - step];
+        }
+        __syncthreads();
+        s_w[tid] += a;
+        s_r[tid] += c;
+        __syncthreads();
+    }
+    const MetaLayout ml = meta_layout(n_shards, n_tables);
+    if (blk == 0 && k == 0) {                   // one workgroup publishes the layout (the host, the peers, the un-router)
+        const uint32_t total_w = s_w[nk - 1], total_r = s_r[nk - 1];
+        if (tid < nk) {
+            const uint32_t d = tid / n_tables, kk = tid - d * n_tables;
+            const uint32_t w0 = s_w[tid] - words;
+            meta[counts_at(d, kk, n_tables)] = n;
+            meta[counts_at(d, kk, n_tables) + 1] = n;
+            meta[ml.base + 2 * tid] = w0;
+            meta[ml.base + 2 * tid + 1] = w0 + pad4(n);
+            meta[ml.row0 + tid] = s_r[tid] - n;
+            if (kk == 0) meta[ml.piece + d] = w0;
+        }
+        if (tid < n_shards) {
+            const uint32_t first = tid * n_tables, next = first + n_tables;
+            const uint32_t w_lo = s_w[first] - 2u * pad4(s_tot[first]), r_lo = s_r[first] - s_tot[first];
+            const uint32_t w_hi = next < nk ? s_w[next] - 2u * pad4(s_tot[next]) : total_w;
+            const uint32_t r_hi = next < nk ? s_r[next] - s_tot[next] : total_r;
+            atomicMax(&s_peak[0], w_hi - w_lo);
+            atomicMax(&s_peak[1], r_hi - r_lo);
+        }
+        if (tid == 0) {
+            meta[ml.piece + n_shards] = total_w;
+            meta[ml.mode] = kModeOneHot;
+        }
+        __syncthreads();
+        if (tid < n_shards) {
+            meta[counts_at(tid, n_tables, n_tables)] = s_peak[0];
+            meta[counts_at(tid, n_tables, n_tables) + 1] = s_peak[1];
+        }
+    }
+    const uint64_t b = (uint64_t)blk * kOneHotBlock + tid;
+    if (b >= n_bags) return;
+    const RouteBagTable &t = rp.t[k];
+    const uint32_t pk = packed[(uint64_t)k * n_bags + b];
+    const uint32_t dest = pk >> 24, e = dest * n_tables + k;
+    const uint32_t slot = s_before[dest] + (pk & 0xffffffu);
+    const uint32_t cnt = s_tot[e], w0 = s_w[e] - 2u * pad4(cnt);
+    send[w0 + slot] = slot;                                              // sub-bag `slot` starts at index `slot`
+    send[w0 + pad4(cnt) + slot] = t.indices[b] - dest * t.rows_per_shard;   // local row id
+    packed[(uint64_t)k * n_bags + b] = (dest << 24) | slot;
+}
+
 // pooled[k][b][:] = sum over the shards d = 0 .. N-1 that served a sub-bag of bag b, IN THAT ORDER, of the partial
 // row that came back: deterministic, and exact for bags that live in one shard (one-hot lookups).
 // `slots` as emb_route_bags left it: meta[mode] == kModeBags: uint32[K][N][n_bags], slot of bag b's sub-bag in
@@ -681,6 +774,13 @@ hipError_t launch_route_bags(const RouteBagDesc *tables, uint32_t n_tables, uint
         const dim3 grid(n_blocks, n_tables, 1);
         hipLaunchKernelGGL(route_onehot_count_kernel, grid, dim3(kOneHotBlock), 0, stream, rp, n_bags, n_shards, n_blocks,
                            slots, work);
+        static const bool no_fuse = getenv("PIMEMB_ROUTE_FUSED") && getenv("PIMEMB_ROUTE_FUSED")[0] == '0';   // A/B switch
+        if (!no_fuse && n_shards * n_tables <= kFusedMaxEntries &&
+            (uint64_t)n_tables * n_blocks * n_shards <= 16ull * kOneHotBlock) {
+            hipLaunchKernelGGL(route_onehot_place_fused_kernel, grid, dim3(kOneHotBlock), 0, stream, rp, n_bags, n_shards,
+                               n_tables, n_blocks, slots, work, meta, send);
+            return hipGetLastError();
+        }
         hipLaunchKernelGGL(route_onehot_layout_kernel, dim3(1), dim3(kBlock), 0, stream, n_shards, n_tables, n_blocks, work,
                            meta);
         hipLaunchKernelGGL(route_onehot_place_kernel, grid, dim3(kOneHotBlock), 0, stream, rp, n_bags, n_shards, n_tables,

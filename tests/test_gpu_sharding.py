@@ -180,7 +180,8 @@ def test_route_bags_row_range_shards_pooled(pel, eng, oracle, dim, ragged):
     assert np.array_equal(run_once()[-1], pooled)          # deterministic: same bits on a second run
 
 
-@pytest.mark.parametrize("dim,N,B", [(16, 8, 39_292), (128, 8, 5_000), (64, 3, 1025), (4, 64, 777), (32, 1, 100)])
+@pytest.mark.parametrize("dim,N,B", [(16, 8, 39_292), (128, 8, 5_000), (64, 3, 1025), (4, 64, 777), (32, 1, 100),
+                                     (16, 32, 140_000)])
 def test_route_bags_one_index_per_bag_fast_path(pel, eng, oracle, dim, N, B):
     """The router's one-index-per-bag path (fixed pooling 1, no offsets: the Criteo shape) against the same host
     restatement as the general path -- same counts, offsets, lists, slot order, peaks -- through ballot ranks in 1024-bag
@@ -188,6 +189,8 @@ def test_route_bags_one_index_per_bag_fast_path(pel, eng, oracle, dim, N, B):
     a Zipf table (a hot shard).  The un-routed rows equal the unsharded oracle bit for bit; twice the same bits."""
     rng = np.random.default_rng(dim * 1000 + N)
     rows = [100_003, 64, 40_001] if N <= 8 else [100_003, 7_000]
+    if B > 100_000:          # 4 tables x 137 blocks x 32 shards of block totals: beyond what the fused layout+place kernel
+        rows = [100_003, 7_000, 50_000, 999]     # re-derives per workgroup -> the three-kernel form of the same path
     pooled, run_once = _router_case(pel, eng, oracle, rng, rows, N, B, dim, False, onehot=True)
     assert np.array_equal(run_once()[-1], pooled)
 
