@@ -626,6 +626,8 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
         kernel_us += e0.elapsed_time(e1) * 1000.0 / 32
     alg_bytes += serve_bytes
 
+    if prof is not None:
+        prof.clear()               # (the priming steps allocate and pin the slots' buffers: not what a step costs)
     for _ in range(args.warmup):
         step(it)
         it += 1
@@ -653,7 +655,7 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
             hsh.update(slots[(it - 1) % NBATCH]["out_sh"][k][:4096].contiguous().cpu().numpy().tobytes())
         digest = hsh.hexdigest()
     if prof is not None and rank == 0:
-        n_calls = args.steps + args.warmup + NBATCH + 2
+        n_calls = args.steps + args.warmup
         print("[dist_bench] host microseconds per step by call:",
               {k: round(v / 1e3 / n_calls, 1) for k, v in prof.items()}, flush=True)
 

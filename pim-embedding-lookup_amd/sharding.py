@@ -404,15 +404,16 @@ class RowRangeExchange:
         that is outgrown is retired with record_stream on every stream the exchange has used.
         n_bags == 0 (a rank with an empty batch) is a valid participant: it sends zero counts and still serves."""
         t, sl = self.torch, self.slots[slot]
-        run_on = stream if stream is not None else t.cuda.current_stream(self.device)
-        self._use_stream(t.cuda.current_stream(self.device))
-        self._use_stream(run_on)
-        self._use_stream(self.side)
+        cur = t.cuda.current_stream(self.device)
+        run_on = stream if stream is not None else cur
+        for st in (cur, run_on, self.side):
+            if st.cuda_stream not in self._streams:
+                self._use_stream(st)
         sl["n_bags"] = n_bags
 
         def enqueue():
             self._prepare(sl, n_bags, total_indices)
-            h = t.cuda.current_stream(self.device).cuda_stream
+            h = run_on.cuda_stream
             if n_bags:
                 self.engine.route_bags(spec, n_bags, self.N, sl["req_send"].data_ptr(), sl["meta"].data_ptr(),
                                        sl["slotmap"].data_ptr(), self.work.data_ptr(), h)
