@@ -1,6 +1,7 @@
-"""Soak: minutes of randomised lookups -- every path (host / device / plan / checked engine / bag router + partial-sum
-un-router emulating N shards in one process), every result compared with the CPU oracle -- watching HBM and host memory.
-    python tests/soak_r2.py [seconds]     (lives under tests/: it uses the oracle as its checker)"""
+"""Soak: minutes of randomised lookups -- every path (host / device / plan / checked engine / checked call / per-table
+lists through the plan cache / bag router, general and one-index-per-bag, + partial-sum un-router emulating N shards in
+one process), every result compared with the CPU oracle -- watching HBM and host memory.
+    python tests/soak.py [seconds]     (lives under tests/: it uses the oracle as its checker)"""
 import os
 import resource
 import sys
@@ -32,6 +33,7 @@ for t in rr_tables:
     for d in range(N):
         lo, hi = min(d * rps[t], tabs[t].shape[0]), min((d + 1) * rps[t], tabs[t].shape[0])
         eng.load_table(20 + t * N + d, tabs[t][lo:hi])
+list_bufs = {}
 t0, it, n_checked, free0, rss0 = time.time(), 0, 0, None, None
 while time.time() - t0 < budget:
     t = it % len(tabs)
@@ -39,8 +41,20 @@ while time.time() - t0 < budget:
     off, n = pel.workloads.ragged_offsets(rng, nb, 6, dtype=np.int64)
     idx = rng.integers(0, tabs[t].shape[0], size=n).astype(np.int64)
     want = oracle.c_bag_sum(tabs[t], idx, off)
-    mode = it % 5
-    if mode == 0:
+    mode = it % 7
+    if mode == 5:                                         # checked call on device tensors (validated, then looked up)
+        got = eng.lookup(t, torch.from_numpy(idx).to(dev), torch.from_numpy(off).to(dev), check=True).cpu().numpy()
+    elif mode == 6:                                       # per-table lists, a handful of recurring shapes: the plan cache
+        nb = (64, 257, 1000)[(it // 7) % 3]
+        off = (np.arange(nb, dtype=np.int64) * 3)
+        idx = rng.integers(0, tabs[t].shape[0], size=3 * nb).astype(np.int64)
+        want = oracle.c_bag_sum(tabs[t], idx, off)
+        key = (t, nb)
+        if key not in list_bufs:
+            list_bufs[key] = (torch.empty(3 * nb, dtype=torch.int64, device=dev), torch.from_numpy(off).to(dev))
+        list_bufs[key][0].copy_(torch.from_numpy(idx))
+        got = eng.lookup_batched([t], [list_bufs[key][0].view(-1)], [list_bufs[key][1].view(-1)])[0].cpu().numpy()
+    elif mode == 0:
         got = eng.lookup(t, idx, off)
     elif mode == 1:
         got = eng.lookup(t, torch.from_numpy(idx).to(dev), torch.from_numpy(off).to(dev)).cpu().numpy()
@@ -50,18 +64,23 @@ while time.time() - t0 < budget:
     elif mode == 3:
         got = chk.lookup(t, idx.astype(np.uint32), off.astype(np.uint32))
     else:                                                 # router: bags -> N shards -> partial rows -> shard-ordered sum
-        t = rr_tables[(it // 5) % 2]
+        t = rr_tables[(it // 7) % 2]
+        onehot = (it // 14) % 2 == 1                      # every other router call: one index per bag (the fast path)
+        if onehot:
+            off, n = np.arange(nb, dtype=np.int64), nb
         idx = rng.integers(0, tabs[t].shape[0], size=n).astype(np.int64)
         want = oracle.c_bag_sum(tabs[t], idx, off)
         dim = tabs[t].shape[1]
         d_i, d_o = torch.from_numpy(idx.astype(np.int32)).to(dev), torch.from_numpy(off.astype(np.int32)).to(dev)
         sz = eng.route_bags_sizes(1, nb, max(n, 1), N)
         bufs = {k: torch.zeros(max(v, 16), dtype=torch.uint8, device=dev) for k, v in sz.items()}
-        eng.route_bags([(d_i.data_ptr() if n else 0, d_o.data_ptr(), n, 0, rps[t])], nb, N, bufs["send"].data_ptr(),
+        spec = (d_i.data_ptr(), None, n, 1, rps[t]) if onehot else (d_i.data_ptr() if n else 0, d_o.data_ptr(), n, 0, rps[t])
+        eng.route_bags([spec], nb, N, bufs["send"].data_ptr(),
                        bufs["meta"].data_ptr(), bufs["slots"].data_ptr(), bufs["work"].data_ptr())
         torch.cuda.synchronize()
-        m = bufs["meta"].view(torch.int32).cpu().numpy().view(np.uint32)
-        counts, base = m[:2 * N].reshape(N, 2), m[2 * N:4 * N].reshape(N, 2)
+        m = bufs["meta"].view(torch.int32).cpu().numpy().view(np.uint32)      # K = 1: counts[N][2][2] | base[N][1][2] | ...
+        counts, base = m[:4 * N].reshape(N, 2, 2)[:, 0, :], m[4 * N:6 * N].reshape(N, 2)
+        assert int(m[6 * N + N + 1 + N]) == (1 if onehot else 0)              # slots encoding the router chose
         words = bufs["send"].view(torch.int32)
         rets = []
         for d in range(N):
@@ -74,6 +93,8 @@ while time.time() - t0 < budget:
         eng.unroute_bags(recv.data_ptr(), bufs["meta"].data_ptr(), bufs["slots"].data_ptr(), 1, nb, N, dim, pooled.data_ptr())
         torch.cuda.synchronize()
         got = pooled[0].cpu().numpy()
+        if onehot:
+            assert np.array_equal(got, want), (it, "router, one index per bag")
         assert float(np.abs(got - want).max()) <= 1e-6, (it, "router")
         got = want                                        # (re-associated: tolerance above, not bits)
     assert np.array_equal(got, want), (it, mode, t)
@@ -89,5 +110,6 @@ free1, rss1 = torch.cuda.mem_get_info()[0], resource.getrusage(resource.RUSAGE_S
 print("soak: %d calls, %d bags checked against the oracle in %.0f s -- all equal" % (it, n_checked, time.time() - t0))
 print("free HBM after 500 calls %d MiB, at the end %d MiB (delta %d KiB); max RSS %d -> %d MiB"
       % (free0 >> 20, free1 >> 20, (free0 - free1) >> 10, rss0 >> 10, rss1 >> 10))
-print("engine stats:", eng.stats()["n_lookup_calls"], "lookups,", eng.stats()["n_kernel_launches"], "launches")
+print("engine stats:", eng.stats()["n_lookup_calls"], "lookups,", eng.stats()["n_kernel_launches"], "launches,",
+      eng.plan_cache_hits, "plan-cache hits")
 eng.close(); chk.close()
