@@ -213,8 +213,8 @@ class EmbeddingEngine:
         # makes them): call signature -> prepared plan.  See _lookup_batched_cuda.
         self._plan_cache: dict[tuple, list] = {}            # key -> [Plan, last use]
         self._plan_seen: dict[tuple, int] = {}              # key -> sightings before a plan is worth building
-        self._plan_clock = 0
-        self._plan_evictions = 0
+        self._plan_clock = 0                                # cacheable calls so far (hits and misses)
+        self._plan_last_evict = -(1 << 30)
         self.plan_cache_size = 16                           # 0 switches the cache off
         self._same_dim: dict[tuple, int] = {}               # table ids -> their common dim (0: dims differ)
         self.plan_cache_hits = 0
@@ -351,11 +351,11 @@ class EmbeddingEngine:
     def _launch_cached(self, key, stream) -> bool:
         """Launch the cached plan of this call signature, if there is one (under the plan lock: see _plan_lock)."""
         with self._plan_lock:
+            self._plan_clock += 1
             ent = self._plan_cache.get(key)
             if ent is None:
                 return False
             if self._L.emb_plan_launch(ent[0]._p, stream) == _l.EMB_OK:
-                self._plan_clock += 1
                 ent[1] = self._plan_clock
                 self.plan_cache_hits += 1
                 return True
@@ -503,9 +503,10 @@ class EmbeddingEngine:
         return list(outs)
 
     def _remember_call(self, key, desc_ptr, n, itype) -> None:
-        """Second sighting of a call signature: build its plan.  The cache holds plan_cache_size plans; the least recently
-        used one goes when it is full, and a caller whose signatures keep changing (64 evictions) switches the cache
-        off -- destroying a plan waits for the device."""
+        """Second sighting of a call signature: build its plan.  The cache holds plan_cache_size plans; when it is full the
+        least recently used one goes -- but at most once per 64 cacheable calls: destroying a plan waits for the device,
+        and a caller whose signatures keep changing must not pay that on every call (its recurring signatures keep their
+        plans meanwhile)."""
         with self._plan_lock:
             self._remember_locked(key, desc_ptr, n, itype)
 
@@ -520,22 +521,15 @@ class EmbeddingEngine:
             return
         self._plan_seen.pop(key, None)
         if len(self._plan_cache) >= self.plan_cache_size:
+            if self._plan_clock - self._plan_last_evict < 64:
+                return
+            self._plan_last_evict = self._plan_clock
             victim = min(self._plan_cache, key=lambda k: self._plan_cache[k][1])
             self._plan_cache.pop(victim)[0].destroy()
-            self._plan_evictions += 1
-            if self._plan_evictions >= 64:
-                for plan, _ in self._plan_cache.values():
-                    plan.destroy()
-                self._plan_cache.clear()
-                self._plan_seen.clear()
-                self.plan_cache_size = 0
-                return
         p = C.c_void_p()
         if self._L.emb_plan_create(self._h, desc_ptr, n, itype, C.byref(p)) != _l.EMB_OK:
             return
-        plan = Plan(self, p.value, None, None)
-        self._plan_clock += 1
-        self._plan_cache[key] = [plan, self._plan_clock]
+        self._plan_cache[key] = [Plan(self, p.value, None, None), self._plan_clock]
 
     _DESC_DT = np.dtype([("table_id", "<u4"), ("fixed_pooling", "<u4"), ("indices", "<u8"), ("offsets", "<u8"),
                          ("n_indices", "<u8"), ("n_bags", "<u8"), ("pooled", "<u8")])
@@ -576,14 +570,20 @@ class EmbeddingEngine:
             out = torch.empty((T, B, dim), dtype=torch.float32, device=indices.device)
         elif tuple(out.shape) != (T, B, dim) or not out.is_contiguous() or out.dtype != torch.float32:
             raise ValueError("out must be a contiguous float32 [T, B, dim] tensor")
-        esz = indices.element_size()
-        arr["indices"] = indices.data_ptr() + steps * np.uint64(N * esz)
-        arr["offsets"] = offsets.data_ptr() + steps * np.uint64(B * esz)
-        arr["pooled"] = out.data_ptr() + steps * np.uint64(B * dim * 4)
-        arr["n_indices"] = N
-        arr["n_bags"] = B
         if stream is None:
             stream = torch.cuda.current_stream(indices.device).cuda_stream
+        i_ptr, o_ptr, out_ptr = indices.data_ptr(), offsets.data_ptr(), out.data_ptr()
+        pkey = None
+        if self.plan_cache_size and not check:       # the same three buffers as an earlier call: one launch of its plan
+            pkey = ("stacked", key, i_ptr, o_ptr, out_ptr, N, B, itype)
+            if self._launch_cached(pkey, stream):
+                return out
+        esz = indices.element_size()
+        arr["indices"] = i_ptr + steps * np.uint64(N * esz)
+        arr["offsets"] = o_ptr + steps * np.uint64(B * esz)
+        arr["pooled"] = out_ptr + steps * np.uint64(B * dim * 4)
+        arr["n_indices"] = N
+        arr["n_bags"] = B
         if check:
             bad = C.c_uint64()
             rc = self._L.emb_lookup_batched_checked(self._h, arr_ptr, T, itype, _l.EMB_MEM_DEVICE, stream, C.byref(bad))
@@ -593,6 +593,8 @@ class EmbeddingEngine:
             _l.check(rc)
             return out
         _l.check(self._L.emb_lookup_batched(self._h, arr_ptr, T, itype, _l.EMB_MEM_DEVICE, stream))
+        if pkey is not None:
+            self._remember_call(pkey, arr_ptr, T, itype)
         return out
 
     def lookup_descs(self, descs: np.ndarray, itype: int = _l.EMB_IDX_U32, stream: int | None = None) -> None:

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 BAG_FIXTURES = sorted(os.path.basename(p) for p in glob.glob(
     os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
@@ -1430,6 +1431,17 @@ def test_plan_cache_of_per_table_list_calls(pel, oracle, marshal, monkeypatch):
     ref = [k.clone() for k in keep]
     idx[0].copy_(torch.from_numpy(rng.integers(0, rows[0], size=idx[0].numel())).to(dev))
     assert same(call(), want()) and all(torch.equal(k, r) for k, r in zip(keep, ref))
+    # the stacked form ([T, N] / [T, B] tensors) goes through the same cache
+    si = torch.stack([torch.from_numpy(rng.integers(0, 33, size=4 * B)).to(dev) for _ in range(2)])
+    so = torch.stack([torch.arange(0, 4 * B, 4, dtype=torch.int64, device=dev)] * 2)
+    sout = torch.empty((2, B, D), device=dev)
+    hits = e.plan_cache_hits
+    for rep in range(4):
+        si.copy_(torch.from_numpy(rng.integers(0, 33, size=(2, 4 * B))).to(dev))
+        got = e.lookup_stacked([1, 1], si, so, out=sout)
+        for r in range(2):
+            assert np.array_equal(got[r].cpu().numpy(), oracle.c_bag_sum(tabs[1], si[r].cpu().numpy(), so[r].cpu().numpy()))
+    assert e.plan_cache_hits == hits + 2
     # checked calls never use the cache, and refuse bad input whatever is cached
     idx[2][5] = rows[2]
     with pytest.raises(IndexError):
@@ -1468,6 +1480,58 @@ def test_checked_lookup_is_ordered_on_the_callers_stream(pel, oracle):
     side.synchronize()
     assert np.array_equal(out.cpu().numpy(), oracle.c_bag_sum(tab, good.cpu().numpy(), off.cpu().numpy()))
     e.close()
+
+
+def test_checked_lookup_with_descriptors_copied_to_hbm():
+    """PIMEMB_DESC_MODE=copy (launch images staged into HBM instead of read from the pinned ring): the validation kernel
+    must disarm the HBM twin the lookup kernels read, and still report through the pinned words.  Own process (the mode is
+    read at engine creation)."""
+    import subprocess
+    import sys
+    import textwrap
+    script = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r)
+        import numpy as np, torch
+        import pim_embedding_lookup_amd as pel
+        from oracle import oracle
+        dev = torch.device("cuda", 0)
+        rng = np.random.default_rng(3)
+        e = pel.EmbeddingEngine(device=0, max_tables=4)
+        tabs = [pel.workloads.dlrm_table(rng, n, 16) for n in (700, 90_000)]
+        for t, w in enumerate(tabs):
+            e.load_table(t, w)
+        idx = [torch.from_numpy(rng.integers(0, n, size=6000)).to(dev) for n in (700, 90_000)]
+        off = [torch.arange(0, 6000, 3, dtype=torch.int64, device=dev) for _ in range(2)]
+        outs = [torch.full((2000, 16), 7.0, device=dev) for _ in range(2)]
+        idx[1][4321] = 90_000
+        try:
+            e.lookup_batched([0, 1], idx, off, outs, check=True)
+            raise SystemExit("bad index accepted")
+        except IndexError as ex:
+            assert str(ex).startswith("1 index")
+        torch.cuda.synchronize()
+        assert all(bool((o == 7.0).all()) for o in outs)
+        assert e.validate([0, 1], idx, off) == 1
+        idx[1][4321] = 89_999
+        got = e.lookup_batched([0, 1], idx, off, outs, check=True)
+        for t in range(2):
+            assert np.array_equal(got[t].cpu().numpy(), oracle.c_bag_sum(tabs[t], idx[t].cpu().numpy(), off[t].cpu().numpy()))
+        # host pointers through the checked entry point
+        hi, ho = idx[0].cpu().numpy(), off[0].cpu().numpy()
+        assert np.array_equal(e.lookup(0, hi, ho, check=True), oracle.c_bag_sum(tabs[0], hi, ho))
+        hi[5] = 700
+        try:
+            e.lookup(0, hi, ho, check=True)
+            raise SystemExit("bad host index accepted")
+        except IndexError:
+            pass
+        e.close()
+        print("copy-mode checked ok")
+    """ % ROOT)
+    res = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, PIMEMB_DESC_MODE="copy"))
+    assert res.returncode == 0 and "copy-mode checked ok" in res.stdout, res.stdout[-1000:] + res.stderr[-3000:]
 
 
 def test_checked_engine_refuses_bad_indices(pel, oracle):
