@@ -303,6 +303,27 @@ int emb_unroute_bags(emb_engine *e, const float *recv, const uint32_t *meta, con
                      uint32_t n_tables, uint64_t n_bags, uint32_t n_shards, uint32_t dim,
                      float *pooled /* [n_tables][n_bags][dim] */, void *stream);
 
+/* Host-side arithmetic of one exchange step (no GPU work, no engine): what a rank derives from the counts message it
+ * SENT (the first N*(K+1)*2 words of its `meta`, copied to the host) and the counts messages it RECEIVED (one
+ * [K+1][2] block per source, in source order) -- so that callers in any language need not restate the layout rule.
+ *   req_out_words[d]   uint32 words of the request piece this rank sends to d      (split sizes of the request exchange)
+ *   req_in_words[s]    words of the piece it receives from s
+ *   ret_rows_back[d]   partial rows shard d returns to this rank                    (split sizes of the return exchange,
+ *   ret_rows_served[s] partial rows this rank returns to source s                    in rows of dim floats)
+ *   peak_req_bytes / peak_ret_bytes: the JOB's largest request / return piece in bytes (the maximum over the peaks
+ *   entries of all received messages, this rank's own included): every rank computes the same two numbers. */
+int emb_route_exchange_sizes(const uint32_t *sent, const uint32_t *received, uint32_t n_tables, uint32_t n_shards,
+                             uint32_t dim, uint64_t *req_out_words, uint64_t *req_in_words, uint64_t *ret_rows_back,
+                             uint64_t *ret_rows_served, uint64_t *peak_req_bytes, uint64_t *peak_ret_bytes);
+/* The descriptors of the ONE fused lookup that serves everything a rank received: `req_recv` (DEVICE) holds the pieces
+ * of source 0, 1, ... back to back as they arrived; shard_table_ids[k] is this rank's engine table for row-split table
+ * k; the partial rows of (source s, table k) go to ret_send (DEVICE) back to back in (s, k) order -- the layout the
+ * return exchange sends.  Writes at most N*K descriptors (pieces with no sub-bag are skipped), their number and the
+ * launch's algorithmic bytes; pass the array to emb_lookup_batched(..., EMB_IDX_U32, EMB_MEM_DEVICE, stream). */
+int emb_route_serve_descs(const uint32_t *received, uint32_t n_tables, uint32_t n_shards, uint32_t dim,
+                          const uint32_t *shard_table_ids, const void *req_recv, float *ret_send,
+                          emb_lookup_desc *descs, uint32_t *n_descs, uint64_t *algorithmic_bytes);
+
 /* ---- optional native exchange (multi-GPU sharded lookup) --------------------------------------- */
 /* All-to-all of byte ranges issued directly to RCCL (grouped ncclSend/ncclRecv) on the caller's stream:
  * the "indices in / pooled rows out" step of the sharded lookup without torch.distributed's per-call

@@ -1348,6 +1348,72 @@ int emb_route_bags(emb_engine *e, const emb_route_table *tables, uint32_t n_tabl
     return EMB_OK;
 }
 
+int emb_route_exchange_sizes(const uint32_t *sent, const uint32_t *received, uint32_t n_tables, uint32_t n_shards,
+                             uint32_t dim, uint64_t *req_out_words, uint64_t *req_in_words, uint64_t *ret_rows_back,
+                             uint64_t *ret_rows_served, uint64_t *peak_req_bytes, uint64_t *peak_ret_bytes) {
+    if (!sent || !received || !req_out_words || !req_in_words || !ret_rows_back || !ret_rows_served)
+        return fail(EMB_ERR_INVALID, "emb_route_exchange_sizes: NULL argument");
+    if (n_tables == 0 || n_tables > pimemb::kRouteBagMaxTables || n_shards == 0 || n_shards > 255)
+        return fail(EMB_ERR_INVALID, "emb_route_exchange_sizes: 1..64 tables and 1..255 shards");
+    auto pad4 = [](uint64_t v) { return (v + 3u) & ~(uint64_t)3u; };
+    const uint32_t stride = 2 * (n_tables + 1);          // one [K+1][2] block per peer
+    uint64_t peak_w = 0, peak_r = 0;
+    for (uint32_t p = 0; p < n_shards; p++) {
+        const uint32_t *so = sent + (size_t)p * stride, *ri = received + (size_t)p * stride;
+        uint64_t wo = 0, wi = 0, rb = 0, rs = 0;
+        for (uint32_t k = 0; k < n_tables; k++) {
+            wo += pad4(so[2 * k]) + pad4(so[2 * k + 1]);
+            wi += pad4(ri[2 * k]) + pad4(ri[2 * k + 1]);
+            rb += so[2 * k];
+            rs += ri[2 * k];
+        }
+        req_out_words[p] = wo;
+        req_in_words[p] = wi;
+        ret_rows_back[p] = rb;
+        ret_rows_served[p] = rs;
+        peak_w = std::max<uint64_t>(peak_w, ri[2 * n_tables]);         // every sender's own largest piece
+        peak_r = std::max<uint64_t>(peak_r, ri[2 * n_tables + 1]);
+    }
+    if (peak_req_bytes) *peak_req_bytes = peak_w * 4;
+    if (peak_ret_bytes) *peak_ret_bytes = peak_r * (uint64_t)dim * 4;
+    return EMB_OK;
+}
+
+int emb_route_serve_descs(const uint32_t *received, uint32_t n_tables, uint32_t n_shards, uint32_t dim,
+                          const uint32_t *shard_table_ids, const void *req_recv, float *ret_send,
+                          emb_lookup_desc *descs, uint32_t *n_descs, uint64_t *algorithmic_bytes) {
+    if (!received || !shard_table_ids || !descs || !n_descs)
+        return fail(EMB_ERR_INVALID, "emb_route_serve_descs: NULL argument");
+    if (n_tables == 0 || n_tables > pimemb::kRouteBagMaxTables || n_shards == 0 || n_shards > 255 || dim == 0)
+        return fail(EMB_ERR_INVALID, "emb_route_serve_descs: 1..64 tables, 1..255 shards, dim > 0");
+    auto pad4 = [](uint64_t v) { return (v + 3u) & ~(uint64_t)3u; };
+    const uint32_t *words = static_cast<const uint32_t *>(req_recv);
+    const uint32_t stride = 2 * (n_tables + 1);
+    uint64_t start = 0, row0 = 0, bytes = 0;
+    uint32_t n = 0;
+    for (uint32_t s = 0; s < n_shards; s++)
+        for (uint32_t k = 0; k < n_tables; k++) {
+            const uint64_t ns = received[(size_t)s * stride + 2 * k], ni = received[(size_t)s * stride + 2 * k + 1];
+            if (ns) {
+                if (!req_recv || !ret_send) return fail(EMB_ERR_INVALID, "emb_route_serve_descs: NULL buffer");
+                emb_lookup_desc &d = descs[n++];
+                d.table_id = shard_table_ids[k];
+                d.fixed_pooling = 0;
+                d.offsets = words + start;
+                d.indices = words + start + pad4(ns);
+                d.n_indices = ni;
+                d.n_bags = ns;
+                d.pooled = ret_send + row0 * dim;
+                bytes += ni * ((uint64_t)dim * 4 + 4) + ns * (4 + (uint64_t)dim * 4);
+            }
+            start += pad4(ns) + pad4(ni);
+            row0 += ns;
+        }
+    *n_descs = n;
+    if (algorithmic_bytes) *algorithmic_bytes = bytes;
+    return EMB_OK;
+}
+
 int emb_unroute_bags(emb_engine *e, const float *recv, const uint32_t *meta, const uint32_t *slots,
                      uint32_t n_tables, uint64_t n_bags, uint32_t n_shards, uint32_t dim, float *pooled,
                      void *stream) {

@@ -495,6 +495,8 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
     # the exchange itself is library code (sharding.RowRangeExchange); this leg only pipelines its four phases
     ex = sh.RowRangeExchange(eng, [T + k for k in range(K)], rps, dim, rank, world, dev, n_slots=NBATCH,
                              stage_cpu=stage_cpu, native=native) if K else None
+    if ex is not None:
+        ex.compute = stream          # every phase of this leg is issued from this (the current) stream
 
     slots = []
     for j in range(NBATCH):
@@ -662,7 +664,7 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
     result = None
     if rank == 0:
         ach = alg_bytes / (kernel_us * 1e-6) / 1e9 if kernel_us > 0 else 0.0
-        sent = ex.slots[(it - 1) % NBATCH]["sent"] if K else np.zeros((N, 1, 2), np.int64)
+        sent = ex.sent_counts((it - 1) % NBATCH) if K else np.zeros((N, 1, 2), np.int64)
         clk = clock_fields(wall_ev, wall_sync, args.steps, world * args.steps * T * B)
         bytes_out = 0
         if K:        # what rank 0 handed to OTHER ranks in the last step: counts message, request pieces, returned partial rows

@@ -676,6 +676,40 @@ class EmbeddingEngine:
             arr[k] = _l.EmbRouteTable(ip, op, int(n), int(L), int(rps))
         return arr
 
+    def route_exchange_sizes(self, counts_host_ptr: int, n_tables: int, n_shards: int, dim: int):
+        """Split sizes of one exchange step from the counts this rank sent / received: counts_host_ptr addresses
+        uint32 [2][N][K+1][2] on the HOST ([0] sent, [1] received).  Returns (req_out_words, req_in_words,
+        ret_rows_back, ret_rows_served) as lists of N ints and the job's largest request / return piece in bytes
+        (emb_route_exchange_sizes in pimemb.h)."""
+        N = n_shards
+        buf = self._tls.__dict__.get("xsz")
+        if buf is None or len(buf[0]) != 4 * N:
+            buf = self._tls.xsz = ((C.c_uint64 * (4 * N))(), C.c_uint64(), C.c_uint64())
+        arr, pr, pt = buf
+        base = C.addressof(arr)
+        _l.check(self._L.emb_route_exchange_sizes(counts_host_ptr, counts_host_ptr + 8 * N * (n_tables + 1), n_tables, N, dim,
+                                                  base, base + 8 * N, base + 16 * N, base + 24 * N, C.byref(pr), C.byref(pt)))
+        v = arr[:]
+        return v[:N], v[N:2 * N], v[2 * N:3 * N], v[3 * N:], pr.value, pt.value
+
+    def lookup_served(self, received_host_ptr: int, n_tables: int, n_shards: int, dim: int, shard_table_ids,
+                      req_recv_ptr: int, ret_send_ptr: int, stream: int | None = None) -> int:
+        """ONE fused lookup over every request piece a rank received (emb_route_serve_descs + emb_lookup_batched):
+        received_host_ptr addresses the received counts, uint32 [N][K+1][2] on the host.  Returns the launch's
+        algorithmic bytes (0: nothing to serve)."""
+        key = (n_tables, n_shards)
+        cache = self._tls.__dict__.get("served")
+        if cache is None or cache[0] != key or cache[1] != tuple(shard_table_ids):
+            ids = (C.c_uint32 * n_tables)(*[int(x) for x in shard_table_ids])
+            cache = self._tls.served = (key, tuple(shard_table_ids), ids, (_l.EmbLookupDesc * (n_tables * n_shards))(),
+                                        C.c_uint32(), C.c_uint64())
+        _k, _ids_t, ids, descs, n, nbytes = cache
+        _l.check(self._L.emb_route_serve_descs(received_host_ptr, n_tables, n_shards, dim, ids, req_recv_ptr, ret_send_ptr,
+                                               descs, C.byref(n), C.byref(nbytes)))
+        if n.value:
+            _l.check(self._L.emb_lookup_batched(self._h, descs, n.value, _l.EMB_IDX_U32, _l.EMB_MEM_DEVICE, stream))
+        return nbytes.value
+
     def unroute_bags(self, recv_ptr: int, meta_ptr: int, slots_ptr: int, n_tables: int, n_bags: int, n_shards: int,
                      dim: int, pooled_ptr: int, stream: int | None = None) -> None:
         _l.check(self._L.emb_unroute_bags(self._h, recv_ptr, meta_ptr, slots_ptr, n_tables, n_bags, n_shards, dim,

@@ -99,6 +99,10 @@ SIGNATURES = {
                                        C.POINTER(_u64)]),
     "emb_route_bags": (C.c_int, [_vp, C.POINTER(EmbRouteTable), _u32, _u64, _u32, _vp, _vp, _vp, _vp, _vp]),
     "emb_unroute_bags": (C.c_int, [_vp, _vp, _vp, _vp, _u32, _u64, _u32, _u32, _vp, _vp]),
+    "emb_route_exchange_sizes": (C.c_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, C.POINTER(_u64),
+                                           C.POINTER(_u64)]),
+    "emb_route_serve_descs": (C.c_int, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, C.POINTER(EmbLookupDesc), C.POINTER(_u32),
+                                        C.POINTER(_u64)]),
     "emb_configure": (C.c_int, [_u32, _u32, _u32, _u32]),
     "populate_mram": (_vp, [_u32, _u64, _u32, _vp, C.POINTER(DpuRuntimeTotals)]),
     "lookup": (_vp, [_pp, _pp, _pp, _vp, C.c_int64]),

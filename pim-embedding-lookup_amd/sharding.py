@@ -333,10 +333,16 @@ class RowRangeExchange:
         self.slots = [dict() for _ in range(n_slots)]
         self.work = None
         self._streams = {}          # every stream the exchange's buffers have been used on (cuda_stream handle -> Stream)
+        self.compute = None         # the caller's compute stream (a torch.cuda.Stream), when it has told us: a pipelined
+                                    # caller sets it once; forward() sets it per call.  None: asked from torch every time
+                                    # (torch.cuda.current_stream costs ~6 us a call, three of them per step)
         if self.K == 0 or self.K > 64:
             raise ValueError("1..64 row-split tables per exchange")
 
     # ---- buffers ------------------------------------------------------------------------------------
+    def _cur(self):
+        return self.compute if self.compute is not None else self.torch.cuda.current_stream(self.device)
+
     def _retire(self, buf):
         """A buffer about to be dropped may still be read or written by work queued on ANY stream the exchange uses
         (router stream, compute stream, the host-copy side stream): tell the caching allocator, so the block is not
@@ -385,7 +391,7 @@ class RowRangeExchange:
                 esz *= int(d)
             offs = lambda sp: (C.c_uint64 * (self.N + 1))(*([0] + [int(x) * esz for x in _cumsum(sp)]))
             self.native.all_to_all(send.data_ptr(), offs(in_splits), recv.data_ptr(), offs(out_splits),
-                                   t.cuda.current_stream(self.device).cuda_stream)
+                                   self._cur().cuda_stream)
             return None
         if self.stage_cpu:
             r = t.empty((n_out,) + tuple(recv.shape[1:]), dtype=recv.dtype)
@@ -404,7 +410,7 @@ class RowRangeExchange:
         that is outgrown is retired with record_stream on every stream the exchange has used.
         n_bags == 0 (a rank with an empty batch) is a valid participant: it sends zero counts and still serves."""
         t, sl = self.torch, self.slots[slot]
-        cur = t.cuda.current_stream(self.device)
+        cur = self._cur()
         run_on = stream if stream is not None else cur
         for st in (cur, run_on, self.side):
             if st.cuda_stream not in self._streams:
@@ -446,49 +452,33 @@ class RowRangeExchange:
             sl["counts_work"] = None
         else:
             if sl.get("routed_ev") is not None:     # the router ran on another stream (no collective handle to wait on)
-                t.cuda.current_stream(self.device).wait_event(sl["routed_ev"])
+                self._cur().wait_event(sl["routed_ev"])
             sl["counts_host"][0].copy_(counts_out, non_blocking=True)
             sl["counts_host"][1].copy_(sl["counts_in"], non_blocking=True)
-            t.cuda.current_stream(self.device).synchronize()
-        full = sl["counts_host"].numpy().view("uint32").astype("int64")   # [2][peer][table | peaks][2] (uint32 on the device)
-        c = full[:, :, :K, :]                                               # [2][peer][table][{n_sub, n_idx}]
-        words = ((c[..., 0] + 3) // 4 * 4 + (c[..., 1] + 3) // 4 * 4).sum(axis=2)     # [2][peer]
-        sl["req_out_words"], sl["req_in_words"] = words[0].tolist(), words[1].tolist()
-        sl["ret_rows_back"] = c[0, :, :, 0].sum(axis=1).tolist()    # partial rows each shard returns to me
-        sl["ret_rows_served"] = c[1, :, :, 0].sum(axis=1).tolist()  # partial rows I return to each source
-        sl["sent"], sl["served"] = c[0], c[1]
-        # every rank put its largest piece in every counts message, so the maximum over the messages received (my own
-        # included) is the JOB's largest piece: the same number of rounds on every rank, nobody left in a collective
-        peaks = full[1, :, K, :].max(axis=0)
-        sl["req_rounds"] = rounds_for(int(peaks[0]) * 4)
-        sl["ret_rounds"] = rounds_for(int(peaks[1]) * self.dim * 4)
-        recv = self._grown(sl, "req_recv", int(words[1].sum()), t.int32)
+            self._cur().synchronize()
+        # split sizes and the job's largest pieces from the counts, in the library (emb_route_exchange_sizes): every rank
+        # put its largest piece in every counts message, so the maximum over the messages received (my own included) is
+        # the JOB's largest piece -- the same number of rounds on every rank, nobody left in a collective
+        out_w, in_w, back, served, peak_req, peak_ret = self.engine.route_exchange_sizes(
+            sl["counts_host"].data_ptr(), K, self.N, self.dim)
+        sl["req_out_words"], sl["req_in_words"] = out_w, in_w
+        sl["ret_rows_back"], sl["ret_rows_served"] = back, served      # partial rows each shard returns to me / I return
+        sl["req_rounds"], sl["ret_rounds"] = rounds_for(peak_req), rounds_for(peak_ret)
+        recv = self._grown(sl, "req_recv", sum(in_w), t.int32)
         sl["req_work"] = self._exchange(recv, sl["req_send"], sl["req_in_words"], sl["req_out_words"], sl["req_rounds"])
 
     def lookup_received(self, slot: int) -> int:
         """The fused lookup over every request piece received for this slot (no exchange).  Returns its algorithmic
-        bytes.  The N x K descriptors are laid out arithmetically from the counts (numpy), one C call."""
-        import numpy as np
+        bytes.  The N x K descriptors are laid out from the received counts inside the library (emb_route_serve_descs)."""
         t, sl = self.torch, self.slots[slot]
-        c, recv = sl["served"], sl["req_recv"]                      # c: int64 [source][table][{n_sub, n_idx}]
         ret = self._grown(sl, "ret_send", int(sum(sl["ret_rows_served"])), t.float32, (self.dim,))
-        ns, ni = c[:, :, 0].reshape(-1), c[:, :, 1].reshape(-1)
-        p4s, p4i = (ns + 3) // 4 * 4, (ni + 3) // 4 * 4
-        start = np.concatenate([[0], np.cumsum(p4s + p4i)[:-1]])      # word offset of every (source, table) piece
-        row0 = np.concatenate([[0], np.cumsum(ns)[:-1]])
-        live = np.nonzero(ns > 0)[0]
-        if live.size == 0:
-            return 0
-        row_b = self.dim * 4
-        d = np.zeros(live.size, dtype=self.engine._DESC_DT)
-        d["table_id"] = np.asarray(self.ids, dtype=np.uint32)[live % self.K]
-        d["offsets"] = recv.data_ptr() + start[live] * 4
-        d["indices"] = recv.data_ptr() + (start[live] + p4s[live]) * 4
-        d["n_indices"] = ni[live]
-        d["n_bags"] = ns[live]
-        d["pooled"] = ret.data_ptr() + row0[live] * row_b
-        self.engine.lookup_descs(d, stream=t.cuda.current_stream(self.device).cuda_stream)
-        return int((ni[live] * (row_b + 4) + ns[live] * (4 + row_b)).sum())
+        received = sl["counts_host"].data_ptr() + 8 * self.N * (self.K + 1)          # counts_host[1]
+        return self.engine.lookup_served(received, self.K, self.N, self.dim, self.ids, sl["req_recv"].data_ptr(),
+                                         ret.data_ptr(), self._cur().cuda_stream)
+
+    def sent_counts(self, slot: int):
+        """{n_sub, n_idx} per (peer, table) of the requests this rank sent for the slot: int64 [N][K][2] (reporting)."""
+        return self.slots[slot]["counts_host"][0].numpy().view("uint32")[:, :self.K, :].astype("int64")
 
     def serve(self, slot: int) -> int:
         t, sl = self.torch, self.slots[slot]
@@ -510,7 +500,7 @@ class RowRangeExchange:
             return
         self.engine.unroute_bags(sl["ret_recv"].data_ptr(), sl["meta"].data_ptr(), sl["slotmap"].data_ptr(), self.K,
                                  sl["n_bags"], self.N, self.dim, out.data_ptr(),
-                                 self.torch.cuda.current_stream(self.device).cuda_stream)
+                                 self._cur().cuda_stream)
 
     def wait_requests(self, slot: int) -> None:
         sl = self.slots[slot]
@@ -533,10 +523,16 @@ class RowRangeExchange:
             spec = [(i.data_ptr(), None, i.numel(), fixed_pooling, r) for i, r in zip(indices, self.rps)]
         if out is None:
             out = t.empty((self.K, n_bags, self.dim), dtype=t.float32, device=self.device)
-        self.route(slot, self.engine.route_tables(spec), n_bags, sum(int(i.numel()) for i in indices))
-        self.send_requests(slot)
-        self.serve(slot)
-        self.finish(slot, out)
+        pinned = self.compute
+        if pinned is None:
+            self.compute = t.cuda.current_stream(self.device)      # asked once for the four phases
+        try:
+            self.route(slot, self.engine.route_tables(spec), n_bags, sum(int(i.numel()) for i in indices))
+            self.send_requests(slot)
+            self.serve(slot)
+            self.finish(slot, out)
+        finally:
+            self.compute = pinned
         return out
 
 
