@@ -14,8 +14,9 @@ result pull) -- re-thought for 8 GPUs with 288 GB each (SURVEY.md section 8 row 
                       partial pooled sum, the sample owner adds the partials in shard order
                       (deterministic).  Column (D) splitting as in the reference is NOT carried over:
                       rows of <= 1 KiB are already smaller than an efficient transfer unit.
-  * one step = all_to_all(bag lengths + indices) -> ONE fused local lookup (HIP engine) over all
-    units this rank serves -> all_to_all(pooled rows) -> per-table [B, D] outputs.
+  * one step = three collectives: a small head message (piece sizes + what all ranks must agree on: the job's largest
+    pieces, a bad-input flag), all_to_all(per unit: header, bag lengths, indices -- one piece per destination) -> ONE
+    fused local lookup (HIP engine) over all units this rank serves -> all_to_all(pooled rows) -> per-table [B, D].
 
 Nothing here computes a lookup: the local step is delegated to a backend (`EngineBackend` = the HIP
 engine).  Tests inject their own backend to check the routing on CPU."""
@@ -174,36 +175,31 @@ class ShardedLookup:
         new_lens = t.bincount(bag_of[keep], minlength=lens.numel()).to(lens.dtype)
         return idx[keep] - u.row_lo, new_lens
 
-    def _a2a(self, send_parts, dtype, recv_counts=None, small: bool = False):
-        """all_to_all of one 1-D tensor per destination.  recv_counts=None: element counts are exchanged first
-        (alltoallv); otherwise they are known from the plan.  Returns the list of received pieces, one per source rank.
-        Over RCCL the transfer takes as many rounds as the JOB's largest piece needs: every rank sends its own largest
-        count next to each count (or, with known counts, joins a MAX all_reduce), so all ranks arrive at the same number
-        and nobody is left waiting in a collective.  small: the payload is a few words by construction (no agreement)."""
+    def _head(self, rows):
+        """The FIRST message of a step: one small int64 row per destination, equal length everywhere (all_to_all with equal
+        splits).  It carries the element count of the payload piece that follows and what every rank must agree on before
+        it enters the next collectives (largest pieces, the bad-input flag).  The one host read of the step."""
+        t, dist = self.torch, self.dist
+        c = t.tensor(rows, dtype=t.int64, device=self.comm_device)
+        r = t.empty_like(c)
+        dist.all_to_all_single(r, c, group=self.group)
+        return r.cpu()
+
+    def _move(self, send_parts, dtype, recv_counts, worst_elems: int):
+        """all_to_all of one 1-D tensor per destination with known receive counts.  worst_elems: the JOB's largest piece
+        (every rank passes the same number, learnt from the head messages), which sets the number of rounds over RCCL --
+        all ranks enter the same collectives."""
         t, dist = self.torch, self.dist
         counts = [int(p.numel()) for p in send_parts]
-        on_gpu = self.comm_device.type == "cuda"
-        worst = max(counts, default=0)
-        if recv_counts is None:
-            c = t.tensor([[n, worst] for n in counts], dtype=t.int64, device=self.comm_device)
-            r = t.empty((self.world, 2), dtype=t.int64, device=self.comm_device)
-            dist.all_to_all_single(r, c, group=self.group)
-            r = r.cpu()
-            recv_counts = [int(x) for x in r[:, 0].tolist()]
-            worst = int(r[:, 1].max())
-        elif on_gpu and not small:
-            w = t.tensor([max(worst, max(recv_counts, default=0))], dtype=t.int64, device=self.comm_device)
-            dist.all_reduce(w, op=dist.ReduceOp.MAX, group=self.group)
-            worst = int(w.item())
         send = t.cat([p.reshape(-1).to(dtype) for p in send_parts]).to(self.comm_device)
         recv = t.empty(int(sum(recv_counts)), dtype=dtype, device=self.comm_device)
-        if on_gpu:
-            all_to_all_rounds(dist, recv, send, list(recv_counts), counts, rounds_for(worst * send.element_size()),
+        if self.comm_device.type == "cuda":
+            all_to_all_rounds(dist, recv, send, list(recv_counts), counts, rounds_for(worst_elems * send.element_size()),
                               group=self.group).wait()
         else:            # gloo: no piece-size limit (and no list all_to_all)
             dist.all_to_all_single(recv, send, output_split_sizes=list(recv_counts), input_split_sizes=counts,
                                    group=self.group)
-        return list(recv.split(list(recv_counts))), recv_counts
+        return list(recv.split(list(recv_counts)))
 
     def _bad_inputs(self, indices) -> bool:
         """Row ids of the row-split tables are narrowed to uint32 for the GPU router: a negative or >= nr_rows id must
@@ -225,28 +221,42 @@ class ShardedLookup:
         lens = [self._lens(offsets[i], indices[i].numel()) for i in range(T)]
         n_bags = [int(l.numel()) for l in lens]
 
-        # 1. requests per destination: for every unit it owns -> (n_bags header, lens, indices)
-        send_meta, send_lens, send_idx = [], [], []
+        # 1. requests per destination, ONE payload piece each: for every unit the destination owns a {n_bags, n_indices}
+        #    header, then all bag lengths, then all indices (int64 on the wire).  Three collectives per step in all:
+        #    head (counts + what all ranks must agree on), payload, pooled rows back.
+        D = self.plan.dim
+        pieces, n_units = [], []
         for d in range(self.world):
             meta, ls, ix = [], [], []
             for u in self.send_units[d]:
                 i_u, l_u = self._route(u, indices[u.table], lens[u.table])
-                meta.append(t.tensor([l_u.numel(), i_u.numel()], dtype=t.int64))
+                meta += [l_u.numel(), i_u.numel()]
                 ls.append(l_u.to(t.int64))
-                ix.append(i_u)
-            send_meta.append(t.cat(meta + [t.tensor([bad], dtype=t.int64)]))     # last word: "my inputs are out of range"
-            send_lens.append(t.cat(ls) if ls else t.empty(0, dtype=t.int64))
-            send_idx.append(t.cat(ix) if ix else t.empty(0, dtype=idx_dtype))
-        meta_in, _ = self._a2a(send_meta, t.int64, recv_counts=[2 * len(self.served) + 1] * self.world, small=True)
-        culprits = [s for s in range(self.world) if int(meta_in[s][-1])]
+                ix.append(i_u.to(t.int64))
+            pieces.append(t.cat([t.tensor(meta, dtype=t.int64, device=indices[0].device)] + ls + ix) if meta
+                          else t.empty(0, dtype=t.int64, device=indices[0].device))
+            n_units.append(len(self.send_units[d]))
+        out_counts = [sum(n_bags[u.table] for u in self.send_units[d]) * D for d in range(self.world)]   # rows coming back to me
+        worst_piece = max((int(p.numel()) for p in pieces), default=0)
+        head = self._head([[int(pieces[d].numel()), worst_piece, max(out_counts, default=0), bad] for d in range(self.world)])
+        culprits = [s for s in range(self.world) if int(head[s][3])]
         if culprits:         # every rank learns it from the same message and raises together: nobody hangs in a collective
             raise IndexError(f"ShardedLookup: rank(s) {culprits} passed row ids outside [0, nr_rows) of a row-split table")
+        worst_in, worst_out = int(head[:, 1].max()), int(head[:, 2].max())          # the job's largest pieces (elements)
         rr_out = None
         if self._rr is not None:     # row-split tables: GPU routing, counts first (uint32 row ids at that boundary)
             rr_out = self._rr.forward([indices[k].to(t.int32).contiguous() for k in self.split_tables],
                                       [offsets[k].to(t.int32).contiguous() for k in self.split_tables])
-        lens_in, _ = self._a2a(send_lens, t.int64)
-        idx_in, _ = self._a2a(send_idx, idx_dtype)
+        got = self._move(pieces, t.int64, [int(x) for x in head[:, 0].tolist()], worst_in)
+        K = len(self.served)
+        meta_in, lens_in, idx_in = [], [], []
+        heads = t.stack([g[:2 * K] for g in got]).cpu() if K else None      # one host read for all sources
+        for s_ in range(self.world):       # every source sent me {header for my K units | lens | indices}
+            m = heads[s_] if K else got[s_][:0]
+            nb_all, ni_all = (int(m[0::2].sum()), int(m[1::2].sum())) if K else (0, 0)
+            meta_in.append(m)
+            lens_in.append(got[s_][2 * K:2 * K + nb_all])
+            idx_in.append(got[s_][2 * K + nb_all:2 * K + nb_all + ni_all].to(idx_dtype))
 
         # 2. ONE fused local lookup: served units over the bags of every source rank (in rank order)
         #    + replicated units over my own bags
@@ -275,7 +285,6 @@ class ShardedLookup:
         outs = self.backend.lookup(uids, l_idx, l_off, None) if uids else []
 
         # 3. pooled rows back to the ranks that own the bags
-        D = self.plan.dim
         send_out = []
         for s in range(self.world):
             parts = []
@@ -283,8 +292,7 @@ class ShardedLookup:
                 lo = sum(src_bags[k][:s])
                 parts.append(outs[k][lo:lo + src_bags[k][s]].reshape(-1))
             send_out.append(t.cat(parts) if parts else t.empty(0, dtype=t.float32))
-        recv_counts = [sum(n_bags[u.table] for u in self.send_units[d]) * D for d in range(self.world)]
-        out_in, _ = self._a2a(send_out, t.float32, recv_counts=recv_counts)
+        out_in = self._move(send_out, t.float32, out_counts, worst_out)
 
         # 4. assemble per table; row-split partials are added in shard (rank) order
         result = [None] * T
@@ -542,7 +550,7 @@ class RowRangeExchange:
 # moved in several rounds (all_to_all_rounds).  The number of rounds is a JOB-wide decision -- every rank must enter the
 # same collectives -- so it is derived from a number all ranks share: static shapes (dist_bench.run_whole), or the largest
 # piece of the job, which every rank learns from the counts messages (RowRangeExchange: the peaks entry of emb_route_bags'
-# counts; ShardedLookup._a2a: a second word next to every count).  check_piece_sizes is the last line of defence.
+# counts; ShardedLookup: the head message of every step).  check_piece_sizes is the last line of defence.
 A2A_MAX_PIECE_BYTES = 1 << 30
 A2A_ROUND_BYTES = 512 << 20
 
