@@ -536,6 +536,25 @@ def test_distributed_row_shards_four_ranks_pooled_zipf():
     assert sum(d["config"]["last_step_request_indices_per_peer"]) == 5 * 2003 * 3
 
 
+def test_distributed_whole_tables_more_ranks_than_sharded_tables():
+    """Table-id sharding where a rank owns NO sharded table -- what the driver's 8-GPU run of the Kaggle set has (five
+    tables above 64 MiB over eight ranks): four gloo ranks on cuda:0, only the three tables above 400 MiB sharded, so one
+    rank serves nothing, sends only indices and receives only rows.  Every rank verifies all 26 tables bit for bit."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, PIMEMB_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--shard-mode", "whole", "--replicate-mb", "400",
+           "--batch", "4099", "--steps", "4", "--warmup", "2", "--nbatch", "3"]
+    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 4 and d["verified"] is True and "3 whole" in d["config"]["workload"]
+    assert d["config"]["exchange"]["mode"] == "whole" and d["config"]["exchange"]["bytes_out_per_rank_per_step"] > 0
+
+
 def test_distributed_c5_shape_whole_table_shards_two_ranks():
     """BASELINE configs[4] in its multi-GPU form at a size two ranks on one GPU hold: 512 fp16 tables of dim 64 (rows scaled
     to 30M/4096), pooling 32, Zipf on even / uniform on odd tables, tables placed WHOLE on owner ranks (table-id sharding),
