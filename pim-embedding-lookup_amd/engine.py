@@ -212,7 +212,7 @@ class EmbeddingEngine:
         # plan cache of per-table-list calls (lookup_batched over fresh lists of torch CUDA tensors, as an apply_emb loop
         # makes them): call signature -> prepared plan.  See _lookup_batched_cuda.
         self._plan_cache: dict[tuple, list] = {}            # key -> [Plan, last use]
-        self._plan_seen: dict[tuple, int] = {}              # key -> sightings before a plan is worth building
+        self._plan_seen: dict[int, int] = {}                # hash(key) of signatures seen once (a plan is built on the second sighting)
         self._plan_clock = 0                                # cacheable calls so far (hits and misses)
         self._plan_last_evict = -(1 << 30)
         self.plan_cache_size = 16                           # 0 switches the cache off
@@ -513,13 +513,13 @@ class EmbeddingEngine:
     def _remember_locked(self, key, desc_ptr, n, itype) -> None:
         if key in self._plan_cache:
             return
-        seen = self._plan_seen.get(key, 0) + 1
-        if seen < 2:
-            if len(self._plan_seen) > 4 * max(self.plan_cache_size, 1):
-                self._plan_seen.clear()
-            self._plan_seen[key] = seen
+        h = hash(key)                         # (admission bookkeeping only: a collision costs one early plan, nothing else)
+        if self._plan_seen.pop(h, 0) < 1:     # first sighting: remember it among the last few thousand signatures
+            if len(self._plan_seen) >= 4096:
+                for old in list(self._plan_seen)[:2048]:      # dicts keep insertion order: drop the oldest half
+                    del self._plan_seen[old]
+            self._plan_seen[h] = 1
             return
-        self._plan_seen.pop(key, None)
         if len(self._plan_cache) >= self.plan_cache_size:
             if self._plan_clock - self._plan_last_evict < 64:
                 return
