@@ -569,6 +569,19 @@ def test_distributed_c5_shape_whole_table_shards_two_ranks():
     assert "512 whole" in c["workload"] and "fp16" in c["workload"] and "mixed indices" in c["workload"]
 
 
+def test_driver_torchrun_command_two_ranks():
+    """The driver's launch line verbatim -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N --steps 20 --warmup 5` -- with the default flags (both legs), two gloo ranks
+    on the one GPU: one JSON line from rank 0, both clocks, the exchange leg inside config / roofline."""
+    res, d = _bench_two_ranks(["--steps", "20", "--warmup", "5"], launcher="torchrun")
+    assert res.returncode == 0 and d is not None, res.stdout[-2000:] + res.stderr[-4000:]
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["verified"] is True
+    assert d["config"]["bags_per_table_per_rank"] == 39292 and d["config"]["world_size"] == 2
+    assert d["clock"] == "sync" and d["ms_per_step"] == d["ms_per_step_sync"] >= d["ms_per_step_event"] > 0
+    assert d["config"]["exchange"]["verified"] is True and d["roofline"]["exchange"]["step_frac"] > 0
+    assert len([l for l in res.stdout.splitlines() if l.startswith("{")]) == 1
+
+
 def test_driver_command_shape_five_ranks_on_one_gpu():
     """`python3 bench.py --gpus N --steps 20 --warmup 5` -- the shape of the driver's SCALE command: default flags, so
     B = 39 292 bags per table per rank, the data-parallel leg AND the sharded-exchange leg under its 180-s watchdog --
