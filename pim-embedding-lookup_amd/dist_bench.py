@@ -732,8 +732,9 @@ def run_dp(args, hbm_peak_gbs: float, ctx):
     gen, dist_name = index_generator(pel, args)
     idx_host = [[gen(rng, n, B * L, t).view(np.int32) for t, n in enumerate(rows_list)] for _ in range(NBATCH)]
     plans = []
-    for j in range(NBATCH):
-        plans.append(eng.plan(list(range(T)), [torch.from_numpy(i).to(dev) for i in idx_host[j]], [off] * T))
+    for j in range(NBATCH):      # one offsets array PER TABLE, as the reference passes them and as the N = 1 run holds them
+        plans.append(eng.plan(list(range(T)), [torch.from_numpy(i).to(dev) for i in idx_host[j]],
+                              [off.clone() for _ in range(T)]))
     stream = torch.cuda.current_stream(dev)
     h = stream.cuda_stream
     plans[0].launch(h)
