@@ -823,6 +823,12 @@ def run(args, hbm_peak_gbs: float) -> None:
     world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     backend = os.environ.get("PIMEMB_DIST_BACKEND", "nccl")
+    # The job's stdout is for ONE JSON line.  RCCL prints a five-line banner ("RCCL version : ...") to stdout when a
+    # communicator is created, and under torch.distributed.run a rank's stdout IS the job's: keep the real stdout aside
+    # for the line and point file descriptor 1 at stderr for everything else (libraries included).
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     n_dev = torch.cuda.device_count()
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     if backend == "nccl" and n_dev < local_world:
@@ -850,7 +856,7 @@ def run(args, hbm_peak_gbs: float) -> None:
     def emit(res):
         if rank == 0 and res is not None and not state["printed"]:
             state["printed"] = True
-            print(json.dumps(res), flush=True)
+            os.write(json_fd, (json.dumps(res) + "\n").encode())
 
     def finish(res):
         """backend / rank count on every N > 1 line, so a SCALE record shows what RCCL saw."""

@@ -569,6 +569,26 @@ def test_distributed_c5_shape_whole_table_shards_two_ranks():
     assert "512 whole" in c["workload"] and "fp16" in c["workload"] and "mixed indices" in c["workload"]
 
 
+def test_rccl_rank_keeps_the_jobs_stdout_to_one_json_line():
+    """A rank process under RCCL (one rank here: PIMEMB_FORCE_DIST=1, backend nccl): RCCL prints a five-line banner to
+    stdout when its communicator is created -- under torch.distributed.run that stdout is the job's.  The N > 1 code keeps
+    file descriptor 1 for the JSON line alone; the banner goes to stderr."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, PIMEMB_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29617")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "PIMEMB_DIST_BACKEND"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2",
+                          "--batch", "2048", "--nbatch", "3"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["config"]["backend"] == "nccl" and d["config"]["rccl_ranks"] == 1 and d["verified"] is True
+    assert d["config"]["exchange"]["verified"] is True
+
+
 def test_driver_torchrun_command_two_ranks():
     """The driver's launch line verbatim -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
     127.0.0.1 --master-port P bench.py --gpus N --steps 20 --warmup 5` -- with the default flags (both legs), two gloo ranks
@@ -579,7 +599,7 @@ def test_driver_torchrun_command_two_ranks():
     assert d["config"]["bags_per_table_per_rank"] == 39292 and d["config"]["world_size"] == 2
     assert d["clock"] == "sync" and d["ms_per_step"] == d["ms_per_step_sync"] >= d["ms_per_step_event"] > 0
     assert d["config"]["exchange"]["verified"] is True and d["roofline"]["exchange"]["step_frac"] > 0
-    assert len([l for l in res.stdout.splitlines() if l.startswith("{")]) == 1
+    assert len([l for l in res.stdout.splitlines() if l.strip()]) == 1          # nothing but the JSON line on the job's stdout
 
 
 def test_driver_command_shape_four_ranks_on_one_gpu():
