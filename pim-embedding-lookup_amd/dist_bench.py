@@ -829,6 +829,16 @@ def run(args, hbm_peak_gbs: float) -> None:
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    # A rank that never comes back (a peer died before the rendezvous, a collective that cannot complete) must not hold
+    # the job until the driver's own limit: after PIMEMB_RUN_TIMEOUT seconds (default 1800) it says so and leaves.
+    def _give_up():
+        sys.stderr.write("[dist_bench] rank %d: no result after %.0f s -- giving up\n" % (rank, run_limit))
+        sys.stderr.flush()
+        os._exit(5)
+    run_limit = float(os.environ.get("PIMEMB_RUN_TIMEOUT", "1800"))
+    run_dog = threading.Timer(run_limit, _give_up)
+    run_dog.daemon = True
+    run_dog.start()
     n_dev = torch.cuda.device_count()
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     if backend == "nccl" and n_dev < local_world:
@@ -915,3 +925,4 @@ def run(args, hbm_peak_gbs: float) -> None:
     emit(finish(result))
     dist.barrier()
     dist.destroy_process_group()
+    run_dog.cancel()
