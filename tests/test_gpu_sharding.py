@@ -569,6 +569,25 @@ def test_distributed_c5_shape_whole_table_shards_two_ranks():
     assert "512 whole" in c["workload"] and "fp16" in c["workload"] and "mixed indices" in c["workload"]
 
 
+@pytest.mark.parametrize("mode", ["whole", "rows"])
+def test_native_collective_legs_one_rccl_rank(mode):
+    """`bench.py --collective native` (the all-to-all issued from the C side: emb_comm_all_to_all on the compute stream)
+    through both sharded legs with ONE RCCL rank -- all this box can give it (RCCL refuses two ranks on one GPU); every
+    table verified bit for bit by the leg itself."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, PIMEMB_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29619")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "PIMEMB_DIST_BACKEND"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--collective", "native",
+                          "--shard-mode", mode, "--replicate-mb", "64", "--batch", "4099", "--steps", "6", "--warmup", "3",
+                          "--nbatch", "4"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["verified"] is True and d["config"]["exchange"]["mode"] == mode and "natively" in d["config"]["parallelism"]
+
+
 def test_rccl_rank_keeps_the_jobs_stdout_to_one_json_line():
     """A rank process under RCCL (one rank here: PIMEMB_FORCE_DIST=1, backend nccl): RCCL prints a five-line banner to
     stdout when its communicator is created -- under torch.distributed.run that stdout is the job's.  The N > 1 code keeps
