@@ -164,7 +164,12 @@ def run_whole(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
     L = pooling_of(pel, args)               # indices per bag (fixed pooling)
     Bp = (B * L + 3) // 4 * 4               # index slots per (table, rank): keeps every piece 16-B aligned
     T = len(rows_list)
-    NBATCH = max(2, args.nbatch)
+    # how many batches ahead the indices travel: with 1 (default), launch B(i+1) needs collective(i) -- a chain
+    # B -> collective -> B -> ...; with 2 it needs collective(i-1), which has had a whole step to finish.  Tried in round 3
+    # (PIMEMB_WHOLE_DEPTH=2 / 3): 71 / 63 us per step against 63 with one RCCL rank -- the step is bound by the host time
+    # of all_to_all_single, not by that chain (profiles/r02/REJECTED_EXPERIMENTS.md), so the shallower pipeline stays
+    DEPTH = max(1, int(os.environ.get("PIMEMB_WHOLE_DEPTH", "1")))
+    NBATCH = max(DEPTH + 1, args.nbatch)
     plan = sh.plan_shards(rows_list, dim, 2 if TABLE_F16[0] else 4, world, replicate_bytes=rep_bytes, split_bytes=1 << 62)
     served = plan.owned_units(rank)
     local = plan.replicated_units()
@@ -208,8 +213,8 @@ def run_whole(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
         recv = torch.zeros(max(int(out_off[-1]), 16), dtype=torch.uint8, device=dev)   # zeros: index 0 is valid
         slots.append(dict(send=send, recv=recv))
     for j in range(NBATCH):
-        sl, nxt = slots[j], (j + 1) % NBATCH
-        # indices of the NEXT batch ride in this slot's send buffer (static, written once)
+        sl, nxt = slots[j], (j + DEPTH) % NBATCH
+        # indices of the batch DEPTH steps ahead ride in this slot's send buffer (static, written once)
         for d in range(world):
             base = int(in_off[d]) + K * B * row_b
             for q, u in enumerate(send_units[d]):
@@ -221,9 +226,9 @@ def run_whole(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
             sl["plan_a"] = eng.plan([u.uid for u in local], [sl["idx_local"][u.table] for u in local],
                                     [off_dev] * len(local), [sl["out_local"][u.table] for u in local])
     for j in range(NBATCH):
-        sl, prev = slots[j], slots[(j - 1) % NBATCH]
+        sl, prev = slots[j], slots[(j - DEPTH) % NBATCH]
         sl["plan_b"] = None
-        if K:   # indices of batch j arrived with collective(j-1); pooled rows go into collective(j)
+        if K:   # indices of batch j arrived with collective(j-DEPTH); pooled rows go into collective(j)
             ids, ii, oo, uu = [], [], [], []
             for s in range(world):
                 for k, u in enumerate(served):
@@ -235,7 +240,8 @@ def run_whole(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
 
     stream = torch.cuda.current_stream(dev)
     sh_handle = stream.cuda_stream
-    pending = [None]
+    from collections import deque
+    pending = deque()            # work handles of the collectives in flight, oldest first (at most DEPTH)
     native = native_exchange(pel, args, eng, ctx)
     if native is not None:
         a_in, a_out = native.offsets(in_off), native.offsets(out_off)
@@ -257,18 +263,21 @@ def run_whole(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
         sl = slots[i % NBATCH]
         if sl["plan_a"] is not None:
             sl["plan_a"].launch(sh_handle)          # independent of the exchange
-        if pending[0] is not None:
-            pending[0].wait()                       # compute stream waits for collective(i-1)
+        if len(pending) >= DEPTH:
+            w = pending.popleft()
+            if w is not None:
+                w.wait()                            # compute stream waits for collective(i-DEPTH)
         if sl["plan_b"] is not None:
             sl["plan_b"].launch(sh_handle)
-        pending[0] = collective(sl)
+        pending.append(collective(sl))
 
     done_ev = torch.cuda.Event()
 
     def drain():
-        if pending[0] is not None:
-            pending[0].wait()
-            pending[0] = None
+        while pending:
+            w = pending.popleft()
+            if w is not None:
+                w.wait()
         done_ev.record(stream)       # everything of the loop is ordered before this event on the compute stream
         done_ev.synchronize()        # (a device-wide synchronize returns up to a millisecond later once RCCL is loaded)
 
@@ -353,9 +362,9 @@ def run_whole(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
                        "tables": T, "dim": dim, "bags_per_table_per_rank": B, "global_bags_per_table": world * B,
                        "pooling": L,
                        "parallelism": "tables sharded by id (replicate <= %d MiB); one all_to_all per step carries "
-                                      "pooled rows of batch i + indices of batch i+1 (%d B out / %d B in per rank); "
+                                      "pooled rows of batch i + indices of batch i+%d (%d B out / %d B in per rank); "
                                       "backend %s, %s, eager steps" %
-                                      (rep_bytes >> 20, int(in_off[-1]), int(out_off[-1]), backend,
+                                      (rep_bytes >> 20, DEPTH, int(in_off[-1]), int(out_off[-1]), backend,
                                        "collective issued natively to RCCL on the compute stream" if native is not None
                                        else "torch.distributed.all_to_all_single"),
                        "exchange": {"mode": "whole", "value": clk["value"], "ms_per_step": clk["ms_per_step"], "verified": True,
