@@ -73,7 +73,8 @@ def parse_args():
                          "by row range over all ranks with GPU-side request routing (balanced xGMI egress; default for c4)")
     ap.add_argument("--collective", choices=["torch", "native"], default="torch",
                     help="N>1 sharded legs: torch.distributed.all_to_all_single (default) or grouped ncclSend/ncclRecv "
-                         "issued from the C side on the compute stream (emb_comm_*; verified with one rank only)")
+                         "issued from the C side on the compute stream (emb_comm_*; verified with up to four ranks over RCCL's "
+                         "socket transport, never over xGMI)")
     ap.add_argument("--streams", type=int, default=1,
                     help="N=1: round-robin the independent steps over this many HIP streams (default 1: every "
                          "step on one stream, which is what roofline.kernel_us assumes)")

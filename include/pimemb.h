@@ -331,8 +331,9 @@ int emb_route_serve_descs(const uint32_t *received, uint32_t n_tables, uint32_t 
  * emb_comm_unique_id, sends the 128 bytes to the other ranks by any means (the Python side uses
  * torch.distributed.broadcast), every rank calls emb_comm_create.  RCCL is resolved at run time
  * (EMB_ERR_UNSUPPORTED if librccl.so cannot be found).  The reference's counterpart is the broadcast
- * push / gather pull of dpu_push_xfer (emb_host.h:258-287, :321).  Exercised with one rank only so
- * far; bench.py uses torch.distributed unless --collective native is given. */
+ * push / gather pull of dpu_push_xfer (emb_host.h:258-287, :321).  Exercised with one rank and with
+ * three / four ranks over RCCL's socket transport (several ranks on one GPU), never over xGMI; bench.py uses
+ * torch.distributed unless --collective native is given. */
 typedef struct emb_comm emb_comm;
 int emb_comm_unique_id(void *id128);
 int emb_comm_create(emb_engine *e, const void *id128, int32_t rank, int32_t world, emb_comm **out);

@@ -10,8 +10,10 @@
 // runtime), then from librccl.so on the loader path.  The reference has no counterpart: its "exchange"
 // is dpu_push_xfer to every DPU (emb_host.h:258-287) and a pull of the results (:321).
 //
-// STATUS: exercised with one rank on the one-GPU development box only (self send/recv); multi-rank
-// runs need a multi-GPU node.  bench.py keeps torch.distributed as the default (--collective torch).
+// STATUS: exercised with one rank (self send/recv) and with three and four ranks sharing the development box's one GPU
+// (every rank claiming a host of its own, so RCCL connects them through its socket transport:
+// tests/test_gpu_sharding.py::test_rccl_several_ranks_on_one_gpu[native-*], all tables verified on every rank); never
+// over xGMI.  bench.py keeps torch.distributed as the default (--collective torch).
 #include <dlfcn.h>
 
 #include <cstdio>

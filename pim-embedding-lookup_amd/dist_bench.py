@@ -850,9 +850,18 @@ def run(args, hbm_peak_gbs: float) -> None:
     run_dog.start()
     n_dev = torch.cuda.device_count()
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-    if backend == "nccl" and n_dev < local_world:
+    one_gpu = os.environ.get("PIMEMB_RCCL_ONE_GPU") == "1"
+    if one_gpu and backend == "nccl":
+        # Rehearsal of the REAL RCCL path with several ranks on ONE GPU: RCCL refuses two ranks on a device of the same
+        # host ("duplicate GPU"), so every rank claims a host of its own (NCCL_HOSTID) and, being "remote" to its peers, talks
+        # to them through RCCL's socket transport over loopback -- slow, but the same communicator, the same grouped
+        # send / receive calls and the same torch code path as on an 8-GPU node (tools/rccl_one_gpu_ranks_probe.py).
+        os.environ.update(NCCL_HOSTID="pimemb-rank%d" % rank, NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1",
+                          NCCL_P2P_DISABLE="1", NCCL_SHM_DISABLE="1", NCCL_NET_GDR_LEVEL="0")
+    if backend == "nccl" and n_dev < local_world and not one_gpu:
         raise SystemExit(f"bench.py --gpus {world}: {local_world} ranks on this node but {n_dev} GPU(s) visible -- RCCL needs one GPU "
-                         "per rank (PIMEMB_DIST_BACKEND=gloo rehearses the N > 1 code with several ranks on one GPU)")
+                         "per rank (PIMEMB_RCCL_ONE_GPU=1 rehearses the RCCL path, PIMEMB_DIST_BACKEND=gloo the N > 1 code "
+                         "with host-staged collectives, with several ranks on one GPU)")
     dev = torch.device("cuda", local_rank % max(n_dev, 1))
     torch.cuda.set_device(dev)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -883,6 +892,8 @@ def run(args, hbm_peak_gbs: float) -> None:
             res.setdefault("verified", True)     # every leg compares its outputs bit for bit before AND after timing
             res["config"]["backend"] = backend
             res["config"]["rccl_ranks"] = world if backend == "nccl" else 0
+            if one_gpu and backend == "nccl":
+                res["config"]["rccl_transport"] = "sockets over loopback, %d ranks on %d GPU(s) (PIMEMB_RCCL_ONE_GPU=1)" % (world, n_dev)
             res["config"]["world_size"] = world
         return res
 

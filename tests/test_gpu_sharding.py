@@ -569,6 +569,60 @@ def test_distributed_c5_shape_whole_table_shards_two_ranks():
     assert "512 whole" in c["workload"] and "fp16" in c["workload"] and "mixed indices" in c["workload"]
 
 
+# ---------------------------------------------------------------------------------------------------
+# the REAL RCCL path with several ranks on ONE GPU (every rank claims its own host: RCCL's socket transport over loopback)
+# ---------------------------------------------------------------------------------------------------
+def _bench_rccl_ranks(n_ranks, extra, launcher="self", timeout=600):
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, PIMEMB_RCCL_ONE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "PIMEMB_DIST_BACKEND"):
+        env.pop(k, None)
+    bench = [os.path.join(ROOT, "bench.py"), "--gpus", str(n_ranks)] + list(extra)
+    if launcher == "self":
+        cmd = [sys.executable] + bench
+    else:
+        env["MASTER_ADDR"] = "127.0.0.1"
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+               "--master-addr", "127.0.0.1", "--master-port", "29571"] + bench
+    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    return res, lines
+
+
+@pytest.mark.parametrize("mode", ["auto-torchrun", "rows", "rows-pooled-zipf", "whole", "native-whole", "native-rows"])
+def test_rccl_several_ranks_on_one_gpu(mode):
+    """bench.py --gpus N with backend nccl -- RCCL itself, not the gloo stand-in -- and N > 1 ranks on the one GPU
+    (PIMEMB_RCCL_ONE_GPU=1).  What an 8-GPU node runs, minus the links: torch.distributed.all_to_all_single over RCCL
+    with real split sizes between real peers, the counts-first exchange, the job clock's all_reduce, the communicator's
+    start-up and teardown -- and `--collective native`, grouped ncclSend / ncclRecv issued from the C side
+    (emb_comm_all_to_all), with more than one rank.  Every leg verifies all 26 tables on every rank bit for bit."""
+    import json
+    base = ["--steps", "6", "--warmup", "3", "--nbatch", "4", "--batch", "4099"]
+    n, extra, launcher = {
+        "auto-torchrun": (2, ["--steps", "20", "--warmup", "5"], "torchrun"),              # the driver's line, default flags
+        "rows": (4, base + ["--shard-mode", "rows", "--replicate-mb", "64"], "self"),
+        "rows-pooled-zipf": (3, base + ["--shard-mode", "rows", "--replicate-mb", "64", "--pooling", "5", "--index-dist", "zipf"], "self"),
+        "whole": (4, base + ["--shard-mode", "whole", "--replicate-mb", "400"], "self"),    # one rank serves no table
+        "native-whole": (4, base + ["--shard-mode", "whole", "--replicate-mb", "64", "--collective", "native"], "self"),
+        "native-rows": (3, base + ["--shard-mode", "rows", "--replicate-mb", "64", "--collective", "native", "--pooling", "3"], "self"),
+    }[mode]
+    res, lines = _bench_rccl_ranks(n, extra, launcher)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert len(lines) == 1, lines                      # RCCL's banner stays off the job's stdout
+    d = json.loads(lines[0])
+    c = d["config"]
+    assert d["n_gpus"] == n and d["verified"] is True and c["backend"] == "nccl" and c["rccl_ranks"] == n
+    assert "sockets over loopback" in c["rccl_transport"]
+    assert c["exchange"]["verified"] is True and c["exchange"]["bytes_out_per_rank_per_step"] > 0
+    assert d["ms_per_step_sync"] >= d["ms_per_step_event"] > 0
+    if mode.startswith("native"):
+        assert "natively" in c["parallelism"]
+    if mode == "auto-torchrun":
+        assert c["bags_per_table_per_rank"] == 39292 and "replicated on every rank" in c["parallelism"]
+
+
 @pytest.mark.parametrize("mode", ["whole", "rows"])
 def test_native_collective_legs_one_rccl_rank(mode):
     """`bench.py --collective native` (the all-to-all issued from the C side: emb_comm_all_to_all on the compute stream)
