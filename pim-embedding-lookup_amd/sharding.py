@@ -553,6 +553,12 @@ class RowRangeExchange:
 # counts; ShardedLookup: the head message of every step).  check_piece_sizes is the last line of defence.
 A2A_MAX_PIECE_BYTES = 1 << 30
 A2A_ROUND_BYTES = 512 << 20
+try:        # PIMEMB_A2A_ROUND_BYTES: a small round size makes ordinary payloads take several agreed rounds (tests)
+    import os as _os
+    if _os.environ.get("PIMEMB_A2A_ROUND_BYTES"):
+        A2A_ROUND_BYTES = max(16, int(_os.environ["PIMEMB_A2A_ROUND_BYTES"]))
+except ValueError:
+    pass
 
 
 def check_piece_sizes(splits, bytes_per_item: int, what: str = "all_to_all") -> None:

@@ -398,7 +398,7 @@ def test_exchange_leg_failure_is_a_failed_run():
 # ---------------------------------------------------------------------------------------------------
 # the generic ShardedLookup (replicated + whole + row-split tables, ragged pooled bags) over the HIP engine
 # ---------------------------------------------------------------------------------------------------
-def _sharded_lookup_rank(rank, world, port, q):
+def _sharded_lookup_rank(rank, world, port, q, backend="gloo"):
     import sys
     import torch
     import torch.distributed as dist
@@ -408,7 +408,13 @@ def _sharded_lookup_rank(rank, world, port, q):
     from oracle import oracle
     sh = import_module("pim-embedding-lookup_amd.sharding")
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":        # several RCCL ranks on the one GPU: every rank on a host of its own, sockets over loopback
+        os.environ.update(NCCL_HOSTID="pimemb-test-rank%d" % rank, NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1",
+                          NCCL_P2P_DISABLE="1", NCCL_SHM_DISABLE="1", NCCL_NET_GDR_LEVEL="0")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         dev = torch.device("cuda", 0)
         rows, dim = [7, 300, 50_000, 64, 20_000, 9_000], 32
@@ -416,7 +422,7 @@ def _sharded_lookup_rank(rank, world, port, q):
         assert plan.kinds == ["replicated", "whole", "row_split", "replicated", "whole", "whole"], plan.kinds
         tabs = [pel.workloads.dlrm_table(np.random.default_rng(100 + t), n, dim) for t, n in enumerate(rows)]
         eng = pel.EmbeddingEngine(device=0, max_tables=len(plan.units) + 1)
-        sl = sh.ShardedLookup(plan, rank, sh.EngineBackend(eng), device=dev, comm_device="cpu")
+        sl = sh.ShardedLookup(plan, rank, sh.EngineBackend(eng), device=dev, comm_device="cpu" if backend == "gloo" else dev)
         sl.load_tables(lambda t, lo, hi: tabs[t][lo:hi])
         rng = np.random.default_rng(1000 + rank)               # every rank has its OWN ragged bags
         worst = 0.0
@@ -451,17 +457,20 @@ def _sharded_lookup_rank(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_sharded_lookup_over_the_engine_backend_two_ranks():
-    """sharding.ShardedLookup + EngineBackend on the GPU (round 1 only ran it against a CPU stand-in): two gloo
-    ranks sharing cuda:0, planner forced to produce replicated + whole + row-split tables, ragged pooled bags with
-    empty ones, int64 and int32 indices; compared with the single-process oracle -- exact for replicated / whole
-    tables, within 1e-6 for the row-split one (partials added in shard order)."""
+@pytest.mark.parametrize("backend,world", [("gloo", 2), ("nccl", 3)])
+def test_sharded_lookup_over_the_engine_backend_two_ranks(backend, world):
+    """sharding.ShardedLookup + EngineBackend on the GPU (round 1 only ran it against a CPU stand-in): ranks sharing
+    cuda:0 -- two over gloo (collectives staged through the host), three over RCCL itself (collective buffers on the GPU,
+    head / payload / pooled-row messages and the row-range exchange as on a multi-GPU node) --, planner forced to produce
+    replicated + whole + row-split tables, ragged pooled bags with empty ones, int64 and int32 indices; compared with the
+    single-process oracle -- exact for replicated / whole tables, within 1e-6 for the row-split one (partials added in
+    shard order)."""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_sharded_lookup_rank, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_sharded_lookup_rank, args=(r, world, port, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
@@ -572,11 +581,11 @@ def test_distributed_c5_shape_whole_table_shards_two_ranks():
 # ---------------------------------------------------------------------------------------------------
 # the REAL RCCL path with several ranks on ONE GPU (every rank claims its own host: RCCL's socket transport over loopback)
 # ---------------------------------------------------------------------------------------------------
-def _bench_rccl_ranks(n_ranks, extra, launcher="self", timeout=600):
+def _bench_rccl_ranks(n_ranks, extra, launcher="self", timeout=600, env_extra=None):
     import json
     import subprocess
     import sys
-    env = dict(os.environ, PIMEMB_RCCL_ONE_GPU="1")
+    env = dict(os.environ, PIMEMB_RCCL_ONE_GPU="1", **(env_extra or {}))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "PIMEMB_DIST_BACKEND"):
         env.pop(k, None)
     bench = [os.path.join(ROOT, "bench.py"), "--gpus", str(n_ranks)] + list(extra)
@@ -591,7 +600,8 @@ def _bench_rccl_ranks(n_ranks, extra, launcher="self", timeout=600):
     return res, lines
 
 
-@pytest.mark.parametrize("mode", ["auto-torchrun", "rows", "rows-pooled-zipf", "whole", "native-whole", "native-rows"])
+@pytest.mark.parametrize("mode", ["auto-torchrun", "rows", "rows-pooled-zipf", "whole", "native-whole", "native-rows",
+                                  "rows-many-rounds"])
 def test_rccl_several_ranks_on_one_gpu(mode):
     """bench.py --gpus N with backend nccl -- RCCL itself, not the gloo stand-in -- and N > 1 ranks on the one GPU
     (PIMEMB_RCCL_ONE_GPU=1).  What an 8-GPU node runs, minus the links: torch.distributed.all_to_all_single over RCCL
@@ -607,8 +617,11 @@ def test_rccl_several_ranks_on_one_gpu(mode):
         "whole": (4, base + ["--shard-mode", "whole", "--replicate-mb", "400"], "self"),    # one rank serves no table
         "native-whole": (4, base + ["--shard-mode", "whole", "--replicate-mb", "64", "--collective", "native"], "self"),
         "native-rows": (3, base + ["--shard-mode", "rows", "--replicate-mb", "64", "--collective", "native", "--pooling", "3"], "self"),
+        # 64-KiB rounds: every request / return exchange takes several rounds, whose number every rank derives from the
+        # peaks in the counts messages (a one-sided decision left the other ranks in the collective)
+        "rows-many-rounds": (3, base + ["--shard-mode", "rows", "--replicate-mb", "64", "--pooling", "2", "--index-dist", "zipf"], "self"),
     }[mode]
-    res, lines = _bench_rccl_ranks(n, extra, launcher)
+    res, lines = _bench_rccl_ranks(n, extra, launcher, env_extra={"PIMEMB_A2A_ROUND_BYTES": "65536"} if mode == "rows-many-rounds" else None)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     assert len(lines) == 1, lines                      # RCCL's banner stays off the job's stdout
     d = json.loads(lines[0])
@@ -621,6 +634,25 @@ def test_rccl_several_ranks_on_one_gpu(mode):
         assert "natively" in c["parallelism"]
     if mode == "auto-torchrun":
         assert c["bags_per_table_per_rank"] == 39292 and "replicated on every rank" in c["parallelism"]
+
+
+def test_terabyte_shaped_row_shards_two_rccl_ranks_same_bits_as_gloo(oracle, tmp_path):
+    """The C4-shaped two-rank run (1/256 of the rows, 32 indices per bag) over RCCL itself (two ranks on the one GPU) and
+    over gloo: the oracle checks the RCCL run's row-split outputs, and both backends leave the same bits (digest of rank
+    0's outputs, request volumes) -- the transport must not be visible in the results."""
+    import json
+    extra = ["--workload", "c4", "--rows-scale", str(1 / 256), "--steps", "4", "--warmup", "2", "--nbatch", "3",
+             "--batch", "2051", "--replicate-mb", "8", "--pooling", "32"]
+    prefix = str(tmp_path / "rowsplit_rccl")
+    res, lines = _bench_rccl_ranks(2, extra, env_extra={"PIMEMB_DUMP_ROWSPLIT": prefix})
+    assert res.returncode == 0 and len(lines) == 1, res.stdout[-2000:] + res.stderr[-4000:]
+    d = json.loads(lines[0])
+    assert d["verified"] is True and d["config"]["backend"] == "nccl" and d["config"]["rccl_ranks"] == 2
+    _check_row_split_dump_with_oracle(oracle, prefix, 2, 32)
+    res2, d2 = _bench_two_ranks(extra)
+    assert res2.returncode == 0 and d2["config"]["backend"] == "gloo", res2.stderr[-3000:]
+    assert d2["config"]["last_step_outputs_sha1"] == d["config"]["last_step_outputs_sha1"] is not None
+    assert d2["config"]["last_step_request_rows_per_peer"] == d["config"]["last_step_request_rows_per_peer"]
 
 
 @pytest.mark.parametrize("mode", ["whole", "rows"])
