@@ -1534,6 +1534,55 @@ def test_checked_lookup_with_descriptors_copied_to_hbm():
     assert res.returncode == 0 and "copy-mode checked ok" in res.stdout, res.stdout[-1000:] + res.stderr[-3000:]
 
 
+def test_random_multi_table_calls_device_path_hypothesis(pel, oracle):
+    """Property test (hypothesis, seeded) over what one batched call can look like on the DEVICE path: 1-6 tables of mixed
+    dims (16-byte-multiple rows and others), dtypes fp32 / fp16 / fixed point, 1-5000 rows, 0-400 ragged bags with empty
+    ones and duplicates, both index widths, per-table lists of torch tensors (the marshalling helper, the plan cache on a
+    repeat) -- every table bit for bit against the oracle, twice (the second call of each case may be a cached plan)."""
+    import torch
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    dev = torch.device("cuda", 0)
+    e = pel.EmbeddingEngine(device=0, max_tables=8)
+
+    @settings(max_examples=40, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(seed=st.integers(0, 2**31 - 1), n_tables=st.integers(1, 6), wide=st.booleans(), i64=st.booleans(),
+           max_len=st.integers(0, 12))
+    def case(seed, n_tables, wide, i64, max_len):
+        rng = np.random.default_rng(seed)
+        itype = np.int64 if i64 else np.int32
+        tabs, idx, off = [], [], []
+        for t in range(n_tables):
+            dim = int(rng.choice([4, 16, 32, 64, 128, 256] if wide else [1, 2, 3, 10, 17, 30, 100]))
+            kind = int(rng.integers(0, 3))
+            rows = int(rng.integers(1, 5000))
+            if kind == 2:
+                w = rng.integers(-2**30, 2**30, size=(rows, dim)).astype(np.int32)
+            else:
+                w = (rng.standard_normal((rows, dim)) * 0.05).astype(np.float16 if kind == 1 else np.float32)
+            e.load_table(t, w)
+            nb = int(rng.integers(0, 400))
+            o, n = pel.workloads.ragged_offsets(rng, nb, max_len, p_empty=0.2, dtype=itype) if (nb and max_len) else \
+                (np.zeros(nb, itype), 0)
+            tabs.append(w)
+            off.append(o)
+            idx.append(rng.integers(0, rows, size=n).astype(itype))
+        d_idx = [torch.from_numpy(i).to(dev) if i.size else torch.zeros(0, dtype=torch.int64 if i64 else torch.int32, device=dev)
+                 for i in idx]
+        d_off = [torch.from_numpy(o).to(dev) if o.size else torch.zeros(0, dtype=torch.int64 if i64 else torch.int32, device=dev)
+                 for o in off]
+        outs = [torch.full((o.shape[0], w.shape[1]), float("nan"), device=dev) for o, w in zip(off, tabs)]
+        for _rep in range(2):
+            got = e.lookup_batched(list(range(n_tables)), list(d_idx), list(d_off), outs)
+            torch.cuda.synchronize()
+            for t in range(n_tables):
+                want = oracle.c_lookup_fixed32(tabs[t], idx[t].astype(np.uint32), off[t].astype(np.uint32)) \
+                    if tabs[t].dtype == np.int32 else oracle.c_bag_sum(tabs[t], idx[t].astype(np.int64), off[t].astype(np.int64))
+                assert np.array_equal(got[t].cpu().numpy(), want), (seed, t, tabs[t].dtype, tabs[t].shape)
+
+    case()
+    e.close()
+
+
 def test_checked_engine_refuses_bad_indices(pel, oracle):
     """EMB_FLAG_CHECK_INPUTS (emb_config.flags; PIMEMB_CHECK_INPUTS=1 for the engine behind populate_mram / lookup): a
     plan-less lookup with an out-of-range index or broken offsets returns EMB_ERR_RANGE and launches nothing -- host and
