@@ -1135,7 +1135,7 @@ static int checked_launch(emb_engine *e, Resolved &r, emb_index_type itype, hipS
         rc = launch_groups(e, r.groups, itype, s);
         if (rc) {
             (void)hipStreamSynchronize(s);     // keep the counters' bookkeeping in step with the device
-            e->val_bad = result[0];
+            if (result[1] == seq) e->val_bad = result[0];
             return rc;
         }
     }
