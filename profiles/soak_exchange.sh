@@ -15,4 +15,8 @@ echo "three gloo ranks on the one GPU, Kaggle tables, one index per bag, verify 
 PIMEMB_DIST_BACKEND=gloo PIMEMB_VERIFY_EVERY=37 run c python3 "$root/bench.py" --gpus 3 --shard-mode rows --replicate-mb 64 --batch 2003 --steps 1500 --nbatch 4
 echo "three gloo ranks, pooling 5, Zipf, verify every 37th step:" >> "$out"
 PIMEMB_DIST_BACKEND=gloo PIMEMB_VERIFY_EVERY=37 run d python3 "$root/bench.py" --gpus 3 --shard-mode rows --replicate-mb 64 --pooling 5 --index-dist zipf --batch 2003 --steps 1500 --nbatch 4
+echo "three RCCL ranks on the one GPU (PIMEMB_RCCL_ONE_GPU=1: sockets over loopback), Kaggle tables, one index per bag, verify every 37th step:" >> "$out"
+PIMEMB_RCCL_ONE_GPU=1 PIMEMB_VERIFY_EVERY=37 run e python3 "$root/bench.py" --gpus 3 --shard-mode rows --replicate-mb 64 --batch 2003 --steps 600 --nbatch 4
+echo "three RCCL ranks on the one GPU, the library's own grouped send / receive (--collective native), pooling 5, Zipf, verify every 37th step:" >> "$out"
+PIMEMB_RCCL_ONE_GPU=1 PIMEMB_VERIFY_EVERY=37 run f python3 "$root/bench.py" --gpus 3 --shard-mode rows --collective native --replicate-mb 64 --pooling 5 --index-dist zipf --batch 2003 --steps 600 --nbatch 4
 cat "$out"
