@@ -343,6 +343,112 @@ int emb_comm_all_to_all(emb_comm *c, const void *send, const uint64_t *send_off,
                         const uint64_t *recv_off, void *stream);
 int emb_comm_destroy(emb_comm *c);
 
+/* A list of point-to-point transfers issued as ONE RCCL group on `stream` (the all-to-all above is the special case of one
+ * send and one receive per peer).  Transfers between a pair of ranks match in the order they are listed: the k-th send
+ * to peer p pairs with p's k-th receive from this rank, and both sides must give the same byte count.  Zero-byte entries
+ * are skipped (on both sides, since both know the size).  peer == own rank is allowed (a device copy inside RCCL). */
+typedef struct emb_comm_op {
+    int32_t peer;
+    int32_t is_recv;   /* 0: send `bytes` from ptr, 1: receive `bytes` into ptr */
+    void *ptr;         /* DEVICE memory */
+    uint64_t bytes;
+} emb_comm_op;
+int emb_comm_exchange(emb_comm *c, const emb_comm_op *ops, uint32_t n_ops, void *stream);
+int emb_comm_rank(const emb_comm *c, int32_t *rank, int32_t *world);
+
+/* ------------------------------------------------------------------------------------------ */
+/* sharded lookup: ONE call per batch                                                            */
+/* ------------------------------------------------------------------------------------------ */
+/* The reference serves every device from one lookup() call: it pushes the indices to all DPUs (emb_host.h:258-270),
+ * launches them (:297) and pulls every result into the caller's final_results (:312-321).  emb_shard is that call for
+ * tables sharded over the GPUs of one node -- one process per GPU, every rank making the SAME sequence of calls:
+ *
+ *   emb_shard_submit(s, in, n_bags, stream, &seq)   hand over this rank's batch: per table its indices / offsets / where the
+ *                                                    pooled rows go.  Enqueue only (plus one short host wait, see below).
+ *   emb_shard_wait(s, seq, stream)                  make `stream` wait until batch seq's pooled rows are in place
+ *   emb_shard_flush(s)                              push every submitted batch through its remaining stages
+ *   emb_shard_lookup(...)                           submit + flush + wait: the synchronous form (depth 0)
+ *
+ * Placement of a table:
+ *   EMB_PLACE_REPLICATED  every rank holds it: looked up locally, nothing travels;
+ *   EMB_PLACE_WHOLE       one owner rank holds it: the bags' indices travel to the owner exactly as the caller passed
+ *                         them (straight out of the caller's buffers), the owner's fused lookup pools them and the pooled
+ *                         rows arrive straight in the caller's output buffer -- no routing kernel, no copy on either side;
+ *   EMB_PLACE_ROWS        split by ROW RANGE over all ranks (rank r holds rows [r*rows_per_shard, (r+1)*rows_per_shard)):
+ *                         every bag is cut into per-shard sub-bags on the GPU (emb_route_bags), each shard returns one
+ *                         partial row per sub-bag, the bag's owner adds them in shard order (emb_unroute_bags).
+ * Counts first, payload second: what a rank will send each peer (sub-bags and indices per table) leaves before the payload,
+ * so nothing has a capacity that skewed indices could overflow.  The one host wait of a batch is for those counts.
+ *
+ * Stages of batch b and where they run (the library owns four streams: route, comm, compute, un-route):
+ *   R(b) route + counts out | L(b) local lookup of the replicated tables        at submit(b)
+ *   Q(b) host reads the counts, request pieces travel                           at submit(b + d_req)
+ *   S(b) ONE fused lookup over every piece received; T(b) pooled rows return;
+ *   U(b) partial rows added in shard order into the caller's buffers            at submit(b + d_serve)
+ * with (d_req, d_serve) = (0, 0) for depth 0, (0, 1) for depth 1, (1, 2) for depth 2 (default): at depth 2 the counts a
+ * rank waits for were sent a whole call earlier, so the host wait is short, and the return transfer of batch b overlaps the
+ * lookup of batch b + 1.  A batch's inputs and outputs belong to the library from its submit until emb_shard_wait(seq) has
+ * been ordered.  RCCL transfers of all ranks are issued in the same order because all ranks make the same calls: submit /
+ * flush are COLLECTIVE (every rank, same order; a rank with nothing to look up submits n_bags = 0).
+ *
+ * Indices and offsets are uint32 (the reference's width, emb_host.h:234); every table has `dim` columns; a batch has the
+ * same number of bags for every table (the reference's MAX_NR_BATCHES).  At most 64 row-split tables per shard object. */
+typedef struct emb_shard emb_shard;
+#define EMB_PLACE_REPLICATED 0u
+#define EMB_PLACE_WHOLE 1u
+#define EMB_PLACE_ROWS 2u
+typedef struct emb_shard_table {
+    uint32_t placement;      /* EMB_PLACE_* */
+    int32_t owner;           /* EMB_PLACE_WHOLE: the rank that holds the table */
+    uint32_t engine_table;   /* id, in THIS rank's engine, of what this rank holds of the table: the whole table
+                                (replicated; whole, on its owner) or this rank's row range (rows).  Ignored on ranks that
+                                hold nothing of it. */
+    uint32_t rows_per_shard; /* EMB_PLACE_ROWS */
+} emb_shard_table;
+typedef struct emb_shard_input {      /* one per table, in table order */
+    const uint32_t *indices;  /* DEVICE uint32[n_indices] */
+    const uint32_t *offsets;  /* DEVICE uint32[n_bags] bag starts (last bag runs to n_indices), or NULL */
+    uint64_t n_indices;
+    uint32_t fixed_pooling;   /* offsets == NULL: offsets[b] = b * fixed_pooling */
+    uint32_t reserved;
+    float *pooled;            /* DEVICE float[n_bags][dim] */
+} emb_shard_input;
+#define EMB_SHARD_SELF_VIA_COMM 1u /* pieces a rank addresses to ITSELF go through RCCL like any other (rehearsal / A-B);
+                                      default: they are served in place -- no transfer, no copy */
+#define EMB_SHARD_CHECK_SERVED 2u  /* the fused lookup of every batch validates the indices it serves first
+                                      (emb_lookup_batched_checked); a finding makes emb_shard_submit / _flush return
+                                      EMB_ERR_RANGE on the SERVING rank after the batch has gone through all its stages
+                                      (the offending pieces pool to zero rows), so no peer is left in a transfer */
+typedef struct emb_shard_config {
+    uint32_t n_tables;
+    uint32_t dim;
+    uint32_t depth;           /* 0, 1 or 2 (see above) */
+    uint32_t flags;           /* EMB_SHARD_* */
+    const emb_shard_table *tables;
+} emb_shard_config;
+/* what the last completed stages cost and moved (reporting; cumulative since create / reset) */
+typedef struct emb_shard_stats {
+    uint64_t n_batches;               /* batches that went through all stages */
+    uint64_t bytes_to_peers;          /* counts + requests + returned rows handed to OTHER ranks */
+    uint64_t bytes_to_self;           /* the same addressed to this rank itself (served in place unless SELF_VIA_COMM) */
+    uint64_t served_algorithmic_bytes;/* algorithmic bytes of the fused lookups over received pieces */
+    uint64_t local_algorithmic_bytes; /* ... of the lookups of the replicated tables */
+    uint64_t served_sub_bags, served_indices;
+    double us_host_submit;            /* host time inside emb_shard_submit / _flush, all stages */
+    double us_host_wait_counts;       /* ... of it: waiting for the counts */
+} emb_shard_stats;
+/* comm may be NULL for a world of one rank (everything is "self"). */
+int emb_shard_create(emb_engine *e, emb_comm *comm, const emb_shard_config *cfg, emb_shard **out);
+int emb_shard_submit(emb_shard *s, const emb_shard_input *in, uint64_t n_bags, void *stream, uint64_t *seq);
+int emb_shard_flush(emb_shard *s);
+int emb_shard_wait(emb_shard *s, uint64_t seq, void *stream);
+int emb_shard_lookup(emb_shard *s, const emb_shard_input *in, uint64_t n_bags, void *stream);
+int emb_shard_get_stats(emb_shard *s, emb_shard_stats *out, int reset);
+/* Per-(peer, table) request counts {sub-bags, indices} of the row-split tables this rank SENT for batch seq: uint32
+ * [n_ranks][n_row_split][2] (reporting; valid until the batch's slot is reused, four submits later). */
+int emb_shard_sent_counts(emb_shard *s, uint64_t seq, uint32_t *counts, uint32_t capacity_words);
+int emb_shard_destroy(emb_shard *s);
+
 /* ------------------------------------------------------------------------------------------ */
 /* (2) reference-compatible entry points (same names, argument meaning and return values)      */
 /* ------------------------------------------------------------------------------------------ */

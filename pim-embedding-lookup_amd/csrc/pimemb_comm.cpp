@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 #include "pimemb_internal.h"
 
@@ -125,33 +126,55 @@ int emb_comm_create(emb_engine *e, const void *id128, int32_t rank, int32_t worl
     return EMB_OK;
 }
 
-int emb_comm_all_to_all(emb_comm *c, const void *send, const uint64_t *send_off, void *recv,
-                        const uint64_t *recv_off, void *stream) {
-    if (!c || !send || !recv || !send_off || !recv_off) return fail(EMB_ERR_INVALID, "emb_comm_all_to_all: NULL argument");
+// One send / receive moves at most kChunk bytes: RCCL 2.26.6 (the one torch 2.10 bundles) delivers only the first half
+// of a transfer above 1 GiB (tools/a2a_size_probe.py: intact up to 1.0 GiB, corrupt from 1.1 GiB, any element type).
+// Both ends of a pair know the pair's size, so both cut it into the same pieces; pieces to one peer match in order.
+constexpr uint64_t kChunk = 512ull << 20;
+
+int emb_comm_exchange(emb_comm *c, const emb_comm_op *ops, uint32_t n_ops, void *stream) {
+    if (!c || (n_ops && !ops)) return fail(EMB_ERR_INVALID, "emb_comm_exchange: NULL argument");
+    for (uint32_t i = 0; i < n_ops; i++) {
+        if (ops[i].peer < 0 || ops[i].peer >= c->world) return fail(EMB_ERR_INVALID, "emb_comm_exchange: op %u: peer %d of %d", i, ops[i].peer, c->world);
+        if (ops[i].bytes && !ops[i].ptr) return fail(EMB_ERR_INVALID, "emb_comm_exchange: op %u: NULL buffer", i);
+    }
     const Rccl *r = rccl();
     hipStream_t s = static_cast<hipStream_t>(stream);
     int prev = -1;
     (void)hipGetDevice(&prev);
     if (prev != c->device) (void)hipSetDevice(c->device);
-    // One send / receive moves at most kChunk bytes: RCCL 2.26.6 (the one torch 2.10 bundles) delivers only the first half
-    // of a transfer above 1 GiB (tools/a2a_size_probe.py: intact up to 1.0 GiB, corrupt from 1.1 GiB, any element type).
-    // Both ends of a pair know the pair's size, so both cut it into the same pieces; pieces to one peer match in order.
-    constexpr uint64_t kChunk = 512ull << 20;
     ncclResult_t rc = r->GroupStart();
-    for (int p = 0; rc == 0 && p < c->world; p++) {
-        const uint64_t ns = send_off[p + 1] - send_off[p], nr = recv_off[p + 1] - recv_off[p];
-        for (uint64_t o = 0; rc == 0 && o < ns; o += kChunk)
-            rc = r->Send(static_cast<const char *>(send) + send_off[p] + o, ns - o < kChunk ? ns - o : kChunk, kNcclUint8, p,
-                         c->comm, s);
-        for (uint64_t o = 0; rc == 0 && o < nr; o += kChunk)
-            rc = r->Recv(static_cast<char *>(recv) + recv_off[p] + o, nr - o < kChunk ? nr - o : kChunk, kNcclUint8, p,
-                         c->comm, s);
+    for (uint32_t i = 0; rc == 0 && i < n_ops; i++) {
+        const emb_comm_op &op = ops[i];
+        for (uint64_t o = 0; rc == 0 && o < op.bytes; o += kChunk) {
+            const uint64_t n = op.bytes - o < kChunk ? op.bytes - o : kChunk;
+            rc = op.is_recv ? r->Recv(static_cast<char *>(op.ptr) + o, n, kNcclUint8, op.peer, c->comm, s)
+                            : r->Send(static_cast<const char *>(op.ptr) + o, n, kNcclUint8, op.peer, c->comm, s);
+        }
     }
     ncclResult_t rc2 = r->GroupEnd();
     if (prev >= 0 && prev != c->device) (void)hipSetDevice(prev);
     if (rc) return nccl_fail("ncclSend/ncclRecv", rc);
     if (rc2) return nccl_fail("ncclGroupEnd", rc2);
     return EMB_OK;
+}
+
+int emb_comm_rank(const emb_comm *c, int32_t *rank, int32_t *world) {
+    if (!c) return fail(EMB_ERR_INVALID, "emb_comm_rank: comm is NULL");
+    if (rank) *rank = c->rank;
+    if (world) *world = c->world;
+    return EMB_OK;
+}
+
+int emb_comm_all_to_all(emb_comm *c, const void *send, const uint64_t *send_off, void *recv,
+                        const uint64_t *recv_off, void *stream) {
+    if (!c || !send || !recv || !send_off || !recv_off) return fail(EMB_ERR_INVALID, "emb_comm_all_to_all: NULL argument");
+    std::vector<emb_comm_op> ops;
+    ops.reserve(2 * (size_t)c->world);
+    for (int p = 0; p < c->world; p++) {
+        ops.push_back(emb_comm_op{p, 0, const_cast<char *>(static_cast<const char *>(send)) + send_off[p], send_off[p + 1] - send_off[p]});
+        ops.push_back(emb_comm_op{p, 1, static_cast<char *>(recv) + recv_off[p], recv_off[p + 1] - recv_off[p]});
+    }
+    return emb_comm_exchange(c, ops.data(), (uint32_t)ops.size(), stream);
 }
 
 int emb_comm_destroy(emb_comm *c) {

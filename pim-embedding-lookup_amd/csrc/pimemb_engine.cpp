@@ -120,6 +120,9 @@ struct emb_engine {
     // remembers of them -- tickets drawn and offending values found by all earlier calls, and a sequence number
     pimemb::ValidateCtl *d_val = nullptr;
     unsigned long long val_tickets = 0, val_bad = 0, val_seq = 0;
+    std::mutex val_mu;          // checked calls take turns (their findings are read as deltas of one device counter); `mu` is
+                                // held only while such a call enqueues, not while it waits for its result
+    volatile unsigned long long *val_result = nullptr;   // two pinned, device-visible words the validation kernels report into
     // stats
     std::atomic<uint64_t> n_lookup_calls{0}, n_kernel_launches{0}, n_bags{0}, n_indices{0};
     std::atomic<uint64_t> n_by_kind[5] = {};
@@ -802,6 +805,7 @@ int emb_destroy(emb_engine *e) {
     if (e->h_stage) (void)hipHostFree(e->h_stage);
     if (e->d_stage) (void)hipFree(e->d_stage);
     if (e->d_val) (void)hipFree(e->d_val);
+    if (e->val_result) (void)hipHostFree(const_cast<unsigned long long *>(e->val_result));
     delete e;
     return EMB_OK;
 }
@@ -1094,49 +1098,73 @@ int emb_plan_time(emb_plan *p, void *stream, uint32_t warmup, uint32_t iters, fl
     return EMB_OK;
 }
 
+// After a failed enqueue on the validation path: let the stream drain and read the device's counters back, so that the
+// next clean checked call does not see findings (or tickets) of this one as its own.
+static void resync_validation(emb_engine *e, hipStream_t s) {
+    (void)hipStreamSynchronize(s);
+    pimemb::ValidateCtl c{};
+    if (e->d_val && hipMemcpy(&c, e->d_val, sizeof c, hipMemcpyDeviceToHost) == hipSuccess) {
+        e->val_tickets = c.tickets;
+        e->val_bad = c.bad;
+    }
+    (void)hipGetLastError();
+}
+
 // Validate the resolved descriptors of a call (device-resident buffers) on stream `s` and -- with `launch` -- enqueue its
 // lookup kernels right behind the validation kernel, over the SAME launch image: a finding zeroes the descriptors' tile
 // counts on the device, so the lookup does nothing.  The host waits for the validation result only (two pinned words the
 // kernel's last workgroup writes; polled), not for the lookup.  No allocation on this path (the 16-byte HBM counter block
-// is created once), no event, no device-wide synchronize.
+// and the pinned result words are created once), no event, no device-wide synchronize.  Checked calls take turns (val_mu);
+// the engine mutex is held while the call enqueues, not while it waits.
 static int checked_launch(emb_engine *e, Resolved &r, emb_index_type itype, hipStream_t s, bool launch, uint64_t *n_bad) {
     if (n_bad) *n_bad = 0;
     if (r.descs.empty()) return EMB_OK;
-    std::lock_guard<std::mutex> lk(e->mu);
-    if (!e->d_val) {
-        HIP_TRY(hipMalloc((void **)&e->d_val, sizeof(pimemb::ValidateCtl)));
-        HIP_TRY(hipMemset(e->d_val, 0, sizeof(pimemb::ValidateCtl)));
-    }
-    const size_t img = (r.image.size() + 127) / 128 * 128;
-    char *h = nullptr, *d = nullptr;
-    int rc = take_image_space(e, img + 128, s, &h, &d);
-    if (rc) return rc;
-    memcpy(h, r.image.data(), r.image.size());
-    volatile unsigned long long *result = reinterpret_cast<volatile unsigned long long *>(h + img);
-    result[0] = result[1] = 0;
-    char *base = h;        // the kernels' scalar loads read the pinned, device-visible segment itself ...
-    if (d != nullptr) {    // ... or its HBM twin (PIMEMB_DESC_MODE=copy)
-        HIP_TRY(hipMemcpyAsync(d, h, r.image.size(), hipMemcpyHostToDevice, s));
-        base = d;
-    }
-    r.bind(base);
-    uint64_t max_items = 1;
-    for (const DevDesc &dd : r.descs) max_items = std::max<uint64_t>(max_items, std::max<uint64_t>(dd.n_idx, dd.n_bags));
-    const uint32_t wgs = pimemb::validate_workgroups(max_items);
-    const unsigned long long n_wgs = (unsigned long long)wgs * r.descs.size();
-    const unsigned long long seq = ++e->val_seq;
-    const bool tickets = n_wgs <= 32;      // small grid: its last workgroup reports; else a one-thread kernel behind it
-    hipError_t err = pimemb::launch_validate(reinterpret_cast<DevDesc *>(base + r.groups[0].desc_off), (uint32_t)r.descs.size(),
-                                             itype, e->d_val, tickets ? e->val_tickets + n_wgs : 0ull,
-                                             const_cast<unsigned long long *>(result), seq, wgs, /*poison=*/launch, s);
-    if (err != hipSuccess) return fail(EMB_ERR_DEVICE, "validation kernel: %s", hipGetErrorString(err));
-    if (tickets) e->val_tickets += n_wgs;
-    if (launch) {
-        rc = launch_groups(e, r.groups, itype, s);
-        if (rc) {
-            (void)hipStreamSynchronize(s);     // keep the counters' bookkeeping in step with the device
-            if (result[1] == seq) e->val_bad = result[0];
-            return rc;
+    std::lock_guard<std::mutex> vlk(e->val_mu);
+    unsigned long long seq = 0;
+    volatile unsigned long long *result = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(e->mu);        // enqueue only; released before the wait below
+        if (!e->d_val) {
+            HIP_TRY(hipMalloc((void **)&e->d_val, sizeof(pimemb::ValidateCtl)));
+            HIP_TRY(hipMemset(e->d_val, 0, sizeof(pimemb::ValidateCtl)));
+        }
+        if (!e->val_result) {     // its own pinned block, not the launch-image ring: a segment may be recycled while we wait
+            void *p = nullptr;
+            HIP_TRY(hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocCoherent));
+            e->val_result = static_cast<volatile unsigned long long *>(p);
+        }
+        result = e->val_result;
+        char *h = nullptr, *d = nullptr;
+        int rc = take_image_space(e, r.image.size(), s, &h, &d);
+        if (rc) return rc;
+        memcpy(h, r.image.data(), r.image.size());
+        result[0] = result[1] = 0;
+        char *base = h;        // the kernels' scalar loads read the pinned, device-visible segment itself ...
+        if (d != nullptr) {    // ... or its HBM twin (PIMEMB_DESC_MODE=copy)
+            HIP_TRY(hipMemcpyAsync(d, h, r.image.size(), hipMemcpyHostToDevice, s));
+            base = d;
+        }
+        r.bind(base);
+        uint64_t max_items = 1;
+        for (const DevDesc &dd : r.descs) max_items = std::max<uint64_t>(max_items, std::max<uint64_t>(dd.n_idx, dd.n_bags));
+        const uint32_t wgs = pimemb::validate_workgroups(max_items);
+        const unsigned long long n_wgs = (unsigned long long)wgs * r.descs.size();
+        seq = ++e->val_seq;
+        const bool tickets = n_wgs <= 32;      // small grid: its last workgroup reports; else a one-thread kernel behind it
+        hipError_t err = pimemb::launch_validate(reinterpret_cast<DevDesc *>(base + r.groups[0].desc_off), (uint32_t)r.descs.size(),
+                                                 itype, e->d_val, tickets ? e->val_tickets + n_wgs : 0ull,
+                                                 const_cast<unsigned long long *>(result), seq, wgs, /*poison=*/launch, s);
+        if (err != hipSuccess) {               // the validation kernel may be queued without its reporting kernel
+            resync_validation(e, s);
+            return fail(EMB_ERR_DEVICE, "validation kernel: %s", hipGetErrorString(err));
+        }
+        if (tickets) e->val_tickets += n_wgs;
+        if (launch) {
+            rc = launch_groups(e, r.groups, itype, s);
+            if (rc) {
+                resync_validation(e, s);           // keep the counters' bookkeeping in step with the device
+                return rc;
+            }
         }
     }
     bool done = false;
@@ -1144,7 +1172,11 @@ static int checked_launch(emb_engine *e, Resolved &r, emb_index_type itype, hipS
     }
     if (!done) {
         HIP_TRY(hipStreamSynchronize(s));
-        if (result[1] != seq) return fail(EMB_ERR_DEVICE, "validation kernel did not report");
+        if (result[1] != seq) {
+            std::lock_guard<std::mutex> lk(e->mu);
+            resync_validation(e, s);
+            return fail(EMB_ERR_DEVICE, "validation kernel did not report");
+        }
     }
     const unsigned long long total = result[0];
     const unsigned long long bad = total - e->val_bad;

@@ -86,6 +86,18 @@ hipError_t launch_route_bags(const RouteBagDesc *tables, uint32_t n_tables, uint
 uint32_t route_bags_meta_words(uint32_t n_tables, uint32_t n_shards);   // uint32 words of `meta`
 hipError_t launch_unroute_bags(const float *recv, const uint32_t *meta, const uint32_t *slots, uint32_t n_tables,
                                uint64_t n_bags, uint32_t n_shards, uint32_t dim, float *pooled, hipStream_t stream);
+// The same with one output pointer per table (the sharded step writes straight into the caller's per-table buffers).
+hipError_t launch_unroute_bags_to(const float *recv, const uint32_t *meta, const uint32_t *slots, uint32_t n_tables,
+                                  uint64_t n_bags, uint32_t n_shards, uint32_t dim, float *const *pooled_of_table,
+                                  hipStream_t stream);
+// Word offsets inside a routing `meta` block (emb_route_bags): counts of (peer d, table k), first request word of peer d's
+// piece, and the number of leading words that hold all counts.
+uint32_t route_meta_counts_words(uint32_t n_tables, uint32_t n_shards);
+uint32_t route_meta_piece_word(uint32_t n_tables, uint32_t n_shards);
+// Sharded step helpers: up to three word arrays HBM -> pinned host + a flag behind them; zero fill of a few words.
+hipError_t launch_publish_words(const uint32_t *const src[3], const uint32_t n[3], uint32_t *dst_host,
+                                unsigned long long *flag_host, unsigned long long value, hipStream_t stream);
+hipError_t launch_zero_words(uint32_t *p, uint32_t n, hipStream_t stream);
 
 // Record the calling thread's error text (returned by emb_last_error()) and hand `code` back.
 int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));

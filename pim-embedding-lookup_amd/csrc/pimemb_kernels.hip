@@ -709,10 +709,15 @@ route_onehot_place_fused_kernel(RouteBagParams rp, uint64_t n_bags, uint32_t n_s
 // row that came back: deterministic, and exact for bags that live in one shard (one-hot lookups).
 // `slots` as emb_route_bags left it: meta[mode] == kModeBags: uint32[K][N][n_bags], slot of bag b's sub-bag in
 // (d, k)'s request or kNoSlot; kModeOneHot: uint32[K][n_bags], (dest << 24) | slot -- one word and one row per bag.
+struct UnrouteOut {
+    float *p[kRouteBagMaxTables];     // pooled rows of table k: float[n_bags][dim]
+};
+
 __global__ void __launch_bounds__(kBlock)
 unroute_bags_kernel(const float *__restrict__ recv, const uint32_t *__restrict__ meta, const uint32_t *__restrict__ slots,
-                    uint64_t n_bags, uint32_t n_shards, uint32_t dim, float *__restrict__ pooled) {
+                    uint64_t n_bags, uint32_t n_shards, uint32_t dim, UnrouteOut outs) {
     const uint32_t k = blockIdx.y, n_tables = gridDim.y;
+    float *__restrict__ pooled_k = outs.p[k];
     const uint32_t pieces = dim / 4;
     const uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     const uint64_t b = gid / pieces;
@@ -725,7 +730,7 @@ unroute_bags_kernel(const float *__restrict__ recv, const uint32_t *__restrict__
         const uint32_t pk = slots[(uint64_t)k * n_bags + b];
         const uint64_t row = (uint64_t)ret_row0[(pk >> 24) * n_tables + k] + (pk & 0xffffffu);
         acc += *(reinterpret_cast<const f32x4 *>(recv) + row * pieces + piece);
-        __builtin_nontemporal_store(acc, reinterpret_cast<f32x4 *>(pooled + ((uint64_t)k * n_bags + b) * dim) + piece);
+        __builtin_nontemporal_store(acc, reinterpret_cast<f32x4 *>(pooled_k + b * dim) + piece);
         return;
     }
     // eight shards at a time: their slot words are fetched together, then the partial rows that exist, then the adds in
@@ -749,7 +754,7 @@ unroute_bags_kernel(const float *__restrict__ recv, const uint32_t *__restrict__
         for (uint32_t j = 0; j < 8; j++)
             if (slot[j] != kNoSlot) acc += v[j];
     }
-    __builtin_nontemporal_store(acc, reinterpret_cast<f32x4 *>(pooled + ((uint64_t)k * n_bags + b) * dim) + piece);
+    __builtin_nontemporal_store(acc, reinterpret_cast<f32x4 *>(pooled_k + b * dim) + piece);
 }
 
 }  // namespace
@@ -799,13 +804,73 @@ hipError_t launch_route_bags(const RouteBagDesc *tables, uint32_t n_tables, uint
 }
 
 uint32_t route_bags_meta_words(uint32_t n_tables, uint32_t n_shards) { return meta_layout(n_shards, n_tables).words; }
+uint32_t route_meta_counts_words(uint32_t n_tables, uint32_t n_shards) { return meta_layout(n_shards, n_tables).base; }
+uint32_t route_meta_piece_word(uint32_t n_tables, uint32_t n_shards) { return meta_layout(n_shards, n_tables).piece; }
+
+hipError_t launch_unroute_bags_to(const float *recv, const uint32_t *meta, const uint32_t *slots, uint32_t n_tables,
+                                  uint64_t n_bags, uint32_t n_shards, uint32_t dim, float *const *pooled_of_table,
+                                  hipStream_t stream) {
+    if (n_tables == 0 || n_bags == 0) return hipSuccess;
+    if (n_tables > kRouteBagMaxTables) return hipErrorInvalidValue;
+    UnrouteOut outs{};
+    for (uint32_t k = 0; k < n_tables; k++) outs.p[k] = pooled_of_table[k];
+    const uint64_t threads = n_bags * (dim / 4);
+    const dim3 grid((uint32_t)((threads + kBlock - 1) / kBlock), n_tables, 1);
+    hipLaunchKernelGGL(unroute_bags_kernel, grid, dim3(kBlock), 0, stream, recv, meta, slots, n_bags, n_shards, dim, outs);
+    return hipGetLastError();
+}
 
 hipError_t launch_unroute_bags(const float *recv, const uint32_t *meta, const uint32_t *slots, uint32_t n_tables,
                                uint64_t n_bags, uint32_t n_shards, uint32_t dim, float *pooled, hipStream_t stream) {
     if (n_tables == 0 || n_bags == 0) return hipSuccess;
-    const uint64_t threads = n_bags * (dim / 4);
-    const dim3 grid((uint32_t)((threads + kBlock - 1) / kBlock), n_tables, 1);
-    hipLaunchKernelGGL(unroute_bags_kernel, grid, dim3(kBlock), 0, stream, recv, meta, slots, n_bags, n_shards, dim, pooled);
+    if (n_tables > kRouteBagMaxTables) return hipErrorInvalidValue;
+    float *ptrs[kRouteBagMaxTables];
+    for (uint32_t k = 0; k < n_tables; k++) ptrs[k] = pooled + (uint64_t)k * n_bags * dim;
+    return launch_unroute_bags_to(recv, meta, slots, n_tables, n_bags, n_shards, dim, ptrs, stream);
+}
+
+// Sharded step: carry up to three short word arrays (the counts a rank sent / received) from HBM into pinned host memory
+// and raise a flag behind them, so the host learns them by polling one word -- no copy-engine hop, no event.
+struct PublishSrc {
+    const uint32_t *p[3];
+    uint32_t n[3];
+};
+__global__ void __launch_bounds__(kBlock)
+publish_words_kernel(PublishSrc src, uint32_t *__restrict__ dst_host, volatile unsigned long long *flag, unsigned long long value) {
+    uint32_t at = 0;
+    for (int j = 0; j < 3; j++) {         // a missing source leaves its section of dst_host alone (the host fills it)
+        if (src.p[j] != nullptr)
+            for (uint32_t i = threadIdx.x; i < src.n[j]; i += kBlock)
+                dst_host[at + i] = __builtin_nontemporal_load(src.p[j] + i);
+        at += src.n[j];
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        *flag = value;
+    }
+}
+
+hipError_t launch_publish_words(const uint32_t *const src[3], const uint32_t n[3], uint32_t *dst_host,
+                                unsigned long long *flag_host, unsigned long long value, hipStream_t stream) {
+    PublishSrc ps{};
+    for (int j = 0; j < 3; j++) {
+        ps.p[j] = src[j];
+        ps.n[j] = n[j];
+    }
+    hipLaunchKernelGGL(publish_words_kernel, dim3(1), dim3(kBlock), 0, stream, ps, dst_host, flag_host, value);
+    return hipGetLastError();
+}
+
+// Zero the {n_sub, n_idx} counts and peaks of a routing `meta` block (a rank with an empty batch still sends counts).
+__global__ void __launch_bounds__(kBlock)
+zero_words_kernel(uint32_t *__restrict__ p, uint32_t n) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) p[i] = 0u;
+}
+hipError_t launch_zero_words(uint32_t *p, uint32_t n, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(kBlock), 0, stream, p, n);
     return hipGetLastError();
 }
 

@@ -40,9 +40,14 @@ def _marshal():
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "_pimemb_marshal.so")
         if os.path.exists(path) and os.environ.get("PIMEMB_NO_MARSHAL") != "1":
             import torch  # noqa: F401  (the helper links against torch's libraries: they must be mapped first)
-            spec = importlib.util.spec_from_file_location("_pimemb_marshal", path)
-            m = importlib.util.module_from_spec(spec)
-            spec.loader.exec_module(m)
+            try:
+                spec = importlib.util.spec_from_file_location("_pimemb_marshal", path)
+                m = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(m)
+            except (ImportError, OSError) as ex:     # built against another Python / torch: the Python path does the same job
+                import warnings
+                warnings.warn(f"_pimemb_marshal.so could not be loaded ({ex}); tensor lists are unpacked in Python")
+                m = None
         _MARSHAL[0] = m
     return m
 
@@ -216,6 +221,12 @@ class EmbeddingEngine:
         self._plan_clock = 0                                # cacheable calls so far (hits and misses)
         self._plan_last_evict = -(1 << 30)
         self.plan_cache_size = 16                           # 0 switches the cache off
+        # An engine created with check_inputs=True promises that every plan-less lookup validates first; a cached plan
+        # launch (emb_plan_launch) never validates, so such an engine never caches plans (the third call with
+        # the same buffer addresses used to skip the check).
+        self._check_inputs = bool(check_inputs)
+        if self._check_inputs:
+            self.plan_cache_size = 0
         self._same_dim: dict[tuple, int] = {}               # table ids -> their common dim (0: dims differ)
         self.plan_cache_hits = 0
 
@@ -350,6 +361,8 @@ class EmbeddingEngine:
 
     def _launch_cached(self, key, stream) -> bool:
         """Launch the cached plan of this call signature, if there is one (under the plan lock: see _plan_lock)."""
+        if self._check_inputs:               # a checked engine never launches unvalidated (whatever plan_cache_size says)
+            return False
         with self._plan_lock:
             self._plan_clock += 1
             ent = self._plan_cache.get(key)
@@ -511,7 +524,7 @@ class EmbeddingEngine:
             self._remember_locked(key, desc_ptr, n, itype)
 
     def _remember_locked(self, key, desc_ptr, n, itype) -> None:
-        if key in self._plan_cache:
+        if key in self._plan_cache or self._check_inputs:
             return
         h = hash(key)                         # (admission bookkeeping only: a collision costs one early plan, nothing else)
         if self._plan_seen.pop(h, 0) < 1:     # first sighting: remember it among the last few thousand signatures

@@ -40,6 +40,35 @@ class EmbRouteTable(C.Structure):
                 ("fixed_pooling", C.c_uint32), ("rows_per_shard", C.c_uint32)]
 
 
+class EmbCommOp(C.Structure):
+    _fields_ = [("peer", C.c_int32), ("is_recv", C.c_int32), ("ptr", C.c_void_p), ("bytes", C.c_uint64)]
+
+
+EMB_PLACE_REPLICATED, EMB_PLACE_WHOLE, EMB_PLACE_ROWS = 0, 1, 2
+EMB_SHARD_SELF_VIA_COMM, EMB_SHARD_CHECK_SERVED = 1, 2
+
+
+class EmbShardTable(C.Structure):
+    _fields_ = [("placement", C.c_uint32), ("owner", C.c_int32), ("engine_table", C.c_uint32), ("rows_per_shard", C.c_uint32)]
+
+
+class EmbShardInput(C.Structure):
+    _fields_ = [("indices", C.c_void_p), ("offsets", C.c_void_p), ("n_indices", C.c_uint64), ("fixed_pooling", C.c_uint32),
+                ("reserved", C.c_uint32), ("pooled", C.c_void_p)]
+
+
+class EmbShardConfig(C.Structure):
+    _fields_ = [("n_tables", C.c_uint32), ("dim", C.c_uint32), ("depth", C.c_uint32), ("flags", C.c_uint32),
+                ("tables", C.POINTER(EmbShardTable))]
+
+
+class EmbShardStats(C.Structure):
+    _fields_ = [("n_batches", C.c_uint64), ("bytes_to_peers", C.c_uint64), ("bytes_to_self", C.c_uint64),
+                ("served_algorithmic_bytes", C.c_uint64), ("local_algorithmic_bytes", C.c_uint64),
+                ("served_sub_bags", C.c_uint64), ("served_indices", C.c_uint64),
+                ("us_host_submit", C.c_double), ("us_host_wait_counts", C.c_double)]
+
+
 class EmbTraceEvent(C.Structure):
     _fields_ = [("stage", C.c_uint32), ("call_id", C.c_uint32), ("start_us", C.c_double), ("stop_us", C.c_double)]
 
@@ -69,6 +98,16 @@ SIGNATURES = {
     "emb_comm_create": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32, _pp]),
     "emb_comm_all_to_all": (C.c_int, [_vp, _vp, C.POINTER(_u64), _vp, C.POINTER(_u64), _vp]),
     "emb_comm_destroy": (C.c_int, [_vp]),
+    "emb_comm_exchange": (C.c_int, [_vp, C.POINTER(EmbCommOp), _u32, _vp]),
+    "emb_comm_rank": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
+    "emb_shard_create": (C.c_int, [_vp, _vp, C.POINTER(EmbShardConfig), _pp]),
+    "emb_shard_submit": (C.c_int, [_vp, C.POINTER(EmbShardInput), _u64, _vp, C.POINTER(_u64)]),
+    "emb_shard_flush": (C.c_int, [_vp]),
+    "emb_shard_wait": (C.c_int, [_vp, _u64, _vp]),
+    "emb_shard_lookup": (C.c_int, [_vp, C.POINTER(EmbShardInput), _u64, _vp]),
+    "emb_shard_get_stats": (C.c_int, [_vp, C.POINTER(EmbShardStats), C.c_int]),
+    "emb_shard_sent_counts": (C.c_int, [_vp, _u64, C.POINTER(_u32), _u32]),
+    "emb_shard_destroy": (C.c_int, [_vp]),
     "emb_table_info": (C.c_int, [_vp, _u32, _pp, C.POINTER(_u64), C.POINTER(_u32), C.POINTER(C.c_int)]),
     "emb_lookup": (C.c_int, [_vp, _u32, _vp, _u64, _vp, _u64, _vp, C.c_int, C.c_int, _vp]),
     "emb_lookup_batched": (C.c_int, [_vp, C.POINTER(EmbLookupDesc), _u32, C.c_int, C.c_int, _vp]),

@@ -1645,3 +1645,52 @@ def test_checked_engine_refuses_bad_indices(pel, oracle):
     finally:
         os.environ.pop("PIMEMB_CHECK_INPUTS", None)
         compat.reset()
+
+
+@pytest.mark.gpu
+def test_checked_engine_never_launches_a_cached_plan(pel, oracle):
+    """an engine created with check_inputs=True must validate EVERY plan-less lookup -- also the third
+    call with the same device tensors, which on an unchecked engine is one emb_plan_launch of a cached plan (no validation).
+    Three good calls over the same buffers, then a bad index written IN PLACE: EMB_ERR_RANGE, output untouched, and the
+    same through lookup_stacked."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(33)
+    tabs = [pel.workloads.dlrm_table(rng, 400 + 10 * t, 16) for t in range(3)]
+    e = pel.EmbeddingEngine(device=0, max_tables=4, check_inputs=True)
+    for t, w in enumerate(tabs):
+        e.load_table(t, w)
+    idx = [torch.from_numpy(rng.integers(0, 400, size=64)).to(dev) for _ in range(3)]
+    off = [torch.arange(0, 64, 2, dtype=torch.int64, device=dev) for _ in range(3)]
+    outs = [torch.full((32, 16), 7.0, device=dev) for _ in range(3)]
+    for _ in range(4):                                    # same addresses, same lengths: the plan cache's target loop
+        got = e.lookup_batched([0, 1, 2], idx, off, outs)
+    for t in range(3):
+        assert np.array_equal(got[t].cpu().numpy(), oracle.c_bag_sum(tabs[t], idx[t].cpu().numpy(), off[t].cpu().numpy()))
+    assert e.plan_cache_hits == 0 and not e._plan_cache
+    for o in outs:
+        o.fill_(7.0)
+    idx[1][5] = 10_000                                    # in place: same tensor, same address
+    with pytest.raises(pel.PimembError) as ei:
+        e.lookup_batched([0, 1, 2], idx, off, outs)
+    torch.cuda.synchronize()
+    assert ei.value.code == pel.lib.EMB_ERR_RANGE and all(bool((o == 7.0).all()) for o in outs)
+    # the stacked form: [T, N] / [T, B] tensors, three good calls, then a bad value in place
+    si = torch.from_numpy(rng.integers(0, 400, size=(3, 64))).to(dev)
+    so = torch.arange(0, 64, 2, dtype=torch.int64, device=dev).repeat(3, 1).contiguous()
+    sout = torch.full((3, 32, 16), 7.0, device=dev)
+    for _ in range(4):
+        e.lookup_stacked([0, 1, 2], si, so, out=sout)
+    assert e.plan_cache_hits == 0
+    sout.fill_(7.0)
+    si[2, 9] = 999_999
+    with pytest.raises(pel.PimembError) as ei:
+        e.lookup_stacked([0, 1, 2], si, so, out=sout)
+    torch.cuda.synchronize()
+    assert ei.value.code == pel.lib.EMB_ERR_RANGE and bool((sout == 7.0).all())
+    e.plan_cache_size = 16                                # even if a caller turns the cache back on
+    si[2, 9] = 1
+    for _ in range(4):
+        e.lookup_stacked([0, 1, 2], si, so, out=sout)
+    assert e.plan_cache_hits == 0
+    e.close()

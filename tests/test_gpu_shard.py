@@ -1,0 +1,105 @@
+"""GPU: the sharded lookup as one library call per batch (emb_shard_* / ShardedEmbeddingBags) against the oracle -- one
+rank with every placement kind, and several REAL RCCL ranks on the one GPU (every rank claims a host of its own, so RCCL
+connects them through its socket transport; the transfers, their order and their sizes are the ones an 8-GPU node sees,
+minus the links).  The per-rank work is tests/shard_worker.py."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(cfg, world, tmp_path, timeout=420):
+    cfg = dict(cfg, out=str(tmp_path / "shard"))
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", PIMEMB_SHARD_TIMEOUT_S="90")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "shard_worker.py"), json.dumps(cfg)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("sharded job timed out")
+        outs.append(o)
+    res = []
+    for r in range(world):
+        path = cfg["out"] + ".rank%d.json" % r
+        assert os.path.exists(path), f"rank {r} left no result:\n{outs[r][-3000:]}"
+        st = json.load(open(path))
+        assert st["ok"], f"rank {r}:\n{st.get('error')}\n{outs[r][-2000:]}"
+        res.append(st)
+    return res
+
+
+ONE_RANK = dict(rows=[7, 300, 5000, 64, 2000, 900], dim=16, bags=37, max_len=5,
+                kinds=["replicated", "whole", "row_split", "replicated", "row_split", "whole"])
+
+
+@pytest.mark.parametrize("variant", ["ragged", "one-hot", "fixed-pooling", "int64", "f16-dim64"])
+def test_shard_one_rank_every_placement(variant, tmp_path):
+    """A world of one rank (no communicator): replicated, whole and row-split tables in one call, ragged bags (empty ones
+    included), depth 0 (forward) and depth 2 (submit / wait / flush) -- every table bit for bit the oracle's."""
+    cfg = dict(ONE_RANK)
+    if variant == "one-hot":
+        cfg.update(max_len=1, fixed=True)
+    elif variant == "fixed-pooling":
+        cfg.update(max_len=4, fixed=True)
+    elif variant == "int64":
+        cfg.update(int64=True)
+    elif variant == "f16-dim64":
+        cfg.update(f16=True, dim=64)
+    res = _run(cfg, 1, tmp_path)
+    st = res[0]["stats_depth2"]
+    assert st["n_batches"] == 5 and st["bytes_to_peers"] == 0 and st["served_algorithmic_bytes"] > 0
+
+
+@pytest.mark.parametrize("variant,world", [("ragged", 2), ("ragged", 3), ("one-hot", 4), ("pooled-whole", 2), ("self-via-comm", 2),
+                                           ("empty-rank", 3)])
+def test_shard_rccl_ranks_on_one_gpu(variant, world, tmp_path):
+    """2-4 RCCL ranks: planner-made placement (replicated + whole + row-split), every rank its own ragged batches of a
+    different size, both forms of the call, all tables on all ranks against the oracle."""
+    cfg = dict(rows=[7, 300, 5000, 64, 2000, 1500], dim=16, rep=64 * 16 * 4, split=3000 * 16 * 4, bags=29, max_len=6,
+               expect_kinds=["replicated", "whole", "row_split"])
+    if variant == "one-hot":
+        cfg.update(max_len=1, fixed=True, dim=64, rep=64 * 64 * 4, split=3000 * 64 * 4)
+    elif variant == "pooled-whole":        # the planner's return-volume term: the big pooled table stays whole
+        cfg.update(plan_pooling=6.0, expect_kinds=["replicated", "whole"])
+    elif variant == "self-via-comm":
+        cfg.update(self_via_comm=True)
+    elif variant == "empty-rank":
+        cfg.update(empty_rank=1)
+    res = _run(cfg, world, tmp_path)
+    for st in res:
+        assert st["stats_depth0"]["bytes_to_peers"] > 0 and st["stats_depth2"]["n_batches"] == 5
+    if variant == "self-via-comm":
+        assert all(st["stats_depth2"]["bytes_to_self"] > 0 for st in res)
+
+
+def test_shard_bad_index_raises_on_the_serving_rank_and_nobody_hangs(tmp_path):
+    """A row id outside its table, passed by rank 0: the rank that SERVES it (the last shard of a row-split table) raises
+    IndexError after the batch has gone through all its stages; every rank finishes."""
+    cfg = dict(rows=[7, 300, 5000, 64, 2000, 1500], dim=16, rep=64 * 16 * 4, split=3000 * 16 * 4, bags=29, max_len=1, fixed=True,
+               bad_index={"rank": 0, "table": 2}, batches=2)
+    res = _run(cfg, 3, tmp_path)
+    for depth in (0, 2):
+        raised = [st["raised_depth%d" % depth] for st in res]
+        assert raised == [False, False, True], raised
