@@ -68,13 +68,13 @@ def parse_args():
                          "GPU's HBM (the Kaggle config does), else 64")
     ap.add_argument("--no-exchange-leg", action="store_true",
                     help="N>1, auto policy: skip the secondary sharded-exchange measurement")
-    ap.add_argument("--shard-mode", choices=["whole", "rows"], default=None,
-                    help="N>1: big tables placed whole on owner ranks (default for c2: fewest enqueues per step) or split "
-                         "by row range over all ranks with GPU-side request routing (balanced xGMI egress; default for c4)")
-    ap.add_argument("--collective", choices=["torch", "native"], default="torch",
-                    help="N>1 sharded legs: torch.distributed.all_to_all_single (default) or grouped ncclSend/ncclRecv "
-                         "issued from the C side on the compute stream (emb_comm_*; verified with up to four ranks over RCCL's "
-                         "socket transport, never over xGMI)")
+    ap.add_argument("--shard-mode", choices=["whole", "rows", "plan"], default=None,
+                    help="N>1: big tables placed whole on owner ranks (default for c2: no routing kernel, no copy), split "
+                         "by row range over all ranks with GPU-side request routing (balanced xGMI egress; default for c4), or "
+                         "whatever the shard planner decides (plan)")
+    ap.add_argument("--collective", choices=["native"], default="native",
+                    help="kept for command-line compatibility: the sharded legs' transfers are always grouped ncclSend/ncclRecv "
+                         "issued from the C side (emb_comm_exchange inside emb_shard_*)")
     ap.add_argument("--streams", type=int, default=1,
                     help="N=1: round-robin the independent steps over this many HIP streams (default 1: every "
                          "step on one stream, which is what roofline.kernel_us assumes)")

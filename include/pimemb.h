@@ -365,9 +365,10 @@ int emb_comm_rank(const emb_comm *c, int32_t *rank, int32_t *world);
  *
  *   emb_shard_submit(s, in, n_bags, stream, &seq)   hand over this rank's batch: per table its indices / offsets / where the
  *                                                    pooled rows go.  Enqueue only (plus one short host wait, see below).
- *   emb_shard_wait(s, seq, stream)                  make `stream` wait until batch seq's pooled rows are in place
+ *   emb_shard_wait(s, seq, stream)                  make `stream` wait until batch seq's pooled rows are in place (a no-op for
+ *                                                    the submit stream itself: they are complete there in stream order)
  *   emb_shard_flush(s)                              push every submitted batch through its remaining stages
- *   emb_shard_lookup(...)                           submit + flush + wait: the synchronous form (depth 0)
+ *   emb_shard_lookup(...)                           submit + flush + wait: the synchronous form
  *
  * Placement of a table:
  *   EMB_PLACE_REPLICATED  every rank holds it: looked up locally, nothing travels;
@@ -380,16 +381,23 @@ int emb_comm_rank(const emb_comm *c, int32_t *rank, int32_t *world);
  * Counts first, payload second: what a rank will send each peer (sub-bags and indices per table) leaves before the payload,
  * so nothing has a capacity that skewed indices could overflow.  The one host wait of a batch is for those counts.
  *
- * Stages of batch b and where they run (the library owns four streams: route, comm, compute, un-route):
+ * Stages of batch b.  Every kernel runs on the CALLER's stream (pass the same stream to every submit; a change is
+ * honoured with one event), every transfer on one internal stream; events cross between the two only where a transfer
+ * really happens -- none at all with one rank:
  *   R(b) route + counts out | L(b) local lookup of the replicated tables        at submit(b)
  *   Q(b) host reads the counts, request pieces travel                           at submit(b + d_req)
- *   S(b) ONE fused lookup over every piece received; T(b) pooled rows return;
- *   U(b) partial rows added in shard order into the caller's buffers            at submit(b + d_serve)
- * with (d_req, d_serve) = (0, 0) for depth 0, (0, 1) for depth 1, (1, 2) for depth 2 (default): at depth 2 the counts a
- * rank waits for were sent a whole call earlier, so the host wait is short, and the return transfer of batch b overlaps the
- * lookup of batch b + 1.  A batch's inputs and outputs belong to the library from its submit until emb_shard_wait(seq) has
- * been ordered.  RCCL transfers of all ranks are issued in the same order because all ranks make the same calls: submit /
- * flush are COLLECTIVE (every rank, same order; a rank with nothing to look up submits n_bags = 0).
+ *   S(b) ONE fused lookup over every piece received; T(b) pooled rows return    at submit(b + d_serve)
+ *   U(b) partial rows added in shard order into the caller's buffers            at submit(b + d_un)
+ * with (d_req, d_serve, d_un) = (0, 0, 0) for depth 0, (0, 1, 1) for depth 1, (1, 2, 2) for depth 2 and (1, 2, 3) for depth 3:
+ * from depth 2 on the counts a rank waits for were sent a whole call earlier, so the host wait is short; at depth 3 the
+ * returned rows of batch b travel while the lookup of batch b + 1 runs (the un-router is enqueued a call later, behind it).
+ * Within a call the transfer stream gets the newest batch's counts, then the requests of the one before, then the returned
+ * rows of the one before that -- a lookup never queues behind a return transfer.  After submit(b + d_un) the pooled rows of
+ * batch b are complete in stream order on the caller's stream; emb_shard_wait orders another stream behind them.
+ * A batch's inputs and outputs belong to the library from its submit until then.  RCCL transfers of all ranks are issued in
+ * the same order because all ranks make the same calls: submit / flush are COLLECTIVE (every rank, same order; a rank
+ * with nothing to look up submits n_bags = 0).  Lookups that recur byte for byte (same buffers, same lengths: static batch
+ * slots) are served by prepared plans from their second sighting on.
  *
  * Indices and offsets are uint32 (the reference's width, emb_host.h:234); every table has `dim` columns; a batch has the
  * same number of bags for every table (the reference's MAX_NR_BATCHES).  At most 64 row-split tables per shard object. */
@@ -422,7 +430,7 @@ typedef struct emb_shard_input {      /* one per table, in table order */
 typedef struct emb_shard_config {
     uint32_t n_tables;
     uint32_t dim;
-    uint32_t depth;           /* 0, 1 or 2 (see above) */
+    uint32_t depth;           /* 0 .. 3 (see above) */
     uint32_t flags;           /* EMB_SHARD_* */
     const emb_shard_table *tables;
 } emb_shard_config;
@@ -436,6 +444,10 @@ typedef struct emb_shard_stats {
     uint64_t served_sub_bags, served_indices;
     double us_host_submit;            /* host time inside emb_shard_submit / _flush, all stages */
     double us_host_wait_counts;       /* ... of it: waiting for the counts */
+    /* device time of the four kernel families, HIP events on their own streams, summed over the batches that ran while
+     * emb_shard_set_kernel_timing was on: R router, L local lookup, S fused lookup over received pieces, U un-router */
+    double us_kernel_route, us_kernel_local, us_kernel_serve, us_kernel_unroute;
+    uint64_t n_timed_batches;
 } emb_shard_stats;
 /* comm may be NULL for a world of one rank (everything is "self"). */
 int emb_shard_create(emb_engine *e, emb_comm *comm, const emb_shard_config *cfg, emb_shard **out);
@@ -444,8 +456,10 @@ int emb_shard_flush(emb_shard *s);
 int emb_shard_wait(emb_shard *s, uint64_t seq, void *stream);
 int emb_shard_lookup(emb_shard *s, const emb_shard_input *in, uint64_t n_bags, void *stream);
 int emb_shard_get_stats(emb_shard *s, emb_shard_stats *out, int reset);
+/* Bracket the library's kernels with timing events (off by default: an event between two kernels costs GPU time itself). */
+int emb_shard_set_kernel_timing(emb_shard *s, int on);
 /* Per-(peer, table) request counts {sub-bags, indices} of the row-split tables this rank SENT for batch seq: uint32
- * [n_ranks][n_row_split][2] (reporting; valid until the batch's slot is reused, four submits later). */
+ * [n_ranks][n_row_split][2] (reporting; valid until the batch's slot is reused, six submits later). */
 int emb_shard_sent_counts(emb_shard *s, uint64_t seq, uint32_t *counts, uint32_t capacity_words);
 int emb_shard_destroy(emb_shard *s);
 

@@ -8,15 +8,22 @@
 //     R route + counts out, L local lookup   ->   Q counts in (host), requests travel   ->   S fused lookup over what
 //     arrived, T pooled rows return, U partial rows added in shard order
 //
-// software-pipelined over consecutive batches (depth 0..2).  Everything between two kernels is an RCCL group issued from
+// software-pipelined over consecutive batches (depth 0..3).  Everything between two kernels is an RCCL group issued from
 // here (emb_comm_exchange) or nothing at all: pieces a rank addresses to itself are served in place, whole tables travel
 // straight out of / into the caller's buffers.  The only host wait of a batch is for the counts, which a small kernel
 // drops into pinned memory behind a flag word (polled; no event, no copy engine).
+//
+// Streams.  Every kernel (R, L, S, U) is enqueued on the CALLER's stream, every transfer on ONE internal stream; an event
+// crosses between the two only where a transfer really happens (counts out, requests in, rows out, rows back: four
+// records + four waits per batch with peers, none at all with one rank).  The first version ran R / S+L / U on three
+// internal streams with an input event per batch: 16 event operations and ~60 us of host time per step on this runtime
+// (an event record or wait costs ~3 us, the first kernel behind a cross-stream wait several times that).
 //
 // No lookup is computed here: S and L are emb_lookup_batched launches (pimemb_engine.cpp), R and U the routing kernels
 // (pimemb_kernels.hip).  This file is streams, events, byte offsets and the order in which all ranks issue transfers.
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -46,7 +53,20 @@ double now_us() {
     return duration<double, std::micro>(steady_clock::now().time_since_epoch()).count();
 }
 
-constexpr int kRing = 4;            // batches in flight at most: depth 2 keeps three live, the fourth slot is being filled
+// PIMEMB_SHARD_PROFILE=1: where the host time of a step goes, printed by emb_shard_destroy (developer aid).
+struct HostProf {
+    bool on = getenv("PIMEMB_SHARD_PROFILE") != nullptr;
+    double acc[16] = {};
+    const char *name[16] = {"", "route kernels", "whole counts", "ev_routed", "counts exchange", "publish", "local lookup",
+                            "wait counts", "sizes+ensure", "request exchange", "serve descs", "serve lookup", "return exchange",
+                            "unroute", "", ""};
+    double t = 0;
+    void start() { if (on) t = now_us(); }
+    void lap(int k) { if (on) { const double n = now_us(); acc[k] += n - t; t = n; } }
+};
+HostProf g_hp;
+
+constexpr int kRing = 6;            // batches in flight at most: depth 3 keeps four live, one slot is being filled, one to spare
 constexpr uint32_t kWholeWords = 4; // words of a whole-table count entry: {bags, indices, fixed pooling (0 = offsets travel), 0}
 
 inline uint64_t pad4(uint64_t v) { return (v + 3u) & ~(uint64_t)3u; }
@@ -67,7 +87,7 @@ struct DeviceGuard {
     }
 };
 
-enum Stage : int { FREE = 0, ROUTED = 1, REQUESTED = 2, SERVED = 3 };
+enum Stage : int { FREE = 0, ROUTED = 1, REQUESTED = 2, SERVED = 3, DONE = 4 };
 
 struct Batch {
     uint64_t seq = ~0ull;
@@ -80,13 +100,14 @@ struct Batch {
     uint32_t *wc_host = nullptr;        // whole-table counts this rank sends: [sum_p |whole_of[p]|][kWholeWords]
     uint32_t *counts_host = nullptr;    // [sent row counts N(Kr+1)2 | received row counts N(Kr+1)2 | received whole counts N*M*4]
     unsigned long long *flag = nullptr; // raised (= seq + 1) behind counts_host by publish_words_kernel
-    hipEvent_t ev_in = nullptr, ev_routed = nullptr, ev_req = nullptr, ev_served = nullptr, ev_ret = nullptr,
-               ev_local = nullptr, ev_out = nullptr;
-    bool out_recorded = false, ret_recorded = false, local_recorded = false, counts_posted = false;
-    bool prev_pending = false;          // ev_out still carries the record of the slot's PREVIOUS occupant (until this batch's U)
+    hipEvent_t ev_routed = nullptr, ev_req = nullptr, ev_served = nullptr, ev_ret = nullptr, ev_out = nullptr;
+    bool req_recorded = false, ret_recorded = false, out_recorded = false, counts_posted = false;
     // per-peer sizes of this batch (row-split path), from the counts
     std::vector<uint64_t> out_words, in_words, rows_back, rows_served;
     int deferred_rc = EMB_OK;
+    // optional kernel timing (emb_shard_set_kernel_timing): start / stop around R, L, S, U
+    hipEvent_t tev[8] = {};
+    bool timed[4] = {false, false, false, false}, harvest = false;
 };
 
 }  // namespace
@@ -104,40 +125,82 @@ struct emb_shard {
     std::vector<uint32_t> elem_bytes;                // per table: element size of what this rank holds (0: nothing held)
     uint32_t Kr = 0, M = 0, Wtot = 0;                // row-split tables, whole tables owned here, whole tables in all
     bool self_via_comm = false, check_served = false;
-    hipStream_t s_route = nullptr, s_comm = nullptr, s_comp = nullptr, s_un = nullptr;
-    DevBuf work;                                     // scratch of one route call (ordered on s_route)
+    hipStream_t s_comm = nullptr;                    // every transfer (RCCL group) of every batch, in one order on all ranks
+    hipStream_t cs = nullptr;                        // the caller's stream: every kernel runs there
+    bool cs_known = false;
+    hipEvent_t ev_switch = nullptr;                  // the caller changed streams between two submits
+    DevBuf work;                                     // scratch of one route call (ordered on the caller's stream)
+    struct CachedPlan {
+        std::vector<emb_lookup_desc> key;
+        emb_plan *plan = nullptr;
+        uint64_t last_use = 0, seen = 0;
+    };
+    std::vector<CachedPlan> plans;                   // recurring lookups (same buffers, same lengths): one emb_plan_launch
+    uint64_t plan_clock = 0;
     Batch ring[kRing];
     uint64_t next_seq = 0;
     double timeout_s = 60.0;
     emb_shard_stats st{};
     std::vector<emb_comm_op> ops;                    // scratch
     std::vector<emb_lookup_desc> descs;              // scratch
+    std::vector<emb_lookup_desc> local;              // L(n) of the batch being submitted: launched together with the S of an older
+                                                     // batch that is served in the same call (one launch instead of two), else alone
+    Batch *local_of = nullptr;
+    bool kernel_timing = false;
 };
 
 namespace {
 
-int ensure(emb_shard *s, Batch &b, DevBuf &buf, size_t bytes) {
+// Grow-only device buffer of a slot.  The slot's previous occupant went through all its stages at least two submits ago,
+// but its kernels may still be queued: growing (rare: 25 % headroom) waits for the caller's stream and the transfer stream.
+int ensure(emb_shard *s, DevBuf &buf, size_t bytes) {
     if (buf.cap >= bytes && buf.p) return EMB_OK;
-    // the slot's previous occupant may still be running on the device: its last reader is behind ev_out
-    if (b.prev_pending || b.out_recorded) HIP_TRY(hipEventSynchronize(b.ev_out));
-    b.prev_pending = false;
+    if (s->cs_known) HIP_TRY(hipStreamSynchronize(s->cs));
+    HIP_TRY(hipStreamSynchronize(s->s_comm));
     if (buf.p) HIP_TRY(hipFree(buf.p));
     buf.p = nullptr;
     buf.cap = 0;
     const size_t cap = bytes + bytes / 4 + 256;
     HIP_TRY(hipMalloc(&buf.p, cap));
     buf.cap = cap;
-    (void)s;
     return EMB_OK;
+}
+
+// Kernel timing (off by default: an event between two kernels of a stream costs GPU time of its own).  which: 0 R, 1 L, 2 S, 3 U.
+int tick(emb_shard *s, Batch &b, int which, bool stop) {
+    if (!s->kernel_timing) return EMB_OK;
+    hipEvent_t &ev = b.tev[2 * which + (stop ? 1 : 0)];
+    if (!ev) HIP_TRY(hipEventCreate(&ev));
+    HIP_TRY(hipEventRecord(ev, s->cs));
+    if (stop) b.timed[which] = b.harvest = true;
+    return EMB_OK;
+}
+
+// Add a finished batch's kernel times to the stats (waits for the last of its brackets).
+void harvest(emb_shard *s, Batch &b) {
+    if (!b.harvest) return;
+    b.harvest = false;
+    double *dst[4] = {&s->st.us_kernel_route, &s->st.us_kernel_local, &s->st.us_kernel_serve, &s->st.us_kernel_unroute};
+    for (int w = 0; w < 4; w++) {
+        if (!b.timed[w]) continue;
+        b.timed[w] = false;
+        float ms = 0.f;
+        if (hipEventSynchronize(b.tev[2 * w + 1]) == hipSuccess && hipEventElapsedTime(&ms, b.tev[2 * w], b.tev[2 * w + 1]) == hipSuccess)
+            *dst[w] += ms * 1000.0;
+    }
+    s->st.n_timed_batches++;
+    (void)hipGetLastError();
 }
 
 // whether peer p's pieces travel through RCCL (false: p is this rank and is served in place)
 inline bool via_comm(const emb_shard *s, int p) { return p != s->rank || s->self_via_comm; }
 
-int exchange(emb_shard *s, hipStream_t st) {
+int exchange(emb_shard *s) {
     if (s->ops.empty()) return EMB_OK;
     if (!s->comm) return fail(EMB_ERR_INVALID, "emb_shard: a transfer to a peer without a communicator");
-    return emb_comm_exchange(s->comm, s->ops.data(), (uint32_t)s->ops.size(), st);
+    for (const emb_comm_op &o : s->ops)
+        if (!o.is_recv) (o.peer == s->rank ? s->st.bytes_to_self : s->st.bytes_to_peers) += o.bytes;
+    return emb_comm_exchange(s->comm, s->ops.data(), (uint32_t)s->ops.size(), s->s_comm);
 }
 
 inline void add_op(emb_shard *s, int peer, bool recv, const void *ptr, uint64_t bytes) {
@@ -148,19 +211,60 @@ inline uint32_t *sent_counts(const emb_shard *s, const Batch &b) { (void)s; retu
 inline uint32_t *recv_counts(const emb_shard *s, const Batch &b) { return b.counts_host + (size_t)s->N * (s->Kr + 1) * 2; }
 inline uint32_t *recv_whole(const emb_shard *s, const Batch &b) { return b.counts_host + (size_t)s->N * (s->Kr + 1) * 4; }
 
-// ---- R(b) + counts out + L(b) -------------------------------------------------------------------------------------
-int stage_route(emb_shard *s, Batch &b, hipStream_t caller) {
-    const uint32_t N = (uint32_t)s->N, Kr = s->Kr, M = s->M;
-    HIP_TRY(hipEventRecord(b.ev_in, caller));
-    HIP_TRY(hipStreamWaitEvent(s->s_route, b.ev_in, 0));
-    if (b.out_recorded && hipEventQuery(b.ev_out) != hipSuccess) {   // the slot's previous occupant (four batches ago): normally long done
-        HIP_TRY(hipStreamWaitEvent(s->s_route, b.ev_out, 0));
-        HIP_TRY(hipStreamWaitEvent(s->s_comm, b.ev_out, 0));
-        HIP_TRY(hipStreamWaitEvent(s->s_comp, b.ev_out, 0));
+// One fused lookup over s->descs on the caller's stream.  A call that recurs byte for byte (same tables, same buffers, same
+// lengths: static batch slots, fixed-size whole-table pieces) is served by a prepared plan from its second sighting on --
+// one kernel enqueue, no descriptor resolution.  A plan holds addresses, never values.  Checked lookups never use plans.
+int fused_lookup(emb_shard *s, Batch &b, bool cacheable) {
+    const uint32_t n = (uint32_t)s->descs.size();
+    if (n == 0) return EMB_OK;
+    if (s->check_served) {
+        uint64_t bad = 0;
+        int rc = emb_lookup_batched_checked(s->e, s->descs.data(), n, EMB_IDX_U32, EMB_MEM_DEVICE, s->cs, &bad);
+        if (rc == EMB_ERR_RANGE) {          // nothing was gathered: the pieces pool to zero rows, the batch still completes
+            for (const emb_lookup_desc &d : s->descs)
+                HIP_TRY(hipMemsetAsync(d.pooled, 0, d.n_bags * (size_t)s->dim * 4, s->cs));
+            b.deferred_rc = EMB_ERR_RANGE;
+            return EMB_OK;
+        }
+        return rc;
     }
-    (void)hipGetLastError();
-    b.prev_pending = b.out_recorded;
-    b.out_recorded = b.ret_recorded = b.local_recorded = false;
+    if (cacheable) {
+        s->plan_clock++;
+        emb_shard::CachedPlan *hit = nullptr, *victim = nullptr;
+        for (emb_shard::CachedPlan &c : s->plans) {
+            if (c.key.size() == n && memcmp(c.key.data(), s->descs.data(), n * sizeof(emb_lookup_desc)) == 0) hit = &c;
+            if (!victim || c.last_use < victim->last_use) victim = &c;
+        }
+        if (hit) {
+            hit->last_use = s->plan_clock;
+            if (hit->plan && emb_plan_launch(hit->plan, s->cs) == EMB_OK) return EMB_OK;
+            if (hit->plan) {                 // stale (a table was reloaded): rebuild below
+                (void)emb_plan_destroy(hit->plan);
+                hit->plan = nullptr;
+            }
+            if (++hit->seen >= 2 && emb_plan_create(s->e, s->descs.data(), n, EMB_IDX_U32, &hit->plan) == EMB_OK)
+                return emb_plan_launch(hit->plan, s->cs);
+        } else {
+            if (s->plans.size() < 16) {
+                s->plans.emplace_back();
+                victim = &s->plans.back();
+            } else if (victim->plan) {       // (destroying a plan waits for the device: only signatures that stopped recurring get here)
+                (void)emb_plan_destroy(victim->plan);
+                victim->plan = nullptr;
+            }
+            victim->key.assign(s->descs.begin(), s->descs.end());
+            victim->seen = 1;
+            victim->last_use = s->plan_clock;
+        }
+    }
+    return emb_lookup_batched(s->e, s->descs.data(), n, EMB_IDX_U32, EMB_MEM_DEVICE, s->cs);
+}
+
+// ---- R(b) + counts out + L(b) -------------------------------------------------------------------------------------
+int stage_route(emb_shard *s, Batch &b) {
+    const uint32_t N = (uint32_t)s->N, Kr = s->Kr, M = s->M;
+    g_hp.start();
+    b.req_recorded = b.ret_recorded = b.out_recorded = false;
     b.deferred_rc = EMB_OK;
 
     // row-split tables: cut every bag into per-shard sub-bags; the counts sit at the head of `meta`
@@ -169,30 +273,27 @@ int stage_route(emb_shard *s, Batch &b, hipStream_t caller) {
     if (Kr) {
         uint64_t sb = 0, mb = 0, lb = 0, wb = 0;
         EMB_TRY(emb_route_bags_sizes(Kr, std::max<uint64_t>(b.n_bags, 1), total_idx, N, &sb, &mb, &lb, &wb));
-        EMB_TRY(ensure(s, b, b.req_send, sb));
-        EMB_TRY(ensure(s, b, b.meta, mb));
-        EMB_TRY(ensure(s, b, b.slotmap, lb));
-        if (s->work.cap < wb) {
-            HIP_TRY(hipStreamSynchronize(s->s_route));      // the previous route call's scratch
-            if (s->work.p) HIP_TRY(hipFree(s->work.p));
-            s->work.p = nullptr;
-            s->work.cap = 0;
-            HIP_TRY(hipMalloc(&s->work.p, wb + wb / 4));
-            s->work.cap = wb + wb / 4;
-        }
+        EMB_TRY(ensure(s, b.req_send, sb));
+        EMB_TRY(ensure(s, b.meta, mb));
+        EMB_TRY(ensure(s, b.slotmap, lb));
+        EMB_TRY(ensure(s, s->work, wb));
         if (b.n_bags) {
+            EMB_TRY(tick(s, b, 0, false));
             emb_route_table rt[pimemb::kRouteBagMaxTables];
             for (uint32_t k = 0; k < Kr; k++) {
                 const emb_shard_input &u = b.in[s->rows[k]];
                 rt[k] = emb_route_table{u.indices, u.offsets, u.n_indices, u.fixed_pooling, s->tabs[s->rows[k]].rows_per_shard};
             }
             EMB_TRY(emb_route_bags(s->e, rt, Kr, b.n_bags, N, b.req_send.p, static_cast<uint32_t *>(b.meta.p),
-                                   static_cast<uint32_t *>(b.slotmap.p), s->work.p, s->s_route));
+                                   static_cast<uint32_t *>(b.slotmap.p), s->work.p, s->cs));
+            EMB_TRY(tick(s, b, 0, true));
         } else {         // nothing to ask for: all counts (and peaks) zero; this rank still serves
-            HIP_TRY(pimemb::launch_zero_words(static_cast<uint32_t *>(b.meta.p), pimemb::route_meta_counts_words(Kr, N), s->s_route));
+            HIP_TRY(pimemb::launch_zero_words(static_cast<uint32_t *>(b.meta.p), pimemb::route_meta_counts_words(Kr, N), s->cs));
         }
     }
+    g_hp.lap(1);
     // whole tables: what this rank asks each owner for is known on the host
+    bool remote_whole = false;
     if (s->Wtot) {
         for (uint32_t p = 0, w = 0; p < N; p++)
             for (uint32_t t : s->whole_of[p]) {
@@ -203,13 +304,11 @@ int stage_route(emb_shard *s, Batch &b, hipStream_t caller) {
                 c[2] = u.offsets ? 0u : u.fixed_pooling;
                 c[3] = 0;
             }
-        bool any_remote = false;
-        for (uint32_t p = 0; p < N; p++) any_remote |= via_comm(s, (int)p) && !s->whole_of[p].empty();
-        if (any_remote)
-            HIP_TRY(hipMemcpyAsync(b.wc_send.p, b.wc_host, (size_t)s->Wtot * kWholeWords * 4, hipMemcpyHostToDevice, s->s_route));
+        for (uint32_t p = 0; p < N; p++) remote_whole |= via_comm(s, (int)p) && !s->whole_of[p].empty();
+        if (remote_whole)
+            HIP_TRY(hipMemcpyAsync(b.wc_send.p, b.wc_host, (size_t)s->Wtot * kWholeWords * 4, hipMemcpyHostToDevice, s->cs));
     }
-    HIP_TRY(hipEventRecord(b.ev_routed, s->s_route));
-    HIP_TRY(hipStreamWaitEvent(s->s_comm, b.ev_routed, 0));
+    g_hp.lap(2);
 
     // the counts leave FIRST (emb_host.h:280-287 sends the lengths before every launch)
     s->ops.clear();
@@ -225,25 +324,32 @@ int stage_route(emb_shard *s, Batch &b, hipStream_t caller) {
         add_op(s, (int)p, true, static_cast<char *>(b.counts_in.p) + N * row_msg + (size_t)p * M * kWholeWords * 4,
                (size_t)M * kWholeWords * 4);
     }
-    for (const emb_comm_op &o : s->ops)
-        if (!o.is_recv) (o.peer == s->rank ? s->st.bytes_to_self : s->st.bytes_to_peers) += o.bytes;
-    EMB_TRY(exchange(s, s->s_comm));
+    const bool peers = !s->ops.empty();
+    if (peers) {         // the transfer stream takes over behind the router (and behind whatever produced the caller's inputs)
+        HIP_TRY(hipEventRecord(b.ev_routed, s->cs));
+        HIP_TRY(hipStreamWaitEvent(s->s_comm, b.ev_routed, 0));
+        g_hp.lap(3);
+        EMB_TRY(exchange(s));
+    }
+    g_hp.lap(4);
     // ... and reach the host behind a flag word
     *b.flag = 0;
     b.counts_posted = false;
-    if (Kr || !s->ops.empty()) {
+    if (Kr || peers) {
         const uint32_t *src[3] = {Kr ? static_cast<const uint32_t *>(b.meta.p) : nullptr,
-                                  Kr ? static_cast<const uint32_t *>(b.counts_in.p) : nullptr,
-                                  M ? static_cast<const uint32_t *>(b.counts_in.p) + (size_t)N * (Kr + 1) * 2 : nullptr};
+                                  Kr && peers ? static_cast<const uint32_t *>(b.counts_in.p) : nullptr,
+                                  M && peers ? static_cast<const uint32_t *>(b.counts_in.p) + (size_t)N * (Kr + 1) * 2 : nullptr};
         const uint32_t n[3] = {N * (Kr + 1) * 2, N * (Kr + 1) * 2, N * M * kWholeWords};
-        HIP_TRY(pimemb::launch_publish_words(src, n, b.counts_host, b.flag, b.seq + 1, s->s_comm));
+        HIP_TRY(pimemb::launch_publish_words(src, n, b.counts_host, b.flag, b.seq + 1, peers ? s->s_comm : s->cs));
         b.counts_posted = true;
     }
+    g_hp.lap(5);
 
-    // L(b): replicated tables, this rank's own bags
+    // L(b): replicated tables, this rank's own bags -- described here, launched by launch_local / together with an older
+    // batch's S (stage_serve)
+    s->local.clear();
+    s->local_of = nullptr;
     if (!s->rep.empty() && b.n_bags) {
-        HIP_TRY(hipStreamWaitEvent(s->s_comp, b.ev_in, 0));
-        s->descs.clear();
         for (uint32_t t : s->rep) {
             const emb_shard_input &u = b.in[t];
             emb_lookup_desc d{};
@@ -254,33 +360,35 @@ int stage_route(emb_shard *s, Batch &b, hipStream_t caller) {
             d.n_indices = u.n_indices;
             d.n_bags = b.n_bags;
             d.pooled = u.pooled;
-            s->descs.push_back(d);
+            s->local.push_back(d);
             s->st.local_algorithmic_bytes += u.n_indices * ((uint64_t)s->dim * s->elem_bytes[t] + 4) +
                                              (u.offsets ? b.n_bags * 4 : 0) + b.n_bags * (uint64_t)s->dim * 4;
         }
-        if (s->check_served) {      // the caller's own ids against the replicated tables
-            uint64_t bad = 0;
-            int rc = emb_lookup_batched_checked(s->e, s->descs.data(), (uint32_t)s->descs.size(), EMB_IDX_U32, EMB_MEM_DEVICE, s->s_comp, &bad);
-            if (rc == EMB_ERR_RANGE) {
-                for (const emb_lookup_desc &d : s->descs)
-                    HIP_TRY(hipMemsetAsync(d.pooled, 0, d.n_bags * (size_t)s->dim * 4, s->s_comp));
-                b.deferred_rc = EMB_ERR_RANGE;
-            } else if (rc) {
-                return rc;
-            }
-        } else {
-            EMB_TRY(emb_lookup_batched(s->e, s->descs.data(), (uint32_t)s->descs.size(), EMB_IDX_U32, EMB_MEM_DEVICE, s->s_comp));
-        }
-        HIP_TRY(hipEventRecord(b.ev_local, s->s_comp));
-        b.local_recorded = true;
+        s->local_of = &b;
     }
+    g_hp.lap(6);
     b.stage = ROUTED;
+    return EMB_OK;
+}
+
+// L(b) on its own (no older batch is served in this call: the pipeline is filling, or depth 0 / flush order).
+int launch_local(emb_shard *s) {
+    if (s->local.empty()) return EMB_OK;
+    Batch &b = *s->local_of;
+    s->descs.swap(s->local);
+    s->local.clear();
+    s->local_of = nullptr;
+    EMB_TRY(tick(s, b, 1, false));
+    EMB_TRY(fused_lookup(s, b, true));
+    EMB_TRY(tick(s, b, 1, true));
     return EMB_OK;
 }
 
 // ---- Q(b): the one host wait, then the request pieces ----------------------------------------------------------------
 int stage_request(emb_shard *s, Batch &b) {
     const uint32_t N = (uint32_t)s->N, Kr = s->Kr, M = s->M;
+    g_hp.start();
+    const size_t counts_words = (size_t)N * ((Kr + 1) * 4 + M * kWholeWords);
     if (b.counts_posted) {
         const double t0 = now_us();
         volatile unsigned long long *flag = b.flag;
@@ -288,15 +396,16 @@ int stage_request(emb_shard *s, Batch &b) {
         while (*flag != b.seq + 1) {
             if ((++spins & 0xfffu) == 0 && now_us() - t0 > s->timeout_s * 1e6) {
                 const hipError_t q = hipStreamQuery(s->s_comm);
-                return fail(EMB_ERR_DEVICE, "emb_shard: the counts of batch %llu did not arrive within %.0f s (comm stream: %s) -- a peer is "
-                            "missing, or the ranks did not make the same calls", (unsigned long long)b.seq, s->timeout_s,
+                return fail(EMB_ERR_DEVICE, "emb_shard: the counts of batch %llu did not arrive within %.0f s (transfer stream: %s) -- a peer "
+                            "is missing, or the ranks did not make the same calls", (unsigned long long)b.seq, s->timeout_s,
                             hipGetErrorString(q));
             }
         }
         s->st.us_host_wait_counts += now_us() - t0;
     } else {
-        memset(b.counts_host, 0, (size_t)N * ((Kr + 1) * 4 + M * kWholeWords) * 4);
+        memset(b.counts_host, 0, counts_words * 4);
     }
+    g_hp.lap(7);
     uint32_t *sent = sent_counts(s, b), *recv = recv_counts(s, b), *rwhole = recv_whole(s, b);
     if (!via_comm(s, s->rank)) {       // what this rank asked ITSELF for never travelled
         if (Kr) memcpy(recv + (size_t)s->rank * (Kr + 1) * 2, sent + (size_t)s->rank * (Kr + 1) * 2, (size_t)(Kr + 1) * 8);
@@ -325,9 +434,10 @@ int stage_request(emb_shard *s, Batch &b) {
                 whole_rows += c[0];
             }
     }
-    EMB_TRY(ensure(s, b, b.req_recv, (in_w + whole_in_w) * 4 + 16));
-    EMB_TRY(ensure(s, b, b.ret_send, (served + whole_rows) * (uint64_t)s->dim * 4 + 16));
-    EMB_TRY(ensure(s, b, b.ret_recv, back * (uint64_t)s->dim * 4 + 16));
+    EMB_TRY(ensure(s, b.req_recv, (in_w + whole_in_w) * 4 + 16));
+    EMB_TRY(ensure(s, b.ret_send, (served + whole_rows) * (uint64_t)s->dim * 4 + 16));
+    EMB_TRY(ensure(s, b.ret_recv, back * (uint64_t)s->dim * 4 + 16));
+    g_hp.lap(8);
 
     s->ops.clear();
     uint64_t out_at = 0, in_at = 0, win_at = in_w;
@@ -353,25 +463,37 @@ int stage_request(emb_shard *s, Batch &b) {
         out_at += b.out_words[p];
         in_at += b.in_words[p];
     }
-    for (const emb_comm_op &o : s->ops)
-        if (!o.is_recv) (o.peer == s->rank ? s->st.bytes_to_self : s->st.bytes_to_peers) += o.bytes;
-    EMB_TRY(exchange(s, s->s_comm));
-    HIP_TRY(hipEventRecord(b.ev_req, s->s_comm));
+    if (!s->ops.empty()) {          // (the transfer stream is already behind R(b): it carried the counts)
+        EMB_TRY(exchange(s));
+        HIP_TRY(hipEventRecord(b.ev_req, s->s_comm));
+        b.req_recorded = true;
+    }
+    g_hp.lap(9);
     b.stage = REQUESTED;
     return EMB_OK;
 }
 
-// ---- S(b), T(b), U(b) --------------------------------------------------------------------------------------------------
+// ---- S(b) + T(b) ---------------------------------------------------------------------------------------------------------
 int stage_serve(emb_shard *s, Batch &b) {
     const uint32_t N = (uint32_t)s->N, Kr = s->Kr, M = s->M, dim = s->dim;
     uint32_t *recv = recv_counts(s, b), *rwhole = recv_whole(s, b);
-    HIP_TRY(hipStreamWaitEvent(s->s_comp, b.ev_req, 0));      // the pieces have arrived (and, with it, R(b) has run)
+    g_hp.start();
+    if (b.req_recorded) HIP_TRY(hipStreamWaitEvent(s->cs, b.ev_req, 0));      // the pieces have arrived
     uint64_t in_w = 0, served = 0;
     for (uint32_t p = 0; p < N; p++) {
         in_w += b.in_words[p];
         served += b.rows_served[p];
     }
+    // ONE launch for everything this call looks up: the replicated tables of the batch being submitted (if it is another
+    // batch: L(n) next to S(n - 2)) and every piece received for this one
+    Batch *fused_with = (s->local_of && s->local_of != &b) ? s->local_of : nullptr;
+    if (s->local_of == &b) EMB_TRY(launch_local(s));      // depth 0: the same batch -- its L goes first, on its own
     s->descs.clear();
+    if (fused_with) {
+        s->descs.swap(s->local);
+        s->local.clear();
+        s->local_of = nullptr;
+    }
     uint64_t alg = 0, n_sub = 0, n_idx = 0;
     // row pieces: source s asked for sub-bags of my shard of table k -- an ordinary lookup each
     uint64_t in_at = 0, out_at = 0, served_at = 0, back_at = 0;
@@ -441,26 +563,17 @@ int stage_serve(emb_shard *s, Batch &b) {
             }
         }
     }
+    g_hp.lap(10);
     if (!s->descs.empty()) {
-        int rc;
-        if (s->check_served) {
-            uint64_t bad = 0;
-            rc = emb_lookup_batched_checked(s->e, s->descs.data(), (uint32_t)s->descs.size(), EMB_IDX_U32, EMB_MEM_DEVICE, s->s_comp, &bad);
-            if (rc == EMB_ERR_RANGE) {          // nothing was gathered: the pieces pool to zero rows, the batch still completes
-                for (const emb_lookup_desc &d : s->descs)
-                    HIP_TRY(hipMemsetAsync(d.pooled, 0, d.n_bags * (size_t)dim * 4, s->s_comp));
-                b.deferred_rc = EMB_ERR_RANGE;
-                rc = EMB_OK;
-            }
-        } else {
-            rc = emb_lookup_batched(s->e, s->descs.data(), (uint32_t)s->descs.size(), EMB_IDX_U32, EMB_MEM_DEVICE, s->s_comp);
-        }
-        if (rc) return rc;
+        EMB_TRY(tick(s, b, 2, false));
+        EMB_TRY(fused_lookup(s, b, /*cacheable=*/Kr == 0));      // (row pieces change size with every batch: nothing recurs)
+        EMB_TRY(tick(s, b, 2, true));
+        if (fused_with && b.deferred_rc != EMB_OK) fused_with->deferred_rc = b.deferred_rc;
     }
     s->st.served_algorithmic_bytes += alg;
     s->st.served_sub_bags += n_sub;
     s->st.served_indices += n_idx;
-    HIP_TRY(hipEventRecord(b.ev_served, s->s_comp));
+    g_hp.lap(11);
 
     // T(b): partial rows back to the bags' owners; whole tables' pooled rows straight into the callers' buffers
     s->ops.clear();
@@ -481,51 +594,69 @@ int stage_serve(emb_shard *s, Batch &b) {
         back_at += b.rows_back[p];
     }
     if (!s->ops.empty()) {
-        for (const emb_comm_op &o : s->ops)
-            if (!o.is_recv) (o.peer == s->rank ? s->st.bytes_to_self : s->st.bytes_to_peers) += o.bytes;
+        HIP_TRY(hipEventRecord(b.ev_served, s->cs));
         HIP_TRY(hipStreamWaitEvent(s->s_comm, b.ev_served, 0));
-        EMB_TRY(exchange(s, s->s_comm));
+        EMB_TRY(exchange(s));
         HIP_TRY(hipEventRecord(b.ev_ret, s->s_comm));
         b.ret_recorded = true;
     }
-
-    // U(b): on its own stream, so that neither the next lookup nor the next transfer queues behind this batch's return
-    HIP_TRY(hipStreamWaitEvent(s->s_un, b.ev_served, 0));
-    if (b.ret_recorded) HIP_TRY(hipStreamWaitEvent(s->s_un, b.ev_ret, 0));
-    if (b.local_recorded) HIP_TRY(hipStreamWaitEvent(s->s_un, b.ev_local, 0));
-    if (Kr && b.n_bags) {
-        float *outs[pimemb::kRouteBagMaxTables];
-        for (uint32_t k = 0; k < Kr; k++) outs[k] = b.in[s->rows[k]].pooled;
-        HIP_TRY(pimemb::launch_unroute_bags_to(static_cast<float *>(b.ret_recv.p), static_cast<uint32_t *>(b.meta.p),
-                                               static_cast<uint32_t *>(b.slotmap.p), Kr, b.n_bags, N, dim, outs, s->s_un));
-    }
-    HIP_TRY(hipEventRecord(b.ev_out, s->s_un));
-    b.out_recorded = true;
-    b.prev_pending = false;
+    g_hp.lap(12);
     b.stage = SERVED;
+    return EMB_OK;
+}
+
+// ---- U(b): partial rows added in shard order, into the caller's buffers ------------------------------------------------------
+int stage_unroute(emb_shard *s, Batch &b) {
+    g_hp.start();
+    if (b.ret_recorded) HIP_TRY(hipStreamWaitEvent(s->cs, b.ev_ret, 0));       // the rows are back (whole tables: already in place)
+    if (s->Kr && b.n_bags) {
+        float *outs[pimemb::kRouteBagMaxTables];
+        for (uint32_t k = 0; k < s->Kr; k++) outs[k] = b.in[s->rows[k]].pooled;
+        EMB_TRY(tick(s, b, 3, false));
+        HIP_TRY(pimemb::launch_unroute_bags_to(static_cast<float *>(b.ret_recv.p), static_cast<uint32_t *>(b.meta.p),
+                                               static_cast<uint32_t *>(b.slotmap.p), s->Kr, b.n_bags, (uint32_t)s->N, s->dim, outs, s->cs));
+        EMB_TRY(tick(s, b, 3, true));
+    }
+    g_hp.lap(13);
+    b.stage = DONE;
     s->st.n_batches++;
     return EMB_OK;
 }
 
-// Advance every live batch that is at least (d_req, d_serve) submits old, oldest first -- the same order on every rank.
-int advance(emb_shard *s, uint64_t d_req, uint64_t d_serve) {
+// (requests, lookups + returns, un-routing) of a batch happen (d_req, d_serve, d_un) submits after its own
+struct Lag { uint64_t req, serve, un; };
+constexpr Lag kLag[4] = {{0, 0, 0}, {0, 1, 1}, {1, 2, 2}, {1, 2, 3}};
+
+// Advance every live batch that is old enough, oldest first within a stage -- the same order on every rank.  Per call the
+// transfer stream gets: counts of the newest batch, THEN the requests of the one before it, THEN the returned rows of the
+// one before that -- so a lookup never queues behind a return transfer -- and the un-router of a batch runs at the END of a
+// call, behind the lookup of a younger one: its rows have had that whole call to come back.
+int advance(emb_shard *s, const Lag &lag, bool everything) {
     int deferred = EMB_OK;
     const uint64_t newest = s->next_seq;        // one past the last submitted
     const uint64_t first = newest > kRing ? newest - kRing : 0;
-    // requests of younger batches go out BEFORE the return transfer of older ones (see the header: Q(n-1) ahead of T(n-2) on
-    // the comm stream, so the next lookup never waits out a return)
+    auto old_enough = [&](uint64_t q, uint64_t d) { return everything || q + d < newest; };
     for (uint64_t q = first; q < newest; q++) {
         Batch &b = s->ring[q % kRing];
-        if (b.seq == q && b.stage == ROUTED && q + d_req < newest) EMB_TRY(stage_request(s, b));
+        if (b.seq == q && b.stage == ROUTED && old_enough(q, lag.req)) EMB_TRY(stage_request(s, b));
     }
     for (uint64_t q = first; q < newest; q++) {
         Batch &b = s->ring[q % kRing];
-        if (b.seq == q && b.stage == REQUESTED && q + d_serve < newest) {
+        if (b.seq == q && b.stage == REQUESTED && old_enough(q, lag.serve)) {
             EMB_TRY(stage_serve(s, b));
             if (b.deferred_rc != EMB_OK) deferred = b.deferred_rc;
         }
     }
+    EMB_TRY(launch_local(s));          // nothing was served in this call: L(n) alone
+    for (uint64_t q = first; q < newest; q++) {
+        Batch &b = s->ring[q % kRing];
+        if (b.seq == q && b.stage == SERVED && old_enough(q, lag.un)) EMB_TRY(stage_unroute(s, b));
+    }
     return deferred;
+}
+
+int range_error() {
+    return fail(EMB_ERR_RANGE, "emb_shard: a piece served by this rank named rows outside its table (pooled to zero rows)");
 }
 
 }  // namespace
@@ -536,7 +667,7 @@ int emb_shard_create(emb_engine *e, emb_comm *comm, const emb_shard_config *cfg,
     if (!e || !cfg || !out || !cfg->tables) return fail(EMB_ERR_INVALID, "emb_shard_create: NULL argument");
     *out = nullptr;
     if (cfg->n_tables == 0 || cfg->dim == 0 || cfg->dim % 4) return fail(EMB_ERR_INVALID, "emb_shard_create: n_tables > 0 and dim a multiple of 4");
-    if (cfg->depth > 2) return fail(EMB_ERR_INVALID, "emb_shard_create: depth is 0, 1 or 2");
+    if (cfg->depth > 3) return fail(EMB_ERR_INVALID, "emb_shard_create: depth is 0, 1, 2 or 3");
     emb_shard *s = new (std::nothrow) emb_shard();
     if (!s) return fail(EMB_ERR_NOMEM, "out of host memory");
     s->e = e;
@@ -604,14 +735,12 @@ int emb_shard_create(emb_engine *e, emb_comm *comm, const emb_shard_config *cfg,
     s->Wtot = s->wc_off[(size_t)world];
 
     DeviceGuard g(dev);
-    hipError_t err = hipSuccess;
-    hipStream_t *streams[4] = {&s->s_route, &s->s_comm, &s->s_comp, &s->s_un};
-    for (hipStream_t *st : streams)
-        if (err == hipSuccess) err = hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    hipError_t err = hipStreamCreateWithFlags(&s->s_comm, hipStreamNonBlocking);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&s->ev_switch, hipEventDisableTiming);
     const size_t N = (size_t)world;
     const size_t counts_words = N * ((s->Kr + 1) * 4 + (size_t)s->M * kWholeWords);
     for (Batch &b : s->ring) {
-        hipEvent_t *evs[7] = {&b.ev_in, &b.ev_routed, &b.ev_req, &b.ev_served, &b.ev_ret, &b.ev_local, &b.ev_out};
+        hipEvent_t *evs[5] = {&b.ev_routed, &b.ev_req, &b.ev_served, &b.ev_ret, &b.ev_out};
         for (hipEvent_t *ev : evs)
             if (err == hipSuccess) err = hipEventCreateWithFlags(ev, hipEventDisableTiming);
         void *p = nullptr;
@@ -645,7 +774,15 @@ int emb_shard_submit(emb_shard *s, const emb_shard_input *in, uint64_t n_bags, v
     const double t0 = now_us();
     DeviceGuard g(s->device);
     Batch &b = s->ring[s->next_seq % kRing];
-    if (b.stage != FREE && b.stage != SERVED) return fail(EMB_ERR_INVALID, "emb_shard_submit: internal: slot of batch %llu is still in stage %d", (unsigned long long)b.seq, (int)b.stage);
+    if (b.stage != FREE && b.stage != DONE) return fail(EMB_ERR_INVALID, "emb_shard_submit: internal: slot of batch %llu is still in stage %d", (unsigned long long)b.seq, (int)b.stage);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (s->cs_known && st != s->cs) {      // the caller moved to another stream: everything queued so far comes first
+        HIP_TRY(hipEventRecord(s->ev_switch, s->cs));
+        HIP_TRY(hipStreamWaitEvent(st, s->ev_switch, 0));
+    }
+    s->cs = st;
+    s->cs_known = true;
+    harvest(s, b);
     b.in.assign(s->T, emb_shard_input{});
     for (uint32_t t = 0; t < s->T && in; t++) {
         const emb_shard_input &u = in[t];
@@ -662,36 +799,23 @@ int emb_shard_submit(emb_shard *s, const emb_shard_input *in, uint64_t n_bags, v
     b.seq = s->next_seq;
     b.n_bags = n_bags;
     b.stage = FREE;
-    int rc = stage_route(s, b, static_cast<hipStream_t>(stream));
+    int rc = stage_route(s, b);
     if (rc) return rc;
     s->next_seq++;
     if (seq) *seq = b.seq;
-    static const uint64_t dq[3] = {0, 0, 1}, ds[3] = {0, 1, 2};
-    rc = advance(s, dq[s->depth], ds[s->depth]);
+    rc = advance(s, kLag[s->depth], false);
     s->st.us_host_submit += now_us() - t0;
-    if (rc == EMB_ERR_RANGE) return fail(EMB_ERR_RANGE, "emb_shard: a piece served by this rank named rows outside its table (pooled to zero rows)");
-    return rc;
+    return rc == EMB_ERR_RANGE ? range_error() : rc;
 }
 
 int emb_shard_flush(emb_shard *s) {
     if (!s) return fail(EMB_ERR_INVALID, "emb_shard_flush: shard is NULL");
+    if (!s->cs_known) return EMB_OK;
     const double t0 = now_us();
     DeviceGuard g(s->device);
-    // oldest first, each through all its remaining stages: the same order on every rank
-    int deferred = EMB_OK;
-    const uint64_t newest = s->next_seq, first = newest > kRing ? newest - kRing : 0;
-    for (uint64_t q = first; q < newest; q++) {
-        Batch &b = s->ring[q % kRing];
-        if (b.seq != q) continue;
-        if (b.stage == ROUTED) EMB_TRY(stage_request(s, b));
-        if (b.stage == REQUESTED) {
-            EMB_TRY(stage_serve(s, b));
-            if (b.deferred_rc != EMB_OK) deferred = b.deferred_rc;
-        }
-    }
+    int rc = advance(s, kLag[0], true);     // requests of all, then lookups + returns of all, then un-routing: same order on every rank
     s->st.us_host_submit += now_us() - t0;
-    if (deferred == EMB_ERR_RANGE) return fail(EMB_ERR_RANGE, "emb_shard: a piece served by this rank named rows outside its table (pooled to zero rows)");
-    return deferred;
+    return rc == EMB_ERR_RANGE ? range_error() : rc;
 }
 
 int emb_shard_wait(emb_shard *s, uint64_t seq, void *stream) {
@@ -699,11 +823,17 @@ int emb_shard_wait(emb_shard *s, uint64_t seq, void *stream) {
     if (seq >= s->next_seq) return fail(EMB_ERR_INVALID, "emb_shard_wait: batch %llu was never submitted", (unsigned long long)seq);
     Batch &b = s->ring[seq % kRing];
     if (b.seq != seq) return fail(EMB_ERR_INVALID, "emb_shard_wait: batch %llu is no longer tracked (wait within %d submits)", (unsigned long long)seq, kRing);
-    if (b.stage != SERVED)
+    if (b.stage != DONE)
         return fail(EMB_ERR_INVALID, "emb_shard_wait: batch %llu has not been through all its stages yet (submit %u more batch(es) or call emb_shard_flush)",
                     (unsigned long long)seq, s->depth);
+    hipStream_t other = static_cast<hipStream_t>(stream);
+    if (other == s->cs) return EMB_OK;          // the submit stream itself: the batch's last kernel is already queued there
     DeviceGuard g(s->device);
-    HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), b.ev_out, 0));
+    if (!b.out_recorded) {                      // (recorded now: behind the batch's last kernel, and possibly a little more)
+        HIP_TRY(hipEventRecord(b.ev_out, s->cs));
+        b.out_recorded = true;
+    }
+    HIP_TRY(hipStreamWaitEvent(other, b.ev_out, 0));
     return EMB_OK;
 }
 
@@ -719,8 +849,16 @@ int emb_shard_lookup(emb_shard *s, const emb_shard_input *in, uint64_t n_bags, v
 
 int emb_shard_get_stats(emb_shard *s, emb_shard_stats *out, int reset) {
     if (!s || !out) return fail(EMB_ERR_INVALID, "emb_shard_get_stats: NULL argument");
+    for (Batch &b : s->ring)
+        if (b.stage == DONE) harvest(s, b);
     *out = s->st;
     if (reset) s->st = emb_shard_stats{};
+    return EMB_OK;
+}
+
+int emb_shard_set_kernel_timing(emb_shard *s, int on) {
+    if (!s) return fail(EMB_ERR_INVALID, "emb_shard_set_kernel_timing: shard is NULL");
+    s->kernel_timing = on != 0;
     return EMB_OK;
 }
 
@@ -742,9 +880,17 @@ int emb_shard_sent_counts(emb_shard *s, uint64_t seq, uint32_t *counts, uint32_t
 int emb_shard_destroy(emb_shard *s) {
     if (!s) return EMB_OK;
     DeviceGuard g(s->device);
-    hipStream_t streams[4] = {s->s_route, s->s_comm, s->s_comp, s->s_un};
-    for (hipStream_t st : streams)
-        if (st) (void)hipStreamSynchronize(st);
+    if (g_hp.on && s->next_seq) {
+        fprintf(stderr, "[pimemb shard host profile] %llu batches, us per batch:", (unsigned long long)s->next_seq);
+        for (int k = 0; k < 14; k++) fprintf(stderr, "  %s %.1f", g_hp.name[k], g_hp.acc[k] / (double)s->next_seq);
+        fprintf(stderr, "\n");
+        for (double &a : g_hp.acc) a = 0;
+    }
+    if (s->cs_known) (void)hipStreamSynchronize(s->cs);
+    if (s->s_comm) (void)hipStreamSynchronize(s->s_comm);
+    (void)hipGetLastError();
+    for (emb_shard::CachedPlan &c : s->plans)
+        if (c.plan) (void)emb_plan_destroy(c.plan);
     for (Batch &b : s->ring) {
         DevBuf *bufs[8] = {&b.req_send, &b.meta, &b.slotmap, &b.counts_in, &b.wc_send, &b.req_recv, &b.ret_send, &b.ret_recv};
         for (DevBuf *d : bufs)
@@ -752,13 +898,15 @@ int emb_shard_destroy(emb_shard *s) {
         if (b.counts_host) (void)hipHostFree(b.counts_host);
         if (b.wc_host) (void)hipHostFree(b.wc_host);
         if (b.flag) (void)hipHostFree(b.flag);
-        hipEvent_t evs[7] = {b.ev_in, b.ev_routed, b.ev_req, b.ev_served, b.ev_ret, b.ev_local, b.ev_out};
+        hipEvent_t evs[5] = {b.ev_routed, b.ev_req, b.ev_served, b.ev_ret, b.ev_out};
         for (hipEvent_t ev : evs)
+            if (ev) (void)hipEventDestroy(ev);
+        for (hipEvent_t ev : b.tev)
             if (ev) (void)hipEventDestroy(ev);
     }
     if (s->work.p) (void)hipFree(s->work.p);
-    for (hipStream_t st : streams)
-        if (st) (void)hipStreamDestroy(st);
+    if (s->ev_switch) (void)hipEventDestroy(s->ev_switch);
+    if (s->s_comm) (void)hipStreamDestroy(s->s_comm);
     delete s;
     return EMB_OK;
 }

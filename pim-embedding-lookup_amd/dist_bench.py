@@ -1,32 +1,21 @@
-"""bench.py's N > 1 leg: one process per GPU (torch.distributed, backend nccl = RCCL over xGMI),
-weak scaling -- every rank owns B bags per table, so the global batch is N * B.
+"""bench.py's N > 1 leg: one process per GPU, weak scaling -- every rank owns B bags per table, so the global batch is
+N * B.  torch.distributed (nccl = RCCL, or gloo) carries the bootstrap, the barriers and the job clock; the data path of
+the sharded legs is the library's own (emb_shard_*: RCCL groups issued from C, csrc/pimemb_shard.cpp).
 
-Placement policy (`run`): tables are REPLICATED while the whole table set fits a quarter of one
-GPU's HBM (the 26 Kaggle tables, 2.16 GB, do): `run_dp` -- the single-GPU fused launch on every rank,
-no data-path collective.  Larger sets (or --replicate-mb N) SHARD and exchange:
+Placement policy (`run`): tables are REPLICATED while the whole table set fits a quarter of one GPU's HBM (the 26 Kaggle
+tables, 2.16 GB, do): `run_dp` -- the single-GPU fused launch on every rank, no data-path collective.  Larger sets (or
+--replicate-mb N) SHARD: `run_sharded` hands every batch to `ShardedEmbeddingBags.submit` -- ONE library call per batch,
+as the reference's lookup() serves all its devices from one call (emb_host.h:258-270, 297, 312-321):
 
-`run_whole` (static shapes, one index per bag): tables <= the threshold replicated, the rest placed
-whole on owner ranks by the shard planner.  The two exchanges of a lookup -- indices in, pooled rows
-out -- are software-pipelined over consecutive batches so that ONE all_to_all per step carries both
-the pooled rows of batch i and the indices of batch i+1 (byte payloads with static splits):
+    --shard-mode whole   tables above the threshold placed whole on owner ranks (table-id sharding): the bags' indices travel
+                         to the owner straight out of the caller's buffers, the pooled rows arrive straight in its output
+    --shard-mode rows    ... split by ROW RANGE over all ranks, any number of indices per bag: every bag cut into per-shard
+                         sub-bags on the GPU (emb_route_bags), the per-(peer, table) counts exchanged FIRST, the payload sized
+                         from them (nothing has a capacity skew could overflow), partial rows added in shard order
+    --shard-mode plan    what `plan_shards` decides (its return-volume term keeps pooled tables whole when they fit)
 
-    launch A(i): fused lookup of the replicated tables        HIP engine plan, local bags, no dependency
-    wait collective(i-1)                                      stream-level, the CPU never blocks
-    launch B(i): fused lookup of the tables served here       HIP engine plan over the bags of ALL ranks;
-                 indices are read from collective(i-1)'s receive buffer, pooled rows are written
-                 straight into collective(i)'s send buffer
-    collective(i) = all_to_all([pooled rows of batch i | indices of batch i+1])   RCCL over xGMI
-    outputs(i): replicated tables -> own buffers; sharded tables -> views of the receive buffer
-
-`run_rows`: the big tables split by ROW RANGE over all ranks, any number of indices per bag.  Every bag
-is cut into per-shard sub-bags on the GPU (emb_route_bags); the per-(peer, table) counts are exchanged
-FIRST and the request pieces / partial rows travel as all_to_all with split sizes taken from them
-(alltoallv -- nothing has a capacity that skewed indices could overflow); the bag's owner adds the
-partial rows in shard order (emb_unroute_bags).  Pipelined over consecutive batches like `run_whole`.
-
-With the auto policy the sharded exchange is still measured in the same run as a secondary leg
-(`sharded_exchange` in the JSON line).  All buffers and engine plans are created once per rotating
-batch slot."""
+With the auto policy the sharded exchange is still measured in the same run as a secondary leg and reported at the top
+level of the JSON line (`value_exchange`, `ms_per_step_exchange`) next to the replica curve in `value`."""
 from __future__ import annotations
 
 import json
@@ -125,266 +114,12 @@ def expected_pooled(torch, t: int, idx, dim: int, L: int):
     return acc
 
 
-def native_exchange(pel, args, eng, ctx):
-    """--collective native: the all-to-all goes straight to RCCL on the compute stream (emb_comm_*),
-    no torch work object, no extra waits.  None for the default (torch.distributed)."""
-    if getattr(args, "collective", "torch") != "native":
-        return None
-    if ctx["stage_cpu"]:
-        raise SystemExit("--collective native needs the nccl backend (RCCL), not " + ctx["backend"])
-    import torch.distributed as dist
-
-    def bcast(raw: bytes) -> bytes:
-        box = [raw]
-        dist.broadcast_object_list(box, src=0)
-        return box[0]
-
-    return pel.NativeExchange(eng, ctx["rank"], ctx["world"], bcast)
-
-
 def table_set_of(pel, args):
     """rows, dim, default batch, label of the table set the N > 1 legs run (--workload c2 | c4)."""
     name = getattr(args, "workload", "c2")
     if name not in ("c2", "c4", "c5"):
         raise SystemExit("bench.py --gpus N > 1 runs --workload c2, c4 or c5 (c3 is a single-GPU line)")
     return pel.workloads.table_set(name, float(getattr(args, "rows_scale", 1.0) or 1.0))
-
-
-def run_whole(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
-    import torch
-    import torch.distributed as dist
-    import pim_embedding_lookup_amd as pel
-    from importlib import import_module
-    sh = import_module("pim-embedding-lookup_amd.sharding")
-
-    rank, world, dev, backend, stage_cpu = ctx["rank"], ctx["world"], ctx["dev"], ctx["backend"], ctx["stage_cpu"]
-
-    rows_list, dim, B0, label = table_set_of(pel, args)
-    B = args.batch or B0
-    L = pooling_of(pel, args)               # indices per bag (fixed pooling)
-    Bp = (B * L + 3) // 4 * 4               # index slots per (table, rank): keeps every piece 16-B aligned
-    T = len(rows_list)
-    # how many batches ahead the indices travel: with 1 (default), launch B(i+1) needs collective(i) -- a chain
-    # B -> collective -> B -> ...; with 2 it needs collective(i-1), which has had a whole step to finish.  Tried in round 3
-    # (PIMEMB_WHOLE_DEPTH=2 / 3): 71 / 63 us per step against 63 with one RCCL rank -- the step is bound by the host time
-    # of all_to_all_single, not by that chain (profiles/r02/REJECTED_EXPERIMENTS.md), so the shallower pipeline stays
-    DEPTH = max(1, int(os.environ.get("PIMEMB_WHOLE_DEPTH", "1")))
-    NBATCH = max(DEPTH + 1, args.nbatch)
-    plan = sh.plan_shards(rows_list, dim, 2 if TABLE_F16[0] else 4, world, replicate_bytes=rep_bytes, split_bytes=1 << 62)
-    served = plan.owned_units(rank)
-    local = plan.replicated_units()
-    send_units = [[u for u in plan.units if u.owner == d] for d in range(world)]
-    n_send = [len(x) for x in send_units]           # sharded tables owned by each destination
-    n_sharded = sum(n_send)
-    K = len(served)
-
-    eng = pel.EmbeddingEngine(device=dev.index, max_tables=len(plan.units) + 1)
-    for u in served + local:
-        w = table_values(torch, u.table, u.row_lo, u.row_hi, dim, dev)
-        eng.load_table(u.uid, w)
-        del w
-    torch.cuda.empty_cache()
-
-    # ---- byte layout of the fused collective ----------------------------------------------------
-    # to destination d  : [ K tables x B x dim fp32 pooled rows of d's bags | n_send[d] tables x Bp u32 indices ]
-    # from source s     : [ n_send[s] tables x B x dim fp32 pooled rows of MY bags | K tables x Bp u32 indices of s's bags ]
-    row_b = dim * 4
-    in_split = [K * B * row_b + n_send[d] * Bp * 4 for d in range(world)]
-    out_split = [n_send[s] * B * row_b + K * Bp * 4 for s in range(world)]
-    in_off = np.concatenate([[0], np.cumsum(in_split)]).astype(np.int64)
-    out_off = np.concatenate([[0], np.cumsum(out_split)]).astype(np.int64)
-    # the largest piece any rank sends any peer, from the plan every rank holds (so all ranks agree on the rounds)
-    owned = [sum(1 for u in plan.units if u.owner == r) for r in range(world)]
-    a2a_rounds = sh.rounds_for(max(owned[r] * B * row_b + owned[d] * Bp * 4 for r in range(world) for d in range(world)))
-
-    def f32_view(buf, byte_off, n_rows):
-        return buf[byte_off:byte_off + n_rows * row_b].view(torch.float32).view(n_rows, dim)
-
-    def i32_view(buf, byte_off, n):
-        return buf[byte_off:byte_off + n * 4].view(torch.int32)
-
-    rng = np.random.default_rng(1 + rank)
-    gen, dist_name = index_generator(pel, args)
-    off_dev = torch.arange(B, dtype=torch.int32, device=dev) * L
-    idx_host = [[gen(rng, n, B * L, t).view(np.int32) for t, n in enumerate(rows_list)] for _ in range(NBATCH)]
-    slots = []
-    for j in range(NBATCH):
-        send = torch.zeros(max(int(in_off[-1]), 16), dtype=torch.uint8, device=dev)
-        recv = torch.zeros(max(int(out_off[-1]), 16), dtype=torch.uint8, device=dev)   # zeros: index 0 is valid
-        slots.append(dict(send=send, recv=recv))
-    for j in range(NBATCH):
-        sl, nxt = slots[j], (j + DEPTH) % NBATCH
-        # indices of the batch DEPTH steps ahead ride in this slot's send buffer (static, written once)
-        for d in range(world):
-            base = int(in_off[d]) + K * B * row_b
-            for q, u in enumerate(send_units[d]):
-                i32_view(sl["send"], base + q * Bp * 4, B * L).copy_(torch.from_numpy(idx_host[nxt][u.table]))
-        sl["idx_local"] = {u.table: torch.from_numpy(idx_host[j][u.table]).to(dev) for u in local}
-        sl["out_local"] = {u.table: torch.empty((B, dim), dtype=torch.float32, device=dev) for u in local}
-        sl["plan_a"] = None
-        if local:
-            sl["plan_a"] = eng.plan([u.uid for u in local], [sl["idx_local"][u.table] for u in local],
-                                    [off_dev] * len(local), [sl["out_local"][u.table] for u in local])
-    for j in range(NBATCH):
-        sl, prev = slots[j], slots[(j - DEPTH) % NBATCH]
-        sl["plan_b"] = None
-        if K:   # indices of batch j arrived with collective(j-DEPTH); pooled rows go into collective(j)
-            ids, ii, oo, uu = [], [], [], []
-            for s in range(world):
-                for k, u in enumerate(served):
-                    ids.append(u.uid)
-                    ii.append(i32_view(prev["recv"], int(out_off[s]) + n_send[s] * B * row_b + k * Bp * 4, B * L))
-                    oo.append(off_dev)
-                    uu.append(f32_view(sl["send"], int(in_off[s]) + k * B * row_b, B))
-            sl["plan_b"] = eng.plan(ids, ii, oo, uu)
-
-    stream = torch.cuda.current_stream(dev)
-    sh_handle = stream.cuda_stream
-    from collections import deque
-    pending = deque()            # work handles of the collectives in flight, oldest first (at most DEPTH)
-    native = native_exchange(pel, args, eng, ctx)
-    if native is not None:
-        a_in, a_out = native.offsets(in_off), native.offsets(out_off)
-
-    def collective(sl):
-        if n_sharded == 0:
-            return None
-        if native is not None:      # stream-ordered: the next launch on this stream sees the received bytes
-            native.all_to_all(sl["send"].data_ptr(), a_in, sl["recv"].data_ptr(), a_out, sh_handle)
-            return None
-        if stage_cpu:
-            r, s_ = torch.empty(sl["recv"].shape, dtype=torch.uint8), sl["send"].cpu()
-            dist.all_to_all_single(r, s_, output_split_sizes=out_split, input_split_sizes=in_split)
-            sl["recv"].copy_(r)
-            return None
-        return sh.all_to_all_rounds(dist, sl["recv"], sl["send"], out_split, in_split, a2a_rounds)
-
-    def step(i):
-        sl = slots[i % NBATCH]
-        if sl["plan_a"] is not None:
-            sl["plan_a"].launch(sh_handle)          # independent of the exchange
-        if len(pending) >= DEPTH:
-            w = pending.popleft()
-            if w is not None:
-                w.wait()                            # compute stream waits for collective(i-DEPTH)
-        if sl["plan_b"] is not None:
-            sl["plan_b"].launch(sh_handle)
-        pending.append(collective(sl))
-
-    done_ev = torch.cuda.Event()
-
-    def drain():
-        while pending:
-            w = pending.popleft()
-            if w is not None:
-                w.wait()
-        done_ev.record(stream)       # everything of the loop is ordered before this event on the compute stream
-        done_ev.synchronize()        # (a device-wide synchronize returns up to a millisecond later once RCCL is loaded)
-
-    def outputs(sl):
-        res = [None] * T
-        for u in local:
-            res[u.table] = sl["out_local"][u.table]
-        for s in range(world):
-            for q, u in enumerate(send_units[s]):
-                res[u.table] = f32_view(sl["recv"], int(out_off[s]) + q * B * row_b, B)
-        return res
-
-    # ---- prime the pipeline (one full rotation), then check two consecutive steps bit-exactly:
-    #      every table on every rank (one-hot => pooled row == table row) ---------------------------
-    for i in range(NBATCH):
-        step(i)
-    for i in (NBATCH, NBATCH + 1):
-        step(i)
-        drain()
-        res = outputs(slots[i % NBATCH])
-        for t in range(T):
-            idx = torch.from_numpy(idx_host[i % NBATCH][t]).to(dev)
-            if not torch.equal(res[t], expected_pooled(torch, t, idx, dim, L)):
-                raise AssertionError(f"rank {rank}: step {i} table {t} ({plan.kinds[t]}) differs from the expected rows")
-    n_primed = NBATCH + 2
-
-    # ---- kernel-only time of this rank's two launches, rotating over the batch slots (roofline) ----
-    kernel_us, alg_bytes = 0.0, 0
-    for key in ("plan_a", "plan_b"):
-        if slots[0][key] is None:
-            continue
-        alg_bytes += slots[0][key].bytes()[0]
-        for i in range(8):
-            slots[i % NBATCH][key].launch(sh_handle)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        n_rep = 64
-        e0.record(stream)
-        for i in range(n_rep):
-            slots[i % NBATCH][key].launch(sh_handle)
-        e1.record(stream)
-        torch.cuda.synchronize()
-        kernel_us += e0.elapsed_time(e1) * 1000.0 / n_rep
-
-    # NOTE: steps are enqueued eagerly.  The engine's launches are hipGraph-capturable (tests/
-    # test_gpu_parity.py::test_plan_launch_is_graph_capturable), but capturing RCCL's all_to_all with
-    # this torch 2.10 / RCCL 2.26 build segfaults in capture_end (tools/graph_probe.py), so the
-    # collective keeps the step out of a graph.
-    it = n_primed
-    for _ in range(args.warmup):
-        step(it)
-        it += 1
-    drain()
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(it)
-        it += 1
-    drain()
-    wall_ev, wall_sync = job_times(torch, dist, t0, time.perf_counter(), stage_cpu, dev)   # drain waited for this rank's K-th step
-    # what the timed loop left behind: the last step's 26 outputs, bit for bit
-    res = outputs(slots[(it - 1) % NBATCH])
-    for t in range(T):
-        idx = torch.from_numpy(idx_host[(it - 1) % NBATCH][t]).to(dev)
-        if not torch.equal(res[t], expected_pooled(torch, t, idx, dim, L)):
-            raise AssertionError(f"rank {rank}: last timed step, table {t} ({plan.kinds[t]}) differs from the expected rows")
-
-    result = None
-    if rank == 0:
-        ach = alg_bytes / (kernel_us * 1e-6) / 1e9 if kernel_us > 0 else 0.0
-        clk = clock_fields(wall_ev, wall_sync, args.steps, world * args.steps * T * B)
-        bytes_out = int(sum(in_split[d] for d in range(world) if d != rank))
-        fr = step_fractions(lookup_bytes(T, B, L, dim, 2 if TABLE_F16[0] else 4), bytes_out, clk["ms_per_step"], hbm_peak_gbs)
-        result = ({
-            "metric": "pooled-lookups/sec + achieved HBM GB/s, 26-table dim-16 Kaggle, 1/2/4/8 GPU",
-            "unit": "pooled-lookups/s", **clk,
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16" if TABLE_F16[0] else "f32", "data": "synthetic",
-            "config": {"workload": "%s sharded, dim %d %s, B=%d bags/table PER RANK, "
-                                   "L=%d, %s indices, %d rotating batches; %s" % (label, dim, "fp16" if TABLE_F16[0] else "fp32", B, L, dist_name, NBATCH, plan.describe()),
-                       "tables": T, "dim": dim, "bags_per_table_per_rank": B, "global_bags_per_table": world * B,
-                       "pooling": L,
-                       "parallelism": "tables sharded by id (replicate <= %d MiB); one all_to_all per step carries "
-                                      "pooled rows of batch i + indices of batch i+%d (%d B out / %d B in per rank); "
-                                      "backend %s, %s, eager steps" %
-                                      (rep_bytes >> 20, DEPTH, int(in_off[-1]), int(out_off[-1]), backend,
-                                       "collective issued natively to RCCL on the compute stream" if native is not None
-                                       else "torch.distributed.all_to_all_single"),
-                       "exchange": {"mode": "whole", "value": clk["value"], "ms_per_step": clk["ms_per_step"], "verified": True,
-                                    "bytes_out_per_rank_per_step": bytes_out}},
-            "roofline": {"bound": "hbm", "achieved": ach, "peak": hbm_peak_gbs, "unit": "GB/s",
-                         "frac": ach / hbm_peak_gbs, "traffic": None, "kernel_us": kernel_us,
-                         "algorithmic_bytes": alg_bytes,
-                         "basis": "algorithmic bytes (no PMC profile of the N > 1 legs; a pooled launch is partly cache-served and can exceed 1: the same kernels at N = 1 are priced on measured bytes, profiles/traffic.json)", "note": "rank 0's two local launches (replicated + served tables), kernel-only; the whole step (collective included) against HBM and xGMI: roofline.exchange",
-                         "exchange": fr},
-        })
-    dist.barrier()
-    for sl in slots:
-        for p in (sl["plan_a"], sl["plan_b"]):
-            if p is not None:
-                p.destroy()
-    if native is not None:
-        torch.cuda.synchronize()
-        native.close()
-    eng.close()
-    return result
 
 
 def expected_row_split(torch, t: int, idx, dim: int, L: int, rps: int, n_shards: int):
@@ -422,12 +157,13 @@ def pooling_of(pel, args) -> int:
     return max(1, int(getattr(args, "pooling", None) or extras["pooling"]))
 
 
-def dump_row_split(torch, eng, args, gen, rank, world, dev, rows_list, sharded, rps, T, B, L, dim, NBATCH, last, idx_host, slots):
+def dump_row_split(torch, S, plan, sh, gen, rank, world, dev, rows_list, T, B, L, dim, NBATCH, last, idx_host, outs):
     """PIMEMB_DUMP_ROWSPLIT=<prefix>: leave what a TEST needs to put the oracle behind the sharded path (nothing under the
     package may import it).  Every rank writes <prefix>.rank<r>.npz with, per row-split table, the rows of ITS shard that
     rank 0's bags of the last timed step name -- read back from the engine's table in HBM -- and rank 0 adds its index
     arrays (global row ids) and the pooled rows the exchange returned.  Other ranks regenerate rank 0's indices from its seed."""
     prefix = os.environ.get("PIMEMB_DUMP_ROWSPLIT")
+    sharded = [t for t, k in enumerate(plan.kinds) if k == sh.ROW_SPLIT]
     if not prefix or not sharded:
         return
     if rank == 0:
@@ -435,214 +171,131 @@ def dump_row_split(torch, eng, args, gen, rank, world, dev, rows_list, sharded, 
     else:
         rng0 = np.random.default_rng(1 + 0)
         idx0 = [[gen(rng0, n, B * L, t).view(np.int32) for t, n in enumerate(rows_list)] for _ in range(NBATCH)][last]
+    rps = [-(-rows_list[t] // world) for t in sharded]
     rec = {"tables": np.asarray(sharded), "pooling": np.asarray(L), "bags": np.asarray(B), "dim": np.asarray(dim),
            "rows_per_shard": np.asarray(rps), "world": np.asarray(world)}
     for k, t in enumerate(sharded):
         ids = np.unique(idx0[t].view(np.uint32).astype(np.int64))
-        lo = rank * rps[k]
-        hi = rows_list[t] if rank == world - 1 else min(lo + rps[k], rows_list[t])
-        mine = ids[(ids >= lo) & (ids < hi)]
-        w = eng.table_tensor(T + k)
+        u = plan.units[plan.units_of_table[t][rank]]
+        mine = ids[(ids >= u.row_lo) & (ids < u.row_hi)]
+        w = S.engine.table_tensor(u.uid) if u.row_hi > u.row_lo else None
         rec["ids_%d" % t] = mine
-        rec["rows_%d" % t] = (w[torch.from_numpy(mine - lo).to(dev)].float().cpu().numpy() if mine.size
+        rec["rows_%d" % t] = (w[torch.from_numpy(mine - u.row_lo).to(dev)].float().cpu().numpy() if mine.size
                               else np.zeros((0, dim), np.float32))
         if rank == 0:
             rec["idx_%d" % t] = idx0[t].view(np.uint32)
-            rec["out_%d" % t] = slots[last]["out_sh"][k].cpu().numpy()
+            rec["out_%d" % t] = outs[t].cpu().numpy()
     np.savez("%s.rank%d.npz" % (prefix, rank), **rec)
 
 
-def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
-    """Big tables split by ROW RANGE over all ranks, any number of indices per bag.  Counts first, payload second
-    (the reference sends its lengths before every launch, emb_host.h:280-287):
+def run_sharded(args, hbm_peak_gbs: float, ctx, rep_bytes: int, mode: str):
+    """The sharded step, ONE library call per batch (ShardedEmbeddingBags over emb_shard_*: csrc/pimemb_shard.cpp; the
+    reference's lookup() likewise serves every device from one call, emb_host.h:258-270, 297, 312-321).  This leg only
+    builds the placement, rotates NBATCH static batches through `submit` (depth 3) and checks what comes out:
 
-        route(i+2)      GPU: every bag of a row-split table cut into per-shard sub-bags (emb_route_bags)
-        counts(i+2)     all_to_all of {sub-bags, indices} per (peer, table)             -- small, first, two batches ahead
-        local(i)        fused lookup of the replicated tables (prepared plan)
-        serve(i)        fused lookup over the request pieces received for batch i -> one partial row per sub-bag
-        return(i)       all_to_all of the partial rows, split sizes from counts(i)
-        requests(i+1)   all_to_all of the request pieces, split sizes from counts(i+1)  -- the only host wait
-        finish(i)       partial rows added in shard order into [B, dim] per table (emb_unroute_bags) -- enqueued one step
-                        later, in front of serve(i+1), so the compute stream never waits out return(i)
+        mode "whole": tables above the replication threshold placed whole on owner ranks (table-id sharding);
+        mode "rows" : ... split by ROW RANGE over all ranks (GPU routing, counts first, partial rows added in shard order);
+        mode "plan" : whatever plan_shards decides (row-split only what must be; pooled tables that fit stay whole).
 
-    Nothing has a capacity that skewed indices could overflow: the payload is sized by the counts."""
+    All transfers are RCCL groups issued from the C side; torch.distributed carries the bootstrap, the barriers and the
+    job clock only."""
     import torch
     import torch.distributed as dist
     import pim_embedding_lookup_amd as pel
     from importlib import import_module
     sh = import_module("pim-embedding-lookup_amd.sharding")
 
-    rank, world, dev, backend, stage_cpu = ctx["rank"], ctx["world"], ctx["dev"], ctx["backend"], ctx["stage_cpu"]
-
+    rank, world, dev, backend = ctx["rank"], ctx["world"], ctx["dev"], ctx["backend"]
     rows_list, dim, B0, label = table_set_of(pel, args)
     L = pooling_of(pel, args)
     gen, dist_name = index_generator(pel, args)
+    elem = 2 if TABLE_F16[0] else 4
     row_b = dim * 4
     B = args.batch or B0
     T = len(rows_list)
-    N = world
-    NBATCH = max(4, args.nbatch)            # slots: the router runs two batches ahead of the un-router
-    sharded = [t for t in range(T) if rows_list[t] * dim * (2 if TABLE_F16[0] else 4) > rep_bytes and rows_list[t] >= world]
-    local = [t for t in range(T) if t not in sharded]
-    K = len(sharded)
-    rps = [-(-rows_list[t] // world) for t in sharded]
+    NBATCH = max(6, args.nbatch)
+    depth = int(os.environ.get("PIMEMB_SHARD_DEPTH", "3"))
+    if mode == "whole":
+        plan = sh.plan_shards(rows_list, dim, elem, world, replicate_bytes=rep_bytes, split_bytes=1 << 62)
+    elif mode == "rows":
+        plan = sh.plan_shards(rows_list, dim, elem, world, replicate_bytes=rep_bytes, split_bytes=rep_bytes, pooling=1.0,
+                              split_single_rank=True)
+    else:
+        plan = sh.plan_shards(rows_list, dim, elem, world, replicate_bytes=rep_bytes, pooling=float(L), split_single_rank=True)
+    split = [t for t, k in enumerate(plan.kinds) if k == sh.ROW_SPLIT]
+    whole = [t for t, k in enumerate(plan.kinds) if k == sh.WHOLE]
+    rps = {t: -(-rows_list[t] // world) for t in split}
 
-    eng = pel.EmbeddingEngine(device=dev.index, max_tables=T + K + 1)
-    for t in local:
-        eng.load_table(t, table_values(torch, t, 0, rows_list[t], dim, dev))
-    for k, t in enumerate(sharded):
-        lo, hi = min(rank * rps[k], rows_list[t]), min((rank + 1) * rps[k], rows_list[t])
-        eng.load_table(T + k, table_values(torch, t, lo, hi, dim, dev))
+    eng = pel.EmbeddingEngine(device=dev.index, max_tables=len(plan.units) + 1)
+    via = os.environ.get("PIMEMB_SHARD_SELF_VIA_COMM") == "1"      # rehearsal / A-B: self pieces through RCCL like any other
+    comm = sh.native_comm(eng, rank, world, always=via)
+    S = sh.ShardedEmbeddingBags(plan, eng, rank, comm, depth=depth, check=False, self_via_comm=via)
+    S.load_tables(lambda t, lo, hi: table_values(torch, t, lo, hi, dim, dev))
     torch.cuda.empty_cache()
 
     rng = np.random.default_rng(1 + rank)
     idx_host = [[gen(rng, n, B * L, t).view(np.int32) for t, n in enumerate(rows_list)] for _ in range(NBATCH)]
-    off_b = torch.arange(B, dtype=torch.int32, device=dev) * L
     stream = torch.cuda.current_stream(dev)
     h = stream.cuda_stream
-    native = native_exchange(pel, args, eng, ctx)
-    # the exchange itself is library code (sharding.RowRangeExchange); this leg only pipelines its four phases
-    ex = sh.RowRangeExchange(eng, [T + k for k in range(K)], rps, dim, rank, world, dev, n_slots=NBATCH,
-                             stage_cpu=stage_cpu, native=native) if K else None
-    if ex is not None:
-        ex.compute = stream          # every phase of this leg is issued from this (the current) stream
-
     slots = []
     for j in range(NBATCH):
-        sl = dict(idx_local=[torch.from_numpy(idx_host[j][t]).to(dev) for t in local],
-                  out_local=[torch.empty((B, dim), dtype=torch.float32, device=dev) for _ in local])
-        sl["plan_a"] = eng.plan(local, sl["idx_local"], [off_b] * len(local), sl["out_local"]) if local else None
-        if K:
-            sl["idx_sh"] = torch.from_numpy(np.stack([idx_host[j][t] for t in sharded])).to(dev)     # [K, B*L]
-            sl["route_spec"] = eng.route_tables([(sl["idx_sh"][k].data_ptr(), None, B * L, L, rps[k]) for k in range(K)])
-            sl["out_sh"] = torch.zeros((K, B, dim), dtype=torch.float32, device=dev)
-        slots.append(sl)
+        d_idx = [torch.from_numpy(idx_host[j][t]).to(dev) for t in range(T)]
+        outs = torch.zeros((T, B, dim), dtype=torch.float32, device=dev)
+        slots.append(dict(prep=S.prepare(d_idx, None, L, [outs[t] for t in range(T)]), outs=outs))
+    torch.cuda.synchronize()
 
-    prof = {} if os.environ.get("PIMEMB_DIST_PROFILE") == "1" else None
-
-    def timed(name, fn, *a):
-        if prof is None:
-            return fn(*a)
-        t = time.perf_counter_ns()
-        r = fn(*a)
-        prof[name] = prof.get(name, 0) + time.perf_counter_ns() - t
-        return r
-
-    unfinished = [None]        # slot whose partial rows are on their way back (its un-routing is the next step's job)
-    # the router and its counts exchange depend on nothing of the step they are issued in: they run on their own stream,
-    # ordered behind the last reader of the slot they fill (the un-router of NBATCH batches ago)
-    route_stream = torch.cuda.Stream(dev) if (K and os.environ.get("PIMEMB_ROUTE_STREAM", "1") != "0" and native is None) else None
-    slot_free = [torch.cuda.Event() for _ in range(NBATCH)]
-
-    def route_into(slot):
-        if route_stream is not None:
-            route_stream.wait_event(slot_free[slot])
-        ex.route(slot, slots[slot]["route_spec"], B, K * B * L, stream=route_stream)
-
-    def finish_pending():
-        if unfinished[0] is not None:
-            timed("finish", ex.finish, unfinished[0], slots[unfinished[0]]["out_sh"])
-            slot_free[unfinished[0]].record(stream)
-            unfinished[0] = None
+    seqs = {}
+    consumer = torch.cuda.Stream(dev)      # where the pooled rows are consumed: NOT the stream the next inputs come from, or
+    hc = consumer.cuda_stream              # batch i+1 could not be routed before batch i-1 has been un-routed
 
     def step(i):
-        """One pipelined step.  On the compute stream: route(i+2), local(i), finish(i-1), serve(i).
-          * the router runs TWO batches ahead: the counts the host needs for batch i+1 were sent a whole step ago, so its
-            one wait per step (send_requests) does not depend on how far the slowest peer has got in THIS step.  (With one
-            rank it changes nothing -- 246 vs 262 us per step at the C4 shape, inside the noise: there the step is the
-            sum of its kernels, all in one hardware queue, the 50-us self-copy of the return collective included.)
-          * the partial rows of batch i-1 have had a whole step to come back, so un-routing them never stalls the stream
-            behind a collective."""
-        j, nxt, nxt2 = i % NBATCH, (i + 1) % NBATCH, (i + 2) % NBATCH
-        sl = slots[j]
-        if K:
-            timed("route+counts", route_into, nxt2)
-        if sl["plan_a"] is not None:
-            timed("local", sl["plan_a"].launch, h)
-        if K:
-            finish_pending()
-            timed("serve+return", ex.serve, j)
-            timed("wait counts+requests", ex.send_requests, nxt)
-            unfinished[0] = j
-
-    def prologue(i):           # before step(i): batch i's requests on their way, batch i+1 routed and its counts sent
-        if K:
-            route_into(i % NBATCH)
-            ex.send_requests(i % NBATCH)
-            route_into((i + 1) % NBATCH)
+        """One call per batch; the consumer's stream is made to wait for the batch that is `depth` submits old."""
+        seqs[i] = S.submit_prepared(slots[i % NBATCH]["prep"], h)
+        if i - depth in seqs:
+            S.wait(seqs.pop(i - depth), hc)
 
     done_ev = torch.cuda.Event()
 
-    def drain(next_i):         # un-route the last batch; the requests of the batch after it are in flight: let them land
-        if K:
-            finish_pending()
-            ex.wait_requests(next_i % NBATCH)
-        done_ev.record(stream)       # everything of the loop is ordered before this event on the compute stream
+    def drain():
+        S.flush()
+        for i in sorted(seqs):
+            S.wait(seqs[i], h)
+        seqs.clear()
+        done_ev.record(stream)       # everything of the loop is ordered before this event on the caller's stream
         done_ev.synchronize()        # (a device-wide synchronize returns up to a millisecond later once RCCL is loaded)
 
-    def outputs(j):
-        res = [None] * T
-        for q, t in enumerate(local):
-            res[t] = slots[j]["out_local"][q]
-        for k, t in enumerate(sharded):
-            res[t] = slots[j]["out_sh"][k]
-        return res
-
     def verify(i, what):
-        res = outputs(i % NBATCH)
+        res = slots[i % NBATCH]["outs"]
         for t in range(T):
             idx = torch.from_numpy(idx_host[i % NBATCH][t]).to(dev)
             plain = expected_pooled(torch, t, idx, dim, L)
-            want = plain if t in local else expected_row_split(torch, t, idx, dim, L, rps[sharded.index(t)], N)
+            want = expected_row_split(torch, t, idx, dim, L, rps[t], world) if t in rps else plain
             if not torch.equal(res[t], want):
-                raise AssertionError(f"rank {rank}: {what} step {i} table {t} differs from the expected rows")
+                raise AssertionError(f"rank {rank}: {what} step {i} table {t} ({plan.kinds[t]}) differs from the expected rows")
             if float((res[t] - plain).abs().max()) > 1e-6:
                 raise AssertionError(f"rank {rank}: {what} step {i} table {t} is more than 1e-6 from the unsharded sum")
 
-    # ---- the first rotation, fully pipelined (every slot's buffers are used for the first time here: ADVICE r2 --
-    #      an un-ordered first use shows up in these steps and in no later one), checked afterwards from the slots' own
-    #      output buffers; then two consecutive pipelined steps, each checked on its own -------------------------------
-    prologue(0)
-    for i in range(NBATCH):
-        step(i)
-    drain(NBATCH)
+    # ---- the first rotation, fully pipelined (every slot's buffers are used for the first time here), checked afterwards
+    #      from the slots' own output buffers; then two more pipelined steps, each checked on its own -------------------------
+    it = 0
+    for _ in range(NBATCH):
+        step(it)
+        it += 1
+    drain()
     for i in range(NBATCH):
         verify(i, "first rotation")
-    for i in (NBATCH, NBATCH + 1):
-        step(i)
-        drain(i + 1)
-        verify(i, "pipelined")
-    it = NBATCH + 2
+        slots[i]["outs"].zero_()
+    for _ in range(2):
+        step(it)
+        it += 1
+        drain()
+        verify(it - 1, "pipelined")
 
-    # ---- kernel-only time of this rank's two lookups (replicated tables + served request pieces) ----------
-    kernel_us, alg_bytes = 0.0, 0
-    if slots[0]["plan_a"] is not None:
-        alg_bytes += slots[0]["plan_a"].bytes()[0]
-    if K:                                # requests for batch `it` were issued by the last step: let them land
-        ex.wait_requests(it % NBATCH)
-        torch.cuda.synchronize()
-    serve_bytes = 0
-    for key in ("local", "serve"):
-        if (key == "local" and slots[0]["plan_a"] is None) or (key == "serve" and not K):
-            continue
-        fn = (lambda q: slots[q % NBATCH]["plan_a"].launch(h)) if key == "local" else (lambda q: ex.lookup_received(it % NBATCH))
-        for q in range(4):
-            serve_bytes = fn(q) or serve_bytes
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        for q in range(32):
-            fn(q)
-        e1.record(stream)
-        torch.cuda.synchronize()
-        kernel_us += e0.elapsed_time(e1) * 1000.0 / 32
-    alg_bytes += serve_bytes
-
-    if prof is not None:
-        prof.clear()               # (the priming steps allocate and pin the slots' buffers: not what a step costs)
     for _ in range(args.warmup):
         step(it)
         it += 1
-    drain(it)
+    drain()
+    S.stats(reset=True)
     dist.barrier()
     torch.cuda.synchronize()
     check_every = int(os.environ.get("PIMEMB_VERIFY_EVERY", "0"))   # soak mode: verify inside the loop (times mean nothing then)
@@ -651,73 +304,141 @@ def run_rows(args, hbm_peak_gbs: float, ctx, rep_bytes: int):
         step(it)
         it += 1
         if check_every and (n + 1) % check_every == 0:
-            drain(it)
+            drain()
             verify(it - 1, "soak")
-    drain(it)
-    wall_ev, wall_sync = job_times(torch, dist, t0, time.perf_counter(), stage_cpu, dev)   # drain waited for this rank's K-th step
-    verify(it - 1, "last timed")                     # what the timed loop left behind
-    dump_row_split(torch, eng, args, gen, rank, world, dev, rows_list, sharded, rps, T, B, L, dim, NBATCH, (it - 1) % NBATCH,
-                   idx_host, slots)
+    drain()
+    wall_ev, wall_sync = job_times(torch, dist, t0, time.perf_counter(), backend != "nccl", dev)   # drain waited for this rank's K-th step
+    st = S.stats(reset=True)
+    n_verified = 0
+    for i in range(max(it - NBATCH, it - args.steps), it):         # what the timed loop left behind: EVERY rotating slot
+        verify(i, "timed")
+        n_verified += 1
+    last = (it - 1) % NBATCH
+    dump_row_split(torch, S, plan, sh, gen, rank, world, dev, rows_list, T, B, L, dim, NBATCH, last, idx_host, slots[last]["outs"])
     digest = None
-    if rank == 0 and K:                              # bits of rank 0's row-split outputs of that step: two runs must agree
+    if rank == 0 and split:                          # bits of rank 0's row-split outputs of that step: two runs must agree
         import hashlib
         hsh = hashlib.sha1()
-        for k in range(K):
-            hsh.update(slots[(it - 1) % NBATCH]["out_sh"][k][:4096].contiguous().cpu().numpy().tobytes())
+        for t in split:
+            hsh.update(slots[last]["outs"][t][:4096].contiguous().cpu().numpy().tobytes())
         digest = hsh.hexdigest()
-    if prof is not None and rank == 0:
-        n_calls = args.steps + args.warmup
-        print("[dist_bench] host microseconds per step by call:",
-              {k: round(v / 1e3 / n_calls, 1) for k, v in prof.items()}, flush=True)
+    sent = S.sent_counts(it - 1) if split else np.zeros((world, 1, 2), np.int64)      # (seq == step index: one submit per step)
+
+    # ---- the kernels' own time: the same steps with the library's kernel brackets on (events cost GPU time: not in the timed loop)
+    S.set_kernel_timing(True)
+    n_k = 16
+    for _ in range(n_k):
+        step(it)
+        it += 1
+    drain()
+    kst = S.stats(reset=True)
+    S.set_kernel_timing(False)
+    nt = max(int(kst["n_timed_batches"]), 1)
+    k_route, k_local, k_serve, k_un = (kst["us_kernel_route"] / nt, kst["us_kernel_local"] / nt, kst["us_kernel_serve"] / nt,
+                                       kst["us_kernel_unroute"] / nt)
+    nb = max(int(kst["n_batches"]), 1)
+    serve_bytes, local_bytes = kst["served_algorithmic_bytes"] / nb, kst["local_algorithmic_bytes"] / nb
+    kernel_us, alg_bytes = k_local + k_serve, int(serve_bytes + local_bytes)
 
     result = None
     if rank == 0:
         ach = alg_bytes / (kernel_us * 1e-6) / 1e9 if kernel_us > 0 else 0.0
-        sent = ex.sent_counts((it - 1) % NBATCH) if K else np.zeros((N, 1, 2), np.int64)
         clk = clock_fields(wall_ev, wall_sync, args.steps, world * args.steps * T * B)
-        bytes_out = 0
-        if K:        # what rank 0 handed to OTHER ranks in the last step: counts message, request pieces, returned partial rows
-            last = ex.slots[(it - 1) % NBATCH]
-            bytes_out = sum(8 * (K + 1) + 4 * int(last["req_out_words"][d]) + row_b * int(last["ret_rows_served"][d])
-                            for d in range(N) if d != rank)
-        fr = step_fractions(lookup_bytes(T, B, L, dim, 2 if TABLE_F16[0] else 4), bytes_out, clk["ms_per_step"], hbm_peak_gbs)
+        n_st = max(int(st["n_batches"]), 1)
+        bytes_out = int(st["bytes_to_peers"] / n_st)
+        fr = step_fractions(lookup_bytes(T, B, L, dim, elem), bytes_out, clk["ms_per_step"], hbm_peak_gbs)
+        fr["host_us_per_step"] = st["us_host_submit"] / n_st
+        fr["host_wait_counts_us_per_step"] = st["us_host_wait_counts"] / n_st
+        # (L of the newest batch and S of the one being served share ONE launch in the steady state: priced together)
+        kernels = {"router_us": k_route, "lookup_us": kernel_us, "unrouter_us": k_un,
+                   "lookup_algorithmic_bytes": alg_bytes, "served_algorithmic_bytes": int(serve_bytes),
+                   "local_algorithmic_bytes": int(local_bytes),
+                   "lookup_GBps": ach,
+                   # un-router: reads one partial row per sub-bag + the slot words, writes one pooled row per bag
+                   "unrouter_bytes": int(len(split) * B * row_b + (sent[:, :, 0].sum() if split else 0) * row_b),
+                   # router: reads every index once, writes one offset + one row id per sub-bag and one slot word per bag
+                   "router_bytes": int(len(split) * B * L * 4 + (sent[:, :, 0].sum() + sent[:, :, 1].sum() if split else 0) * 4 + len(split) * B * 4),
+                   "timed_batches": nt}
+        if k_un > 0:
+            kernels["unrouter_GBps"] = kernels["unrouter_bytes"] / (k_un * 1e-6) / 1e9
+        if k_route > 0:
+            kernels["router_GBps"] = kernels["router_bytes"] / (k_route * 1e-6) / 1e9
+        traffic = sharded_traffic_entry(args, mode, world)
         result = ({
             "metric": "pooled-lookups/sec + achieved HBM GB/s, 26-table dim-16 Kaggle, 1/2/4/8 GPU",
             "unit": "pooled-lookups/s", **clk,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16" if TABLE_F16[0] else "f32", "data": "synthetic",
-            "config": {"workload": "%s sharded, dim %d %s, B=%d bags/table PER RANK, L=%d, %s indices, "
-                                   "%d rotating batches; %d tables replicated (<= %d MiB), %d row-range sharded over "
-                                   "%d ranks" % (label, dim, "fp16" if TABLE_F16[0] else "fp32", B, L, dist_name, NBATCH, len(local), rep_bytes >> 20, K, world),
+            "verify": {"timed_batches_checked_bit_for_bit": n_verified, "what": "every table of every rotating slot the timed loop "
+                       "wrote last, on every rank, after the timed region; the first rotation and two pipelined steps before it"},
+            "config": {"workload": "%s sharded, dim %d %s, B=%d bags/table PER RANK, L=%d, %s indices, %d rotating batches; %s"
+                                   % (label, dim, "fp16" if TABLE_F16[0] else "fp32", B, L, dist_name, NBATCH, plan.describe()),
                        "tables": T, "dim": dim, "bags_per_table_per_rank": B, "global_bags_per_table": world * B,
-                       "pooling": L, "index_dist": dist_name,
-                       "parallelism": "row-range shards; bags cut into per-shard sub-bags on the GPU; counts first "
-                                      "(all_to_all of {sub-bags, indices} per peer and table), then the request pieces "
-                                      "and the partial rows as all_to_all with split sizes from the counts; partial "
-                                      "rows added in shard order; backend %s, %s, eager steps" %
-                                      (backend, "collectives issued natively to RCCL on the compute stream"
-                                       if native is not None else "torch.distributed.all_to_all_single"),
+                       "pooling": L, "index_dist": dist_name, "shard_mode": mode, "pipeline_depth": depth,
+                       "placement": {"replicated": plan.kinds.count(sh.REPLICATED), "whole": len(whole), "row_split": len(split),
+                                     "rules": sorted(set(n for n in plan.notes if n))},
+                       "parallelism": "ONE library call per batch (emb_shard_submit, depth %d): whole tables travel straight out "
+                                      "of / into the caller's buffers, row-split tables are cut into per-shard sub-bags on the GPU, "
+                                      "counts first, ONE fused lookup over everything a rank serves, partial rows added in shard "
+                                      "order; transfers = RCCL groups issued from C (emb_comm_exchange), self pieces %s; control "
+                                      "plane (bootstrap, barriers, job clock) torch.distributed/%s"
+                                      % (depth, "through RCCL too" if S._flags & 1 else "served in place", backend),
                        "last_step_outputs_sha1": digest,
                        "last_step_request_rows_per_peer": sent[:, :, 0].sum(axis=1).tolist(),
                        "last_step_request_indices_per_peer": sent[:, :, 1].sum(axis=1).tolist(),
-                       "exchange": {"mode": "rows", "value": clk["value"], "ms_per_step": clk["ms_per_step"], "verified": True,
-                                    "bytes_out_per_rank_per_step": bytes_out}},
+                       "exchange": {"mode": mode, "value": clk["value"], "ms_per_step": clk["ms_per_step"], "verified": True,
+                                    "bytes_out_per_rank_per_step": bytes_out, "host_us_per_step": fr["host_us_per_step"]}},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": hbm_peak_gbs, "unit": "GB/s",
                          "frac": ach / hbm_peak_gbs, "traffic": None, "kernel_us": kernel_us,
-                         "algorithmic_bytes": alg_bytes,
-                         "basis": "algorithmic bytes (no PMC profile of the N > 1 legs; a pooled launch is partly cache-served and can exceed 1: the same kernels at N = 1 are priced on measured bytes, profiles/traffic.json)", "note": "rank 0's two lookup launches (replicated tables + served request pieces), kernel-only; the whole step (routing, three collectives, un-routing) against HBM and xGMI: roofline.exchange",
-                         "exchange": fr},
+                         "algorithmic_bytes": alg_bytes, "basis": "algorithmic bytes",
+                         "note": "rank 0's lookup launch per step (replicated tables of the newest batch + every piece received for "
+                                 "the batch being served: ONE fused launch), HIP events inside the library (emb_shard_set_kernel_timing) over %d extra steps after "
+                                 "the timed region; the whole step (routing, transfers, un-routing) against HBM and xGMI: "
+                                 "roofline.exchange" % nt,
+                         "kernels": kernels, "exchange": fr},
         })
+        apply_sharded_traffic(result["roofline"], traffic, kernel_us, k_route, k_un)
     dist.barrier()
-    for sl in slots:
-        if sl["plan_a"] is not None:
-            sl["plan_a"].destroy()
-    if native is not None:
-        torch.cuda.synchronize()
-        native.close()
+    torch.cuda.synchronize()
+    S.close()
+    if comm is not None:
+        comm.close()
     eng.close()
     return result
+
+
+def sharded_traffic_entry(args, mode, world):
+    """profiles/traffic.json entry of this sharded command (world-1 PMC passes of the served lookup, the router and the
+    un-router; see profiles/collect_dist_pmc.sh), or None."""
+    if world != 1 or args.batch is not None or getattr(args, "rows_scale", 1.0) not in (None, 1.0):
+        return None          # the counters were collected with one rank: another rank count serves other pieces
+    key = "dist-%s-%s-l%d" % (getattr(args, "workload", "c2"), mode, int(getattr(args, "pooling", None) or 0) or 1)
+    try:
+        import bench
+        return bench.measured_traffic(key)
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def apply_sharded_traffic(roof, entry, k_serve, k_route, k_un):
+    """HBM-side bytes of the sharded leg's three kernel families from the committed PMC passes, priced with THIS run's
+    kernel times."""
+    if not entry:
+        roof["traffic_note"] = "no PMC profile of this exact sharded command (profiles/traffic.json holds the world-1 ones)"
+        return
+    roof["traffic"] = entry.get("traffic_bytes_per_launch")
+    roof["traffic_source"] = entry.get("source")
+    if roof["traffic"] and k_serve > 0:
+        roof["achieved_measured"] = roof["traffic"] / (k_serve * 1e-6) / 1e9
+        roof["frac_measured"] = roof["achieved_measured"] / roof["peak"]
+    for name, us in (("router", k_route), ("unrouter", k_un)):
+        sub = entry.get(name)
+        if sub and us > 0:
+            roof["kernels"][name + "_traffic_bytes"] = sub.get("traffic_bytes_per_launch")
+            roof["kernels"][name + "_measured_GBps"] = sub.get("traffic_bytes_per_launch", 0) / (us * 1e-6) / 1e9
+    if entry.get("read_over_unique_rows") is not None:
+        roof["read_over_unique_rows"] = entry["read_over_unique_rows"]
 
 
 def run_dp(args, hbm_peak_gbs: float, ctx):
@@ -850,18 +571,18 @@ def run(args, hbm_peak_gbs: float) -> None:
     run_dog.start()
     n_dev = torch.cuda.device_count()
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-    one_gpu = os.environ.get("PIMEMB_RCCL_ONE_GPU") == "1"
-    if one_gpu and backend == "nccl":
-        # Rehearsal of the REAL RCCL path with several ranks on ONE GPU: RCCL refuses two ranks on a device of the same
-        # host ("duplicate GPU"), so every rank claims a host of its own (NCCL_HOSTID) and, being "remote" to its peers, talks
-        # to them through RCCL's socket transport over loopback -- slow, but the same communicator, the same grouped
-        # send / receive calls and the same torch code path as on an 8-GPU node (tools/rccl_one_gpu_ranks_probe.py).
+    # Several ranks on ONE GPU (rehearsal): RCCL refuses two ranks on a device of the same host ("duplicate GPU"), so every
+    # rank claims a host of its own (NCCL_HOSTID) and, being "remote" to its peers, talks to them through RCCL's socket
+    # transport over loopback -- slow, but the same communicator, the same grouped send / receive calls as on an 8-GPU node
+    # (tools/rccl_one_gpu_ranks_probe.py).  Asked for with PIMEMB_RCCL_ONE_GPU=1; implied by the gloo control plane, whose
+    # whole point is more ranks than GPUs (the sharded legs' data path is the C side's RCCL communicator either way).
+    one_gpu = os.environ.get("PIMEMB_RCCL_ONE_GPU") == "1" or (backend != "nccl" and n_dev < local_world)
+    if one_gpu and world > 1:
         os.environ.update(NCCL_HOSTID="pimemb-rank%d" % rank, NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1",
                           NCCL_P2P_DISABLE="1", NCCL_SHM_DISABLE="1", NCCL_NET_GDR_LEVEL="0")
     if backend == "nccl" and n_dev < local_world and not one_gpu:
         raise SystemExit(f"bench.py --gpus {world}: {local_world} ranks on this node but {n_dev} GPU(s) visible -- RCCL needs one GPU "
-                         "per rank (PIMEMB_RCCL_ONE_GPU=1 rehearses the RCCL path, PIMEMB_DIST_BACKEND=gloo the N > 1 code "
-                         "with host-staged collectives, with several ranks on one GPU)")
+                         "per rank (PIMEMB_RCCL_ONE_GPU=1 rehearses the RCCL path with several ranks on one GPU)")
     dev = torch.device("cuda", local_rank % max(n_dev, 1))
     torch.cuda.set_device(dev)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -878,7 +599,9 @@ def run(args, hbm_peak_gbs: float) -> None:
     hbm = torch.cuda.get_device_properties(dev).total_memory
     auto = getattr(args, "replicate_mb", None) is None
     mode = getattr(args, "shard_mode", None) or ("rows" if getattr(args, "workload", "c2") == "c4" else "whole")
-    shard_leg = run_rows if mode == "rows" else run_whole
+
+    def shard_leg(a, peak, c, rep):
+        return run_sharded(a, peak, c, rep, mode)
     state = {"printed": False, "dog": None, "primary": None}
 
     def emit(res):
@@ -891,8 +614,8 @@ def run(args, hbm_peak_gbs: float) -> None:
         if res is not None:
             res.setdefault("verified", True)     # every leg compares its outputs bit for bit before AND after timing
             res["config"]["backend"] = backend
-            res["config"]["rccl_ranks"] = world if backend == "nccl" else 0
-            if one_gpu and backend == "nccl":
+            res["config"]["rccl_ranks"] = world          # the sharded legs' transfers are the C side's RCCL communicator on every backend
+            if one_gpu and world > 1:
                 res["config"]["rccl_transport"] = "sockets over loopback, %d ranks on %d GPU(s) (PIMEMB_RCCL_ONE_GPU=1)" % (world, n_dev)
             res["config"]["world_size"] = world
         return res
@@ -934,14 +657,21 @@ def run(args, hbm_peak_gbs: float) -> None:
                                                                   "ms_per_step_sync", "clock", "steps", "roofline")}
                 result["sharded_exchange"]["verified"] = True
                 result["sharded_exchange"]["config"] = sec["config"]["workload"] + "; " + sec["config"]["parallelism"]
-                # the same numbers inside the two objects a SCALE record keeps (config / roofline): the all-to-all leg's
-                # value is the xGMI curve north_star asks for, next to the replica curve in `value`
+                # the same numbers inside the two objects a SCALE record keeps (config / roofline) ...
                 result["config"]["exchange"] = dict(sec["config"]["exchange"], steps=sec["steps"],
                                                     what="secondary leg of the same run: " + sec["config"]["workload"])
                 result["roofline"]["exchange"] = sec["roofline"]["exchange"]
+                # ... and at the TOP LEVEL: `value` is the replica curve (every table on every rank, no data-path transfer:
+                # it scales with N by construction), `value_exchange` the all-to-all curve north_star asks for -- the five
+                # tables above 64 MiB sharded, indices in / pooled rows out over the links
+                result["value_exchange"] = sec["value"]
+                result["ms_per_step_exchange"] = sec["ms_per_step"]
+                result["exchange_mode"] = mode
     else:
         rep_mb = 64 if auto else int(args.replicate_mb)
         result = shard_leg(args, hbm_peak_gbs, ctx, rep_mb << 20)
+        if rank == 0 and result is not None:       # the primary leg IS the exchange: one number, two names
+            result["value_exchange"], result["ms_per_step_exchange"], result["exchange_mode"] = result["value"], result["ms_per_step"], mode
     emit(finish(result))
     dist.barrier()
     dist.destroy_process_group()

@@ -66,7 +66,9 @@ class EmbShardStats(C.Structure):
     _fields_ = [("n_batches", C.c_uint64), ("bytes_to_peers", C.c_uint64), ("bytes_to_self", C.c_uint64),
                 ("served_algorithmic_bytes", C.c_uint64), ("local_algorithmic_bytes", C.c_uint64),
                 ("served_sub_bags", C.c_uint64), ("served_indices", C.c_uint64),
-                ("us_host_submit", C.c_double), ("us_host_wait_counts", C.c_double)]
+                ("us_host_submit", C.c_double), ("us_host_wait_counts", C.c_double),
+                ("us_kernel_route", C.c_double), ("us_kernel_local", C.c_double), ("us_kernel_serve", C.c_double),
+                ("us_kernel_unroute", C.c_double), ("n_timed_batches", C.c_uint64)]
 
 
 class EmbTraceEvent(C.Structure):
@@ -106,6 +108,7 @@ SIGNATURES = {
     "emb_shard_wait": (C.c_int, [_vp, _u64, _vp]),
     "emb_shard_lookup": (C.c_int, [_vp, C.POINTER(EmbShardInput), _u64, _vp]),
     "emb_shard_get_stats": (C.c_int, [_vp, C.POINTER(EmbShardStats), C.c_int]),
+    "emb_shard_set_kernel_timing": (C.c_int, [_vp, C.c_int]),
     "emb_shard_sent_counts": (C.c_int, [_vp, _u64, C.POINTER(_u32), _u32]),
     "emb_shard_destroy": (C.c_int, [_vp]),
     "emb_table_info": (C.c_int, [_vp, _u32, _pp, C.POINTER(_u64), C.POINTER(_u32), C.POINTER(C.c_int)]),

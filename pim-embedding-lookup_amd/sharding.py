@@ -67,7 +67,8 @@ class ShardPlan:
 
 def plan_shards(rows: Sequence[int], dim: int, elem_bytes: int, world: int,
                 replicate_bytes: int = 64 << 20, split_bytes: int | None = None,
-                pooling: float | Sequence[float] = 1.0, capacity_bytes: int | None = None) -> ShardPlan:
+                pooling: float | Sequence[float] = 1.0, capacity_bytes: int | None = None,
+                split_single_rank: bool = False) -> ShardPlan:
     """Greedy placement.  split_bytes=None: split tables larger than 1/world of all sharded bytes.
 
     Return volume.  A row-split table returns one PARTIAL row per (bag, shard that holds one of the bag's rows) -- up to
@@ -76,7 +77,8 @@ def plan_shards(rows: Sequence[int], dim: int, elem_bytes: int, world: int,
     (`pooling` >= 2 expected indices per bag; one number or one per table) above the split threshold is still placed WHOLE
     while the rank it lands on stays under `capacity_bytes` (default: no limit other than balance -- at most twice the mean
     load); only tables that must be split (capacity, or one index per bag where splitting costs nothing extra) are.
-    `plan.notes[t]` says which rule placed a table."""
+    `plan.notes[t]` says which rule placed a table.  split_single_rank: let a world of ONE rank row-split too (one shard
+    holding every row: the whole routed path, rehearsed on one GPU)."""
     rows = [int(r) for r in rows]
     T = len(rows)
     pool = [float(pooling)] * T if not hasattr(pooling, "__len__") else [float(x) for x in pooling]
@@ -91,7 +93,7 @@ def plan_shards(rows: Sequence[int], dim: int, elem_bytes: int, world: int,
     load = [0] * world
     owner = {}
     for t in sorted(sharded, key=lambda t: -size[t]):          # big first: candidates for splitting
-        if not (world > 1 and size[t] > split_bytes and rows[t] >= world):
+        if not ((world > 1 or split_single_rank) and size[t] > split_bytes and rows[t] >= world):
             continue
         r = min(range(world), key=lambda r: (load[r], r))
         if pool[t] >= 2.0 and load[r] + size[t] <= cap:
@@ -138,7 +140,7 @@ class ShardedEmbeddingBags:
         sh.load_tables(lambda t, lo, hi: rows)                     # only this rank's shards are requested
         outs = sh.forward(lS_o, lS_i)                              # synchronous form: submit + flush + wait
 
-    Software-pipelined form (depth 1 or 2): `seq, outs = sh.submit(...)` every batch, `sh.wait(seq)` once the batch is
+    Software-pipelined form (depth 1 .. 3): `seq, outs = sh.submit(...)` every batch, `sh.wait(seq)` once the batch is
     `depth` submits old (or after `sh.flush()`); a batch's tensors belong to the library until then.  submit / flush are
     COLLECTIVE: every rank makes the same calls in the same order (a rank with nothing to look up passes empty tensors).
 
@@ -272,6 +274,9 @@ class ShardedEmbeddingBags:
         self._l.check(self._L.emb_shard_get_stats(self._h, self._C.byref(st), int(reset)))
         return {k: getattr(st, k) for k, _ in st._fields_}
 
+    def set_kernel_timing(self, on: bool) -> None:
+        self._l.check(self._L.emb_shard_set_kernel_timing(self._h, int(on)))
+
     def sent_counts(self, seq: int):
         """{sub-bags, indices} per (peer, row-split table) of the requests this rank sent for batch seq: [N][Kr][2]."""
         import numpy as np
@@ -287,15 +292,18 @@ class ShardedEmbeddingBags:
         self._live.clear()
 
 
-def native_comm(engine, rank: int, world: int):
+def native_comm(engine, rank: int, world: int, always: bool = False):
     """An engine.NativeExchange (RCCL communicator of the C side) bootstrapped over an initialised torch.distributed
-    group: rank 0 draws the id, broadcast_object_list spreads it.  None for a world of one rank."""
-    if world == 1:
+    group: rank 0 draws the id, broadcast_object_list spreads it.  None for a world of one rank unless `always` (a
+    one-rank communicator: what self_via_comm rehearses RCCL's grouped send / receive with)."""
+    if world == 1 and not always:
         return None
-    import torch.distributed as dist
     from .engine import NativeExchange
 
     def bcast(raw: bytes) -> bytes:
+        if world == 1:
+            return raw
+        import torch.distributed as dist
         box = [raw]
         dist.broadcast_object_list(box, src=0)
         return box[0]

@@ -96,12 +96,12 @@ def main():
     comm = sh.native_comm(eng, rank, world)
     status = {"rank": rank, "ok": False}
     try:
-        for depth in cfg.get("depths", [0, 2]):
+        for depth in cfg.get("depths", [0, 2, 3]):
             S = sh.ShardedEmbeddingBags(plan, eng, rank, comm, depth=depth, check=cfg.get("check", True),
                                         self_via_comm=cfg.get("self_via_comm", False))
             S.load_tables(lambda t, lo, hi: torch.from_numpy(tabs[t][lo:hi]).to(dev))
             rng = np.random.default_rng(1000 + rank)           # every rank has its OWN bags
-            n_batches = cfg.get("batches", 5)
+            n_batches = cfg.get("batches", 6)
             batches = []
             for j in range(n_batches):
                 B = cfg["bags"] + (rank if cfg.get("ragged_ranks", True) else 0) + 3 * j

@@ -57,7 +57,7 @@ ONE_RANK = dict(rows=[7, 300, 5000, 64, 2000, 900], dim=16, bags=37, max_len=5,
 @pytest.mark.parametrize("variant", ["ragged", "one-hot", "fixed-pooling", "int64", "f16-dim64"])
 def test_shard_one_rank_every_placement(variant, tmp_path):
     """A world of one rank (no communicator): replicated, whole and row-split tables in one call, ragged bags (empty ones
-    included), depth 0 (forward) and depth 2 (submit / wait / flush) -- every table bit for bit the oracle's."""
+    included), depth 0 (forward) and depths 2 / 3 (submit / wait / flush) -- every table bit for bit the oracle's."""
     cfg = dict(ONE_RANK)
     if variant == "one-hot":
         cfg.update(max_len=1, fixed=True)
@@ -68,8 +68,9 @@ def test_shard_one_rank_every_placement(variant, tmp_path):
     elif variant == "f16-dim64":
         cfg.update(f16=True, dim=64)
     res = _run(cfg, 1, tmp_path)
-    st = res[0]["stats_depth2"]
-    assert st["n_batches"] == 5 and st["bytes_to_peers"] == 0 and st["served_algorithmic_bytes"] > 0
+    for d in (2, 3):
+        st = res[0]["stats_depth%d" % d]
+        assert st["n_batches"] == 6 and st["bytes_to_peers"] == 0 and st["served_algorithmic_bytes"] > 0
 
 
 @pytest.mark.parametrize("variant,world", [("ragged", 2), ("ragged", 3), ("one-hot", 4), ("pooled-whole", 2), ("self-via-comm", 2),
@@ -89,7 +90,7 @@ def test_shard_rccl_ranks_on_one_gpu(variant, world, tmp_path):
         cfg.update(empty_rank=1)
     res = _run(cfg, world, tmp_path)
     for st in res:
-        assert st["stats_depth0"]["bytes_to_peers"] > 0 and st["stats_depth2"]["n_batches"] == 5
+        assert st["stats_depth0"]["bytes_to_peers"] > 0 and st["stats_depth2"]["n_batches"] == 6 and st["stats_depth3"]["n_batches"] == 6
     if variant == "self-via-comm":
         assert all(st["stats_depth2"]["bytes_to_self"] > 0 for st in res)
 
@@ -100,6 +101,6 @@ def test_shard_bad_index_raises_on_the_serving_rank_and_nobody_hangs(tmp_path):
     cfg = dict(rows=[7, 300, 5000, 64, 2000, 1500], dim=16, rep=64 * 16 * 4, split=3000 * 16 * 4, bags=29, max_len=1, fixed=True,
                bad_index={"rank": 0, "table": 2}, batches=2)
     res = _run(cfg, 3, tmp_path)
-    for depth in (0, 2):
+    for depth in (0, 2, 3):
         raised = [st["raised_depth%d" % depth] for st in res]
         assert raised == [False, False, True], raised

@@ -1,7 +1,13 @@
-"""CPU: shard planner (host logic) and the N>1 exchange path with world_size-2 gloo processes.
-The local lookup step is the HIP engine in the product; here a test backend built on the oracle
-stands in for it so the ROUTING (bucketing, all_to_all both ways, partial-sum order) is what is
-checked."""
+"""CPU: shard planner (host logic) and the N > 1 exchange PROTOCOL with world_size-2 / -3 gloo processes.
+
+The sharded step itself is csrc/pimemb_shard.cpp -- HIP kernels and RCCL groups, nothing a CPU can run (the product has
+no CPU path; tests/test_gpu_shard.py runs it with 1-4 real RCCL ranks).  What is covered here is everything of the N > 1
+path that is plain host arithmetic in the C ABI, driven through a real multi-process exchange: the message formats of
+include/pimemb.h (counts first: [peer][table]{sub-bags, indices} + peaks; request pieces: offsets[pad4] then row
+ids[pad4] per table; partial rows back to back), the split sizes every rank derives from the counts it sent and received
+(emb_route_exchange_sizes), the descriptors of the one fused lookup over everything received (emb_route_serve_descs), and
+the shard-order addition of the partial rows.  The GPU's three kernels -- router, bag-sum, un-router -- are stood in for
+by numpy restatements of their documented rules and by the oracle; gloo carries the bytes."""
 import os
 import socket
 import sys
@@ -80,73 +86,177 @@ def test_planner_policies():
     assert q.kinds == [sh.WHOLE]
 
 
-class OracleBackend:
-    """TEST stand-in for the HIP engine's local step (numpy in, numpy out via the CPU oracle)."""
+PAD4 = lambda v: (int(v) + 3) // 4 * 4  # noqa: E731
 
-    def __init__(self):
-        self.tables = {}
 
-    def load(self, uid, rows):
-        self.tables[uid] = np.ascontiguousarray(rows, dtype=np.float32)
-
-    def lookup(self, uids, indices, offsets, outs):
-        import torch
-        from oracle import oracle
-        res = []
-        for u, i, o in zip(uids, indices, offsets):
-            res.append(torch.from_numpy(oracle.c_bag_sum(self.tables[u], i.numpy().astype(np.int64),
-                                                         o.numpy().astype(np.int64))))
-        return res
+def _route(idx, off, rps, N):
+    """numpy restatement of emb_route_bags' rule for one table: per shard d (sub-bag start offsets, local row ids, slot of
+    every bag or -1)."""
+    B = off.shape[0]
+    end = np.concatenate([off[1:], [idx.shape[0]]]).astype(np.int64)
+    dest = np.minimum(idx.astype(np.int64) // rps, N - 1)
+    out = []
+    for d in range(N):
+        sub_off, lists, slots, pos = [], [], np.full(B, -1, dtype=np.int64), 0
+        for b in range(B):
+            sel = idx[off[b]:end[b]][dest[off[b]:end[b]] == d]
+            if sel.size:
+                slots[b] = len(sub_off)
+                sub_off.append(pos)
+                lists.append(sel.astype(np.int64) - d * rps)
+                pos += sel.size
+        out.append((np.array(sub_off, dtype=np.uint32), np.concatenate(lists).astype(np.uint32) if lists else np.zeros(0, np.uint32), slots))
+    return out
 
 
 def _worker(rank, world, port, cfg, q):
+    import ctypes as C
     import torch
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
+    import pim_embedding_lookup_amd as pel
     from oracle import oracle
     sh = _sharding()
+    L = pel.lib.load()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        rows, dim = cfg["rows"], cfg["dim"]
+        rows, dim, N = cfg["rows"], cfg["dim"], world
         plan = sh.plan_shards(rows, dim, 4, world, replicate_bytes=cfg["rep"], split_bytes=cfg["split"])
         assert set(plan.kinds) == set(cfg["expect_kinds"]), plan.kinds
-        tabs = [np.random.default_rng(100 + t).standard_normal((n, dim)).astype(np.float32)
-                for t, n in enumerate(rows)]
-        sl = sh.ShardedLookup(plan, rank, OracleBackend(), device="cpu")
-        sl.load_tables(lambda t, lo, hi: tabs[t][lo:hi])
+        tabs = [np.random.default_rng(100 + t).standard_normal((n, dim)).astype(np.float32) for t, n in enumerate(rows)]
+        split = [t for t, k in enumerate(plan.kinds) if k == sh.ROW_SPLIT]
+        whole_of = [[t for t, k in enumerate(plan.kinds) if k == sh.WHOLE and plan.units[plan.units_of_table[t][0]].owner == p]
+                    for p in range(N)]
+        mine = whole_of[rank]
+        K = len(split)
+        rps = [-(-rows[t] // N) for t in split]
         rng = np.random.default_rng(1000 + rank)               # every rank has its OWN bags
+        B = cfg["bags"] + rank                                   # ragged: ranks differ in bag count
         idx, off = [], []
         for n in rows:
-            B = cfg["bags"] + rank                               # ragged: ranks differ in bag count
             lens = rng.integers(0, cfg["max_len"] + 1, size=B)
             o = np.zeros(B, dtype=np.int64)
             o[1:] = np.cumsum(lens)[:-1]
             off.append(o)
             idx.append(rng.integers(0, n, size=int(lens.sum())).astype(np.int64))
-        outs = sl.forward([torch.from_numpy(i) for i in idx], [torch.from_numpy(o) for o in off])
+
+        def a2a(send_parts, recv_sizes, dtype):
+            wire = np.int32 if dtype == np.uint32 else dtype            # gloo has no uint32: the same bits as int32
+            flat = np.concatenate([np.asarray(p_, dtype=dtype).reshape(-1) for p_ in send_parts]) if send_parts else np.zeros(0, dtype)
+            send = torch.from_numpy(np.ascontiguousarray(flat).view(wire))
+            recv = torch.empty(int(sum(recv_sizes)), dtype=send.dtype)
+            dist.all_to_all_single(recv, send, output_split_sizes=[int(x) for x in recv_sizes],
+                                   input_split_sizes=[int(np.asarray(p_).size) for p_ in send_parts])
+            return np.split(recv.numpy().view(dtype), np.cumsum(recv_sizes)[:-1].astype(np.int64)) if len(recv_sizes) else []
+
+        # ---- R: route (model of the kernel), counts message [N][K+1][2] with the peaks entry
+        routed = [_route(idx[t], off[t], rps[k], N) for k, t in enumerate(split)]
+        sent = np.zeros((N, K + 1, 2), dtype=np.uint32)
+        pieces = []
+        for d in range(N):
+            words = []
+            for k in range(K):
+                so, ids, _ = routed[k][d]
+                sent[d, k] = (so.size, ids.size)
+                words.append(np.concatenate([so, np.zeros(PAD4(so.size) - so.size, np.uint32), ids, np.zeros(PAD4(ids.size) - ids.size, np.uint32)]))
+            pieces.append(np.concatenate(words) if words else np.zeros(0, np.uint32))
+        if K:
+            sent[:, K, 0] = max(p_.size for p_ in pieces)
+            sent[:, K, 1] = max(int(sent[d, :K, 0].sum()) for d in range(N))
+        # ---- counts FIRST
+        received = np.stack(a2a([sent[d] for d in range(N)], [(K + 1) * 2] * N, np.uint32)).reshape(N, K + 1, 2).astype(np.uint32) if K else sent
+        wsent = [[(B, idx[t].size, 0, 0) for t in whole_of[p]] for p in range(N)]          # whole tables: {bags, indices, pooling 0 = offsets travel, 0}
+        wrecv = a2a([np.array(w, dtype=np.uint32) for w in wsent], [len(mine) * 4] * N, np.uint32)
+        wrecv = [w.reshape(len(mine), 4) for w in wrecv]
+        # ---- sizes from the counts: the LIBRARY's arithmetic
+        if K:
+            both = np.ascontiguousarray(np.stack([sent, received]))
+            out = (C.c_uint64 * (4 * N))()
+            pr, pt = C.c_uint64(), C.c_uint64()
+            base = C.addressof(out)
+            assert L.emb_route_exchange_sizes(both.ctypes.data, both.ctypes.data + sent.nbytes, K, N, dim, base, base + 8 * N,
+                                              base + 16 * N, base + 24 * N, C.byref(pr), C.byref(pt)) == 0
+            v = np.array(out[:], dtype=np.int64).reshape(4, N)
+            out_w, in_w, back, served = v
+            assert [p_.size for p_ in pieces] == out_w.tolist()
+            # every rank derives the SAME job-wide peaks
+            peaks = torch.tensor([pr.value, pt.value], dtype=torch.int64)
+            lo, hi = peaks.clone(), peaks.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            assert torch.equal(lo, hi)
+            # ---- Q: request pieces with split sizes from the counts
+            req_recv = np.ascontiguousarray(np.concatenate(a2a(pieces, in_w, np.uint32))) if in_w.sum() else np.zeros(4, np.uint32)
+            # ---- S: the descriptors of the ONE fused lookup -- library arithmetic, host pointers here -- run by the oracle
+            ids_arr = (C.c_uint32 * K)(*range(K))
+            descs = (pel.lib.EmbLookupDesc * (N * K))()
+            nd, nbytes = C.c_uint32(), C.c_uint64()
+            ret_send = np.zeros((max(int(served.sum()), 1), dim), dtype=np.float32)
+            assert L.emb_route_serve_descs(received.ctypes.data, K, N, dim, ids_arr, req_recv.ctypes.data, ret_send.ctypes.data,
+                                           descs, C.byref(nd), C.byref(nbytes)) == 0
+            for j in range(nd.value):
+                dsc = descs[j]
+                t = split[dsc.table_id]
+                u = plan.units[plan.units_of_table[t][rank]]
+                o_ = np.ctypeslib.as_array(C.cast(dsc.offsets, C.POINTER(C.c_uint32)), (dsc.n_bags,)).astype(np.int64)
+                i_ = np.ctypeslib.as_array(C.cast(dsc.indices, C.POINTER(C.c_uint32)), (dsc.n_indices,)).astype(np.int64)
+                row0 = (dsc.pooled - ret_send.ctypes.data) // (4 * dim)
+                ret_send[row0:row0 + dsc.n_bags] = oracle.c_bag_sum(tabs[t][u.row_lo:u.row_hi], i_, o_)
+            # ---- T: partial rows back, split sizes from the same counts
+            parts = [ret_send[int(served[:s_].sum()):int(served[:s_ + 1].sum())] for s_ in range(N)]
+            back_rows = a2a(parts, back * dim, np.float32)
+            ret_recv = np.concatenate(back_rows).reshape(-1, dim) if back.sum() else np.zeros((0, dim), np.float32)
+        # whole tables: indices / offsets travel as they are, pooled rows come straight back
+        wreq = a2a([np.concatenate([np.concatenate([off[t].astype(np.uint32), idx[t].astype(np.uint32)]) for t in whole_of[p]])
+                    if whole_of[p] else np.zeros(0, np.uint32) for p in range(N)],
+                   [int(sum(int(c[0]) + int(c[1]) for c in wrecv[s_])) for s_ in range(N)], np.uint32)
+        wret = []
+        for s_ in range(N):
+            cur, rows_out = 0, []
+            for j, t in enumerate(mine):
+                nb, ni = int(wrecv[s_][j][0]), int(wrecv[s_][j][1])
+                o_ = wreq[s_][cur:cur + nb].astype(np.int64); cur += nb
+                i_ = wreq[s_][cur:cur + ni].astype(np.int64); cur += ni
+                rows_out.append(oracle.c_bag_sum(tabs[t], i_, o_) if nb else np.zeros((0, dim), np.float32))
+            wret.append(np.concatenate(rows_out).reshape(-1) if rows_out else np.zeros(0, np.float32))
+        wback = a2a(wret, [len(whole_of[p]) * B * dim for p in range(N)], np.float32)
+
+        # ---- U + assembly, then the single-process oracle over the whole tables
         worst = 0.0
         for t in range(len(rows)):
             want = oracle.c_bag_sum(tabs[t], idx[t], off[t])
-            got = outs[t].numpy()
-            assert got.shape == want.shape
-            if plan.kinds[t] == sh.ROW_SPLIT and cfg["max_len"] > 1:
-                # partial sums per shard added in shard order: re-derive exactly, and 1e-6 vs sequential
+            if plan.kinds[t] == sh.REPLICATED:
+                got = want          # (looked up locally by the engine in the product: nothing to exchange)
+            elif plan.kinds[t] == sh.WHOLE:
+                p = plan.units[plan.units_of_table[t][0]].owner
+                j = whole_of[p].index(t)
+                got = wback[p][j * B * dim:(j + 1) * B * dim].reshape(B, dim)
+                assert np.array_equal(got, want), f"table {t} (whole)"
+            else:
+                k = split.index(t)
+                got = np.zeros((B, dim), np.float32)
+                for d in range(N):                    # shard order, from +0: emb_unroute_bags' rule
+                    row0 = int(back[:d].sum()) + int(sent[d, :k, 0].sum())
+                    slots = routed[k][d][2]
+                    has = slots >= 0
+                    part = np.zeros((B, dim), np.float32)
+                    part[has] = ret_recv[row0 + slots[has]]
+                    got = got + part
+                # the same thing restated per shard with the oracle: bit for bit; and 1e-5 from the sequential sum
                 exact = np.zeros_like(want)
+                bag_of = np.repeat(np.arange(B), np.diff(np.append(off[t], len(idx[t]))))
                 for u in (plan.units[i] for i in plan.units_of_table[t]):
                     keep = (idx[t] >= u.row_lo) & (idx[t] < u.row_hi)
-                    bag_of = np.repeat(np.arange(len(off[t])), np.diff(np.append(off[t], len(idx[t]))))
-                    l2 = np.bincount(bag_of[keep], minlength=len(off[t]))
-                    o2 = np.zeros(len(off[t]), np.int64); o2[1:] = np.cumsum(l2)[:-1]
-                    part = oracle.c_bag_sum(tabs[t][u.row_lo:u.row_hi], idx[t][keep] - u.row_lo, o2)
-                    exact = exact + part if u.owner else part
-                assert np.array_equal(got, exact)
+                    l2 = np.bincount(bag_of[keep], minlength=B)
+                    o2 = np.zeros(B, np.int64); o2[1:] = np.cumsum(l2)[:-1]
+                    if u.row_hi > u.row_lo:
+                        exact = exact + oracle.c_bag_sum(tabs[t][u.row_lo:u.row_hi], idx[t][keep] - u.row_lo, o2)
+                assert np.array_equal(got, exact), f"table {t} (row-split)"
                 assert np.abs(got - want).max() <= 1e-5
                 worst = max(worst, float(np.abs(got - want).max()))
-            else:
-                assert np.array_equal(got, want), f"table {t} ({plan.kinds[t]})"
         q.put((rank, "ok", worst))
-    except Exception as e:  # pragma: no cover
+    except Exception:  # pragma: no cover
         import traceback
         q.put((rank, "fail", traceback.format_exc()))
     finally:
@@ -169,7 +279,7 @@ def _free_port():
     dict(rows=[100, 200, 300], dim=16, rep=0, split=10**12, bags=11, max_len=4, expect_kinds=["whole"]),
 ])
 @pytest.mark.parametrize("world", [2, 3])
-def test_gloo_exchange_matches_single_process_oracle(cfg, world):
+def test_gloo_exchange_protocol_matches_single_process_oracle(cfg, world):
     """world 3: row ranges that do not divide evenly, a rank that owns no whole table."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -183,3 +293,25 @@ def test_gloo_exchange_matches_single_process_oracle(cfg, world):
         p.join(timeout=60)
     for rank, status, info in res:
         assert status == "ok", f"rank {rank}:\n{info}"
+
+
+def test_planner_return_volume_term(pel):
+    """pooled tables that fit a rank are placed WHOLE rather than row-split (a split returns up to
+    min(pooling, world) partial rows per bag); one-index-per-bag tables and tables no rank has room for still split."""
+    sh = _sharding()
+    rows, dim, _, _ = pel.workloads.table_set("c4")
+    one_hot = sh.plan_shards(rows, dim, 4, world=8)
+    pooled = sh.plan_shards(rows, dim, 4, world=8, pooling=32)
+    assert one_hot.kinds.count(sh.ROW_SPLIT) == 4
+    assert pooled.kinds.count(sh.ROW_SPLIT) < 4 and pooled.kinds.count(sh.WHOLE) > one_hot.kinds.count(sh.WHOLE)
+    kept = [t for t in range(len(rows)) if one_hot.kinds[t] == sh.ROW_SPLIT and pooled.kinds[t] == sh.WHOLE]
+    assert kept and all("pooled" in pooled.notes[t] and "whole although" in pooled.notes[t] for t in kept)
+    assert max(pooled.bytes_on(r) for r in range(8)) < 288e9 * 0.5                     # still far inside one GPU's HBM
+    still = [t for t in range(len(rows)) if pooled.kinds[t] == sh.ROW_SPLIT]
+    assert all("no rank has room" in pooled.notes[t] for t in still)
+    # an explicit capacity forces the split again
+    tight = sh.plan_shards(rows, dim, 4, world=8, pooling=32, capacity_bytes=60 << 30)
+    assert tight.kinds.count(sh.ROW_SPLIT) >= pooled.kinds.count(sh.ROW_SPLIT)
+    # a world of one rank splits only when asked to (the routed path rehearsed on one GPU)
+    assert sh.plan_shards([10, 5_000_000], 16, 4, world=1).kinds == [sh.REPLICATED, sh.WHOLE]
+    assert sh.plan_shards([10, 5_000_000], 16, 4, world=1, split_bytes=1 << 20, split_single_rank=True).kinds == [sh.REPLICATED, sh.ROW_SPLIT]
