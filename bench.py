@@ -130,17 +130,68 @@ def profile_key(args, spec):
     return key
 
 
-def measured_traffic(key):
+KERNEL_OF_KIND = ["bag_sum_wavebatch_kernel", "bag_sum_group_kernel", "bag_sum_wavebatch_kernel", "bag_sum_anydim", "bag_sum_hot_kernel"]
+KERNEL_SOURCES = ["pimemb_bag_kernels.h", "pimemb_kernels.hip", "pimemb_xcd_map.h", "pimemb_internal.h", "pimemb_engine.cpp", "pimemb_shard.cpp"]
+
+
+def library_identity():
+    """What a profiles/traffic.json entry is tied to: the sha256 of the loaded libpimemb.so and of the sources its kernels
+    and launch logic are built from (a rebuild of unchanged sources may differ in bytes; changed sources never match)."""
+    import hashlib
+    pkg = os.path.join(ROOT, "pim-embedding-lookup_amd")
+    out = {"lib_sha256": None, "src_sha256": None}
+    try:
+        with open(os.path.join(pkg, "lib", "libpimemb.so"), "rb") as f:
+            out["lib_sha256"] = hashlib.sha256(f.read()).hexdigest()
+    except OSError:
+        pass
+    try:
+        h = hashlib.sha256()
+        for name in KERNEL_SOURCES:
+            with open(os.path.join(pkg, "csrc", name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+        out["src_sha256"] = h.hexdigest()
+    except OSError:
+        pass
+    return out
+
+
+def traffic_entry_status(entry, kernel_name=None, ident=None):
+    """None when the committed PMC entry may be used for this run, else the reason it must not be: it was collected with
+    another build of the library (neither the library's nor the kernel sources' hash matches), or the launch's dominant
+    kernel is not the one the counters were summed over (an entry keyed by workload name only mis-prices
+    frac_measured silently after a kernel change)."""
+    if not entry:
+        return "no entry"
+    ident = ident or library_identity()
+    have = [entry.get("lib_sha256"), entry.get("src_sha256")]
+    if not any(have):
+        return "the entry records no library / source hash (collected before round 4): re-collect it"
+    if not ((entry.get("lib_sha256") and entry["lib_sha256"] == ident["lib_sha256"]) or
+            (entry.get("src_sha256") and entry["src_sha256"] == ident["src_sha256"])):
+        return "collected with another build (library %s.., sources %s..; loaded: %s.., %s..)" % (
+            str(entry.get("lib_sha256"))[:10], str(entry.get("src_sha256"))[:10], str(ident["lib_sha256"])[:10], str(ident["src_sha256"])[:10])
+    if kernel_name and entry.get("kernel") and kernel_name not in entry["kernel"]:
+        return "the counters were summed over %s, this launch runs %s" % (entry["kernel"][:60], kernel_name)
+    return None
+
+
+def measured_traffic(key, kernel_name=None):
     """This command's entry of profiles/traffic.json: HBM-side bytes per launch of the dominant kernel from the
     committed rocprofv3 PMC passes (collected and corrected as MI355X_MICROARCH.md "HBM" prescribes), L2 hit / miss
-    requests per launch.  None when no profile exists for the command being run."""
+    requests per launch.  None when no profile exists for the command being run; {"dropped": reason} when one exists but
+    belongs to another build of the library or another kernel (traffic_entry_status)."""
     if key is None:
         return None
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            return json.load(f).get(key)
+            entry = json.load(f).get(key)
     except (OSError, ValueError):
         return None
+    if entry is None:
+        return None
+    why = traffic_entry_status(entry, kernel_name)
+    return entry if why is None else {"dropped": why, "source": entry.get("source")}
 
 
 def unique_row_bytes(batch, row_bytes):
@@ -162,6 +213,9 @@ def roofline_object(alg_bytes, kernel_us, entry, uniq_bytes, meta_bytes=0):
     r = {"bound": "hbm", "achieved": alg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / HBM_PEAK_GBS,
          "traffic": None, "basis": "algorithmic bytes", "kernel_us": kernel_us, "algorithmic_bytes": alg_bytes,
          "achieved_algorithmic": alg}
+    if entry and entry.get("dropped"):
+        r["traffic_dropped"] = "profiles/traffic.json entry (%s) not used: %s" % (entry.get("source"), entry["dropped"])
+        entry = None
     if entry:
         traffic = entry.get("traffic_bytes_per_launch")
         r["traffic"] = traffic
@@ -449,14 +503,19 @@ def run_single(args):
     wall, wall_event, dev_ms = timed_region(graph)
     kernel_us = dev_ms * 1000.0 / args.steps          # avg launch duration on the launch stream
 
-    # what was just timed, checked outside the timed region: every bag of the last batch (all tables) bit for bit
-    # against an in-order torch gather-sum, plus the oracle on a sample of bags per table
-    last = (args.steps - 1) % len(plans) if args.steps > 0 else 0
+    # what was just timed, checked outside the timed region: every bag of EVERY rotating batch the timed loop wrote (all
+    # NBATCH plans' output buffers, not only the last one's) bit for bit against an in-order torch gather-sum, plus the
+    # oracle on a sample of bags per table
+    touched = sorted({(args.steps - 1 - j) % len(plans) for j in range(min(args.steps, len(plans)))}) if args.steps > 0 else [0]
+    n_checked = 0
     try:
-        n_checked = verify_last_batch(torch, eng, plans[last], plan_idx[last], spec["L"])
+        for q in touched:
+            n_checked += verify_last_batch(torch, eng, plans[q], plan_idx[q], spec["L"])
     except AssertionError as ex:
         print(f"bench.py: VERIFICATION FAILED: {ex}", file=sys.stderr, flush=True)
         raise SystemExit(1)
+    kinds = eng.stats()["n_launches_by_kind"]
+    dominant_kernel = KERNEL_OF_KIND[max(range(len(kinds)), key=lambda k: kinds[k])]
     result = {
         "metric": "pooled-lookups/sec + achieved HBM GB/s, 26-table dim-16 Kaggle, 1/2/4/8 GPU",
         "value": args.steps * n_bags / wall,
@@ -470,8 +529,13 @@ def run_single(args):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": spec.get("dtype", "f32"), "data": "synthetic",
         "verified": True,
-        "verify": {"bags_bit_exact_vs_torch_gather": n_checked, "oracle_sample_bags_per_table": 32,
-                   "what": "outputs of the last timed batch, all %d tables, after the timed region" % T},
+        "verify": {"bags_bit_exact_vs_torch_gather": n_checked, "oracle_sample_bags_per_table": 32, "batches_checked": len(touched),
+                   "what": "outputs of every rotating batch the timed loop wrote (%d of %d plans), all %d tables, after the timed region"
+                           % (len(touched), len(plans), T)},
+        # the same W warm-up + K timed steps measured BEFORE the device pre-warm (a fresh process, idle clocks): `value` is the
+        # warmed figure, this the cold one
+        "value_cold": None if cold_sync is None else args.steps * n_bags / cold_sync,
+        "ms_per_step_cold": None if cold_sync is None else cold_sync * 1000.0 / args.steps,
         "config": {"workload": "%s, %d rotating batches" % (spec["name"], len(plans)),
                    "tables": T, "dim": dim, "bags_per_table": B, "pooling": spec["L"],
                    "table_bytes": eng.stats()["table_bytes"], "hot_rows_hint": args.hot_rows,
@@ -481,9 +545,9 @@ def run_single(args):
                    "timed_without_prewarm_us": None if cold_sync is None else cold_sync * 1e6 / args.steps,
                    "kernel_without_prewarm_us": None if cold_ms is None else cold_ms * 1000.0 / args.steps,
                    "launch_mode": "one hipGraph holding the K launches" if args.graph else "K eager kernel enqueues",
-                   "launches_by_kind": eng.stats()["n_launches_by_kind"],
+                   "launches_by_kind": kinds, "dominant_kernel": dominant_kernel,
                    "parallelism": "single" if len(handles) == 1 else "single GPU, %d streams" % len(handles)},
-        "roofline": roofline_object(alg_bytes, kernel_us, measured_traffic(profile_key(args, spec)),
+        "roofline": roofline_object(alg_bytes, kernel_us, measured_traffic(profile_key(args, spec), dominant_kernel),
                                     unique_row_bytes(batches[0], dim * (2 if spec.get("dtype") == "f16" else 4))
                                     if spec["L"] > 1 or spec["dist"] != "uniform" else None,
                                     meta_bytes=4 * (n_idx + n_bags)),

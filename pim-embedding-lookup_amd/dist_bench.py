@@ -364,6 +364,8 @@ def run_sharded(args, hbm_peak_gbs: float, ctx, rep_bytes: int, mode: str):
         if k_route > 0:
             kernels["router_GBps"] = kernels["router_bytes"] / (k_route * 1e-6) / 1e9
         traffic = sharded_traffic_entry(args, mode, world)
+        if world == 1:       # every table is looked up here: compulsory table bytes of one step = every DISTINCT row once
+            uniq = sum(int(np.unique(idx_host[0][t]).shape[0]) for t in range(T)) * dim * elem
         result = ({
             "metric": "pooled-lookups/sec + achieved HBM GB/s, 26-table dim-16 Kaggle, 1/2/4/8 GPU",
             "unit": "pooled-lookups/s", **clk,
@@ -398,6 +400,8 @@ def run_sharded(args, hbm_peak_gbs: float, ctx, rep_bytes: int, mode: str):
                                  "roofline.exchange" % nt,
                          "kernels": kernels, "exchange": fr},
         })
+        if world == 1:
+            result["roofline"]["unique_row_bytes"], result["roofline"]["index_bytes"] = uniq, T * B * L * 4
         apply_sharded_traffic(result["roofline"], traffic, kernel_us, k_route, k_un)
     dist.barrier()
     torch.cuda.synchronize()
@@ -411,12 +415,16 @@ def run_sharded(args, hbm_peak_gbs: float, ctx, rep_bytes: int, mode: str):
 def sharded_traffic_entry(args, mode, world):
     """profiles/traffic.json entry of this sharded command (world-1 PMC passes of the served lookup, the router and the
     un-router; see profiles/collect_dist_pmc.sh), or None."""
-    if world != 1 or args.batch is not None or getattr(args, "rows_scale", 1.0) not in (None, 1.0):
+    if world != 1 or args.batch is not None:
         return None          # the counters were collected with one rank: another rank count serves other pieces
+    if getattr(args, "workload", "c2") == "c4" and abs(float(getattr(args, "rows_scale", 1.0) or 1.0) - 0.125) > 1e-9:
+        return None          # (C4 is profiled at one of 8 ranks' share of the rows)
     key = "dist-%s-%s-l%d" % (getattr(args, "workload", "c2"), mode, int(getattr(args, "pooling", None) or 0) or 1)
+    if getattr(args, "index_dist", None):
+        key += "-" + args.index_dist
     try:
         import bench
-        return bench.measured_traffic(key)
+        return bench.measured_traffic(key, "bag_sum")
     except Exception:  # noqa: BLE001
         return None
 
@@ -424,8 +432,11 @@ def sharded_traffic_entry(args, mode, world):
 def apply_sharded_traffic(roof, entry, k_serve, k_route, k_un):
     """HBM-side bytes of the sharded leg's three kernel families from the committed PMC passes, priced with THIS run's
     kernel times."""
+    if entry and entry.get("dropped"):
+        roof["traffic_dropped"] = "profiles/traffic.json entry (%s) not used: %s" % (entry.get("source"), entry["dropped"])
+        entry = None
     if not entry:
-        roof["traffic_note"] = "no PMC profile of this exact sharded command (profiles/traffic.json holds the world-1 ones)"
+        roof["traffic_note"] = "no usable PMC profile of this exact sharded command (profiles/traffic.json holds the world-1 ones)"
         return
     roof["traffic"] = entry.get("traffic_bytes_per_launch")
     roof["traffic_source"] = entry.get("source")
@@ -437,8 +448,8 @@ def apply_sharded_traffic(roof, entry, k_serve, k_route, k_un):
         if sub and us > 0:
             roof["kernels"][name + "_traffic_bytes"] = sub.get("traffic_bytes_per_launch")
             roof["kernels"][name + "_measured_GBps"] = sub.get("traffic_bytes_per_launch", 0) / (us * 1e-6) / 1e9
-    if entry.get("read_over_unique_rows") is not None:
-        roof["read_over_unique_rows"] = entry["read_over_unique_rows"]
+    if roof.get("unique_row_bytes") and entry.get("read_bytes"):      # table bytes read (indices taken out) per distinct-row byte
+        roof["read_over_unique_rows"] = max(entry["read_bytes"] - roof.get("index_bytes", 0), 0) / roof["unique_row_bytes"]
 
 
 def run_dp(args, hbm_peak_gbs: float, ctx):

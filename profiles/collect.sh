@@ -21,4 +21,5 @@ for counters in "FETCH_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RD
         --steps 24 --warmup 8 --prewarm-ms 0 "$@" > "$scratch/pmc$pass.log" 2>&1 || { echo "pmc pass $pass failed for $key"; tail -5 "$scratch/pmc$pass.log"; exit 1; }
 done
 python3 "$root/profiles/pmc_summary.py" "$scratch" bag_sum > "$out/${key}_pmc_summary.txt"
+(cd "$root" && python3 -c "import json, bench; print(json.dumps(bench.library_identity()))") > "$out/${key}_identity.json"
 echo "== $key"; head -3 "$out/${key}_kernel_stats.csv" | cut -c1-260; cat "$out/${key}_pmc_summary.txt"

@@ -10,6 +10,8 @@ import os
 import sys
 
 here = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(here))
+import bench  # noqa: E402  (library_identity: the hashes an entry is tied to)
 rnd = sys.argv[1]
 keys = sys.argv[2:] or sorted(os.path.basename(f)[:-len("_pmc_summary.txt")]
                               for f in glob.glob(os.path.join(here, rnd, "*_pmc_summary.txt")))
@@ -30,6 +32,9 @@ for key in keys:
     wr = int(c["WRITE_SIZE"] * 1024)
     e = {"round": rnd, "source": f"profiles/{src}", "read_bytes": rd, "write_bytes": wr,
          "traffic_bytes_per_launch": rd + wr}
+    ident_file = os.path.join(here, rnd, f"{key}_identity.json")     # written on the GPU box next to the counters (collect.sh)
+    ident = json.load(open(ident_file)) if os.path.exists(ident_file) else bench.library_identity()
+    e["lib_sha256"], e["src_sha256"] = ident.get("lib_sha256"), ident.get("src_sha256")
     if "FETCH_SIZE" in c:
         e["fetch_size_x2_bytes"] = int(c["FETCH_SIZE"] * 1024 * 2)     # cross-check of read_bytes
     if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
@@ -41,6 +46,7 @@ for key in keys:
         if rows:
             top = max(rows, key=lambda r: float(r["TotalDurationNs"]))
             e["kernel_avg_ns"], e["kernel_calls"] = float(top["AverageNs"]), int(top["Calls"])
+            e["kernel"] = top["Name"]
     data[key] = e
     print(key, e)
 json.dump(data, open(path, "w"), indent=2)

@@ -34,9 +34,15 @@ def test_profile_key_of_a_command():
 def test_traffic_json_entries_are_backed_by_files():
     data = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     keys = [k for k in data if not k.startswith("_")]
-    assert {"c2", "c2-zipf", "c3", "c3-uniform", "c4", "c4-l32", "c5"} <= set(keys)
+    assert {"c2", "c2-zipf", "c3", "c3-uniform", "c4", "c4-l32", "c5", "dist-c4-rows-l1", "dist-c4-rows-l32"} <= set(keys)
     for k in keys:
         e = data[k]
+        if e.get("round", "r00") >= "r04":          # entries collected from round 4 on are tied to a build and a kernel
+            assert len(e["lib_sha256"]) == 64 and len(e["src_sha256"]) == 64 and "bag_sum" in e["kernel"], k
+        if k.startswith("dist-"):                   # the sharded step: lookup entry + router / un-router sub-entries, per step
+            for sub in ("router", "unrouter"):
+                assert e[sub]["traffic_bytes_per_launch"] == e[sub]["read_bytes"] + e[sub]["write_bytes"] > 0
+                assert e[sub]["kernel_avg_ns"] > 0
         assert os.path.exists(os.path.join(ROOT, e["source"])), e["source"]
         assert e["traffic_bytes_per_launch"] == e["read_bytes"] + e["write_bytes"] > 0
         if "fetch_size_x2_bytes" in e:      # FETCH_SIZE tallies a 128-B request at 64 B on gfx950: 2x it ~ the RDREQ-derived bytes
@@ -67,3 +73,25 @@ def test_roofline_object_pricing():
     r0 = bench.roofline_object(alg3, us3, None, None)
     assert r0["traffic"] is None and r0["frac"] > 1 and "not an HBM utilisation" in r0["basis"] and "frac_measured" not in r0
     assert bench.roofline_object(alg, us, None, None)["basis"] == "algorithmic bytes"
+
+
+def test_traffic_entry_is_dropped_when_the_library_or_the_kernel_differs():
+    """an entry of profiles/traffic.json is used only for the build it was collected with (the library's
+    sha256 or the kernel sources' sha256 must match the loaded one) and for the kernel it was summed over; otherwise the
+    line carries no traffic / frac_measured and says why."""
+    ident = dict(lib_sha256="a" * 64, src_sha256="b" * 64)
+    good = dict(traffic_bytes_per_launch=100, read_bytes=40, write_bytes=60, source="profiles/r04/x.txt", lib_sha256="a" * 64,
+                src_sha256="c" * 64, kernel="void pimemb::bag_sum_wavebatch_kernel<unsigned int, 0, 4, ...>(...)")
+    assert bench.traffic_entry_status(good, "bag_sum_wavebatch_kernel", ident) is None          # same library
+    assert bench.traffic_entry_status(dict(good, lib_sha256="d" * 64, src_sha256="b" * 64), "bag_sum_wavebatch_kernel", ident) is None   # a rebuild of the same sources
+    assert "another build" in bench.traffic_entry_status(dict(good, lib_sha256="d" * 64), "bag_sum_wavebatch_kernel", ident)
+    assert "summed over" in bench.traffic_entry_status(good, "bag_sum_group_kernel", ident)
+    old = {k: v for k, v in good.items() if k not in ("lib_sha256", "src_sha256")}
+    assert "no library / source hash" in bench.traffic_entry_status(old, "bag_sum_wavebatch_kernel", ident)
+    assert bench.traffic_entry_status(None) == "no entry"
+    # what the JSON line then looks like: algorithmic figures only, and the reason
+    r = bench.roofline_object(138_936_512, 20.0, {"dropped": "collected with another build (...)", "source": "profiles/r03/c2_pmc_summary.txt"}, None)
+    assert r["traffic"] is None and "frac_measured" not in r and "another build" in r["traffic_dropped"]
+    # the identity of THIS tree is computable without a GPU, and the committed round-4 entries carry hashes of the same shape
+    me = bench.library_identity()
+    assert me["src_sha256"] and len(me["src_sha256"]) == 64
