@@ -86,6 +86,11 @@ def parse_args():
                     help="untimed device pre-warm before the W warm-up steps (clock ramp of a fresh process; N=1 and the data-parallel N>1 leg); 0 = off")
     ap.add_argument("--graph", action="store_true",
                     help="N=1: capture the K timed launches in one hipGraph and replay it (tried in round 3: see DESIGN.md section 5)")
+    ap.add_argument("--coalesce", type=int, default=0,
+                    help="N=1: serve the workload's batch as R independent REQUESTS per step through the request queue "
+                         "(emb_queue_*: R x add + ONE flush = one fused launch) instead of one prepared plan per step -- the "
+                         "reference's serving shapes (--workload c1: mini-batch 1; --batch 32 / 512) are launch-bound one by one; "
+                         "0 = off.  The line also carries the back-to-back figure (R separate launches) it is to be compared with")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     return ap.parse_args()
@@ -560,6 +565,127 @@ def run_single(args):
     eng.close()
 
 
+def run_coalesced(args):
+    """--coalesce R: a step = R independent requests (each one lookup() call's worth: all T tables, B bags) added to the
+    request queue and ONE flush -- one fused launch -- against the same R requests issued back to back as R prepared-plan
+    launches (the fastest one-by-one form there is).  Inputs and outputs resident in HBM; every request of every rotating
+    slot is checked against the in-order torch gather-sum and the oracle after the timed region."""
+    import torch
+    import pim_embedding_lookup_amd as pel
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    spec = workload_spec(pel, args)
+    rows_list, dim, B, R = spec["rows"], spec["dim"], spec["B"], args.coalesce
+    T = len(rows_list)
+    eng = pel.EmbeddingEngine(device=0, max_tables=T)
+    make_tables_on_gpu(torch, eng, rows_list, dim, dev, dtype=spec.get("dtype", "f32"))
+    nslots = max(2, min(args.nbatch, 4))
+    batches = make_batches(pel, spec, nslots * R)
+    q = pel.RequestQueue(eng, pel.EMB_IDX_U32, pel.EMB_MEM_DEVICE)
+    slots = []
+    for j in range(nslots):
+        reqs = []
+        for r in range(R):
+            idx, off = batches[j * R + r]
+            d_idx = [torch.from_numpy(i.view(np.int32)).to(dev) for i in idx]
+            d_off = [torch.from_numpy(o.view(np.int32)).to(dev) for o in off]
+            d_out = [torch.empty((B, dim), dtype=torch.float32, device=dev) for _ in range(T)]
+            arr, n, _res, keep = q.descriptors(list(range(T)), d_idx, d_off, d_out)
+            reqs.append(dict(arr=arr, n=n, keep=keep, idx=d_idx, plan=eng.plan(list(range(T)), d_idx, d_off, d_out)))
+        slots.append(reqs)
+    import ctypes as C
+    many = []                         # per slot: the R requests' descriptors back to back + descriptors per request (emb_queue_add_many)
+    for reqs in slots:
+        arr = (pel.lib.EmbLookupDesc * sum(rq["n"] for rq in reqs))()
+        at = 0
+        for rq in reqs:
+            C.memmove(C.byref(arr, at * C.sizeof(pel.lib.EmbLookupDesc)), rq["arr"], rq["n"] * C.sizeof(pel.lib.EmbLookupDesc))
+            at += rq["n"]
+        many.append((arr, (C.c_uint32 * len(reqs))(*[rq["n"] for rq in reqs])))
+    stream = torch.cuda.current_stream(dev)
+    sh = stream.cuda_stream
+    one_add_per_request = os.environ.get("PIMEMB_QUEUE_ADD", "many") == "each"
+
+    def step_queue(i):
+        if one_add_per_request:          # R calls (R client threads would make them): ~1 us of Python + ctypes each
+            for rq in slots[i % nslots]:
+                q.add_descriptors(rq["arr"], rq["n"])
+        else:                            # a front end that drained R requests hands them over in one call
+            q.add_many(*many[i % nslots])
+        q.flush(sh)
+
+    def step_one_by_one(i):
+        for rq in slots[i % nslots]:
+            rq["plan"].launch(sh)
+
+    def timed(step):
+        for i in range(args.warmup):
+            step(i)
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for i in range(args.steps):
+            step(i)
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, ev0.elapsed_time(ev1) * 1e-3
+
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < args.prewarm_ms * 1e-3:
+        for i in range(16):
+            step_one_by_one(i)
+        torch.cuda.synchronize()
+    for rq in slots[0]:
+        for o in rq["plan"].outputs:
+            o.zero_()
+    wall_1, dev_1 = timed(step_one_by_one)
+    for reqs in slots:                      # the queue must write every output itself
+        for rq in reqs:
+            for o in rq["plan"].outputs:
+                o.fill_(float("nan"))
+    wall_q, dev_q = timed(step_queue)
+    n_checked = 0
+    try:
+        for reqs in slots[:min(nslots, args.steps)]:
+            for rq in reqs:
+                n_checked += verify_last_batch(torch, eng, rq["plan"], rq["idx"], spec["L"], n_sample=8)
+    except AssertionError as ex:
+        print(f"bench.py: VERIFICATION FAILED: {ex}", file=sys.stderr, flush=True)
+        raise SystemExit(1)
+    alg_bytes, n_bags, _n_idx = slots[0][0]["plan"].bytes()
+    lookups = args.steps * R * n_bags
+    result = {
+        "metric": "pooled-lookups/sec + achieved HBM GB/s, 26-table dim-16 Kaggle, 1/2/4/8 GPU",
+        "value": lookups / wall_q, "unit": "pooled-lookups/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": wall_q * 1000.0 / args.steps, "clock": "sync",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": spec.get("dtype", "f32"), "data": "synthetic",
+        "verified": True,
+        "verify": {"bags_bit_exact_vs_torch_gather": n_checked, "what": "every request of every rotating slot the queued loop wrote "
+                   "(outputs NaN-filled before it), after the timed region"},
+        "coalesce": {"requests_per_flush": R, "us_per_request_queued": wall_q * 1e6 / (args.steps * R),
+                     "us_per_request_one_by_one": wall_1 * 1e6 / (args.steps * R),
+                     "value_one_by_one": lookups / wall_1, "speedup": wall_1 / wall_q,
+                     "device_us_per_flush": dev_q * 1e6 / args.steps, "device_us_per_R_launches": dev_1 * 1e6 / args.steps,
+                     "add": "each" if one_add_per_request else "many",
+                     "what": "a step = R requests (each: all %d tables, %d bags) -- queued: emb_queue_add_many (or R x emb_queue_add: "
+                             "PIMEMB_QUEUE_ADD=each) + ONE emb_queue_flush (one fused launch); one by one: R prepared-plan launches "
+                             "back to back" % (T, B)},
+        "config": {"workload": "%s; served as %d independent requests per step through the request queue, %d rotating slots"
+                               % (spec["name"], R, nslots),
+                   "tables": T, "dim": dim, "bags_per_table": B, "pooling": spec["L"], "requests_per_step": R,
+                   "parallelism": "single"},
+        "roofline": roofline_object(alg_bytes * R, dev_q * 1e6 / args.steps, None, None),
+    }
+    print(json.dumps(result))
+    for reqs in slots:
+        for rq in reqs:
+            rq["plan"].destroy()
+    q.close()
+    eng.close()
+
+
 def self_launch(n_ranks: int, argv, script: str | None = None) -> int:
     """`python bench.py --gpus N` with no launcher around it.  This process has made no GPU call and makes
     none: it starts one fresh child per rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on
@@ -638,6 +764,8 @@ def main():
     if args.gpus > 1 or world > 1 or os.environ.get("PIMEMB_FORCE_DIST") == "1":   # last: 1-rank RCCL rehearsal
         from importlib import import_module
         import_module("pim-embedding-lookup_amd.dist_bench").run(args, HBM_PEAK_GBS)
+    elif args.coalesce > 0:
+        run_coalesced(args)
     else:
         run_single(args)
 

@@ -247,6 +247,37 @@ int emb_synchronize(emb_engine *e, void *stream);
 int emb_device_of(emb_engine *e, int32_t *device);
 
 /* ------------------------------------------------------------------------------------------ */
+/* request queue: R pending SMALL lookups -> ONE launch                                         */
+/* ------------------------------------------------------------------------------------------ */
+/* The reference serves DLRM at mini-batch 1 (README.md:6) and 32 with MAX_NR_BATCHES = 512 (upmem/run.sh:40-45,119): a
+ * 26-table lookup of a handful of bags.  On the GPU such a call is one ~3.5-us kernel launch whatever it gathers, so a
+ * server that issues them back to back is launch-bound.  A queue collects requests as they arrive -- from any number of
+ * threads, under the queue's own short lock: emb_queue_add resolves the request's descriptors on the spot and never takes
+ * the engine's mutex -- and emb_queue_flush runs everything pending as ONE fused launch (each request keeps its own
+ * buffers and gets exactly the bits a lookup of its own would give).
+ *   EMB_MEM_DEVICE: the descriptors' pointers are used as they are; results are complete in stream order behind the flush.
+ *   EMB_MEM_HOST  : emb_queue_add copies the request's indices / offsets into pinned, device-visible memory of the queue;
+ *                   the kernel gathers from there and stores the pooled rows there (no copy engine); emb_queue_wait(ticket)
+ *                   blocks until the flush that carried the request has finished and copies its rows into the caller's
+ *                   buffers (every waiter copies its own request: threads unpack in parallel).
+ * All tables of a queue share one (dtype, dim) -- every reference preset does (NR_COLS); other shapes: emb_lookup_batched.
+ * A host-space request must be waited for before the fourth flush after its own (its staging is reused then).  No event is
+ * recorded per flush (an event between two kernels costs GPU time): a host queue's kernel is followed by a one-thread kernel that
+ * stores the flush number into a pinned word its waiters poll; a device queue's results are simply complete in stream order
+ * behind the flush (emb_queue_wait on a device queue synchronises the flush's stream). */
+typedef struct emb_queue emb_queue;
+int emb_queue_create(emb_engine *e, emb_index_type itype, emb_memspace space, emb_queue **out);
+int emb_queue_add(emb_queue *q, const emb_lookup_desc *descs, uint32_t n_descs, uint64_t *ticket);
+/* Several requests in one call (a front end that drained its socket): descs holds them back to back, request r has
+ * n_descs[r] descriptors; tickets are consecutive from *first_ticket. */
+int emb_queue_add_many(emb_queue *q, const emb_lookup_desc *descs, const uint32_t *n_descs, uint32_t n_requests,
+                       uint64_t *first_ticket);
+/* ONE launch over every request added since the last flush (*n_requests: how many; 0 = nothing was pending). */
+int emb_queue_flush(emb_queue *q, void *stream, uint32_t *n_requests);
+int emb_queue_wait(emb_queue *q, uint64_t ticket);
+int emb_queue_destroy(emb_queue *q);
+
+/* ------------------------------------------------------------------------------------------ */
 /* multi-GPU routing for ROW-RANGE sharded tables, any number of indices per bag:                  */
 /* counts first, payload second                                                                   */
 /* ------------------------------------------------------------------------------------------ */

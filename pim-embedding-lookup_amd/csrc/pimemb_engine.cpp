@@ -83,6 +83,20 @@ struct DescSlot {
 };
 constexpr int kSlots = 4;
 constexpr size_t kSlotBytes = 256u << 10;
+struct ImageRing {              // the engine has one (under its mutex); a request queue has its own (under the queue's lock)
+    DescSlot slots[kSlots];
+    int next_slot = 0;
+    int desc_mode = 1;          // 1: kernels read descriptors from the pinned segment; 0: copied into HBM per call
+    unsigned slot_flags = 0;    // hipHostMalloc flags of the segments
+    void release() {
+        for (DescSlot &sl : slots) {
+            if (sl.h) (void)hipHostFree(sl.h);
+            if (sl.d) (void)hipFree(sl.d);
+            if (sl.done) (void)hipEventDestroy(sl.done);
+            sl = DescSlot{};
+        }
+    }
+};
 
 // XCD-aware workgroup maps of transient (plan-less) launches, kept in HBM and found again by launch
 // shape: the map depends on the tile counts and table sizes only, never on the buffers of a call.
@@ -105,12 +119,9 @@ struct emb_engine {
     std::mutex host_mu;  // serialises host-pointer calls (they share one staging buffer) -- held for the whole call
     pimemb::HostCopier copier;   // packs inputs / unpacks results of host-pointer calls (used under host_mu)
     hipEvent_t pipe_ev[4] = {};  // pipelined zero-copy calls: "tables of part k are done"
-    DescSlot slots[kSlots];
-    int next_slot = 0;
+    ImageRing ring;
     std::vector<XmapCacheEntry> xmap_cache;
     uint64_t xmap_clock = 0;
-    int desc_mode = 1;          // 1: kernels read descriptors from the pinned segment; 0: copied into HBM per call
-    unsigned slot_flags = 0;    // hipHostMalloc flags of the descriptor slots
     // staging for EMB_MEM_HOST calls
     char *h_stage = nullptr;
     size_t h_stage_cap = 0;
@@ -413,14 +424,14 @@ int launch_groups(emb_engine *e, const std::vector<PlanGroup> &groups, emb_index
 }
 
 // Space for an n-byte launch image on stream s: *h (host view) and *d (HBM twin or null).
-int take_image_space(emb_engine *e, size_t n, hipStream_t s, char **h, char **d) {
+int take_image_space(ImageRing &r, size_t n, hipStream_t s, char **h, char **d) {
     n = (n + 127) / 128 * 128;
-    DescSlot *sl = &e->slots[e->next_slot];
+    DescSlot *sl = &r.slots[r.next_slot];
     if (sl->used && (sl->used + n > sl->cap || sl->stream != s)) {   // close the segment, move on
         if (hipEventRecord(sl->done, sl->stream) == hipSuccess) {
             sl->pending = true;
-            e->next_slot = (e->next_slot + 1) % kSlots;
-            sl = &e->slots[e->next_slot];
+            r.next_slot = (r.next_slot + 1) % kSlots;
+            sl = &r.slots[r.next_slot];
         } else {                       // e.g. the caller destroyed that stream: drain everything instead
             (void)hipGetLastError();
             HIP_TRY(hipDeviceSynchronize());
@@ -443,8 +454,8 @@ int take_image_space(emb_engine *e, size_t n, hipStream_t s, char **h, char **d)
         sl->d = nullptr;
         sl->cap = 0;
         const size_t cap = n < kSlotBytes ? kSlotBytes : n + n / 4;
-        HIP_TRY(hipHostMalloc((void **)&sl->h, cap, e->slot_flags));
-        if (e->desc_mode == 0) HIP_TRY(hipMalloc((void **)&sl->d, cap));
+        HIP_TRY(hipHostMalloc((void **)&sl->h, cap, r.slot_flags));
+        if (r.desc_mode == 0) HIP_TRY(hipMalloc((void **)&sl->d, cap));
         sl->cap = cap;
     }
     if (!sl->done) HIP_TRY(hipEventCreateWithFlags(&sl->done, hipEventDisableTiming));
@@ -471,7 +482,7 @@ int launch_resolved(emb_engine *e, Resolved &r, emb_index_type itype, hipStream_
     std::lock_guard<std::mutex> lk(e->mu);
     const double p0 = g_prof.on ? now_us() : 0;
     char *h = nullptr, *d = nullptr;
-    int rc = take_image_space(e, r.image.size(), s, &h, &d);
+    int rc = take_image_space(e->ring, r.image.size(), s, &h, &d);
     if (rc) return rc;
     const double p1 = g_prof.on ? now_us() : 0;
     memcpy(h, r.image.data(), r.image.size());
@@ -768,8 +779,8 @@ int emb_create(const emb_config *cfg, emb_engine **out) {
         // tools/transient_probe.py: 20.6 vs 22.4 us per C2-shaped call, 5.6 vs 8.7 us at 2048 bags per
         // table); PIMEMB_DESC_MODE=copy stages them into HBM with an in-stream copy instead
         const char *m = getenv("PIMEMB_DESC_MODE");
-        e->desc_mode = (m && m[0] == 'c') ? 0 : 1;
-        e->slot_flags = hipHostMallocMapped | hipHostMallocCoherent;
+        e->ring.desc_mode = (m && m[0] == 'c') ? 0 : 1;
+        e->ring.slot_flags = hipHostMallocMapped | hipHostMallocCoherent;
     }
     uint32_t max_tables = (cfg && cfg->max_tables) ? cfg->max_tables : 1024;
     e->tables.resize(max_tables);
@@ -794,11 +805,7 @@ int emb_destroy(emb_engine *e) {
         clear_hot(t);
         if (t.rows) (void)hipFree(t.rows);
     }
-    for (DescSlot &sl : e->slots) {
-        if (sl.h) (void)hipHostFree(sl.h);
-        if (sl.d) (void)hipFree(sl.d);
-        if (sl.done) (void)hipEventDestroy(sl.done);
-    }
+    e->ring.release();
     for (XmapCacheEntry &c : e->xmap_cache) (void)hipFree(c.d_map);
     for (hipEvent_t ev : e->pipe_ev)
         if (ev) (void)hipEventDestroy(ev);
@@ -1135,7 +1142,7 @@ static int checked_launch(emb_engine *e, Resolved &r, emb_index_type itype, hipS
         }
         result = e->val_result;
         char *h = nullptr, *d = nullptr;
-        int rc = take_image_space(e, r.image.size(), s, &h, &d);
+        int rc = take_image_space(e->ring, r.image.size(), s, &h, &d);
         if (rc) return rc;
         memcpy(h, r.image.data(), r.image.size());
         result[0] = result[1] = 0;
@@ -1335,6 +1342,326 @@ int emb_synchronize(emb_engine *e, void *stream) {
 int emb_device_of(emb_engine *e, int32_t *device) {
     if (!e || !device) return fail(EMB_ERR_INVALID, "engine or device is NULL");
     *device = e->device;
+    return EMB_OK;
+}
+
+// ---- request queue: R pending small lookups -> ONE launch (see pimemb.h) ---------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+constexpr int kQueueGens = 4;              // flushes whose staging / bookkeeping is alive at once
+constexpr size_t kQueueBlock = 1u << 20;   // pinned staging is handed out from 1-MiB blocks (never moved: descriptors point into them)
+
+struct QueueRequest {
+    uint32_t first_desc = 0, n_descs = 0;
+    std::vector<pimemb::CopyPiece> out;     // host queues: staging -> caller's buffers, done by emb_queue_wait
+};
+
+struct QueueGen {
+    uint64_t first_ticket = 0, flush_no = 0;
+    std::vector<DevDesc> descs;
+    std::vector<QueueRequest> reqs;
+    uint32_t max_tiles = 0;
+    uint64_t bags = 0, idx = 0;
+    std::vector<char *> blocks;             // pinned staging of host queues
+    size_t block_at = 0, block_used = 0;
+    hipStream_t stream = nullptr;           // the stream its flush went to
+    bool in_flight = false;
+};
+
+}  // namespace
+
+struct emb_queue {
+    emb_engine *e = nullptr;
+    emb_index_type itype = EMB_IDX_U32;
+    emb_memspace space = EMB_MEM_DEVICE;
+    std::mutex mu;
+    QueueGen gen[kQueueGens];
+    int open = 0;
+    uint64_t next_ticket = 0, n_flushes = 0;
+    ImageRing ring;                         // the launches' descriptor images: ONE event per 256-KiB segment, not per flush
+    // host queues: done[g] = number of the last flush of generation g whose rows are in its staging (a one-thread kernel
+    // behind the lookup stores it: no event -- an event between two kernels costs GPU time -- and waiters poll a word)
+    volatile unsigned long long *done = nullptr;
+    bool shaped = false;
+    emb_dtype dtype = EMB_F32;
+    uint32_t dim = 0;
+    LaunchGeom geom{};
+    KernelKind kind = pimemb::KERNEL_GROUP;
+    uint32_t bpt = 1;
+};
+
+namespace {
+
+// `bytes` of the open generation's pinned staging, 16-byte aligned (host queues).  Blocks are kept for later flushes.
+char *queue_stage(QueueGen &g, size_t bytes) {
+    bytes = (bytes + 15) / 16 * 16;
+    if (bytes > kQueueBlock) return nullptr;
+    if (g.block_at < g.blocks.size() && g.block_used + bytes > kQueueBlock) {
+        g.block_at++;
+        g.block_used = 0;
+    }
+    if (g.block_at >= g.blocks.size()) {
+        void *p = nullptr;
+        if (hipHostMalloc(&p, kQueueBlock, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return nullptr;
+        g.blocks.push_back(static_cast<char *>(p));
+        g.block_used = 0;
+    }
+    char *r = g.blocks[g.block_at] + g.block_used;
+    g.block_used += bytes;
+    return r;
+}
+
+// One request into the open generation (caller holds q->mu).
+int queue_add_locked(emb_queue *q, const emb_lookup_desc *descs, uint32_t n_descs, uint64_t *ticket) {
+    emb_engine *e = q->e;
+    const size_t isz = index_size(q->itype);
+    QueueGen &g = q->gen[q->open];
+    const size_t first = g.descs.size();
+    if (first + n_descs > 65535u) return fail(EMB_ERR_UNSUPPORTED, "emb_queue_add: more than 65535 descriptors pending: flush first");
+    QueueRequest rq;
+    rq.first_desc = (uint32_t)first;
+    rq.n_descs = n_descs;
+    const size_t block_at0 = g.block_at, block_used0 = g.block_used;
+    auto undo = [&]() {
+        g.descs.resize(first);
+        g.block_at = block_at0;
+        g.block_used = block_used0;
+    };
+    uint64_t bags = 0, idx = 0;
+    uint32_t max_tiles = g.max_tiles;
+    for (uint32_t i = 0; i < n_descs; i++) {
+        const emb_lookup_desc &u = descs[i];
+        if (u.table_id >= e->tables.size() || e->tables[u.table_id].rows == nullptr) {
+            undo();
+            return fail(EMB_ERR_INVALID, "emb_queue_add: desc %u: table %u is not loaded", i, u.table_id);
+        }
+        const Table &t = e->tables[u.table_id];
+        if (!q->shaped) {            // the first request fixes the queue's row shape (and with it the kernel)
+            q->shaped = true;
+            q->dtype = t.dtype;
+            q->dim = t.dim;
+            q->geom = t.geom;
+            q->kind = t.geom.scalar_lanes ? pimemb::KERNEL_ANYDIM : pimemb::KERNEL_GROUP;
+            q->bpt = pimemb::bags_per_tile(q->kind, q->geom);
+        } else if (t.dtype != q->dtype || t.dim != q->dim) {
+            undo();
+            return fail(EMB_ERR_UNSUPPORTED, "emb_queue_add: desc %u: table %u is dim %u / dtype %d, the queue serves dim %u / dtype %d "
+                        "(one row shape per queue)", i, u.table_id, t.dim, (int)t.dtype, q->dim, (int)q->dtype);
+        }
+        if ((u.n_bags > 0 && !u.pooled) || (u.n_indices > 0 && !u.indices) ||
+            (!u.offsets && ((u.n_bags > 0 && u.fixed_pooling == 0) || (uint64_t)u.fixed_pooling * u.n_bags != u.n_indices))) {
+            undo();
+            return fail(EMB_ERR_INVALID, "emb_queue_add: desc %u: bad buffers (NULL pointer, or offsets NULL and fixed_pooling*n_bags != n_indices)", i);
+        }
+        DevDesc d{};
+        d.weights = t.rows;
+        d.indices = u.indices;
+        d.offsets = u.offsets;
+        d.out = u.pooled;
+        d.n_idx = u.n_indices;
+        d.n_bags = u.n_bags;
+        d.nr_rows = t.nr_rows;
+        d.fixed_pooling = u.offsets ? 0u : u.fixed_pooling;
+        const uint64_t tiles = (u.n_bags + q->bpt - 1) / q->bpt;
+        if (tiles > 0x0fffffffull) {
+            undo();
+            return fail(EMB_ERR_UNSUPPORTED, "emb_queue_add: desc %u: too many bags for a queued request", i);
+        }
+        d.n_tiles = (uint32_t)tiles;
+        if (q->space == EMB_MEM_HOST) {       // stage the inputs now; the rows come back through the same pinned memory
+            const size_t ib = u.n_indices * isz, ob = u.offsets ? u.n_bags * isz : 0, rb = u.n_bags * (size_t)t.dim * 4;
+            char *pi = ib ? queue_stage(g, ib) : nullptr, *po = ob ? queue_stage(g, ob) : nullptr, *pr = rb ? queue_stage(g, rb) : nullptr;
+            if ((ib && !pi) || (ob && !po) || (rb && !pr)) {
+                undo();
+                return fail(EMB_ERR_UNSUPPORTED, "emb_queue_add: desc %u: a buffer of more than 1 MiB -- not a small request: use emb_lookup_batched", i);
+            }
+            if (ib) memcpy(pi, u.indices, ib);
+            if (ob) memcpy(po, u.offsets, ob);
+            d.indices = pi;
+            d.offsets = po;
+            d.out = reinterpret_cast<float *>(pr);
+            if (rb) rq.out.push_back({u.pooled, pr, rb});
+        }
+        if (d.n_tiles > max_tiles) max_tiles = d.n_tiles;
+        g.descs.push_back(d);
+        bags += u.n_bags;
+        idx += u.n_indices;
+    }
+    if (g.reqs.empty()) g.first_ticket = q->next_ticket;
+    g.reqs.push_back(std::move(rq));
+    g.max_tiles = max_tiles;
+    g.bags += bags;
+    g.idx += idx;
+    if (ticket) *ticket = q->next_ticket;
+    q->next_ticket++;
+    return EMB_OK;
+}
+
+}  // namespace
+
+namespace pimemb {
+hipError_t launch_store_word(volatile unsigned long long *dst, unsigned long long value, hipStream_t stream);   // pimemb_kernels.hip
+}
+
+extern "C" {
+
+int emb_queue_create(emb_engine *e, emb_index_type itype, emb_memspace space, emb_queue **out) {
+    if (!e || !out) return fail(EMB_ERR_INVALID, "emb_queue_create: NULL argument");
+    *out = nullptr;
+    if (itype != EMB_IDX_U32 && itype != EMB_IDX_I64) return fail(EMB_ERR_INVALID, "emb_queue_create: bad index type");
+    emb_queue *q = new (std::nothrow) emb_queue();
+    if (!q) return fail(EMB_ERR_NOMEM, "out of host memory");
+    q->e = e;
+    q->itype = itype;
+    q->space = space;
+    q->ring.desc_mode = 1;
+    q->ring.slot_flags = hipHostMallocMapped | hipHostMallocCoherent;
+    DeviceGuard g(e->device);
+    e->live_plans.fetch_add(1);      // (the engine must outlive its queues, like its plans)
+    void *p = nullptr;
+    if (hipHostMalloc(&p, 64 * kQueueGens, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+        (void)emb_queue_destroy(q);
+        return fail(EMB_ERR_NOMEM, "emb_queue_create: pinned memory");
+    }
+    q->done = static_cast<volatile unsigned long long *>(p);
+    for (int k = 0; k < kQueueGens; k++) q->done[8 * k] = 0;
+    *out = q;
+    return EMB_OK;
+}
+
+int emb_queue_add(emb_queue *q, const emb_lookup_desc *descs, uint32_t n_descs, uint64_t *ticket) {
+    if (!q || !descs || n_descs == 0) return fail(EMB_ERR_INVALID, "emb_queue_add: NULL argument or empty request");
+    std::lock_guard<std::mutex> lk(q->mu);
+    return queue_add_locked(q, descs, n_descs, ticket);
+}
+
+int emb_queue_add_many(emb_queue *q, const emb_lookup_desc *descs, const uint32_t *n_descs, uint32_t n_requests, uint64_t *first_ticket) {
+    if (!q || !descs || !n_descs || n_requests == 0) return fail(EMB_ERR_INVALID, "emb_queue_add_many: NULL argument or no request");
+    std::lock_guard<std::mutex> lk(q->mu);
+    size_t at = 0;
+    for (uint32_t r = 0; r < n_requests; r++) {
+        if (n_descs[r] == 0) return fail(EMB_ERR_INVALID, "emb_queue_add_many: request %u is empty", r);
+        uint64_t t = 0;
+        const int rc = queue_add_locked(q, descs + at, n_descs[r], &t);
+        if (rc) return rc;            // requests 0 .. r-1 stay queued (their tickets: *first_ticket .. *first_ticket + r - 1)
+        if (r == 0 && first_ticket) *first_ticket = t;
+        at += n_descs[r];
+    }
+    return EMB_OK;
+}
+
+int emb_queue_flush(emb_queue *q, void *stream, uint32_t *n_requests) {
+    if (!q) return fail(EMB_ERR_INVALID, "emb_queue_flush: queue is NULL");
+    if (n_requests) *n_requests = 0;
+    emb_engine *e = q->e;
+    DeviceGuard dg(e->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    std::lock_guard<std::mutex> lk(q->mu);
+    QueueGen &g = q->gen[q->open];
+    if (g.reqs.empty()) return EMB_OK;
+    // requests were tiled for the lane-group kernel as they came in; a flush that adds up to a big one-hot launch runs the
+    // wave-batch kernel instead (choose_kernel's rule for any launch): its tiles are larger, so the counts are redone
+    KernelKind kind = q->kind;
+    uint32_t max_tiles = g.max_tiles;
+    if (kind == pimemb::KERNEL_GROUP) {
+        kind = pimemb::choose_kernel(g.bags, g.idx, q->geom);
+        if (kind != pimemb::KERNEL_GROUP) {
+            const uint32_t bpt = pimemb::bags_per_tile(kind, q->geom);
+            max_tiles = 0;
+            for (DevDesc &dd : g.descs) {
+                dd.n_tiles = (uint32_t)((dd.n_bags + bpt - 1) / bpt);
+                if (dd.n_tiles > max_tiles) max_tiles = dd.n_tiles;
+            }
+        }
+    }
+    const size_t bytes = g.descs.size() * sizeof(DevDesc);
+    char *h = nullptr, *d = nullptr;
+    int rc = take_image_space(q->ring, bytes, s, &h, &d);
+    if (rc) return rc;
+    memcpy(h, g.descs.data(), bytes);
+    if (max_tiles)
+        HIP_TRY(pimemb::launch_bag_sum(reinterpret_cast<const DevDesc *>(h), (uint32_t)g.descs.size(), max_tiles, q->dtype,
+                                       q->itype, q->geom, kind, nullptr, 0, false, s));
+    g.flush_no = ++q->n_flushes;
+    g.stream = s;
+    g.in_flight = true;
+    if (q->space == EMB_MEM_HOST)      // waiters poll this word; device queues are complete in stream order and need nothing
+        HIP_TRY(pimemb::launch_store_word(q->done + 8 * q->open, g.flush_no, s));
+    e->n_lookup_calls.fetch_add(g.reqs.size(), std::memory_order_relaxed);
+    e->n_kernel_launches.fetch_add(1, std::memory_order_relaxed);
+    e->n_by_kind[kind].fetch_add(1, std::memory_order_relaxed);
+    e->n_bags.fetch_add(g.bags, std::memory_order_relaxed);
+    e->n_indices.fetch_add(g.idx, std::memory_order_relaxed);
+    if (n_requests) *n_requests = (uint32_t)g.reqs.size();
+    // open the next generation; a host queue's staging of four flushes ago must have been read before it is written again
+    q->open = (q->open + 1) % kQueueGens;
+    QueueGen &nx = q->gen[q->open];
+    if (nx.in_flight && q->space == EMB_MEM_HOST) {
+        volatile unsigned long long *w = q->done + 8 * q->open;
+        for (uint64_t spin = 0; *w < nx.flush_no; spin++)
+            if (spin > 2000000) {
+                HIP_TRY(hipStreamSynchronize(nx.stream));
+                break;
+            }
+    }
+    nx.in_flight = false;
+    nx.descs.clear();
+    nx.reqs.clear();
+    nx.max_tiles = 0;
+    nx.bags = nx.idx = 0;
+    nx.block_at = nx.block_used = 0;
+    nx.first_ticket = q->next_ticket;
+    return EMB_OK;
+}
+
+int emb_queue_wait(emb_queue *q, uint64_t ticket) {
+    if (!q) return fail(EMB_ERR_INVALID, "emb_queue_wait: queue is NULL");
+    std::vector<pimemb::CopyPiece> out;
+    volatile unsigned long long *w = nullptr;
+    uint64_t flush_no = 0;
+    hipStream_t stream = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(q->mu);
+        if (ticket >= q->next_ticket) return fail(EMB_ERR_INVALID, "emb_queue_wait: ticket %llu was never handed out", (unsigned long long)ticket);
+        int at = -1;
+        for (int k = 0; k < kQueueGens; k++) {
+            QueueGen &c = q->gen[k];
+            if (!c.reqs.empty() && ticket >= c.first_ticket && ticket < c.first_ticket + c.reqs.size()) at = k;
+        }
+        if (at < 0) return fail(EMB_ERR_INVALID, "emb_queue_wait: request %llu is no longer tracked (wait before the fourth flush after its own)", (unsigned long long)ticket);
+        if (at == q->open) return fail(EMB_ERR_INVALID, "emb_queue_wait: request %llu has not been flushed yet", (unsigned long long)ticket);
+        QueueGen &g = q->gen[at];
+        out = g.reqs[ticket - g.first_ticket].out;
+        w = q->done + 8 * at;
+        flush_no = g.flush_no;
+        stream = g.stream;
+    }
+    DeviceGuard dg(q->e->device);
+    if (q->space == EMB_MEM_HOST) {
+        const double t0 = now_us();
+        for (uint64_t spin = 0; *w < flush_no; spin++)
+            if ((spin & 0xffff) == 0xffff && now_us() - t0 > 30e6) return fail(EMB_ERR_DEVICE, "emb_queue_wait: flush %llu did not finish within 30 s", (unsigned long long)flush_no);
+        for (const pimemb::CopyPiece &c : out) memcpy(c.dst, c.src, c.bytes);
+    } else {
+        HIP_TRY(hipStreamSynchronize(stream));      // (device queues: results are complete in stream order; this is the blunt form)
+    }
+    return EMB_OK;
+}
+
+int emb_queue_destroy(emb_queue *q) {
+    if (!q) return EMB_OK;
+    DeviceGuard dg(q->e->device);
+    for (QueueGen &g : q->gen)
+        if (g.in_flight) (void)hipStreamSynchronize(g.stream);
+    (void)hipGetLastError();
+    for (QueueGen &g : q->gen)
+        for (char *b : g.blocks) (void)hipHostFree(b);
+    q->ring.release();
+    if (q->done) (void)hipHostFree(const_cast<unsigned long long *>(q->done));
+    q->e->live_plans.fetch_sub(1);
+    delete q;
     return EMB_OK;
 }
 

@@ -863,6 +863,16 @@ hipError_t launch_publish_words(const uint32_t *const src[3], const uint32_t n[3
     return hipGetLastError();
 }
 
+// One thread: everything queued before it on the stream is done (kernel boundary) -> say so in a pinned word the host polls.
+__global__ void store_word_kernel(volatile unsigned long long *dst, unsigned long long value) {
+    __threadfence_system();
+    *dst = value;
+}
+hipError_t launch_store_word(volatile unsigned long long *dst, unsigned long long value, hipStream_t stream) {
+    hipLaunchKernelGGL(store_word_kernel, dim3(1), dim3(1), 0, stream, dst, value);
+    return hipGetLastError();
+}
+
 // Zero the {n_sub, n_idx} counts and peaks of a routing `meta` block (a rank with an empty batch still sends counts).
 __global__ void __launch_bounds__(kBlock)
 zero_words_kernel(uint32_t *__restrict__ p, uint32_t n) {

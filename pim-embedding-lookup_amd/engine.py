@@ -156,6 +156,64 @@ class Plan:
             self._p = None
 
 
+class RequestQueue:
+    """R pending SMALL lookups -> ONE launch (emb_queue_* in pimemb.h): the reference's serving shapes -- mini-batch 1
+    (README.md:6), 32 with MAX_NR_BATCHES = 512 (upmem/run.sh:40-45,119) -- are one ~3.5-us launch each on the GPU, so a
+    server that issues them back to back is launch-bound.  add() may be called from any number of threads (the queue's own
+    short lock, never the engine's); flush() runs everything pending as one fused launch; every request keeps its own
+    buffers and gets the bits a lookup of its own would give.
+
+    space: EMB_MEM_HOST   add(table_ids, indices, offsets, outs) with numpy arrays; wait(ticket) blocks until the request's
+                           rows are in `outs`
+           EMB_MEM_DEVICE torch CUDA tensors / DeviceBuffer; results complete in stream order behind the flush"""
+
+    def __init__(self, engine: "EmbeddingEngine", itype: int = _l.EMB_IDX_U32, space: int = _l.EMB_MEM_HOST):
+        self.engine, self._L, self.itype, self.space = engine, engine._L, itype, space
+        h = C.c_void_p()
+        _l.check(self._L.emb_queue_create(engine._h, itype, space, C.byref(h)))
+        self._h = h
+        self._keep = {}
+
+    def descriptors(self, table_ids, indices, offsets, outs, fixed_pooling=0):
+        """The request as a reusable descriptor array (a server that re-posts the same buffers builds it once)."""
+        arr, n, itype, space, results, keep = self.engine._descs(table_ids, indices, offsets, outs, fixed_pooling)
+        if itype != self.itype or space != self.space:
+            raise TypeError("request buffers do not match the queue's index width / memory space")
+        return arr, n, results, keep
+
+    def add(self, table_ids, indices, offsets, outs, fixed_pooling=0) -> int:
+        arr, n, _res, keep = self.descriptors(table_ids, indices, offsets, outs, fixed_pooling)
+        t = self.add_descriptors(arr, n)
+        self._keep[t] = keep
+        return t
+
+    def add_descriptors(self, arr, n: int) -> int:
+        t = C.c_uint64()
+        _l.check(self._L.emb_queue_add(self._h, arr, n, C.byref(t)))
+        return t.value
+
+    def add_many(self, arr, counts) -> int:
+        """Several requests in one call: `arr` holds their descriptors back to back (an EmbLookupDesc array), `counts` a
+        ctypes uint32 array of descriptors per request.  Returns the first ticket (the others follow consecutively)."""
+        t = C.c_uint64()
+        _l.check(self._L.emb_queue_add_many(self._h, arr, counts, len(counts), C.byref(t)))
+        return t.value
+
+    def flush(self, stream: int | None = None) -> int:
+        n = C.c_uint32()
+        _l.check(self._L.emb_queue_flush(self._h, stream, C.byref(n)))
+        return n.value
+
+    def wait(self, ticket: int) -> None:
+        _l.check(self._L.emb_queue_wait(self._h, ticket))
+        self._keep.pop(ticket, None)
+
+    def close(self) -> None:
+        if self._h:
+            self._L.emb_queue_destroy(self._h)
+            self._h = None
+
+
 class NativeExchange:
     """All-to-all of byte ranges issued straight to RCCL on a HIP stream (emb_comm_* in pimemb.h).
     Bootstrap: rank 0 draws the RCCL unique id, `broadcast` (a callable bytes -> bytes that returns rank

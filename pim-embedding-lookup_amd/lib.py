@@ -114,6 +114,12 @@ SIGNATURES = {
     "emb_table_info": (C.c_int, [_vp, _u32, _pp, C.POINTER(_u64), C.POINTER(_u32), C.POINTER(C.c_int)]),
     "emb_lookup": (C.c_int, [_vp, _u32, _vp, _u64, _vp, _u64, _vp, C.c_int, C.c_int, _vp]),
     "emb_lookup_batched": (C.c_int, [_vp, C.POINTER(EmbLookupDesc), _u32, C.c_int, C.c_int, _vp]),
+    "emb_queue_create": (C.c_int, [_vp, C.c_int, C.c_int, _pp]),
+    "emb_queue_add": (C.c_int, [_vp, C.POINTER(EmbLookupDesc), _u32, C.POINTER(_u64)]),
+    "emb_queue_add_many": (C.c_int, [_vp, C.POINTER(EmbLookupDesc), C.POINTER(_u32), _u32, C.POINTER(_u64)]),
+    "emb_queue_flush": (C.c_int, [_vp, _vp, C.POINTER(_u32)]),
+    "emb_queue_wait": (C.c_int, [_vp, _u64]),
+    "emb_queue_destroy": (C.c_int, [_vp]),
     "emb_plan_create": (C.c_int, [_vp, C.POINTER(EmbLookupDesc), _u32, C.c_int, _pp]),
     "emb_plan_launch": (C.c_int, [_vp, _vp]),
     "emb_plan_destroy": (C.c_int, [_vp]),

@@ -1694,3 +1694,73 @@ def test_checked_engine_never_launches_a_cached_plan(pel, oracle):
         e.lookup_stacked([0, 1, 2], si, so, out=sout)
     assert e.plan_cache_hits == 0
     e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("space", ["host", "device"])
+def test_request_queue_fuses_small_requests_into_one_launch(pel, oracle, space):
+    """emb_queue_*: R pending small requests -- the reference's serving shapes, mini-batch 1 and 32 (README.md:6,
+    upmem/run.sh:119), ragged ones too -- run as ONE launch; every request gets exactly the oracle's bits in its own
+    buffers, from several threads, over several flushes, with uint32 and int64 indices."""
+    import threading
+    import torch
+    rng = np.random.default_rng(77)
+    rows = pel.workloads.KAGGLE_ROWS[:9]
+    tabs = [pel.workloads.dlrm_table(rng, min(n, 60_000), 16) for n in rows]
+    eng = pel.EmbeddingEngine(device=0, max_tables=16)
+    for t, w in enumerate(tabs):
+        eng.load_table(t, w)
+    dev = torch.device("cuda", 0)
+    for itype, npdt in ((pel.EMB_IDX_U32, np.uint32), (pel.EMB_IDX_I64, np.int64)):
+        q = pel.RequestQueue(eng, itype, pel.EMB_MEM_HOST if space == "host" else pel.EMB_MEM_DEVICE)
+        launches0 = eng.stats()["n_kernel_launches"]
+        for flush_no in range(6):                       # more flushes than staging generations
+            reqs, lock = [], threading.Lock()
+
+            def client(seed, B):
+                r = np.random.default_rng(seed)
+                idx, off, outs = [], [], []
+                for t, w in enumerate(tabs):
+                    lens = r.integers(0, 4, size=B) if B > 1 else np.array([1])
+                    o = np.zeros(B, dtype=np.int64); o[1:] = np.cumsum(lens)[:-1]
+                    idx.append(r.integers(0, w.shape[0], size=int(lens.sum())).astype(npdt))
+                    off.append(o.astype(npdt))
+                    outs.append(np.full((B, 16), 7.0, np.float32))
+                if space == "device":
+                    d = lambda a: torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).to(dev)   # noqa: E731
+                    di, do, du = [d(a) for a in idx], [d(a) for a in off], [torch.from_numpy(a).to(dev) for a in outs]
+                    ticket = q.add(list(range(len(tabs))), di, do, du)
+                    with lock:
+                        reqs.append((ticket, idx, off, du))
+                else:
+                    ticket = q.add(list(range(len(tabs))), idx, off, outs)
+                    with lock:
+                        reqs.append((ticket, idx, off, outs))
+
+            threads = [threading.Thread(target=client, args=(1000 * flush_no + k, B)) for k, B in enumerate([1, 1, 32, 5, 1, 32, 2, 17])]
+            for th in threads:
+                th.start()
+            for th in threads:
+                th.join()
+            assert q.flush() == 8 and q.flush() == 0
+            for ticket, idx, off, outs in reqs:
+                q.wait(ticket)
+                for t, w in enumerate(tabs):
+                    got = outs[t].cpu().numpy() if space == "device" else outs[t]
+                    assert np.array_equal(got, oracle.c_bag_sum(w, idx[t].astype(np.int64), off[t].astype(np.int64)))
+        assert eng.stats()["n_kernel_launches"] - launches0 == 6          # ONE launch per flush, 8 requests each
+        with pytest.raises(pel.PimembError):
+            q.wait(10 ** 9)
+        q.close()
+    # one row shape per queue; a big request is refused by a host queue (it is not what the queue is for)
+    eng.load_table(12, pel.workloads.dlrm_table(rng, 100, 32))
+    q = pel.RequestQueue(eng, pel.EMB_IDX_U32, pel.EMB_MEM_HOST)
+    one = (np.zeros(1, np.uint32), np.zeros(1, np.uint32))
+    q.add([0], [one[0]], [one[1]], [np.zeros((1, 16), np.float32)])
+    with pytest.raises(pel.PimembError):
+        q.add([12], [one[0]], [one[1]], [np.zeros((1, 32), np.float32)])
+    with pytest.raises(pel.PimembError):
+        q.add([0], [np.zeros(400_000, np.uint32)], [np.zeros(1, np.uint32)], [np.zeros((1, 16), np.float32)])
+    assert q.flush() == 1
+    q.close()
+    eng.close()
