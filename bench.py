@@ -72,6 +72,10 @@ def parse_args():
                     help="N>1: big tables placed whole on owner ranks (default for c2: no routing kernel, no copy), split "
                          "by row range over all ranks with GPU-side request routing (balanced xGMI egress; default for c4), or "
                          "whatever the shard planner decides (plan)")
+    ap.add_argument("--exchange", choices=["rccl", "peer"], default="rccl",
+                    help="N>1 sharded legs: how pieces travel between ranks -- grouped ncclSend/ncclRecv issued from C (rccl, default) "
+                         "or the collective-free exchange (peer: HIP IPC mappings, the owner gathers a requester's indices in place "
+                         "and stores pooled rows straight into its HBM; handshake through a shared-memory segment, no RCCL in the data path)")
     ap.add_argument("--collective", choices=["native"], default="native",
                     help="kept for command-line compatibility: the sharded legs' transfers are always grouped ncclSend/ncclRecv "
                          "issued from the C side (emb_comm_exchange inside emb_shard_*)")

@@ -387,6 +387,23 @@ typedef struct emb_comm_op {
 int emb_comm_exchange(emb_comm *c, const emb_comm_op *ops, uint32_t n_ops, void *stream);
 int emb_comm_rank(const emb_comm *c, int32_t *rank, int32_t *world);
 
+/* ---- peer group: ranks that read and write each other's HBM directly (no collectives library) -------------------- */
+/* The substrate of the sharded lookup's collective-free exchange (EMB_SHARD_PEER_STORES below).  One process per GPU; every
+ * rank calls emb_peer_create with the same job_tag (any string unique to the job) and world.  The group is set up through
+ * one POSIX shared-memory segment (`/pimemb-<tag>`, unlinked again once every rank has mapped it) and HIP IPC handles:
+ * each rank allocates an ARENA of arena_bytes -- one device allocation (fine-grained where the runtime can export it) that
+ * every peer maps -- and everything a peer may touch (index / offset arrays, output rows) must be carved from it with
+ * emb_peer_alloc (a bump allocator: nothing is freed before emb_peer_destroy).  The segment also carries small mailboxes
+ * [dst][src][slot] for the per-batch handshake: written by tiny kernels in stream order, read by the host with plain loads.
+ * Exercised with 2-4 processes on ONE GPU; never over xGMI (link rates and cross-link visibility are unmeasured). */
+typedef struct emb_peer emb_peer;
+int emb_peer_create(emb_engine *e, const char *job_tag, int32_t rank, int32_t world, uint64_t arena_bytes, emb_peer **out);
+int emb_peer_alloc(emb_peer *p, uint64_t bytes, void **ptr);
+int emb_peer_info(emb_peer *p, int32_t *rank, int32_t *world, void **arena, uint64_t *arena_bytes, uint64_t *used,
+                  int32_t *fine_grained);
+int emb_peer_barrier(emb_peer *p);   /* host barrier of the group through the shared segment (start-up, teardown, tests) */
+int emb_peer_destroy(emb_peer *p);   /* call emb_peer_barrier first: a peer may still be reading this rank's arena */
+
 /* ------------------------------------------------------------------------------------------ */
 /* sharded lookup: ONE call per batch                                                            */
 /* ------------------------------------------------------------------------------------------ */
@@ -458,12 +475,20 @@ typedef struct emb_shard_input {      /* one per table, in table order */
                                       (emb_lookup_batched_checked); a finding makes emb_shard_submit / _flush return
                                       EMB_ERR_RANGE on the SERVING rank after the batch has gone through all its stages
                                       (the offending pieces pool to zero rows), so no peer is left in a transfer */
+#define EMB_SHARD_PEER_STORES 4u   /* the collective-free exchange (needs emb_shard_config.peer): nothing travels through RCCL.  A
+                                      rank posts what it asks each peer for -- counts and buffer addresses -- into the peer's
+                                      mailbox; the owner's ONE fused lookup gathers the requester's indices IN PLACE (its mapped
+                                      arena) and stores the pooled rows straight into the requester's HBM; a one-thread kernel
+                                      behind it raises "served".  No request transfer, no return transfer, no staging copies; the
+                                      host's waits are polls of mailbox words.  The caller's index / offset / output buffers of
+                                      tables held by OTHER ranks, whole or split, must come from emb_peer_alloc. */
 typedef struct emb_shard_config {
     uint32_t n_tables;
     uint32_t dim;
     uint32_t depth;           /* 0 .. 3 (see above) */
     uint32_t flags;           /* EMB_SHARD_* */
     const emb_shard_table *tables;
+    emb_peer *peer;           /* EMB_SHARD_PEER_STORES: the group (rank / world are taken from it; comm may be NULL) */
 } emb_shard_config;
 /* what the last completed stages cost and moved (reporting; cumulative since create / reset) */
 typedef struct emb_shard_stats {
@@ -475,6 +500,7 @@ typedef struct emb_shard_stats {
     uint64_t served_sub_bags, served_indices;
     double us_host_submit;            /* host time inside emb_shard_submit / _flush, all stages */
     double us_host_wait_counts;       /* ... of it: waiting for the counts */
+    double us_host_wait_served;       /* ... of it (EMB_SHARD_PEER_STORES): waiting for the peers' "served" words */
     /* device time of the four kernel families, HIP events on their own streams, summed over the batches that ran while
      * emb_shard_set_kernel_timing was on: R router, L local lookup, S fused lookup over received pieces, U un-router */
     double us_kernel_route, us_kernel_local, us_kernel_serve, us_kernel_unroute;

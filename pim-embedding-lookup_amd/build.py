@@ -8,7 +8,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "lib", "libpimemb.so")
 MARSHAL_PATH = os.path.join(PKG_DIR, "lib", "_pimemb_marshal.so")
-SOURCES = ["pimemb_kernels.hip", "pimemb_engine.cpp", "pimemb_compat.cpp", "pimemb_comm.cpp", "pimemb_shard.cpp", "pimemb_internal.h", "pimemb_torch_marshal.cpp",
+SOURCES = ["pimemb_kernels.hip", "pimemb_engine.cpp", "pimemb_compat.cpp", "pimemb_comm.cpp", "pimemb_shard.cpp", "pimemb_peer.cpp", "pimemb_peer.h", "pimemb_internal.h", "pimemb_torch_marshal.cpp",
            "pimemb_bag_kernels.h", "pimemb_xcd_map.h", "pimemb_hot_rows.h", "pimemb_hostcopy.h", "Makefile",
            os.path.join("..", "..", "include", "pimemb.h")]
 

@@ -3,6 +3,7 @@
 #include <cstdlib>
 
 #include "pimemb_internal.h"
+#include "pimemb_peer.h"
 
 namespace pimemb {
 namespace {
@@ -870,6 +871,59 @@ __global__ void store_word_kernel(volatile unsigned long long *dst, unsigned lon
 }
 hipError_t launch_store_word(volatile unsigned long long *dst, unsigned long long value, hipStream_t stream) {
     hipLaunchKernelGGL(store_word_kernel, dim3(1), dim3(1), 0, stream, dst, value);
+    return hipGetLastError();
+}
+
+// ---- collective-free exchange: the per-batch handshake through the job's shared segment (pimemb_peer.h) -----------------
+// One workgroup.  For every remote destination p: the message = p's counts out of `meta` (+ where p's piece and p's partial
+// rows sit), then this rank's host-written constants for p; all of it stored into mailbox [p][me][slot], a system-scope
+// fence, then the `posted` word.  Runs on the caller's stream behind the router and behind whatever produced the caller's
+// index buffers: a peer that sees `posted` may read both.
+__global__ void __launch_bounds__(kBlock)
+peer_post_kernel(const uint32_t *__restrict__ meta, uint32_t n_row_tables, uint32_t n_shards, PeerPostArgs a, unsigned long long value) {
+    const uint32_t Kr = n_row_tables;
+    const MetaLayout ml = meta_layout(n_shards, Kr ? Kr : 1);
+    for (uint32_t p = 0; p < n_shards; p++) {
+        if (a.box[p] == 0) continue;
+        PeerMsg *box = reinterpret_cast<PeerMsg *>(a.box[p]);
+        uint32_t at = 0;
+        if (Kr) {
+            const uint32_t n = 2 * (Kr + 1);
+            for (uint32_t i = threadIdx.x; i < n; i += kBlock) box->words[i] = meta[counts_at(p, 0, Kr) + i];
+            if (threadIdx.x == 0) {
+                box->words[n] = meta[ml.piece + p];
+                box->words[n + 1] = meta[ml.row0 + p * Kr];
+            }
+            at = n + 2;
+        }
+        for (uint32_t i = threadIdx.x; i < a.n_consts[p]; i += kBlock) box->words[at + i] = __builtin_nontemporal_load(a.consts[p] + i);
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        for (uint32_t p = 0; p < n_shards; p++)
+            if (a.box[p] != 0) reinterpret_cast<PeerMsg *>(a.box[p])->posted = value;
+    }
+}
+
+hipError_t launch_peer_post(const uint32_t *meta, uint32_t n_row_tables, uint32_t n_shards, const PeerPostArgs &args,
+                            unsigned long long value, hipStream_t stream) {
+    if (n_shards > 64) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(peer_post_kernel, dim3(1), dim3(kBlock), 0, stream, meta, n_row_tables, n_shards, args, value);
+    return hipGetLastError();
+}
+
+// One thread, behind the fused lookup that stored pooled rows into the requesters' HBM: the kernel boundary has completed
+// those stores; say so to every requester.
+__global__ void peer_done_kernel(PeerDoneArgs a, unsigned long long value) {
+    __threadfence_system();
+    for (uint32_t i = 0; i < a.n; i++) reinterpret_cast<PeerMsg *>(a.box[i])->served = value;
+}
+
+hipError_t launch_peer_done(const PeerDoneArgs &args, unsigned long long value, hipStream_t stream) {
+    if (args.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(peer_done_kernel, dim3(1), dim3(1), 0, stream, args, value);
     return hipGetLastError();
 }
 

@@ -1,0 +1,56 @@
+// Internal view of a peer group (pimemb_peer.cpp) for the sharded step (pimemb_shard.cpp) and its handshake kernels.
+#pragma once
+
+#include "pimemb_internal.h"
+
+namespace pimemb {
+
+constexpr uint32_t kPeerSlots = 8;          // mailbox slots per (dst, src): a batch uses slot seq % kPeerSlots
+constexpr uint32_t kPeerMsgBytes = 32768;   // one mailbox: two flag words + the request message (up to ~680 whole tables per owner)
+constexpr uint32_t kPeerMsgWords = (kPeerMsgBytes - 64) / 4;
+
+// mailbox [dst][src][slot], in the job's shared segment: written by SRC's GPU (tiny kernels, in stream order behind the
+// data they announce), read by DST's host with plain loads
+struct PeerMsg {
+    volatile unsigned long long posted;    // = seq + 1 once `words` describe what src asks dst for in batch seq
+    volatile unsigned long long served;    // = seq + 1 once everything src OWES dst for batch seq is in dst's HBM
+    unsigned long long pad[6];
+    uint32_t words[kPeerMsgWords];
+};
+static_assert(sizeof(PeerMsg) == kPeerMsgBytes, "mailbox size");
+
+// what the posting kernel needs besides the routing `meta` block: where this rank's constants for destination p sit
+// (pinned host memory the kernel reads) and how many words they are
+struct PeerPostArgs {
+    unsigned long long box[64];     // device address of mailbox [p][me][slot] (0: p is not a remote peer)
+    const uint32_t *consts[64];     // per destination: host-written words appended to the message
+    uint32_t n_consts[64];
+};
+
+PeerMsg *peer_box(emb_peer *p, int dst, int src, uint32_t slot);
+PeerMsg *peer_box_dev(emb_peer *p, int dst, int src, uint32_t slot);
+int peer_rank(const emb_peer *p);
+int peer_world(const emb_peer *p);
+char *peer_base(const emb_peer *p, int r);
+uint64_t peer_arena_bytes(const emb_peer *p, int r);
+double peer_timeout_s(const emb_peer *p);
+// Users of the group's mailboxes (shard objects) are created in the same order on every rank: the n-th one tags its flag
+// words with n, so words left behind by an earlier user never look like news.
+uint64_t peer_next_epoch(emb_peer *p);
+bool peer_owns(const emb_peer *p, const void *ptr, uint64_t bytes);
+
+// Message of src for dst, batch seq (all uint32 words):
+//   [0 .. 2(Kr+1))  {sub-bags, indices} per row-split table + the peaks entry   (copied from meta by the kernel)
+//   [2(Kr+1)]       first word of dst's request piece inside src's req_send      (meta.piece[dst])
+//   [2(Kr+1)+1]     first partial row of shard dst inside src's ret_recv        (meta.ret_row0[dst * Kr])
+//   then the host-written constants of this destination (PeerPostArgs::consts)
+hipError_t launch_peer_post(const uint32_t *meta, uint32_t n_row_tables, uint32_t n_shards, const PeerPostArgs &args,
+                            unsigned long long value, hipStream_t stream);
+// served-flags: boxes[i]->served = value for every listed mailbox (device addresses), behind everything queued before
+struct PeerDoneArgs {
+    unsigned long long box[64];
+    uint32_t n;
+};
+hipError_t launch_peer_done(const PeerDoneArgs &args, unsigned long long value, hipStream_t stream);
+
+}  // namespace pimemb

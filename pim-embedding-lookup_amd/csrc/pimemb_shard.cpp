@@ -22,6 +22,7 @@
 // No lookup is computed here: S and L are emb_lookup_batched launches (pimemb_engine.cpp), R and U the routing kernels
 // (pimemb_kernels.hip).  This file is streams, events, byte offsets and the order in which all ranks issue transfers.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -30,6 +31,7 @@
 #include <vector>
 
 #include "pimemb_internal.h"
+#include "pimemb_peer.h"
 
 namespace {
 
@@ -67,14 +69,26 @@ struct HostProf {
 HostProf g_hp;
 
 constexpr int kRing = 6;            // batches in flight at most: depth 3 keeps four live, one slot is being filled, one to spare
-constexpr uint32_t kWholeWords = 4; // words of a whole-table count entry: {bags, indices, fixed pooling (0 = offsets travel), 0}
+// words of a whole-table count entry: {bags, indices, fixed pooling (0 = offsets travel), 0} and -- for the collective-free
+// exchange only -- where the requester's arrays sit in its arena: {indices, offsets, pooled} as 64-bit byte offsets, 2 spare
+constexpr uint32_t kWholeWords = 12;
+constexpr uint32_t kPeerConstHead = 8;   // host-written words in front of a destination's whole entries: req_send offset (2), ret_recv offset (2), bags, whole entries, 2 spare
 
 inline uint64_t pad4(uint64_t v) { return (v + 3u) & ~(uint64_t)3u; }
 
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    bool arena = false;      // carved from the peer group's arena (peers address it): never freed, outgrown pieces are abandoned
 };
+
+// what a peer told this rank about its side of a batch (collective-free exchange)
+struct PeerFrom {
+    uint64_t req_send_off = 0, ret_recv_off = 0;   // byte offsets inside the peer's arena
+    uint32_t piece_word = 0, ret_row0 = 0;
+};
+
+enum Via : int { SELF = 0, COMM = 1, PEER = 2 };
 
 struct DeviceGuard {
     int prev = -1;
@@ -98,6 +112,8 @@ struct Batch {
     DevBuf req_send, meta, slotmap, counts_in, wc_send, req_recv, ret_send, ret_recv;
     // pinned host
     uint32_t *wc_host = nullptr;        // whole-table counts this rank sends: [sum_p |whole_of[p]|][kWholeWords]
+    uint32_t *pc_host = nullptr;        // collective-free exchange: per destination, the constants its mailbox message ends with
+    std::vector<PeerFrom> from;         // ... and what every source told this rank
     uint32_t *counts_host = nullptr;    // [sent row counts N(Kr+1)2 | received row counts N(Kr+1)2 | received whole counts N*M*4]
     unsigned long long *flag = nullptr; // raised (= seq + 1) behind counts_host by publish_words_kernel
     hipEvent_t ev_routed = nullptr, ev_req = nullptr, ev_served = nullptr, ev_ret = nullptr, ev_out = nullptr;
@@ -115,6 +131,9 @@ struct Batch {
 struct emb_shard {
     emb_engine *e = nullptr;
     emb_comm *comm = nullptr;
+    emb_peer *peer = nullptr;
+    bool peer_mode = false;
+    uint64_t peer_tag = 0;                           // (epoch of this object among the group's users) << 40: added to every flag value
     int device = 0;
     int rank = 0, N = 1;
     uint32_t T = 0, dim = 0, depth = 2, flags = 0;
@@ -155,6 +174,14 @@ namespace {
 // but its kernels may still be queued: growing (rare: 25 % headroom) waits for the caller's stream and the transfer stream.
 int ensure(emb_shard *s, DevBuf &buf, size_t bytes) {
     if (buf.cap >= bytes && buf.p) return EMB_OK;
+    if (buf.arena) {             // peers hold addresses inside the arena: a larger piece is carved, the old one abandoned
+        const size_t cap = 2 * bytes + 256;
+        void *p = nullptr;
+        EMB_TRY(emb_peer_alloc(s->peer, cap, &p));
+        buf.p = p;
+        buf.cap = cap;
+        return EMB_OK;
+    }
     if (s->cs_known) HIP_TRY(hipStreamSynchronize(s->cs));
     HIP_TRY(hipStreamSynchronize(s->s_comm));
     if (buf.p) HIP_TRY(hipFree(buf.p));
@@ -192,8 +219,24 @@ void harvest(emb_shard *s, Batch &b) {
     (void)hipGetLastError();
 }
 
-// whether peer p's pieces travel through RCCL (false: p is this rank and is served in place)
-inline bool via_comm(const emb_shard *s, int p) { return p != s->rank || s->self_via_comm; }
+// how peer p's pieces travel: not at all (p is this rank: served in place), through RCCL, or by direct loads / stores
+// into p's mapped arena
+inline Via via(const emb_shard *s, int p) {
+    if (p == s->rank && !s->self_via_comm) return SELF;
+    return s->peer_mode ? PEER : COMM;
+}
+inline bool via_comm(const emb_shard *s, int p) { return via(s, p) == COMM; }
+inline uint64_t arena_off(const emb_shard *s, const void *ptr) { return (uint64_t)(static_cast<const char *>(ptr) - pimemb::peer_base(s->peer, s->rank)); }
+
+// Poll a mailbox word until it carries `want` (written by a peer's GPU through the job's shared segment).
+int poll_word(emb_shard *s, volatile unsigned long long *w, unsigned long long want, const char *what, int peer, uint64_t seq) {
+    const double t0 = now_us(), limit = pimemb::peer_timeout_s(s->peer) * 1e6;
+    for (uint64_t spin = 0; *w != want; spin++)
+        if ((spin & 0xfff) == 0xfff && now_us() - t0 > limit)
+            return fail(EMB_ERR_DEVICE, "emb_shard: rank %d %s batch %llu within %.0f s -- it is missing, or the ranks did not make the same calls",
+                        peer, what, (unsigned long long)seq, limit / 1e6);
+    return EMB_OK;
+}
 
 int exchange(emb_shard *s) {
     if (s->ops.empty()) return EMB_OK;
@@ -274,6 +317,8 @@ int stage_route(emb_shard *s, Batch &b) {
         uint64_t sb = 0, mb = 0, lb = 0, wb = 0;
         EMB_TRY(emb_route_bags_sizes(Kr, std::max<uint64_t>(b.n_bags, 1), total_idx, N, &sb, &mb, &lb, &wb));
         EMB_TRY(ensure(s, b.req_send, sb));
+        if (s->peer_mode)        // peers store their partial rows straight into ret_recv: it must exist (and be known) before they do
+            EMB_TRY(ensure(s, b.ret_recv, std::min<uint64_t>(total_idx, b.n_bags * (uint64_t)N * Kr) * s->dim * 4 + 256));
         EMB_TRY(ensure(s, b.meta, mb));
         EMB_TRY(ensure(s, b.slotmap, lb));
         EMB_TRY(ensure(s, s->work, wb));
@@ -303,6 +348,16 @@ int stage_route(emb_shard *s, Batch &b) {
                 c[1] = (uint32_t)u.n_indices;
                 c[2] = u.offsets ? 0u : u.fixed_pooling;
                 c[3] = 0;
+                if (via(s, (int)p) == PEER && b.n_bags) {     // the owner gathers / stores in place: the arrays must be where it can
+                    if (!pimemb::peer_owns(s->peer, u.indices, u.n_indices * 4) || (u.offsets && !pimemb::peer_owns(s->peer, u.offsets, b.n_bags * 4)) ||
+                        !pimemb::peer_owns(s->peer, u.pooled, b.n_bags * (uint64_t)s->dim * 4))
+                        return fail(EMB_ERR_INVALID, "emb_shard_submit: table %u is held by rank %u: with EMB_SHARD_PEER_STORES its indices / offsets / "
+                                    "pooled buffers must come from emb_peer_alloc", t, p);
+                    const uint64_t io = arena_off(s, u.indices), oo = u.offsets ? arena_off(s, u.offsets) : 0, ro = arena_off(s, u.pooled);
+                    c[4] = (uint32_t)io; c[5] = (uint32_t)(io >> 32);
+                    c[6] = (uint32_t)oo; c[7] = (uint32_t)(oo >> 32);
+                    c[8] = (uint32_t)ro; c[9] = (uint32_t)(ro >> 32);
+                }
             }
         for (uint32_t p = 0; p < N; p++) remote_whole |= via_comm(s, (int)p) && !s->whole_of[p].empty();
         if (remote_whole)
@@ -342,6 +397,28 @@ int stage_route(emb_shard *s, Batch &b) {
         const uint32_t n[3] = {N * (Kr + 1) * 2, N * (Kr + 1) * 2, N * M * kWholeWords};
         HIP_TRY(pimemb::launch_publish_words(src, n, b.counts_host, b.flag, b.seq + 1, peers ? s->s_comm : s->cs));
         b.counts_posted = true;
+    }
+    if (s->peer_mode) {        // the same news for the peers: counts + where things are, into their mailboxes, behind the router
+        pimemb::PeerPostArgs pa{};
+        bool any = false;
+        const uint64_t rs = Kr ? arena_off(s, b.req_send.p) : 0, rr = Kr ? arena_off(s, b.ret_recv.p) : 0;
+        uint32_t at = 0;
+        for (uint32_t p = 0; p < N; p++) {
+            if (via(s, (int)p) != PEER) continue;
+            uint32_t *c = b.pc_host + at;
+            const uint32_t nw = (uint32_t)s->whole_of[p].size();
+            c[0] = (uint32_t)rs; c[1] = (uint32_t)(rs >> 32);
+            c[2] = (uint32_t)rr; c[3] = (uint32_t)(rr >> 32);
+            c[4] = (uint32_t)b.n_bags; c[5] = nw; c[6] = c[7] = 0;
+            memcpy(c + kPeerConstHead, b.wc_host + (size_t)s->wc_off[p] * kWholeWords, (size_t)nw * kWholeWords * 4);
+            pa.box[p] = (unsigned long long)(uintptr_t)pimemb::peer_box_dev(s->peer, (int)p, s->rank, (uint32_t)(b.seq % pimemb::kPeerSlots));
+            pa.consts[p] = c;
+            pa.n_consts[p] = kPeerConstHead + nw * kWholeWords;
+            at += pa.n_consts[p];
+            any = true;
+        }
+        if (any)
+            HIP_TRY(pimemb::launch_peer_post(Kr ? static_cast<const uint32_t *>(b.meta.p) : nullptr, Kr, N, pa, s->peer_tag + b.seq + 1, s->cs));
     }
     g_hp.lap(5);
 
@@ -410,6 +487,29 @@ int stage_request(emb_shard *s, Batch &b) {
     if (!via_comm(s, s->rank)) {       // what this rank asked ITSELF for never travelled
         if (Kr) memcpy(recv + (size_t)s->rank * (Kr + 1) * 2, sent + (size_t)s->rank * (Kr + 1) * 2, (size_t)(Kr + 1) * 8);
         if (M) memcpy(rwhole + (size_t)s->rank * M * kWholeWords, b.wc_host + (size_t)s->wc_off[s->rank] * kWholeWords, (size_t)M * kWholeWords * 4);
+    }
+    b.from.assign(N, PeerFrom{});
+    if (s->peer_mode) {        // what every peer posted for this batch: its counts and where its buffers are
+        const double t0 = now_us();
+        for (uint32_t p = 0; p < N; p++) {
+            if (via(s, (int)p) != PEER) continue;
+            pimemb::PeerMsg *box = pimemb::peer_box(s->peer, s->rank, (int)p, (uint32_t)(b.seq % pimemb::kPeerSlots));
+            EMB_TRY(poll_word(s, &box->posted, s->peer_tag + b.seq + 1, "did not post its requests of", (int)p, b.seq));
+            std::atomic_thread_fence(std::memory_order_acquire);
+            const uint32_t *w = box->words;
+            uint32_t at = 0;
+            if (Kr) {
+                memcpy(recv + (size_t)p * (Kr + 1) * 2, w, (size_t)(Kr + 1) * 8);
+                b.from[p].piece_word = w[2 * (Kr + 1)];
+                b.from[p].ret_row0 = w[2 * (Kr + 1) + 1];
+                at = 2 * (Kr + 1) + 2;
+            }
+            b.from[p].req_send_off = (uint64_t)w[at] | ((uint64_t)w[at + 1] << 32);
+            b.from[p].ret_recv_off = (uint64_t)w[at + 2] | ((uint64_t)w[at + 3] << 32);
+            if (w[at + 5] != M) return fail(EMB_ERR_INVALID, "emb_shard: rank %u posted %u whole-table entries, this rank owns %u (different placements?)", p, w[at + 5], M);
+            if (M) memcpy(rwhole + (size_t)p * M * kWholeWords, w + at + kPeerConstHead, (size_t)M * kWholeWords * 4);
+        }
+        s->st.us_host_wait_counts += now_us() - t0;
     }
     b.out_words.assign(N, 0);
     b.in_words.assign(N, 0);
@@ -498,10 +598,17 @@ int stage_serve(emb_shard *s, Batch &b) {
     // row pieces: source s asked for sub-bags of my shard of table k -- an ordinary lookup each
     uint64_t in_at = 0, out_at = 0, served_at = 0, back_at = 0;
     for (uint32_t p = 0; p < N; p++) {
-        const bool remote = via_comm(s, (int)p);
-        const uint32_t *words = remote ? static_cast<uint32_t *>(b.req_recv.p) + in_at : static_cast<uint32_t *>(b.req_send.p) + out_at;
-        // rows for a remote source go to ret_send (T sends them); my own go where the un-router reads shard `rank`'s rows
-        float *rows_dst = remote ? static_cast<float *>(b.ret_send.p) + served_at * dim : static_cast<float *>(b.ret_recv.p) + back_at * dim;
+        const Via how = via(s, (int)p);
+        // the request piece: where it arrived (RCCL), where it was written (my own), or where it sits in the peer's HBM
+        const uint32_t *words = how == COMM ? static_cast<uint32_t *>(b.req_recv.p) + in_at
+                              : how == SELF ? static_cast<uint32_t *>(b.req_send.p) + out_at
+                                            : reinterpret_cast<uint32_t *>(pimemb::peer_base(s->peer, (int)p) + b.from[p].req_send_off) + b.from[p].piece_word;
+        // rows for a remote source go to ret_send (T sends them); my own go where the un-router reads shard `rank`'s rows; a
+        // peer's go straight into ITS ret_recv, at the row where it expects this shard's
+        float *rows_dst = how == COMM ? static_cast<float *>(b.ret_send.p) + served_at * dim
+                        : how == SELF ? static_cast<float *>(b.ret_recv.p) + back_at * dim
+                                      : reinterpret_cast<float *>(pimemb::peer_base(s->peer, (int)p) + b.from[p].ret_recv_off) + (uint64_t)b.from[p].ret_row0 * dim;
+        if (how == PEER) s->st.bytes_to_peers += b.in_words[p] * 4 + b.rows_served[p] * (uint64_t)dim * 4;     // read from / stored into the peer's HBM
         uint64_t cur = 0, row = 0;
         for (uint32_t k = 0; k < Kr; k++) {
             const uint64_t ns = recv[((size_t)p * (Kr + 1) + k) * 2], ni = recv[((size_t)p * (Kr + 1) + k) * 2 + 1];
@@ -529,7 +636,8 @@ int stage_serve(emb_shard *s, Batch &b) {
     // whole tables owned here: source p's bags exactly as p's caller passed them
     uint64_t win_at = in_w, wrow_at = served;
     for (uint32_t p = 0; p < N; p++) {
-        const bool remote = via_comm(s, (int)p);
+        const Via how = via(s, (int)p);
+        const bool remote = how == COMM;
         for (uint32_t j = 0; j < M; j++) {
             const uint32_t t = s->whole_of[s->rank][j];
             const uint32_t *c = rwhole + ((size_t)p * M + j) * kWholeWords;
@@ -548,6 +656,17 @@ int stage_serve(emb_shard *s, Batch &b) {
                 win_at += pad4(ni);
                 d.pooled = static_cast<float *>(b.ret_send.p) + wrow_at * dim;
                 wrow_at += nb;
+            } else if (how == PEER) {      // the requester's arrays in place, its output buffer in place
+                char *base = pimemb::peer_base(s->peer, (int)p);
+                const uint64_t io = (uint64_t)c[4] | ((uint64_t)c[5] << 32), oo = (uint64_t)c[6] | ((uint64_t)c[7] << 32), ro = (uint64_t)c[8] | ((uint64_t)c[9] << 32);
+                const uint64_t lim = pimemb::peer_arena_bytes(s->peer, (int)p);
+                if (nb && (io + ni * 4 > lim || ro + nb * (uint64_t)dim * 4 > lim || (!c[2] && oo + nb * 4 > lim)))
+                    return fail(EMB_ERR_INVALID, "emb_shard: rank %u posted buffer offsets outside its arena", p);
+                d.fixed_pooling = c[2];
+                d.offsets = c[2] ? nullptr : base + oo;
+                d.indices = base + io;
+                d.pooled = reinterpret_cast<float *>(base + ro);
+                s->st.bytes_to_peers += ni * 4 + (c[2] ? 0 : nb * 4) + nb * (uint64_t)dim * 4;
             } else {           // my own bags of my own table: in place, straight into the caller's buffer
                 const emb_shard_input &u = b.in[t];
                 d.fixed_pooling = u.offsets ? 0u : u.fixed_pooling;
@@ -573,6 +692,13 @@ int stage_serve(emb_shard *s, Batch &b) {
     s->st.served_algorithmic_bytes += alg;
     s->st.served_sub_bags += n_sub;
     s->st.served_indices += n_idx;
+    if (s->peer_mode) {        // behind the lookup (its kernel boundary completes the stores into the peers' HBM): "served"
+        pimemb::PeerDoneArgs da{};
+        for (uint32_t p = 0; p < N; p++)
+            if (via(s, (int)p) == PEER)
+                da.box[da.n++] = (unsigned long long)(uintptr_t)pimemb::peer_box_dev(s->peer, (int)p, s->rank, (uint32_t)(b.seq % pimemb::kPeerSlots));
+        HIP_TRY(pimemb::launch_peer_done(da, s->peer_tag + b.seq + 1, s->cs));
+    }
     g_hp.lap(11);
 
     // T(b): partial rows back to the bags' owners; whole tables' pooled rows straight into the callers' buffers
@@ -608,6 +734,16 @@ int stage_serve(emb_shard *s, Batch &b) {
 // ---- U(b): partial rows added in shard order, into the caller's buffers ------------------------------------------------------
 int stage_unroute(emb_shard *s, Batch &b) {
     g_hp.start();
+    if (s->peer_mode) {        // every peer has stored what it owes this rank for the batch (host poll: nothing to enqueue)
+        const double t0 = now_us();
+        for (uint32_t p = 0; p < (uint32_t)s->N; p++)
+            if (via(s, (int)p) == PEER) {
+                pimemb::PeerMsg *box = pimemb::peer_box(s->peer, s->rank, (int)p, (uint32_t)(b.seq % pimemb::kPeerSlots));
+                EMB_TRY(poll_word(s, &box->served, s->peer_tag + b.seq + 1, "did not serve", (int)p, b.seq));
+            }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        s->st.us_host_wait_served += now_us() - t0;
+    }
     if (b.ret_recorded) HIP_TRY(hipStreamWaitEvent(s->cs, b.ev_ret, 0));       // the rows are back (whole tables: already in place)
     if (s->Kr && b.n_bags) {
         float *outs[pimemb::kRouteBagMaxTables];
@@ -674,7 +810,21 @@ int emb_shard_create(emb_engine *e, emb_comm *comm, const emb_shard_config *cfg,
     s->comm = comm;
     int32_t dev = 0, rank = 0, world = 1;
     int rc = emb_device_of(e, &dev);
-    if (rc == EMB_OK && comm) rc = emb_comm_rank(comm, &rank, &world);
+    s->peer_mode = (cfg->flags & EMB_SHARD_PEER_STORES) != 0;
+    if (s->peer_mode) {
+        if (!cfg->peer) {
+            delete s;
+            return fail(EMB_ERR_INVALID, "emb_shard_create: EMB_SHARD_PEER_STORES needs emb_shard_config.peer (emb_peer_create)");
+        }
+        s->peer = cfg->peer;
+        s->peer_tag = pimemb::peer_next_epoch(cfg->peer) << 40;
+        rank = pimemb::peer_rank(cfg->peer);
+        world = pimemb::peer_world(cfg->peer);
+        if (cfg->flags & EMB_SHARD_SELF_VIA_COMM) {
+            delete s;
+            return fail(EMB_ERR_INVALID, "emb_shard_create: EMB_SHARD_SELF_VIA_COMM and EMB_SHARD_PEER_STORES exclude each other");
+        }
+    } else if (rc == EMB_OK && comm) rc = emb_comm_rank(comm, &rank, &world);
     if (rc) {
         delete s;
         return rc;
@@ -728,6 +878,12 @@ int emb_shard_create(emb_engine *e, emb_comm *comm, const emb_shard_config *cfg,
     }
     if (s->rows.size() > pimemb::kRouteBagMaxTables) return bail(fail(EMB_ERR_UNSUPPORTED, "emb_shard_create: at most %u row-split tables", pimemb::kRouteBagMaxTables));
     if (world > 255) return bail(fail(EMB_ERR_UNSUPPORTED, "emb_shard_create: at most 255 ranks"));
+    if (s->peer_mode) {
+        size_t most = 0;
+        for (const auto &w : s->whole_of) most = std::max(most, w.size());
+        if (2 * (s->rows.size() + 1) + 2 + kPeerConstHead + most * kWholeWords > pimemb::kPeerMsgWords)
+            return bail(fail(EMB_ERR_UNSUPPORTED, "emb_shard_create: %zu whole tables on one owner do not fit a mailbox message (%u words)", most, pimemb::kPeerMsgWords));
+    }
     s->Kr = (uint32_t)s->rows.size();
     s->M = (uint32_t)s->whole_of[(size_t)rank].size();
     s->wc_off.assign((size_t)world + 1, 0);
@@ -749,6 +905,12 @@ int emb_shard_create(emb_engine *e, emb_comm *comm, const emb_shard_config *cfg,
         p = nullptr;
         if (err == hipSuccess) err = hipHostMalloc(&p, (size_t)s->Wtot * kWholeWords * 4 + 64, hipHostMallocMapped | hipHostMallocCoherent);
         b.wc_host = static_cast<uint32_t *>(p);
+        p = nullptr;
+        if (err == hipSuccess && s->peer_mode) {
+            err = hipHostMalloc(&p, (N * kPeerConstHead + (size_t)s->Wtot * kWholeWords) * 4 + 64, hipHostMallocMapped | hipHostMallocCoherent);
+            b.pc_host = static_cast<uint32_t *>(p);
+            b.req_send.arena = b.ret_recv.arena = true;      // peers gather from / store into these two
+        }
         p = nullptr;
         if (err == hipSuccess) err = hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocCoherent);
         b.flag = static_cast<unsigned long long *>(p);
@@ -894,7 +1056,8 @@ int emb_shard_destroy(emb_shard *s) {
     for (Batch &b : s->ring) {
         DevBuf *bufs[8] = {&b.req_send, &b.meta, &b.slotmap, &b.counts_in, &b.wc_send, &b.req_recv, &b.ret_send, &b.ret_recv};
         for (DevBuf *d : bufs)
-            if (d->p) (void)hipFree(d->p);
+            if (d->p && !d->arena) (void)hipFree(d->p);
+        if (b.pc_host) (void)hipHostFree(b.pc_host);
         if (b.counts_host) (void)hipHostFree(b.counts_host);
         if (b.wc_host) (void)hipHostFree(b.wc_host);
         if (b.flag) (void)hipHostFree(b.flag);

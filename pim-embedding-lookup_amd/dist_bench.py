@@ -228,8 +228,18 @@ def run_sharded(args, hbm_peak_gbs: float, ctx, rep_bytes: int, mode: str):
 
     eng = pel.EmbeddingEngine(device=dev.index, max_tables=len(plan.units) + 1)
     via = os.environ.get("PIMEMB_SHARD_SELF_VIA_COMM") == "1"      # rehearsal / A-B: self pieces through RCCL like any other
-    comm = sh.native_comm(eng, rank, world, always=via)
-    S = sh.ShardedEmbeddingBags(plan, eng, rank, comm, depth=depth, check=False, self_via_comm=via)
+    use_peer = getattr(args, "exchange", "rccl") == "peer"
+    peer = comm = None
+    if use_peer:                  # the collective-free exchange: no RCCL communicator in the data path at all
+        box = [os.urandom(6).hex()]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)         # one job tag for the shared-memory segment
+        n_split = sum(1 for k in plan.kinds if k == sh.ROW_SPLIT)
+        arena = int(1.25 * NBATCH * T * B * (L * 4 + dim * 4)) + 8 * 2 * n_split * B * (L * 8 + min(L, world) * dim * 4 * 2) + (256 << 20)
+        peer = sh.PeerGroup(eng, "bench-" + box[0], rank, world, arena_bytes=arena)
+    else:
+        comm = sh.native_comm(eng, rank, world, always=via)
+    S = sh.ShardedEmbeddingBags(plan, eng, rank, comm, depth=depth, check=False, self_via_comm=via and not use_peer, peer=peer)
     S.load_tables(lambda t, lo, hi: table_values(torch, t, lo, hi, dim, dev))
     torch.cuda.empty_cache()
 
@@ -241,6 +251,13 @@ def run_sharded(args, hbm_peak_gbs: float, ctx, rep_bytes: int, mode: str):
     for j in range(NBATCH):
         d_idx = [torch.from_numpy(idx_host[j][t]).to(dev) for t in range(T)]
         outs = torch.zeros((T, B, dim), dtype=torch.float32, device=dev)
+        if peer is not None:      # peers gather from / store into these in place: they live in this rank's arena
+            a_idx = [peer.empty(x.shape, torch.int32) for x in d_idx]
+            for a, x in zip(a_idx, d_idx):
+                a.copy_(x)
+            d_idx = a_idx
+            outs = peer.empty((T, B, dim), torch.float32)
+            outs.zero_()
         slots.append(dict(prep=S.prepare(d_idx, None, L, [outs[t] for t in range(T)]), outs=outs))
     torch.cuda.synchronize()
 
@@ -316,12 +333,18 @@ def run_sharded(args, hbm_peak_gbs: float, ctx, rep_bytes: int, mode: str):
     last = (it - 1) % NBATCH
     dump_row_split(torch, S, plan, sh, gen, rank, world, dev, rows_list, T, B, L, dim, NBATCH, last, idx_host, slots[last]["outs"])
     digest = None
-    if rank == 0 and split:                          # bits of rank 0's row-split outputs of that step: two runs must agree
+    digest_all = None
+    if rank == 0:                                    # bits of rank 0's outputs of that step: two runs / two transports must agree
         import hashlib
+        if split:
+            hsh = hashlib.sha1()
+            for t in split:
+                hsh.update(slots[last]["outs"][t][:4096].contiguous().cpu().numpy().tobytes())
+            digest = hsh.hexdigest()
         hsh = hashlib.sha1()
-        for t in split:
-            hsh.update(slots[last]["outs"][t][:4096].contiguous().cpu().numpy().tobytes())
-        digest = hsh.hexdigest()
+        for t in split + whole:
+            hsh.update(slots[last]["outs"][t].contiguous().cpu().numpy().tobytes())
+        digest_all = hsh.hexdigest()
     sent = S.sent_counts(it - 1) if split else np.zeros((world, 1, 2), np.int64)      # (seq == step index: one submit per step)
 
     # ---- the kernels' own time: the same steps with the library's kernel brackets on (events cost GPU time: not in the timed loop)
@@ -349,6 +372,7 @@ def run_sharded(args, hbm_peak_gbs: float, ctx, rep_bytes: int, mode: str):
         fr = step_fractions(lookup_bytes(T, B, L, dim, elem), bytes_out, clk["ms_per_step"], hbm_peak_gbs)
         fr["host_us_per_step"] = st["us_host_submit"] / n_st
         fr["host_wait_counts_us_per_step"] = st["us_host_wait_counts"] / n_st
+        fr["host_wait_served_us_per_step"] = st["us_host_wait_served"] / n_st
         # (L of the newest batch and S of the one being served share ONE launch in the steady state: priced together)
         kernels = {"router_us": k_route, "lookup_us": kernel_us, "unrouter_us": k_un,
                    "lookup_algorithmic_bytes": alg_bytes, "served_algorithmic_bytes": int(serve_bytes),
@@ -383,10 +407,15 @@ def run_sharded(args, hbm_peak_gbs: float, ctx, rep_bytes: int, mode: str):
                        "parallelism": "ONE library call per batch (emb_shard_submit, depth %d): whole tables travel straight out "
                                       "of / into the caller's buffers, row-split tables are cut into per-shard sub-bags on the GPU, "
                                       "counts first, ONE fused lookup over everything a rank serves, partial rows added in shard "
-                                      "order; transfers = RCCL groups issued from C (emb_comm_exchange), self pieces %s; control "
+                                      "order; transfers = %s, self pieces %s; control "
                                       "plane (bootstrap, barriers, job clock) torch.distributed/%s"
-                                      % (depth, "through RCCL too" if S._flags & 1 else "served in place", backend),
-                       "last_step_outputs_sha1": digest,
+                                      % (depth, "NONE -- the owner's fused lookup gathers a requester's indices in place and stores its pooled "
+                                                "rows straight into the requester's HBM (EMB_SHARD_PEER_STORES: HIP IPC mappings, handshake through "
+                                                "a shared-memory segment)" if peer is not None else "RCCL groups issued from C (emb_comm_exchange)",
+                                         "through RCCL too" if S._flags & 1 else "served in place", backend),
+                       "last_step_outputs_sha1": digest, "last_step_sharded_outputs_sha1": digest_all,
+                       "exchange_transport": "peer stores (HIP IPC, no RCCL in the data path; %s arena)" % ("fine-grained" if peer.info()["fine_grained"] else "ordinary device memory")
+                                             if peer is not None else "RCCL groups issued from C",
                        "last_step_request_rows_per_peer": sent[:, :, 0].sum(axis=1).tolist(),
                        "last_step_request_indices_per_peer": sent[:, :, 1].sum(axis=1).tolist(),
                        "exchange": {"mode": mode, "value": clk["value"], "ms_per_step": clk["ms_per_step"], "verified": True,
@@ -406,6 +435,8 @@ def run_sharded(args, hbm_peak_gbs: float, ctx, rep_bytes: int, mode: str):
     dist.barrier()
     torch.cuda.synchronize()
     S.close()
+    if peer is not None:
+        peer.close()
     if comm is not None:
         comm.close()
     eng.close()

@@ -45,7 +45,7 @@ class EmbCommOp(C.Structure):
 
 
 EMB_PLACE_REPLICATED, EMB_PLACE_WHOLE, EMB_PLACE_ROWS = 0, 1, 2
-EMB_SHARD_SELF_VIA_COMM, EMB_SHARD_CHECK_SERVED = 1, 2
+EMB_SHARD_SELF_VIA_COMM, EMB_SHARD_CHECK_SERVED, EMB_SHARD_PEER_STORES = 1, 2, 4
 
 
 class EmbShardTable(C.Structure):
@@ -59,14 +59,14 @@ class EmbShardInput(C.Structure):
 
 class EmbShardConfig(C.Structure):
     _fields_ = [("n_tables", C.c_uint32), ("dim", C.c_uint32), ("depth", C.c_uint32), ("flags", C.c_uint32),
-                ("tables", C.POINTER(EmbShardTable))]
+                ("tables", C.POINTER(EmbShardTable)), ("peer", C.c_void_p)]
 
 
 class EmbShardStats(C.Structure):
     _fields_ = [("n_batches", C.c_uint64), ("bytes_to_peers", C.c_uint64), ("bytes_to_self", C.c_uint64),
                 ("served_algorithmic_bytes", C.c_uint64), ("local_algorithmic_bytes", C.c_uint64),
                 ("served_sub_bags", C.c_uint64), ("served_indices", C.c_uint64),
-                ("us_host_submit", C.c_double), ("us_host_wait_counts", C.c_double),
+                ("us_host_submit", C.c_double), ("us_host_wait_counts", C.c_double), ("us_host_wait_served", C.c_double),
                 ("us_kernel_route", C.c_double), ("us_kernel_local", C.c_double), ("us_kernel_serve", C.c_double),
                 ("us_kernel_unroute", C.c_double), ("n_timed_batches", C.c_uint64)]
 
@@ -102,6 +102,11 @@ SIGNATURES = {
     "emb_comm_destroy": (C.c_int, [_vp]),
     "emb_comm_exchange": (C.c_int, [_vp, C.POINTER(EmbCommOp), _u32, _vp]),
     "emb_comm_rank": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
+    "emb_peer_create": (C.c_int, [_vp, C.c_char_p, C.c_int32, C.c_int32, _u64, _pp]),
+    "emb_peer_alloc": (C.c_int, [_vp, _u64, _pp]),
+    "emb_peer_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), _pp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_i32)]),
+    "emb_peer_barrier": (C.c_int, [_vp]),
+    "emb_peer_destroy": (C.c_int, [_vp]),
     "emb_shard_create": (C.c_int, [_vp, _vp, C.POINTER(EmbShardConfig), _pp]),
     "emb_shard_submit": (C.c_int, [_vp, C.POINTER(EmbShardInput), _u64, _vp, C.POINTER(_u64)]),
     "emb_shard_flush": (C.c_int, [_vp]),

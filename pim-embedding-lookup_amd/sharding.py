@@ -150,15 +150,16 @@ class ShardedEmbeddingBags:
     in a transfer; the offending pieces pool to zero rows."""
 
     def __init__(self, plan: ShardPlan, engine, rank: int, comm=None, depth: int = 0, check: bool = True,
-                 self_via_comm: bool = False):
+                 self_via_comm: bool = False, peer: "PeerGroup | None" = None):
         import ctypes as C
         import torch
         from . import lib as _l
         self.torch, self._l, self._C = torch, _l, C
         self.plan, self.engine, self.rank, self.world, self.comm = plan, engine, int(rank), plan.world, comm
         self.depth, self.dim, self.T = int(depth), plan.dim, len(plan.rows)
-        if comm is None and plan.world != 1:
-            raise ValueError("a world of %d ranks needs a communicator (engine.NativeExchange)" % plan.world)
+        self.peer = peer           # the collective-free exchange (EMB_SHARD_PEER_STORES): buffers of tables other ranks hold come from peer.empty()
+        if comm is None and peer is None and plan.world != 1:
+            raise ValueError("a world of %d ranks needs a communicator (engine.NativeExchange) or a PeerGroup" % plan.world)
         self._L = engine._L
         tabs = (_l.EmbShardTable * self.T)()
         for t, k in enumerate(plan.kinds):
@@ -170,7 +171,8 @@ class ShardedEmbeddingBags:
             else:
                 tabs[t] = _l.EmbShardTable(_l.EMB_PLACE_ROWS, -1, us[self.rank].uid, -(-plan.rows[t] // plan.world))
         self._tabs = tabs
-        self._flags = (_l.EMB_SHARD_CHECK_SERVED if check else 0) | (_l.EMB_SHARD_SELF_VIA_COMM if self_via_comm else 0)
+        self._flags = (_l.EMB_SHARD_CHECK_SERVED if check else 0) | (_l.EMB_SHARD_SELF_VIA_COMM if self_via_comm else 0) | \
+                      (_l.EMB_SHARD_PEER_STORES if peer is not None else 0)
         self._h = None
         self._live = {}            # seq -> tensors kept alive until the batch is waited for
 
@@ -186,7 +188,7 @@ class ShardedEmbeddingBags:
         C, _l = self._C, self._l
         if self._h is not None:
             return
-        cfg = _l.EmbShardConfig(self.T, self.dim, self.depth, self._flags, self._tabs)
+        cfg = _l.EmbShardConfig(self.T, self.dim, self.depth, self._flags, self._tabs, self.peer._h if self.peer is not None else None)
         h = C.c_void_p()
         _l.check(self._L.emb_shard_create(self.engine._h, self.comm._h if self.comm is not None else None, C.byref(cfg), C.byref(h)))
         self._h = h
@@ -217,7 +219,8 @@ class ShardedEmbeddingBags:
             n_bags = int(idx[0].numel()) // int(fixed_pooling)
         dev = idx[0].device
         if outs is None:
-            one = t.empty((self.T, n_bags, self.dim), dtype=t.float32, device=dev)
+            one = (self.peer.empty if self.peer is not None else lambda sh_, dtype: t.empty(sh_, dtype=dtype, device=dev))(
+                (self.T, n_bags, self.dim), t.float32)
             outs = [one[k] for k in range(self.T)]
         arr = (self._l.EmbShardInput * self.T)()
         for k in range(self.T):
@@ -290,6 +293,62 @@ class ShardedEmbeddingBags:
             self._L.emb_shard_destroy(self._h)
             self._h = None
         self._live.clear()
+
+
+class PeerGroup:
+    """Ranks that read and write each other's HBM directly (emb_peer_* in pimemb.h): the substrate of the collective-free
+    exchange (`ShardedEmbeddingBags(..., peer=group)`).  Every rank creates it with the same `tag` (any string unique to the
+    job) and `world`; set-up goes through one POSIX shared-memory segment and HIP IPC handles -- no RCCL, no torch.  Everything
+    a peer may touch (indices / offsets / outputs of tables other ranks hold) must be carved from the arena: `empty()`."""
+
+    def __init__(self, engine, tag: str, rank: int, world: int, arena_bytes: int = 256 << 20):
+        import ctypes as C
+        from . import lib as _l
+        self._C, self._l, self._L, self.engine = C, _l, engine._L, engine
+        self.rank, self.world = int(rank), int(world)
+        h = C.c_void_p()
+        _l.check(self._L.emb_peer_create(engine._h, tag.encode(), rank, world, int(arena_bytes), C.byref(h)))
+        self._h = h
+
+    def alloc(self, nbytes: int) -> int:
+        p = self._C.c_void_p()
+        self._l.check(self._L.emb_peer_alloc(self._h, int(nbytes), self._C.byref(p)))
+        return p.value
+
+    def empty(self, shape, dtype):
+        """A torch CUDA tensor living in this rank's arena (peers can address it)."""
+        import torch
+        shape = tuple(int(x) for x in (shape if hasattr(shape, "__len__") else (shape,)))
+        n = 1
+        for x in shape:
+            n *= x
+        esz = torch.empty(0, dtype=dtype).element_size()
+        ptr = self.alloc(max(n * esz, 16))
+        typestr = {torch.float32: "<f4", torch.int32: "<i4", torch.int64: "<i8", torch.float16: "<f2", torch.uint8: "|u1"}[dtype]
+
+        class _View:
+            __cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False), "version": 2, "strides": None}
+        if n == 0:
+            return torch.empty(shape, dtype=dtype, device=torch.device("cuda", self.engine.device))
+        return torch.as_tensor(_View(), device=torch.device("cuda", self.engine.device))
+
+    def info(self) -> dict:
+        C = self._C
+        r, w, fg = C.c_int32(), C.c_int32(), C.c_int32()
+        a, nb, used = C.c_void_p(), C.c_uint64(), C.c_uint64()
+        self._l.check(self._L.emb_peer_info(self._h, C.byref(r), C.byref(w), C.byref(a), C.byref(nb), C.byref(used), C.byref(fg)))
+        return dict(rank=r.value, world=w.value, arena=a.value, arena_bytes=nb.value, used=used.value, fine_grained=bool(fg.value))
+
+    def barrier(self) -> None:
+        self._l.check(self._L.emb_peer_barrier(self._h))
+
+    def close(self) -> None:
+        if self._h:
+            try:
+                self.barrier()          # a peer may still be gathering from / storing into this rank's arena
+            finally:
+                self._L.emb_peer_destroy(self._h)
+                self._h = None
 
 
 def native_comm(engine, rank: int, world: int, always: bool = False):

@@ -63,7 +63,7 @@ def main():
     torch.cuda.set_device(dev)
     sys.stdout.flush()
     os.dup2(2, 1)              # RCCL's banner goes to stderr with everything else
-    if world > 1:
+    if world > 1 and not cfg.get("peer"):
         dist.init_process_group("gloo", rank=rank, world_size=world)      # bootstrap only (the unique id): the data path is the C side's RCCL
     rows, dim = cfg["rows"], cfg["dim"]
     f16 = cfg.get("f16", False)
@@ -93,12 +93,15 @@ def main():
             for t, n in enumerate(rows)]
     tabs32 = [w.astype(np.float32) for w in tabs]
     eng = pel.EmbeddingEngine(device=0, max_tables=len(plan.units) + 1)
-    comm = sh.native_comm(eng, rank, world)
+    peer = sh.PeerGroup(eng, cfg["peer_tag"], rank, world, arena_bytes=256 << 20) if cfg.get("peer") else None
+    comm = sh.native_comm(eng, rank, world) if peer is None else None
     status = {"rank": rank, "ok": False}
+    if peer is not None:
+        status["peer"] = peer.info()
     try:
         for depth in cfg.get("depths", [0, 2, 3]):
             S = sh.ShardedEmbeddingBags(plan, eng, rank, comm, depth=depth, check=cfg.get("check", True),
-                                        self_via_comm=cfg.get("self_via_comm", False))
+                                        self_via_comm=cfg.get("self_via_comm", False), peer=peer)
             S.load_tables(lambda t, lo, hi: torch.from_numpy(tabs[t][lo:hi]).to(dev))
             rng = np.random.default_rng(1000 + rank)           # every rank has its OWN bags
             n_batches = cfg.get("batches", 6)
@@ -110,8 +113,16 @@ def main():
                 batches.append(make_batch(rng, rows, B, cfg["max_len"], cfg.get("fixed", False)))
             dt = torch.int64 if cfg.get("int64", False) else torch.int32
 
+            def to_dev(a):
+                x = torch.from_numpy(a).to(dev).to(dt)
+                if peer is None:
+                    return x
+                y = peer.empty(x.shape, torch.int32)          # peers gather from it in place: it must live in the arena
+                y.copy_(x.to(torch.int32))
+                return y
+
             def dev_batch(b):
-                return [torch.from_numpy(i).to(dev).to(dt) for i in b[0]], [torch.from_numpy(o).to(dev).to(dt) for o in b[1]]
+                return [to_dev(i) for i in b[0]], [to_dev(o) for o in b[1]]
 
             def check(outs, b, what):
                 torch.cuda.synchronize()
@@ -155,7 +166,7 @@ def main():
                 t_bad = cfg["bad_index"]["table"]
                 if rank == cfg["bad_index"]["rank"]:
                     b[0][t_bad][3] = rows[t_bad] + 5
-                di = [torch.from_numpy(i).to(dev).to(dt) for i in b[0]]
+                di = [to_dev(i) for i in b[0]]
                 raised = False
                 try:
                     if depth == 0:
@@ -174,10 +185,12 @@ def main():
         status["error"] = traceback.format_exc()
     finally:
         torch.cuda.synchronize()
+        if peer is not None:
+            peer.close()
         if comm is not None:
             comm.close()
         eng.close()
-        if world > 1:
+        if world > 1 and not cfg.get("peer"):
             dist.destroy_process_group()
     with open(cfg["out"] + ".rank%d.json" % rank, "w") as f:
         json.dump(status, f)

@@ -95,6 +95,39 @@ def test_shard_rccl_ranks_on_one_gpu(variant, world, tmp_path):
         assert all(st["stats_depth2"]["bytes_to_self"] > 0 for st in res)
 
 
+@pytest.mark.parametrize("variant,world", [("ragged", 2), ("ragged", 3), ("one-hot", 4), ("whole-only", 2), ("empty-rank", 3)])
+def test_shard_peer_stores_ranks_on_one_gpu(variant, world, tmp_path):
+    """EMB_SHARD_PEER_STORES: the collective-free exchange with 2-4 PROCESSES on the one GPU (HIP IPC mappings of each
+    other's arenas, handshake through the job's shared-memory segment; no RCCL communicator exists in these jobs).  The
+    owner's fused lookup gathers the requesters' indices in place and stores pooled rows straight into their buffers; every
+    table on every rank against the oracle, depth 0 / 2 / 3, and -- being the same arithmetic -- the same bits as the RCCL path."""
+    import uuid
+    cfg = dict(rows=[7, 300, 5000, 64, 2000, 1500], dim=16, rep=64 * 16 * 4, split=3000 * 16 * 4, bags=29, max_len=6,
+               expect_kinds=["replicated", "whole", "row_split"], peer=True, peer_tag="t" + uuid.uuid4().hex[:12])
+    if variant == "one-hot":
+        cfg.update(max_len=1, fixed=True, dim=64, rep=64 * 64 * 4, split=3000 * 64 * 4)
+    elif variant == "whole-only":
+        cfg.update(split=10 ** 12, expect_kinds=["replicated", "whole"], max_len=5, fixed=True)
+    elif variant == "empty-rank":
+        cfg.update(empty_rank=1)
+    res = _run(cfg, world, tmp_path)
+    for st in res:
+        assert st["peer"]["world"] == world and st["stats_depth3"]["n_batches"] == 6 and st["stats_depth0"]["bytes_to_peers"] > 0
+
+
+def test_shard_peer_stores_missing_rank_times_out_nonzero(tmp_path):
+    """A rank that never joins: the others give up after PIMEMB_SHARD_TIMEOUT_S with an error (non-zero exit), no hang."""
+    import uuid
+    cfg = dict(rows=[7, 300], dim=16, rep=0, split=10 ** 12, bags=5, max_len=2, peer=True, peer_tag="t" + uuid.uuid4().hex[:12],
+               out=str(tmp_path / "shard"), depths=[0])
+    env = dict(os.environ, RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY="0", PIMEMB_SHARD_TIMEOUT_S="3", PIMEMB_TEST_NO_TORCH_DIST="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "shard_worker.py"), json.dumps(cfg)], env=env,
+                       capture_output=True, text=True, timeout=180)
+    assert p.returncode != 0
+    assert "did not" in p.stdout + p.stderr or "within" in p.stdout + p.stderr
+
+
 def test_shard_bad_index_raises_on_the_serving_rank_and_nobody_hangs(tmp_path):
     """A row id outside its table, passed by rank 0: the rank that SERVES it (the last shard of a row-split table) raises
     IndexError after the batch has gone through all its stages; every rank finishes."""
