@@ -1,5 +1,5 @@
 """GPU: the multi-GPU routing pieces of the sharded lookup on the real HIP engine -- bag routing to row-range
-shards (counts first), partial-sum un-routing, the generic ShardedLookup over the engine backend, and the
+shards (counts first), partial-sum un-routing, and the
 bench's N > 1 legs with two ranks sharing cuda:0 (collectives over gloo).  Through the C ABI throughout."""
 import os
 
@@ -665,3 +665,28 @@ def test_driver_command_shape_four_ranks_on_one_gpu():
     assert d["roofline"]["exchange"]["step_frac"] > 0 and d["roofline"]["exchange"]["xgmi_frac"] > 0
     assert d["ms_per_step_sync"] >= d["ms_per_step_event"] > 0
     assert wall < 300, f"{wall:.0f} s for the rehearsal: too close to the driver's limit"
+
+
+@pytest.mark.parametrize("leg", ["c2-whole", "c2-rows-pooled", "c5-shaped"])
+def test_peer_store_exchange_leaves_the_same_bits_as_rccl(leg):
+    """`bench.py --exchange peer` (EMB_SHARD_PEER_STORES: no RCCL in the data path -- the owner gathers a requester's indices in
+    place and stores pooled rows straight into its HBM through HIP IPC mappings) against `--exchange rccl` on two-rank runs:
+    both verify all tables on every rank themselves; the digest over rank 0's sharded outputs of the last timed step must be
+    the same -- the transport must not be visible in the results."""
+    import json
+    extra = {"c2-whole": ["--shard-mode", "whole", "--replicate-mb", "64", "--batch", "4099", "--steps", "8", "--warmup", "3"],
+             "c2-rows-pooled": ["--shard-mode", "rows", "--replicate-mb", "64", "--batch", "2003", "--pooling", "5", "--index-dist", "zipf",
+                                "--steps", "8", "--warmup", "3"],
+             "c5-shaped": ["--workload", "c5", "--rows-scale", str(1 / 4096), "--replicate-mb", "0", "--batch", "257", "--steps", "4",
+                           "--warmup", "2"]}[leg]
+    got = {}
+    for ex in ("rccl", "peer"):
+        res, lines = _bench_rccl_ranks(2, extra + ["--exchange", ex], timeout=900)
+        assert res.returncode == 0 and len(lines) == 1, res.stdout[-2000:] + res.stderr[-4000:]
+        d = json.loads(lines[0])
+        assert d["verified"] is True and d["config"]["exchange"]["verified"] is True
+        assert ("peer stores" in d["config"]["exchange_transport"]) == (ex == "peer")
+        if ex == "peer":
+            assert "NONE" in d["config"]["parallelism"] and d["roofline"]["exchange"]["host_wait_served_us_per_step"] >= 0
+        got[ex] = d["config"]["last_step_sharded_outputs_sha1"]
+    assert got["rccl"] == got["peer"] is not None
