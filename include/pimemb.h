@@ -178,6 +178,15 @@ int emb_lookup(emb_engine *e, uint32_t table_id, const void *indices, uint64_t n
 int emb_lookup_batched(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs,
                        emb_index_type itype, emb_memspace space, void *stream);
 
+/* One index per bag, served by ROW RANGE (DEVICE buffers, uint32 indices): for every descriptor, pooled[b] = the row
+ * indices[b] - row_lo[i] of the table for the bags whose index falls into [row_lo[i], row_lo[i] + the table's rows); every
+ * other bag of `pooled` is left untouched.  The building block of the sharded lookup's direct path for one-hot row-split
+ * tables: every shard scans the requester's raw index array and stores only the rows it holds, straight into the
+ * requester's output -- each bag has exactly one shard, so there is nothing to route and nothing to add up
+ * (emb_dpu_lookup.c:113-114 is the gather being served; the reference's column shards likewise all read the same index list,
+ * emb_host.h:258-263).  offsets must be NULL and fixed_pooling 1; rows are 16-byte multiples up to 1 KiB. */
+int emb_lookup_ranged(emb_engine *e, const emb_lookup_desc *descs, const uint64_t *row_lo, uint32_t n_descs, void *stream);
+
 /* Prepared lookup over DEVICE buffers: descriptors are resolved and uploaded once, every launch is
  * then a single kernel enqueue (graph-capturable: no allocation, copy or sync inside).  The plan
  * holds the pointers it was given: buffers must stay allocated; re-allocating one of its tables
@@ -426,6 +435,11 @@ int emb_peer_destroy(emb_peer *p);   /* call emb_peer_barrier first: a peer may 
  *   EMB_PLACE_ROWS        split by ROW RANGE over all ranks (rank r holds rows [r*rows_per_shard, (r+1)*rows_per_shard)):
  *                         every bag is cut into per-shard sub-bags on the GPU (emb_route_bags), each shard returns one
  *                         partial row per sub-bag, the bag's owner adds them in shard order (emb_unroute_bags).
+ * DIRECT path: when a batch has ONE index per bag on every row-split table and no peer sits behind RCCL (every peer is this
+ * rank itself or a peer-store peer), those tables are not routed at all -- every shard scans the requester's raw index array
+ * and serves the bags whose row it holds straight into the requester's output (emb_lookup_ranged): no router, no counts, no
+ * un-router.  Decided per batch and per rank; same bits (a one-index bag's pooled row IS the table row).  Not taken by a
+ * shard created with EMB_SHARD_CHECK_SERVED (the ranged lookup validates nothing) or EMB_SHARD_NO_DIRECT.
  * Counts first, payload second: what a rank will send each peer (sub-bags and indices per table) leaves before the payload,
  * so nothing has a capacity that skewed indices could overflow.  The one host wait of a batch is for those counts.
  *
@@ -482,6 +496,7 @@ typedef struct emb_shard_input {      /* one per table, in table order */
                                       behind it raises "served".  No request transfer, no return transfer, no staging copies; the
                                       host's waits are polls of mailbox words.  The caller's index / offset / output buffers of
                                       tables held by OTHER ranks, whole or split, must come from emb_peer_alloc. */
+#define EMB_SHARD_NO_DIRECT 8u      /* never take the direct path for one-index-per-bag row-split tables (below): always route */
 typedef struct emb_shard_config {
     uint32_t n_tables;
     uint32_t dim;
@@ -505,6 +520,7 @@ typedef struct emb_shard_stats {
      * emb_shard_set_kernel_timing was on: R router, L local lookup, S fused lookup over received pieces, U un-router */
     double us_kernel_route, us_kernel_local, us_kernel_serve, us_kernel_unroute;
     uint64_t n_timed_batches;
+    double us_kernel_direct;          /* ... D: the ranged one-hot lookups of the direct path */
 } emb_shard_stats;
 /* comm may be NULL for a world of one rank (everything is "self"). */
 int emb_shard_create(emb_engine *e, emb_comm *comm, const emb_shard_config *cfg, emb_shard **out);

@@ -1011,6 +1011,71 @@ int emb_lookup(emb_engine *e, uint32_t table_id, const void *indices, uint64_t n
     return emb_lookup_batched(e, &d, 1, itype, space, stream);
 }
 
+int emb_lookup_ranged(emb_engine *e, const emb_lookup_desc *descs, const uint64_t *row_lo, uint32_t n_descs, void *stream) {
+    if (!e) return fail(EMB_ERR_INVALID, "engine is NULL");
+    if (n_descs == 0) return EMB_OK;
+    if (!descs || !row_lo) return fail(EMB_ERR_INVALID, "emb_lookup_ranged: NULL argument");
+    DeviceGuard g(e->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint32_t bpt = pimemb::onehot_ranged_bags_per_tile();
+    // one launch per (dtype, dim) among the descriptors (every BASELINE config and reference preset has one)
+    std::map<std::pair<int, uint32_t>, std::vector<uint32_t>> by_shape;
+    for (uint32_t i = 0; i < n_descs; i++) {
+        const emb_lookup_desc &u = descs[i];
+        if (u.table_id >= e->tables.size() || e->tables[u.table_id].rows == nullptr)
+            return fail(EMB_ERR_INVALID, "emb_lookup_ranged: desc %u: table %u is not loaded", i, u.table_id);
+        if (u.offsets != nullptr || u.fixed_pooling != 1 || u.n_indices != u.n_bags)
+            return fail(EMB_ERR_INVALID, "emb_lookup_ranged: desc %u: one index per bag only (offsets NULL, fixed_pooling 1)", i);
+        if (u.n_bags && (!u.indices || !u.pooled)) return fail(EMB_ERR_INVALID, "emb_lookup_ranged: desc %u: NULL buffer", i);
+        const Table &t = e->tables[u.table_id];
+        if (t.geom.scalar_lanes) return fail(EMB_ERR_UNSUPPORTED, "emb_lookup_ranged: desc %u: rows must be 16-byte multiples up to 1 KiB", i);
+        by_shape[{(int)t.dtype, t.dim}].push_back(i);
+    }
+    uint64_t bags = 0;
+    for (auto &kv : by_shape) {
+        std::vector<DevDesc> img;
+        uint32_t max_tiles = 0;
+        const Table &t0 = e->tables[descs[kv.second[0]].table_id];
+        for (uint32_t i : kv.second) {
+            const emb_lookup_desc &u = descs[i];
+            const Table &t = e->tables[u.table_id];
+            const uint64_t tiles = (u.n_bags + bpt - 1) / bpt;
+            if (tiles > 0x0fffffffull) return fail(EMB_ERR_UNSUPPORTED, "emb_lookup_ranged: desc %u: too many bags", i);
+            DevDesc d{};
+            d.weights = t.rows;
+            d.indices = u.indices;
+            d.out = u.pooled;
+            d.n_idx = u.n_bags;
+            d.n_bags = u.n_bags;
+            d.nr_rows = t.nr_rows;
+            d.fixed_pooling = 1;
+            d.n_tiles = (uint32_t)tiles;
+            d.pad_[0] = row_lo[i];
+            if (d.n_tiles > max_tiles) max_tiles = d.n_tiles;
+            img.push_back(d);
+            bags += u.n_bags;
+        }
+        if (img.size() > 65535u) return fail(EMB_ERR_UNSUPPORTED, "emb_lookup_ranged: more than 65535 descriptors of one shape");
+        std::lock_guard<std::mutex> lk(e->mu);
+        char *h = nullptr, *d = nullptr;
+        int rc = take_image_space(e->ring, img.size() * sizeof(DevDesc), s, &h, &d);
+        if (rc) return rc;
+        memcpy(h, img.data(), img.size() * sizeof(DevDesc));
+        const DevDesc *dev_img = reinterpret_cast<const DevDesc *>(h);
+        if (d != nullptr) {
+            HIP_TRY(hipMemcpyAsync(d, h, img.size() * sizeof(DevDesc), hipMemcpyHostToDevice, s));
+            dev_img = reinterpret_cast<const DevDesc *>(d);
+        }
+        HIP_TRY(pimemb::launch_onehot_ranged(dev_img, (uint32_t)img.size(), max_tiles, t0.dtype, t0.geom, s));
+        e->n_kernel_launches.fetch_add(1, std::memory_order_relaxed);
+        e->n_by_kind[pimemb::KERNEL_WAVEBATCH].fetch_add(1, std::memory_order_relaxed);
+    }
+    e->n_lookup_calls.fetch_add(1, std::memory_order_relaxed);
+    e->n_bags.fetch_add(bags, std::memory_order_relaxed);
+    e->n_indices.fetch_add(bags, std::memory_order_relaxed);
+    return EMB_OK;
+}
+
 int emb_plan_create(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs,
                     emb_index_type itype, emb_plan **out) {
     if (!e || !out) return fail(EMB_ERR_INVALID, "engine or out is NULL");

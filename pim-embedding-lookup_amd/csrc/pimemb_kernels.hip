@@ -889,10 +889,11 @@ peer_post_kernel(const uint32_t *__restrict__ meta, uint32_t n_row_tables, uint3
         uint32_t at = 0;
         if (Kr) {
             const uint32_t n = 2 * (Kr + 1);
-            for (uint32_t i = threadIdx.x; i < n; i += kBlock) box->words[i] = meta[counts_at(p, 0, Kr) + i];
+            // (meta == nullptr: nothing was routed for this batch -- the direct one-hot path: all counts zero)
+            for (uint32_t i = threadIdx.x; i < n; i += kBlock) box->words[i] = meta ? meta[counts_at(p, 0, Kr) + i] : 0u;
             if (threadIdx.x == 0) {
-                box->words[n] = meta[ml.piece + p];
-                box->words[n + 1] = meta[ml.row0 + p * Kr];
+                box->words[n] = meta ? meta[ml.piece + p] : 0u;
+                box->words[n + 1] = meta ? meta[ml.row0 + p * Kr] : 0u;
             }
             at = n + 2;
         }
@@ -1014,6 +1015,42 @@ hipError_t launch_bag_sum_hot(const DevDesc *d_descs, uint32_t n_descs, uint32_t
     return itype == EMB_IDX_U32 ? launch_hot_dtype<uint32_t>(d_descs, n_descs, wgs, lds_bytes, dtype, g, stream)
                                 : launch_hot_dtype<int64_t>(d_descs, n_descs, wgs, lds_bytes, dtype, g, stream);
 }
+
+// One index per bag, served by row range (bag_onehot_ranged_kernel): descriptors carry row_lo in pad_[0]; 2-D grid.
+template <int DT>
+hipError_t launch_ranged_lpr(const DevDesc *d, uint32_t n, uint32_t max_tiles, const LaunchGeom &g, hipStream_t s) {
+    const dim3 grid(max_tiles, n, 1), block(WaveCfg::kBlock);
+    switch (g.lanes_per_row) {
+#define PIMEMB_CASE(L)                                                                                         \
+    case L:                                                                                                    \
+        hipLaunchKernelGGL((bag_onehot_ranged_kernel<DT, L, WaveCfg>), grid, block, 0, s, d, g.chunks);        \
+        break;
+        PIMEMB_CASE(1)
+        PIMEMB_CASE(2)
+        PIMEMB_CASE(4)
+        PIMEMB_CASE(8)
+        PIMEMB_CASE(16)
+        PIMEMB_CASE(32)
+        PIMEMB_CASE(64)
+#undef PIMEMB_CASE
+        default:
+            return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_onehot_ranged(const DevDesc *d_descs, uint32_t n_descs, uint32_t max_tiles, emb_dtype dtype,
+                                const LaunchGeom &g, hipStream_t stream) {
+    if (n_descs == 0 || max_tiles == 0) return hipSuccess;
+    if (n_descs > 65535u || g.scalar_lanes) return hipErrorInvalidValue;
+    switch (dtype) {
+        case EMB_F32: return launch_ranged_lpr<EMB_F32>(d_descs, n_descs, max_tiles, g, stream);
+        case EMB_F16: return launch_ranged_lpr<EMB_F16>(d_descs, n_descs, max_tiles, g, stream);
+        case EMB_FIXED32: return launch_ranged_lpr<EMB_FIXED32>(d_descs, n_descs, max_tiles, g, stream);
+    }
+    return hipErrorInvalidValue;
+}
+uint32_t onehot_ranged_bags_per_tile() { return 64u * (WaveCfg::kBlock / 64); }
 
 hipError_t launch_scatter_column(int32_t *table, const int32_t *column, uint64_t nr_rows,
                                  uint32_t dim, uint32_t col, hipStream_t stream) {

@@ -20,6 +20,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -43,13 +44,29 @@ double now_s() {
 
 constexpr uint64_t kMagic = 0x70696d656d623034ull;     // "pimemb04"
 
+// PIMEMB_PEER_TRACE=1: a line per set-up step on stderr (which call is a group stuck in?)
+void trace(int rank, const char *what) {
+    static const bool on = getenv("PIMEMB_PEER_TRACE") != nullptr;
+    if (on) {
+        fprintf(stderr, "[pimemb peer %d] %.3f %s\n", rank, now_s(), what);
+        fflush(stderr);
+    }
+}
+
+// The arena is a set of CHUNKS, each a device allocation of its own with its own IPC handle: hipIpcOpenMemHandle of an
+// allocation above 2 GiB never returns on this runtime (ROCm 7.0 / 7.2, same-device peers; tools/peer_arena_probe.py:
+// 1.9 GiB maps in milliseconds, 2.1 GiB hangs, fine- or coarse-grained alike).  An arena OFFSET is chunk * kChunkBytes +
+// the byte inside the chunk; an allocation never straddles two chunks.
+constexpr uint64_t kChunkShift = 30, kChunkBytes = 1ull << kChunkShift;
+constexpr uint32_t kMaxChunks = 192;   // 192 GiB of peer-visible memory per rank at most
+
 struct RankInfo {
-    std::atomic<uint64_t> ready;       // 1: handle and sizes below are valid; 2: this rank has mapped every peer
+    std::atomic<uint64_t> ready;       // 1: handles and sizes below are valid; 2: this rank has mapped every peer
     std::atomic<uint64_t> barrier;     // generation counter of emb_peer_barrier
     uint64_t arena_bytes;
     int32_t device, pid;
-    hipIpcMemHandle_t handle;
-    char pad[128 - 32 - sizeof(hipIpcMemHandle_t) % 128];
+    uint32_t n_chunks, pad0;
+    hipIpcMemHandle_t handle[kMaxChunks];
 };
 
 struct ShmHeader {
@@ -81,10 +98,10 @@ struct emb_peer {
     char *shm_dev = nullptr;       // the same bytes as the GPU addresses them
     size_t shm_bytes = 0;
     bool registered = false, creator = false;
-    char *arena = nullptr;
+    std::vector<char *> chunks;    // this rank's arena
     uint64_t arena_bytes = 0, arena_used = 0;
     bool fine_grained = false;
-    std::vector<char *> base;      // base[p]: rank p's arena as THIS process addresses it (base[rank] == arena)
+    std::vector<std::vector<char *>> base;   // base[p][c]: chunk c of rank p's arena as THIS process addresses it
     std::vector<uint64_t> peer_bytes;
     uint64_t barrier_gen = 0, epochs = 0;
     double timeout_s = 60.0;
@@ -105,14 +122,26 @@ PeerMsg *peer_box_dev(emb_peer *p, int dst, int src, uint32_t slot) {
 }
 int peer_rank(const emb_peer *p) { return p->rank; }
 int peer_world(const emb_peer *p) { return p->world; }
-char *peer_base(const emb_peer *p, int r) { return p->base[(size_t)r]; }
 uint64_t peer_arena_bytes(const emb_peer *p, int r) { return p->peer_bytes[(size_t)r]; }
+// `bytes` at arena offset `off` of rank r, as this process addresses them; nullptr when the range leaves the arena or
+// straddles two chunks (no allocation does)
+char *peer_ptr(const emb_peer *p, int r, uint64_t off, uint64_t bytes) {
+    const uint64_t c = off >> kChunkShift, last = (off + (bytes ? bytes - 1 : 0)) >> kChunkShift;
+    if (c != last || off + bytes > p->peer_bytes[(size_t)r] || c >= p->base[(size_t)r].size()) return nullptr;
+    return p->base[(size_t)r][c] + (off & (kChunkBytes - 1));
+}
+// arena offset of a pointer into THIS rank's arena (~0 when it is not inside one chunk of it)
+uint64_t peer_offset(const emb_peer *p, const void *ptr, uint64_t bytes) {
+    const char *c = static_cast<const char *>(ptr);
+    for (size_t k = 0; k < p->chunks.size(); k++) {
+        const uint64_t len = std::min<uint64_t>(kChunkBytes, p->arena_bytes - k * kChunkBytes);
+        if (c >= p->chunks[k] && c + bytes <= p->chunks[k] + len) return k * kChunkBytes + (uint64_t)(c - p->chunks[k]);
+    }
+    return ~0ull;
+}
 double peer_timeout_s(const emb_peer *p) { return p->timeout_s; }
 uint64_t peer_next_epoch(emb_peer *p) { return ++p->epochs; }
-bool peer_owns(const emb_peer *p, const void *ptr, uint64_t bytes) {
-    const char *c = static_cast<const char *>(ptr);
-    return c >= p->arena && c + bytes <= p->arena + p->arena_bytes;
-}
+bool peer_owns(const emb_peer *p, const void *ptr, uint64_t bytes) { return peer_offset(p, ptr, bytes) != ~0ull; }
 
 }  // namespace pimemb
 
@@ -177,6 +206,7 @@ int emb_peer_create(emb_engine *e, const char *job_tag, int32_t rank, int32_t wo
         if ((int)h->world != world || h->msg_bytes != pimemb::kPeerMsgBytes)
             return bail(fail(EMB_ERR_INVALID, "emb_peer_create: %s belongs to a group of %u ranks (this one: %d) -- use a fresh job tag", p->shm_name.c_str(), h->world, world));
     }
+    trace(rank, "segment mapped; hipHostRegister");
     // the GPU writes mailbox words: map the segment into the device's address space
     hipError_t err = hipHostRegister(p->shm, p->shm_bytes, hipHostRegisterMapped);
     if (err != hipSuccess) return bail(fail(EMB_ERR_DEVICE, "emb_peer_create: hipHostRegister of the shared segment: %s", hipGetErrorString(err)));
@@ -186,44 +216,48 @@ int emb_peer_create(emb_engine *e, const char *job_tag, int32_t rank, int32_t wo
     if (err != hipSuccess) return bail(fail(EMB_ERR_DEVICE, "emb_peer_create: hipHostGetDevicePointer: %s", hipGetErrorString(err)));
     p->shm_dev = static_cast<char *>(dptr);
 
-    // ---- the arena: everything a peer may read or write lives here.  Fine-grained by default (stores of one agent are
-    // visible to another without waiting for a cache write-back); PIMEMB_PEER_ARENA=coarse takes ordinary device memory
+    // ---- the arena: everything a peer may read or write lives here, in chunks of at most 1 GiB (see RankInfo).  Fine-grained
+    // by default (stores of one agent are visible to another without waiting for a cache write-back);
+    // PIMEMB_PEER_ARENA=coarse takes ordinary device memory
     const char *mode = getenv("PIMEMB_PEER_ARENA");
-    void *a = nullptr;
-    if (!(mode && mode[0] == 'c')) {
-        err = hipExtMallocWithFlags(&a, arena_bytes, hipDeviceMallocFinegrained);
-        if (err == hipSuccess) p->fine_grained = true;
-        else (void)hipGetLastError();
-    }
-    if (!a) {
-        err = hipMalloc(&a, arena_bytes);
-        if (err != hipSuccess) return bail(fail(EMB_ERR_NOMEM, "emb_peer_create: %llu bytes of arena: %s", (unsigned long long)arena_bytes, hipGetErrorString(err)));
-    }
-    p->arena = static_cast<char *>(a);
-    p->arena_bytes = arena_bytes;
+    const uint32_t n_chunks = (uint32_t)((arena_bytes + kChunkBytes - 1) >> kChunkShift);
+    if (n_chunks > kMaxChunks) return bail(fail(EMB_ERR_UNSUPPORTED, "emb_peer_create: an arena of %llu bytes needs %u chunks (limit %u)", (unsigned long long)arena_bytes, n_chunks, kMaxChunks));
     RankInfo *me = pimemb::peer_rank_info(p, rank);
-    err = hipIpcGetMemHandle(&me->handle, p->arena);
-    if (err != hipSuccess && p->fine_grained) {      // (a runtime that cannot export fine-grained memory: ordinary memory instead)
-        (void)hipGetLastError();
-        (void)hipFree(p->arena);
-        p->arena = nullptr;
-        p->fine_grained = false;
-        err = hipMalloc(&a, arena_bytes);
-        if (err == hipSuccess) {
-            p->arena = static_cast<char *>(a);
-            err = hipIpcGetMemHandle(&me->handle, p->arena);
+    p->fine_grained = !(mode && mode[0] == 'c');
+    for (int attempt = 0; attempt < 2 && p->chunks.empty(); attempt++) {
+        bool ok = true;
+        for (uint32_t c = 0; c < n_chunks && ok; c++) {
+            const uint64_t len = std::min<uint64_t>(kChunkBytes, arena_bytes - (uint64_t)c * kChunkBytes);
+            void *a = nullptr;
+            err = p->fine_grained ? hipExtMallocWithFlags(&a, len, hipDeviceMallocFinegrained) : hipMalloc(&a, len);
+            if (err == hipSuccess) {
+                p->chunks.push_back(static_cast<char *>(a));
+                err = hipIpcGetMemHandle(&me->handle[c], a);
+            }
+            ok = err == hipSuccess;
+        }
+        if (!ok) {          // (a runtime that cannot allocate / export fine-grained memory: ordinary memory instead, once)
+            (void)hipGetLastError();
+            for (char *c : p->chunks) (void)hipFree(c);
+            p->chunks.clear();
+            if (!p->fine_grained)
+                return bail(fail(err == hipErrorOutOfMemory ? EMB_ERR_NOMEM : EMB_ERR_DEVICE, "emb_peer_create: %llu bytes of arena: %s (HSA_ENABLE_IPC_MODE_LEGACY=0 set?)",
+                                 (unsigned long long)arena_bytes, hipGetErrorString(err)));
+            p->fine_grained = false;
         }
     }
-    if (err != hipSuccess) return bail(fail(EMB_ERR_DEVICE, "emb_peer_create: hipIpcGetMemHandle: %s (HSA_ENABLE_IPC_MODE_LEGACY=0 set?)", hipGetErrorString(err)));
+    p->arena_bytes = arena_bytes;
+    trace(rank, p->fine_grained ? "arena allocated (fine-grained), handles taken" : "arena allocated (ordinary), handles taken");
     me->arena_bytes = arena_bytes;
+    me->n_chunks = n_chunks;
     me->device = dev;
     me->pid = (int32_t)getpid();
     me->ready.store(1, std::memory_order_release);
 
     // ---- map every peer's arena
-    p->base.assign((size_t)world, nullptr);
+    p->base.assign((size_t)world, {});
     p->peer_bytes.assign((size_t)world, 0);
-    p->base[(size_t)rank] = p->arena;
+    p->base[(size_t)rank] = p->chunks;
     p->peer_bytes[(size_t)rank] = arena_bytes;
     const double t0 = now_s();
     for (int r = 0; r < world; r++) {
@@ -233,12 +267,15 @@ int emb_peer_create(emb_engine *e, const char *job_tag, int32_t rank, int32_t wo
             if (now_s() - t0 > p->timeout_s) return bail(fail(EMB_ERR_DEVICE, "emb_peer_create: rank %d did not join %s within %.0f s", r, p->shm_name.c_str(), p->timeout_s));
             std::this_thread::sleep_for(std::chrono::milliseconds(1));
         }
-        void *mapped = nullptr;
-        err = hipIpcOpenMemHandle(&mapped, ri->handle, hipIpcMemLazyEnablePeerAccess);
-        if (err != hipSuccess) return bail(fail(EMB_ERR_DEVICE, "emb_peer_create: hipIpcOpenMemHandle of rank %d's arena: %s", r, hipGetErrorString(err)));
-        p->base[(size_t)r] = static_cast<char *>(mapped);
+        for (uint32_t c = 0; c < ri->n_chunks; c++) {
+            void *mapped = nullptr;
+            err = hipIpcOpenMemHandle(&mapped, ri->handle[c], hipIpcMemLazyEnablePeerAccess);
+            if (err != hipSuccess) return bail(fail(EMB_ERR_DEVICE, "emb_peer_create: hipIpcOpenMemHandle of rank %d's arena (chunk %u): %s", r, c, hipGetErrorString(err)));
+            p->base[(size_t)r].push_back(static_cast<char *>(mapped));
+        }
         p->peer_bytes[(size_t)r] = ri->arena_bytes;
     }
+    trace(rank, "peers mapped; barrier");
     me->ready.store(2, std::memory_order_release);
     *out = p;
     rc = emb_peer_barrier(p);       // nobody proceeds (or tears the segment down) before everyone has mapped everyone
@@ -252,12 +289,16 @@ int emb_peer_create(emb_engine *e, const char *job_tag, int32_t rank, int32_t wo
 
 int emb_peer_alloc(emb_peer *p, uint64_t bytes, void **ptr) {
     if (!p || !ptr) return fail(EMB_ERR_INVALID, "emb_peer_alloc: NULL argument");
-    const uint64_t at = (p->arena_used + 255) / 256 * 256;
+    uint64_t at = (p->arena_used + 255) / 256 * 256;
     if (bytes == 0) bytes = 256;
+    if (bytes > kChunkBytes)
+        return fail(EMB_ERR_UNSUPPORTED, "emb_peer_alloc: one allocation of %llu bytes -- the arena is made of 1-GiB chunks (IPC mappings above 2 GiB "
+                    "hang on this runtime): allocate per table", (unsigned long long)bytes);
+    if ((at >> kChunkShift) != ((at + bytes - 1) >> kChunkShift)) at = ((at >> kChunkShift) + 1) << kChunkShift;      // never across two chunks
     if (at + bytes > p->arena_bytes)
         return fail(EMB_ERR_NOMEM, "emb_peer_alloc: %llu bytes do not fit the arena (%llu of %llu used): create the group with a larger one",
                     (unsigned long long)bytes, (unsigned long long)p->arena_used, (unsigned long long)p->arena_bytes);
-    *ptr = p->arena + at;
+    *ptr = p->chunks[(size_t)(at >> kChunkShift)] + (at & (kChunkBytes - 1));
     p->arena_used = at + bytes;
     return EMB_OK;
 }
@@ -266,7 +307,7 @@ int emb_peer_info(emb_peer *p, int32_t *rank, int32_t *world, void **arena, uint
     if (!p) return fail(EMB_ERR_INVALID, "emb_peer_info: group is NULL");
     if (rank) *rank = p->rank;
     if (world) *world = p->world;
-    if (arena) *arena = p->arena;
+    if (arena) *arena = p->chunks.empty() ? nullptr : p->chunks[0];
     if (arena_bytes) *arena_bytes = p->arena_bytes;
     if (used) *used = p->arena_used;
     if (fine_grained) *fine_grained = p->fine_grained ? 1 : 0;
@@ -291,8 +332,9 @@ int emb_peer_destroy(emb_peer *p) {
     DeviceGuard g(p->device);
     (void)hipDeviceSynchronize();
     for (int r = 0; r < (int)p->base.size(); r++)
-        if (r != p->rank && p->base[(size_t)r]) (void)hipIpcCloseMemHandle(p->base[(size_t)r]);
-    if (p->arena) (void)hipFree(p->arena);
+        if (r != p->rank)
+            for (char *c : p->base[(size_t)r]) (void)hipIpcCloseMemHandle(c);
+    for (char *c : p->chunks) (void)hipFree(c);
     if (p->registered) (void)hipHostUnregister(p->shm);
     if (p->shm) (void)munmap(p->shm, p->shm_bytes);
     if (p->fd >= 0) (void)close(p->fd);

@@ -31,7 +31,10 @@ PeerMsg *peer_box(emb_peer *p, int dst, int src, uint32_t slot);
 PeerMsg *peer_box_dev(emb_peer *p, int dst, int src, uint32_t slot);
 int peer_rank(const emb_peer *p);
 int peer_world(const emb_peer *p);
-char *peer_base(const emb_peer *p, int r);
+// `bytes` at arena offset `off` of rank r as this process addresses them (nullptr: outside the arena / across two of its chunks)
+char *peer_ptr(const emb_peer *p, int r, uint64_t off, uint64_t bytes);
+// arena offset of a pointer into THIS rank's arena (~0: not inside it)
+uint64_t peer_offset(const emb_peer *p, const void *ptr, uint64_t bytes);
 uint64_t peer_arena_bytes(const emb_peer *p, int r);
 double peer_timeout_s(const emb_peer *p);
 // Users of the group's mailboxes (shard objects) are created in the same order on every rank: the n-th one tags its flag

@@ -86,6 +86,10 @@ struct DevBuf {
 struct PeerFrom {
     uint64_t req_send_off = 0, ret_recv_off = 0;   // byte offsets inside the peer's arena
     uint32_t piece_word = 0, ret_row0 = 0;
+    // the source handed its one-index-per-bag row-split tables over DIRECTLY: raw index array + output buffer per table
+    bool direct = false;
+    uint64_t n_bags = 0;
+    std::vector<uint64_t> idx_off, out_off;        // per row-split table (peers: arena offsets; this rank itself: unused)
 };
 
 enum Via : int { SELF = 0, COMM = 1, PEER = 2 };
@@ -121,9 +125,10 @@ struct Batch {
     // per-peer sizes of this batch (row-split path), from the counts
     std::vector<uint64_t> out_words, in_words, rows_back, rows_served;
     int deferred_rc = EMB_OK;
+    bool direct = false;                // this batch's row-split tables skip router and un-router (see stage_route)
     // optional kernel timing (emb_shard_set_kernel_timing): start / stop around R, L, S, U
-    hipEvent_t tev[8] = {};
-    bool timed[4] = {false, false, false, false}, harvest = false;
+    hipEvent_t tev[10] = {};
+    bool timed[5] = {false, false, false, false, false}, harvest = false;
 };
 
 }  // namespace
@@ -166,6 +171,8 @@ struct emb_shard {
                                                      // batch that is served in the same call (one launch instead of two), else alone
     Batch *local_of = nullptr;
     bool kernel_timing = false;
+    bool allow_direct = true;                        // PIMEMB_SHARD_DIRECT=0 switches the direct one-hot path off (A/B, rehearsal)
+    std::vector<uint64_t> row_lo;                    // scratch
 };
 
 namespace {
@@ -193,7 +200,7 @@ int ensure(emb_shard *s, DevBuf &buf, size_t bytes) {
     return EMB_OK;
 }
 
-// Kernel timing (off by default: an event between two kernels of a stream costs GPU time of its own).  which: 0 R, 1 L, 2 S, 3 U.
+// Kernel timing (off by default: an event between two kernels of a stream costs GPU time of its own).  which: 0 R, 1 L, 2 S, 3 U, 4 D (direct one-hot lookup).
 int tick(emb_shard *s, Batch &b, int which, bool stop) {
     if (!s->kernel_timing) return EMB_OK;
     hipEvent_t &ev = b.tev[2 * which + (stop ? 1 : 0)];
@@ -207,8 +214,8 @@ int tick(emb_shard *s, Batch &b, int which, bool stop) {
 void harvest(emb_shard *s, Batch &b) {
     if (!b.harvest) return;
     b.harvest = false;
-    double *dst[4] = {&s->st.us_kernel_route, &s->st.us_kernel_local, &s->st.us_kernel_serve, &s->st.us_kernel_unroute};
-    for (int w = 0; w < 4; w++) {
+    double *dst[5] = {&s->st.us_kernel_route, &s->st.us_kernel_local, &s->st.us_kernel_serve, &s->st.us_kernel_unroute, &s->st.us_kernel_direct};
+    for (int w = 0; w < 5; w++) {
         if (!b.timed[w]) continue;
         b.timed[w] = false;
         float ms = 0.f;
@@ -226,7 +233,7 @@ inline Via via(const emb_shard *s, int p) {
     return s->peer_mode ? PEER : COMM;
 }
 inline bool via_comm(const emb_shard *s, int p) { return via(s, p) == COMM; }
-inline uint64_t arena_off(const emb_shard *s, const void *ptr) { return (uint64_t)(static_cast<const char *>(ptr) - pimemb::peer_base(s->peer, s->rank)); }
+inline uint64_t arena_off(const emb_shard *s, const void *ptr) { return pimemb::peer_offset(s->peer, ptr, 1); }
 
 // Poll a mailbox word until it carries `want` (written by a peer's GPU through the job's shared segment).
 int poll_word(emb_shard *s, volatile unsigned long long *w, unsigned long long want, const char *what, int peer, uint64_t seq) {
@@ -310,10 +317,33 @@ int stage_route(emb_shard *s, Batch &b) {
     b.req_recorded = b.ret_recorded = b.out_recorded = false;
     b.deferred_rc = EMB_OK;
 
-    // row-split tables: cut every bag into per-shard sub-bags; the counts sit at the head of `meta`
+    // One index per bag and no peer behind RCCL (every peer is this rank itself or reachable by loads / stores): the
+    // row-split tables need NO routing at all -- every shard scans the requester's raw index array and serves the bags whose
+    // row it holds, straight into the requester's output (emb_lookup_ranged); each bag has exactly one shard, so there are
+    // no counts to exchange, no partial rows to add.  Decided per batch and per rank; a peer learns it from the mailbox.
+    b.direct = false;
+    if (Kr && s->allow_direct) {
+        bool ok = true;
+        for (uint32_t p = 0; p < N && ok; p++) ok = via(s, (int)p) != COMM;
+        for (uint32_t k = 0; k < Kr && ok; k++) {
+            const emb_shard_input &u = b.in[s->rows[k]];
+            ok = u.offsets == nullptr && u.fixed_pooling == 1;
+            if (ok && s->peer_mode && N > 1 && b.n_bags)       // peers gather from / store into these in place
+                ok = pimemb::peer_owns(s->peer, u.indices, b.n_bags * 4) && pimemb::peer_owns(s->peer, u.pooled, b.n_bags * (uint64_t)s->dim * 4);
+        }
+        b.direct = ok;
+    }
     uint64_t total_idx = 0;
     for (uint32_t k = 0; k < Kr; k++) total_idx += b.in[s->rows[k]].n_indices;
-    if (Kr) {
+    if (b.direct) {          // accounted on the requester's side: every bag is served exactly once, by one of the shards
+        for (uint32_t k = 0; k < Kr; k++)
+            s->st.served_algorithmic_bytes += b.n_bags * ((uint64_t)s->dim * s->elem_bytes[s->rows[k]] + 4 + (uint64_t)s->dim * 4) +
+                                              (uint64_t)(N - 1) * b.n_bags * 4;
+        s->st.served_sub_bags += b.n_bags * Kr;
+        s->st.served_indices += b.n_bags * Kr;
+    }
+    // row-split tables: cut every bag into per-shard sub-bags; the counts sit at the head of `meta`
+    if (Kr && !b.direct) {
         uint64_t sb = 0, mb = 0, lb = 0, wb = 0;
         EMB_TRY(emb_route_bags_sizes(Kr, std::max<uint64_t>(b.n_bags, 1), total_idx, N, &sb, &mb, &lb, &wb));
         EMB_TRY(ensure(s, b.req_send, sb));
@@ -390,9 +420,10 @@ int stage_route(emb_shard *s, Batch &b) {
     // ... and reach the host behind a flag word
     *b.flag = 0;
     b.counts_posted = false;
-    if (Kr || peers) {
-        const uint32_t *src[3] = {Kr ? static_cast<const uint32_t *>(b.meta.p) : nullptr,
-                                  Kr && peers ? static_cast<const uint32_t *>(b.counts_in.p) : nullptr,
+    const bool routed = Kr && !b.direct;
+    if (routed || peers) {
+        const uint32_t *src[3] = {routed ? static_cast<const uint32_t *>(b.meta.p) : nullptr,
+                                  routed && peers ? static_cast<const uint32_t *>(b.counts_in.p) : nullptr,
                                   M && peers ? static_cast<const uint32_t *>(b.counts_in.p) + (size_t)N * (Kr + 1) * 2 : nullptr};
         const uint32_t n[3] = {N * (Kr + 1) * 2, N * (Kr + 1) * 2, N * M * kWholeWords};
         HIP_TRY(pimemb::launch_publish_words(src, n, b.counts_host, b.flag, b.seq + 1, peers ? s->s_comm : s->cs));
@@ -401,7 +432,7 @@ int stage_route(emb_shard *s, Batch &b) {
     if (s->peer_mode) {        // the same news for the peers: counts + where things are, into their mailboxes, behind the router
         pimemb::PeerPostArgs pa{};
         bool any = false;
-        const uint64_t rs = Kr ? arena_off(s, b.req_send.p) : 0, rr = Kr ? arena_off(s, b.ret_recv.p) : 0;
+        const uint64_t rs = routed ? arena_off(s, b.req_send.p) : 0, rr = routed ? arena_off(s, b.ret_recv.p) : 0;
         uint32_t at = 0;
         for (uint32_t p = 0; p < N; p++) {
             if (via(s, (int)p) != PEER) continue;
@@ -409,16 +440,27 @@ int stage_route(emb_shard *s, Batch &b) {
             const uint32_t nw = (uint32_t)s->whole_of[p].size();
             c[0] = (uint32_t)rs; c[1] = (uint32_t)(rs >> 32);
             c[2] = (uint32_t)rr; c[3] = (uint32_t)(rr >> 32);
-            c[4] = (uint32_t)b.n_bags; c[5] = nw; c[6] = c[7] = 0;
+            c[4] = (uint32_t)b.n_bags; c[5] = nw; c[6] = b.direct ? 1u : 0u; c[7] = 0;
             memcpy(c + kPeerConstHead, b.wc_host + (size_t)s->wc_off[p] * kWholeWords, (size_t)nw * kWholeWords * 4);
+            uint32_t extra = 0;
+            if (b.direct) {          // where this rank's raw index arrays and output buffers of the row-split tables sit
+                uint32_t *r = c + kPeerConstHead + nw * kWholeWords;
+                for (uint32_t k = 0; k < Kr; k++) {
+                    const emb_shard_input &u = b.in[s->rows[k]];
+                    const uint64_t io = b.n_bags ? arena_off(s, u.indices) : 0, ro = b.n_bags ? arena_off(s, u.pooled) : 0;
+                    r[4 * k] = (uint32_t)io; r[4 * k + 1] = (uint32_t)(io >> 32);
+                    r[4 * k + 2] = (uint32_t)ro; r[4 * k + 3] = (uint32_t)(ro >> 32);
+                }
+                extra = 4 * Kr;
+            }
             pa.box[p] = (unsigned long long)(uintptr_t)pimemb::peer_box_dev(s->peer, (int)p, s->rank, (uint32_t)(b.seq % pimemb::kPeerSlots));
             pa.consts[p] = c;
-            pa.n_consts[p] = kPeerConstHead + nw * kWholeWords;
+            pa.n_consts[p] = kPeerConstHead + nw * kWholeWords + extra;
             at += pa.n_consts[p];
             any = true;
         }
         if (any)
-            HIP_TRY(pimemb::launch_peer_post(Kr ? static_cast<const uint32_t *>(b.meta.p) : nullptr, Kr, N, pa, s->peer_tag + b.seq + 1, s->cs));
+            HIP_TRY(pimemb::launch_peer_post(routed ? static_cast<const uint32_t *>(b.meta.p) : nullptr, Kr, N, pa, s->peer_tag + b.seq + 1, s->cs));
     }
     g_hp.lap(5);
 
@@ -484,6 +526,7 @@ int stage_request(emb_shard *s, Batch &b) {
     }
     g_hp.lap(7);
     uint32_t *sent = sent_counts(s, b), *recv = recv_counts(s, b), *rwhole = recv_whole(s, b);
+    if (Kr && b.direct) memset(sent, 0, (size_t)N * (Kr + 1) * 8);      // nothing was routed: this rank asked no shard for sub-bags
     if (!via_comm(s, s->rank)) {       // what this rank asked ITSELF for never travelled
         if (Kr) memcpy(recv + (size_t)s->rank * (Kr + 1) * 2, sent + (size_t)s->rank * (Kr + 1) * 2, (size_t)(Kr + 1) * 8);
         if (M) memcpy(rwhole + (size_t)s->rank * M * kWholeWords, b.wc_host + (size_t)s->wc_off[s->rank] * kWholeWords, (size_t)M * kWholeWords * 4);
@@ -508,8 +551,23 @@ int stage_request(emb_shard *s, Batch &b) {
             b.from[p].ret_recv_off = (uint64_t)w[at + 2] | ((uint64_t)w[at + 3] << 32);
             if (w[at + 5] != M) return fail(EMB_ERR_INVALID, "emb_shard: rank %u posted %u whole-table entries, this rank owns %u (different placements?)", p, w[at + 5], M);
             if (M) memcpy(rwhole + (size_t)p * M * kWholeWords, w + at + kPeerConstHead, (size_t)M * kWholeWords * 4);
+            b.from[p].n_bags = w[at + 4];
+            b.from[p].direct = w[at + 6] != 0;
+            if (b.from[p].direct) {
+                const uint32_t *r = w + at + kPeerConstHead + M * kWholeWords;
+                b.from[p].idx_off.resize(Kr);
+                b.from[p].out_off.resize(Kr);
+                for (uint32_t k = 0; k < Kr; k++) {
+                    b.from[p].idx_off[k] = (uint64_t)r[4 * k] | ((uint64_t)r[4 * k + 1] << 32);
+                    b.from[p].out_off[k] = (uint64_t)r[4 * k + 2] | ((uint64_t)r[4 * k + 3] << 32);
+                }
+            }
         }
         s->st.us_host_wait_counts += now_us() - t0;
+    }
+    if (via(s, s->rank) == SELF) {
+        b.from[(size_t)s->rank].direct = b.direct;
+        b.from[(size_t)s->rank].n_bags = b.n_bags;
     }
     b.out_words.assign(N, 0);
     b.in_words.assign(N, 0);
@@ -602,12 +660,14 @@ int stage_serve(emb_shard *s, Batch &b) {
         // the request piece: where it arrived (RCCL), where it was written (my own), or where it sits in the peer's HBM
         const uint32_t *words = how == COMM ? static_cast<uint32_t *>(b.req_recv.p) + in_at
                               : how == SELF ? static_cast<uint32_t *>(b.req_send.p) + out_at
-                                            : reinterpret_cast<uint32_t *>(pimemb::peer_base(s->peer, (int)p) + b.from[p].req_send_off) + b.from[p].piece_word;
+                                            : reinterpret_cast<uint32_t *>(pimemb::peer_ptr(s->peer, (int)p, b.from[p].req_send_off + 4ull * b.from[p].piece_word, b.in_words[p] * 4));
         // rows for a remote source go to ret_send (T sends them); my own go where the un-router reads shard `rank`'s rows; a
         // peer's go straight into ITS ret_recv, at the row where it expects this shard's
         float *rows_dst = how == COMM ? static_cast<float *>(b.ret_send.p) + served_at * dim
                         : how == SELF ? static_cast<float *>(b.ret_recv.p) + back_at * dim
-                                      : reinterpret_cast<float *>(pimemb::peer_base(s->peer, (int)p) + b.from[p].ret_recv_off) + (uint64_t)b.from[p].ret_row0 * dim;
+                                      : reinterpret_cast<float *>(pimemb::peer_ptr(s->peer, (int)p, b.from[p].ret_recv_off + (uint64_t)b.from[p].ret_row0 * dim * 4, b.rows_served[p] * (uint64_t)dim * 4));
+        if (how == PEER && (b.in_words[p] || b.rows_served[p]) && (!words || !rows_dst))
+            return fail(EMB_ERR_INVALID, "emb_shard: rank %u posted buffer offsets outside its arena", p);
         if (how == PEER) s->st.bytes_to_peers += b.in_words[p] * 4 + b.rows_served[p] * (uint64_t)dim * 4;     // read from / stored into the peer's HBM
         uint64_t cur = 0, row = 0;
         for (uint32_t k = 0; k < Kr; k++) {
@@ -657,15 +717,13 @@ int stage_serve(emb_shard *s, Batch &b) {
                 d.pooled = static_cast<float *>(b.ret_send.p) + wrow_at * dim;
                 wrow_at += nb;
             } else if (how == PEER) {      // the requester's arrays in place, its output buffer in place
-                char *base = pimemb::peer_base(s->peer, (int)p);
                 const uint64_t io = (uint64_t)c[4] | ((uint64_t)c[5] << 32), oo = (uint64_t)c[6] | ((uint64_t)c[7] << 32), ro = (uint64_t)c[8] | ((uint64_t)c[9] << 32);
-                const uint64_t lim = pimemb::peer_arena_bytes(s->peer, (int)p);
-                if (nb && (io + ni * 4 > lim || ro + nb * (uint64_t)dim * 4 > lim || (!c[2] && oo + nb * 4 > lim)))
-                    return fail(EMB_ERR_INVALID, "emb_shard: rank %u posted buffer offsets outside its arena", p);
                 d.fixed_pooling = c[2];
-                d.offsets = c[2] ? nullptr : base + oo;
-                d.indices = base + io;
-                d.pooled = reinterpret_cast<float *>(base + ro);
+                d.offsets = c[2] ? nullptr : pimemb::peer_ptr(s->peer, (int)p, oo, nb * 4);
+                d.indices = pimemb::peer_ptr(s->peer, (int)p, io, ni * 4);
+                d.pooled = reinterpret_cast<float *>(pimemb::peer_ptr(s->peer, (int)p, ro, nb * (uint64_t)dim * 4));
+                if (nb && ((ni && !d.indices) || !d.pooled || (!c[2] && !d.offsets)))
+                    return fail(EMB_ERR_INVALID, "emb_shard: rank %u posted buffer offsets outside its arena", p);
                 s->st.bytes_to_peers += ni * 4 + (c[2] ? 0 : nb * 4) + nb * (uint64_t)dim * 4;
             } else {           // my own bags of my own table: in place, straight into the caller's buffer
                 const emb_shard_input &u = b.in[t];
@@ -692,6 +750,38 @@ int stage_serve(emb_shard *s, Batch &b) {
     s->st.served_algorithmic_bytes += alg;
     s->st.served_sub_bags += n_sub;
     s->st.served_indices += n_idx;
+    // sources that handed their one-index-per-bag row-split tables over directly: scan their raw index arrays, serve the bags
+    // whose row this shard holds, straight into their outputs
+    s->descs.clear();
+    s->row_lo.clear();
+    for (uint32_t p = 0; p < N; p++) {
+        const PeerFrom &f = b.from[p];
+        if (!f.direct || f.n_bags == 0) continue;
+        const Via how = via(s, (int)p);
+        for (uint32_t k = 0; k < Kr; k++) {
+            const uint32_t t = s->rows[k];
+            emb_lookup_desc d{};
+            d.table_id = s->tabs[t].engine_table;
+            d.fixed_pooling = 1;
+            d.n_indices = d.n_bags = f.n_bags;
+            if (how == SELF) {
+                d.indices = b.in[t].indices;
+                d.pooled = b.in[t].pooled;
+            } else {
+                d.indices = pimemb::peer_ptr(s->peer, (int)p, f.idx_off[k], f.n_bags * 4);
+                d.pooled = reinterpret_cast<float *>(pimemb::peer_ptr(s->peer, (int)p, f.out_off[k], f.n_bags * (uint64_t)dim * 4));
+                if (!d.indices || !d.pooled) return fail(EMB_ERR_INVALID, "emb_shard: rank %u posted buffer offsets outside its arena", p);
+                s->st.bytes_to_peers += f.n_bags * 4;       // (+ the rows this shard stores: their number is not known on the host)
+            }
+            s->descs.push_back(d);
+            s->row_lo.push_back((uint64_t)s->rank * s->tabs[t].rows_per_shard);
+        }
+    }
+    if (!s->descs.empty()) {
+        EMB_TRY(tick(s, b, 4, false));
+        EMB_TRY(emb_lookup_ranged(s->e, s->descs.data(), s->row_lo.data(), (uint32_t)s->descs.size(), s->cs));
+        EMB_TRY(tick(s, b, 4, true));
+    }
     if (s->peer_mode) {        // behind the lookup (its kernel boundary completes the stores into the peers' HBM): "served"
         pimemb::PeerDoneArgs da{};
         for (uint32_t p = 0; p < N; p++)
@@ -745,7 +835,7 @@ int stage_unroute(emb_shard *s, Batch &b) {
         s->st.us_host_wait_served += now_us() - t0;
     }
     if (b.ret_recorded) HIP_TRY(hipStreamWaitEvent(s->cs, b.ev_ret, 0));       // the rows are back (whole tables: already in place)
-    if (s->Kr && b.n_bags) {
+    if (s->Kr && b.n_bags && !b.direct) {
         float *outs[pimemb::kRouteBagMaxTables];
         for (uint32_t k = 0; k < s->Kr; k++) outs[k] = b.in[s->rows[k]].pooled;
         EMB_TRY(tick(s, b, 3, false));
@@ -843,6 +933,8 @@ int emb_shard_create(emb_engine *e, emb_comm *comm, const emb_shard_config *cfg,
         return fail(EMB_ERR_INVALID, "emb_shard_create: EMB_SHARD_SELF_VIA_COMM needs a communicator");
     }
     if (const char *t = getenv("PIMEMB_SHARD_TIMEOUT_S")) s->timeout_s = atof(t) > 0 ? atof(t) : s->timeout_s;
+    if (const char *t = getenv("PIMEMB_SHARD_DIRECT")) s->allow_direct = t[0] != '0';
+    if (cfg->flags & (EMB_SHARD_NO_DIRECT | EMB_SHARD_CHECK_SERVED)) s->allow_direct = false;    // (the ranged lookup validates nothing: a checked shard routes)
     s->tabs.assign(cfg->tables, cfg->tables + cfg->n_tables);
     s->whole_of.assign((size_t)world, {});
     s->elem_bytes.assign(cfg->n_tables, 0);
@@ -881,7 +973,7 @@ int emb_shard_create(emb_engine *e, emb_comm *comm, const emb_shard_config *cfg,
     if (s->peer_mode) {
         size_t most = 0;
         for (const auto &w : s->whole_of) most = std::max(most, w.size());
-        if (2 * (s->rows.size() + 1) + 2 + kPeerConstHead + most * kWholeWords > pimemb::kPeerMsgWords)
+        if (2 * (s->rows.size() + 1) + 2 + kPeerConstHead + most * kWholeWords + 4 * s->rows.size() > pimemb::kPeerMsgWords)
             return bail(fail(EMB_ERR_UNSUPPORTED, "emb_shard_create: %zu whole tables on one owner do not fit a mailbox message (%u words)", most, pimemb::kPeerMsgWords));
     }
     s->Kr = (uint32_t)s->rows.size();
@@ -907,7 +999,7 @@ int emb_shard_create(emb_engine *e, emb_comm *comm, const emb_shard_config *cfg,
         b.wc_host = static_cast<uint32_t *>(p);
         p = nullptr;
         if (err == hipSuccess && s->peer_mode) {
-            err = hipHostMalloc(&p, (N * kPeerConstHead + (size_t)s->Wtot * kWholeWords) * 4 + 64, hipHostMallocMapped | hipHostMallocCoherent);
+            err = hipHostMalloc(&p, (N * (kPeerConstHead + 4 * (size_t)s->Kr) + (size_t)s->Wtot * kWholeWords) * 4 + 64, hipHostMallocMapped | hipHostMallocCoherent);
             b.pc_host = static_cast<uint32_t *>(p);
             b.req_send.arena = b.ret_recv.arena = true;      // peers gather from / store into these two
         }

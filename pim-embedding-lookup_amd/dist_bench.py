@@ -250,15 +250,18 @@ def run_sharded(args, hbm_peak_gbs: float, ctx, rep_bytes: int, mode: str):
     slots = []
     for j in range(NBATCH):
         d_idx = [torch.from_numpy(idx_host[j][t]).to(dev) for t in range(T)]
-        outs = torch.zeros((T, B, dim), dtype=torch.float32, device=dev)
-        if peer is not None:      # peers gather from / store into these in place: they live in this rank's arena
-            a_idx = [peer.empty(x.shape, torch.int32) for x in d_idx]
+        if peer is not None:      # peers gather from / store into these in place: they live in this rank's arena (one
+            a_idx = [peer.empty(x.shape, torch.int32) for x in d_idx]       # allocation per table: a chunk of it holds 1 GiB)
             for a, x in zip(a_idx, d_idx):
                 a.copy_(x)
             d_idx = a_idx
-            outs = peer.empty((T, B, dim), torch.float32)
-            outs.zero_()
-        slots.append(dict(prep=S.prepare(d_idx, None, L, [outs[t] for t in range(T)]), outs=outs))
+            outs = [peer.empty((B, dim), torch.float32) for _ in range(T)]
+            for o in outs:
+                o.zero_()
+        else:
+            one = torch.zeros((T, B, dim), dtype=torch.float32, device=dev)
+            outs = [one[t] for t in range(T)]
+        slots.append(dict(prep=S.prepare(d_idx, None, L, outs), outs=outs))
     torch.cuda.synchronize()
 
     seqs = {}
@@ -301,7 +304,8 @@ def run_sharded(args, hbm_peak_gbs: float, ctx, rep_bytes: int, mode: str):
     drain()
     for i in range(NBATCH):
         verify(i, "first rotation")
-        slots[i]["outs"].zero_()
+        for o in slots[i]["outs"]:
+            o.zero_()
     for _ in range(2):
         step(it)
         it += 1
@@ -359,9 +363,11 @@ def run_sharded(args, hbm_peak_gbs: float, ctx, rep_bytes: int, mode: str):
     nt = max(int(kst["n_timed_batches"]), 1)
     k_route, k_local, k_serve, k_un = (kst["us_kernel_route"] / nt, kst["us_kernel_local"] / nt, kst["us_kernel_serve"] / nt,
                                        kst["us_kernel_unroute"] / nt)
+    k_direct = kst["us_kernel_direct"] / nt          # the ranged one-hot lookups of the direct path (no router / un-router then)
     nb = max(int(kst["n_batches"]), 1)
     serve_bytes, local_bytes = kst["served_algorithmic_bytes"] / nb, kst["local_algorithmic_bytes"] / nb
-    kernel_us, alg_bytes = k_local + k_serve, int(serve_bytes + local_bytes)
+    kernel_us, alg_bytes = k_local + k_serve + k_direct, int(serve_bytes + local_bytes)
+    direct = k_direct > 0 and k_route == 0
 
     result = None
     if rank == 0:
@@ -374,7 +380,7 @@ def run_sharded(args, hbm_peak_gbs: float, ctx, rep_bytes: int, mode: str):
         fr["host_wait_counts_us_per_step"] = st["us_host_wait_counts"] / n_st
         fr["host_wait_served_us_per_step"] = st["us_host_wait_served"] / n_st
         # (L of the newest batch and S of the one being served share ONE launch in the steady state: priced together)
-        kernels = {"router_us": k_route, "lookup_us": kernel_us, "unrouter_us": k_un,
+        kernels = {"router_us": k_route, "lookup_us": kernel_us, "unrouter_us": k_un, "direct_lookup_us": k_direct,
                    "lookup_algorithmic_bytes": alg_bytes, "served_algorithmic_bytes": int(serve_bytes),
                    "local_algorithmic_bytes": int(local_bytes),
                    "lookup_GBps": ach,
@@ -402,6 +408,9 @@ def run_sharded(args, hbm_peak_gbs: float, ctx, rep_bytes: int, mode: str):
                                    % (label, dim, "fp16" if TABLE_F16[0] else "fp32", B, L, dist_name, NBATCH, plan.describe()),
                        "tables": T, "dim": dim, "bags_per_table_per_rank": B, "global_bags_per_table": world * B,
                        "pooling": L, "index_dist": dist_name, "shard_mode": mode, "pipeline_depth": depth,
+                       # one index per bag and no peer behind RCCL: row-split tables are not routed -- every shard scans the
+                       # requesters' raw index arrays and serves the bags whose row it holds (PIMEMB_SHARD_DIRECT=0: always route)
+                       "direct_one_hot_path": bool(direct),
                        "placement": {"replicated": plan.kinds.count(sh.REPLICATED), "whole": len(whole), "row_split": len(split),
                                      "rules": sorted(set(n for n in plan.notes if n))},
                        "parallelism": "ONE library call per batch (emb_shard_submit, depth %d): whole tables travel straight out "
@@ -607,6 +616,9 @@ def run(args, hbm_peak_gbs: float) -> None:
         sys.stderr.write("[dist_bench] rank %d: no result after %.0f s -- giving up\n" % (rank, run_limit))
         sys.stderr.flush()
         os._exit(5)
+    if os.environ.get("PIMEMB_DUMP_AFTER"):       # where is this rank stuck?  Python stacks of all threads to stderr after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["PIMEMB_DUMP_AFTER"]), repeat=False, file=sys.stderr)
     run_limit = float(os.environ.get("PIMEMB_RUN_TIMEOUT", "1800"))
     run_dog = threading.Timer(run_limit, _give_up)
     run_dog.daemon = True

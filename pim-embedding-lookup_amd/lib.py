@@ -45,7 +45,7 @@ class EmbCommOp(C.Structure):
 
 
 EMB_PLACE_REPLICATED, EMB_PLACE_WHOLE, EMB_PLACE_ROWS = 0, 1, 2
-EMB_SHARD_SELF_VIA_COMM, EMB_SHARD_CHECK_SERVED, EMB_SHARD_PEER_STORES = 1, 2, 4
+EMB_SHARD_SELF_VIA_COMM, EMB_SHARD_CHECK_SERVED, EMB_SHARD_PEER_STORES, EMB_SHARD_NO_DIRECT = 1, 2, 4, 8
 
 
 class EmbShardTable(C.Structure):
@@ -68,7 +68,7 @@ class EmbShardStats(C.Structure):
                 ("served_sub_bags", C.c_uint64), ("served_indices", C.c_uint64),
                 ("us_host_submit", C.c_double), ("us_host_wait_counts", C.c_double), ("us_host_wait_served", C.c_double),
                 ("us_kernel_route", C.c_double), ("us_kernel_local", C.c_double), ("us_kernel_serve", C.c_double),
-                ("us_kernel_unroute", C.c_double), ("n_timed_batches", C.c_uint64)]
+                ("us_kernel_unroute", C.c_double), ("n_timed_batches", C.c_uint64), ("us_kernel_direct", C.c_double)]
 
 
 class EmbTraceEvent(C.Structure):
@@ -125,6 +125,7 @@ SIGNATURES = {
     "emb_queue_flush": (C.c_int, [_vp, _vp, C.POINTER(_u32)]),
     "emb_queue_wait": (C.c_int, [_vp, _u64]),
     "emb_queue_destroy": (C.c_int, [_vp]),
+    "emb_lookup_ranged": (C.c_int, [_vp, C.POINTER(EmbLookupDesc), C.POINTER(_u64), _u32, _vp]),
     "emb_plan_create": (C.c_int, [_vp, C.POINTER(EmbLookupDesc), _u32, C.c_int, _pp]),
     "emb_plan_launch": (C.c_int, [_vp, _vp]),
     "emb_plan_destroy": (C.c_int, [_vp]),

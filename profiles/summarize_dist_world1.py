@@ -1,50 +1,41 @@
 #!/usr/bin/env python3
-"""profiles/<round>/dist_world1/*.json (+ host_us.txt, kernel stats) -> profiles/<round>/dist_world1.md.
-usage: summarize_dist_world1.py r03        (after copying gpurun_out/profiles_<round>/dist_world1 into profiles/<round>/)"""
-import csv
+"""Table of the world-1 sharded legs (collect_dist_world1.sh) next to the previous round's lines of the same commands.
+usage: summarize_dist_world1.py <dir with this round's *.json> [<dir with last round's *.json>]"""
+import glob
 import json
 import os
-import re
 import sys
 
-rnd = sys.argv[1]
-here = os.path.dirname(os.path.abspath(__file__))
-d = os.path.join(here, rnd, "dist_world1") + "/"
-rows = [("c2_auto_k20", "`--steps 20 --warmup 5` (the driver's command shape: replica leg + `whole` exchange leg)"),
-        ("c2_auto", "`--steps 2000 --warmup 200`"),
-        ("c2_whole", "`--shard-mode whole --replicate-mb 64`"),
-        ("c2_rows", "`--shard-mode rows --replicate-mb 64`"),
-        ("c4_rows_L1", "`--workload c4 --rows-scale 0.125 --pooling 1 --replicate-mb 64`"),
-        ("c4_rows_L32", "`--workload c4 --rows-scale 0.125 --pooling 32 --replicate-mb 64`"),
-        ("c4_rows_L32_zipf", "`... --pooling 32 --index-dist zipf`")]
-out = ["# N > 1 legs rehearsed with ONE RCCL rank (%s; `PIMEMB_FORCE_DIST=1 python bench.py --gpus 1 ...`, self exchange)" % rnd, "",
-       "Collected by `profiles/collect_dist_world1.sh %s` on the one-GPU box, summarised by `profiles/summarize_dist_world1.py`." % rnd,
-       "`ms / step` is the sync clock (the primary one on every line), the event clock beside it; `step_frac` = algorithmic bytes",
-       "of the rank's own bags ÷ step time ÷ 8 TB/s; bytes out are 0 with one rank (the exchange is a self copy).  Host µs per",
-       "call include blocking on the GPU; they show where the host waits.", "",
-       "| run | flags | primary leg | ms / step (sync / event) | lookup kernels µs | `roofline.exchange.step_frac` | exchange leg ms / step | host µs / step by call |",
-       "|---|---|---|---|---|---|---|---|"]
-for k, flags in rows:
-    j = json.load(open(d + k + ".json"))
-    host = open(d + k + ".host_us.txt").read().strip()
-    host = host.split("by call:")[1].strip() if "by call:" in host else "—"
-    ex, cx = j["roofline"].get("exchange", {}), j["config"].get("exchange", {})
-    leg = "replica (data-parallel)" if "replicated on every rank" in j["config"]["parallelism"] else cx.get("mode", "")
-    sec = "%.4f (%s)" % (cx["ms_per_step"], cx["mode"]) if leg.startswith("replica") else "—"
-    out.append("| %s | %s | %s | %.4f / %.4f | %.1f | %.3f | %s | %s |" % (
-        k, flags, leg, j["ms_per_step"], j["ms_per_step_event"], j["roofline"]["kernel_us"], ex.get("step_frac", 0), sec, host))
-out += ["", "All runs `verified: true` (every table on the rank bit for bit: the first rotation, two pipelined steps, the last timed step).", "",
-        "## Kernels of the C4 row-range step, L = 1 (`dist_world1/c4_rows_L1_kernel_stats.csv`, rocprofv3 `--kernel-trace --stats`, 200 timed steps)", "",
-        "| kernel | calls | average µs |", "|---|---|---|"]
-gpu = 0.0
-for r in csv.DictReader(open(d + "c4_rows_L1_kernel_stats.csv")):
-    n = r["Name"]
-    if "pimemb" in n or "rccl" in n:
-        m = re.search(r"(rcclGenericKernel|bag_sum_\w+|unroute_bags_kernel|route_\w+_kernel|validate_\w+)", n)
-        us = float(r["AverageNs"]) / 1e3
-        gpu += us * (3 if "rccl" in n else 1)
-        out.append("| `%s` | %s | %.1f |" % (m.group(1) if m else n[:50], r["Calls"], us))
-out += ["", "One step = replicated-table lookup (wave-batch, 18 tables) + served lookup (the request pieces received) + router (two kernels)",
-        "+ un-router + three self-collectives (`rcclGenericKernel`: counts, requests, partial rows): ≈ %.0f µs of GPU work per step." % gpu]
-open(os.path.join(here, rnd, "dist_world1.md"), "w").write("\n".join(out) + "\n")
-print("\n".join(out))
+cur, old = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else None)
+print("# N > 1 legs with ONE rank on the one-GPU box (`PIMEMB_FORCE_DIST=1 python bench.py --gpus 1 ...`, self pieces served in place)\n")
+print("Collected by `profiles/collect_dist_world1.sh`.  `ms / step` is the sync clock.  `host us` = time inside `emb_shard_submit` per step")
+print("(of it waiting for the counts: when the GPU is the bottleneck the host waits there).  Kernel times from HIP events inside the")
+print("library over 16 extra steps (`emb_shard_set_kernel_timing`).  `same bits` = the digest of rank 0's row-split outputs of the last")
+print("timed step equals the previous round's for the same command (the previous round ran the step as a pipeline inside the bench).\n")
+print("| run | placement | ms / step | previous round ms / step | same bits | host us / step (waiting for counts) | kernels us: router / lookups (direct part) / un-router | step_frac |")
+print("|---|---|---|---|---|---|---|---|")
+for f in sorted(glob.glob(os.path.join(cur, "*.json"))):
+    key = os.path.basename(f)[:-5]
+    try:
+        d = json.load(open(f))
+    except ValueError:
+        print(f"| {key} | unreadable | | | | | | |")
+        continue
+    prev = same = ""
+    base = key.replace("_direct", "").replace("_self_via_rccl", "").replace("_peer", "")
+    if old and os.path.exists(os.path.join(old, base + ".json")):
+        o = json.load(open(os.path.join(old, base + ".json")))
+        prev = "%.4f" % o["ms_per_step"]
+        a, b = o["config"].get("last_step_outputs_sha1"), d["config"].get("last_step_outputs_sha1")
+        same = "yes" if a and a == b else ("n/a" if not a or not b else "NO")
+    r = d["roofline"]
+    k, x = r.get("kernels"), r.get("exchange", {})
+    if k is None:       # replica leg: the exchange leg sits beside it
+        print("| %s | replica (+ exchange leg %s: %.4f ms) | %.4f | %s | %s | | %.1f | %.3f |" % (
+            key, d.get("exchange_mode"), d.get("ms_per_step_exchange", 0), d["ms_per_step"], prev, same, r["kernel_us"], x.get("step_frac", 0)))
+        continue
+    pl = d["config"]["placement"]
+    print("| %s | %d repl / %d whole / %d split%s | %.4f | %s | %s | %.1f (%.1f) | %.1f / %.1f (%.1f) / %.1f | %.3f |" % (
+        key, pl["replicated"], pl["whole"], pl["row_split"], ", direct one-hot path" if d["config"].get("direct_one_hot_path") else "",
+        d["ms_per_step"], prev, same, x.get("host_us_per_step", 0), x.get("host_wait_counts_us_per_step", 0),
+        k["router_us"], k["lookup_us"], k.get("direct_lookup_us", 0), k["unrouter_us"], x.get("step_frac", 0)))

@@ -93,7 +93,10 @@ def main():
             for t, n in enumerate(rows)]
     tabs32 = [w.astype(np.float32) for w in tabs]
     eng = pel.EmbeddingEngine(device=0, max_tables=len(plan.units) + 1)
-    peer = sh.PeerGroup(eng, cfg["peer_tag"], rank, world, arena_bytes=256 << 20) if cfg.get("peer") else None
+    peer = sh.PeerGroup(eng, cfg["peer_tag"], rank, world, arena_bytes=cfg.get("arena_bytes", 256 << 20)) if cfg.get("peer") else None
+    if peer is not None and cfg.get("arena_filler"):       # push what follows into the arena's later chunks (each chunk is its own IPC mapping)
+        for nbytes in cfg["arena_filler"]:
+            peer.alloc(nbytes)
     comm = sh.native_comm(eng, rank, world) if peer is None else None
     status = {"rank": rank, "ok": False}
     if peer is not None:
@@ -160,6 +163,19 @@ def main():
                     S.wait(q)
                     check(o, bb, f"depth {depth} drained batch {q}")
             st = S.stats()
+            if cfg.get("expect_direct"):          # the direct one-hot path ran: nothing was routed, nothing un-routed
+                S.set_kernel_timing(True)
+                b = batches[0]
+                di, _do = dev_batch(b)
+                outs = S.forward(None, di, fixed_pooling=cfg["max_len"]) if depth == 0 else None
+                if depth:
+                    q, outs = S.submit(di, None, fixed_pooling=cfg["max_len"])
+                    S.flush()
+                    S.wait(q)
+                check(outs, b, "timed direct batch")
+                kst = S.stats()
+                assert kst["us_kernel_direct"] > 0 and kst["us_kernel_route"] == 0 and kst["us_kernel_unroute"] == 0, kst
+                S.set_kernel_timing(False)
             status["stats_depth%d" % depth] = {k: (int(v) if isinstance(v, int) else float(v)) for k, v in st.items()}
             if cfg.get("bad_index"):           # a row id outside the table: the SERVING rank raises, nobody hangs
                 b = make_batch(rng, rows, cfg["bags"], max(1, cfg["max_len"]), True)

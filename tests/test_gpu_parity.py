@@ -1764,3 +1764,44 @@ def test_request_queue_fuses_small_requests_into_one_launch(pel, oracle, space):
     assert q.flush() == 1
     q.close()
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,dtype", [(16, np.float32), (128, np.float32), (64, np.float16), (4, np.float32), (256, np.float32)])
+def test_lookup_ranged_serves_only_its_row_range(pel, oracle, dim, dtype):
+    """emb_lookup_ranged: one index per bag, every shard scans the SAME raw index array and stores only the rows it holds,
+    straight into the shared output -- after all shards have run, every bag carries exactly the oracle's row; a shard leaves
+    the other shards' bags untouched (NaN-filled before), indices outside every range stay untouched."""
+    import ctypes as C
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(5)
+    rows, N, B = 5003, 3, 4099
+    tab = (rng.standard_normal((rows, dim)) * 0.1).astype(dtype)
+    per = -(-rows // N)
+    eng = pel.EmbeddingEngine(device=0, max_tables=8)
+    for d in range(N):
+        eng.load_table(d, tab[d * per:min((d + 1) * per, rows)])
+    idx = rng.integers(0, rows, size=B).astype(np.uint32)
+    idx[7] = rows + 100                                     # belongs to nobody
+    d_idx = torch.from_numpy(idx.view(np.int32)).to(dev)
+    out = torch.full((B, dim), float("nan"), device=dev)
+    L = pel.lib.load()
+    want = tab.astype(np.float32)[np.minimum(idx, rows - 1)]
+    seen = np.zeros(B, bool)
+    for d in range(N):
+        desc = (pel.lib.EmbLookupDesc * 1)(pel.lib.EmbLookupDesc(d, 1, d_idx.data_ptr(), None, B, B, out.data_ptr()))
+        lo = (C.c_uint64 * 1)(d * per)
+        pel.lib.check(L.emb_lookup_ranged(eng._h, desc, lo, 1, None))
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        mine = (idx >= d * per) & (idx < min((d + 1) * per, rows))
+        seen |= mine
+        assert np.array_equal(got[mine], want[mine])
+        assert np.isnan(got[~seen]).all()                   # bags of later shards (and nobody's) untouched
+    assert not seen[7] and seen.sum() == B - 1
+    # refused: ragged bags, pooled bags
+    off = torch.zeros(B, dtype=torch.int32, device=dev)
+    bad = (pel.lib.EmbLookupDesc * 1)(pel.lib.EmbLookupDesc(0, 0, d_idx.data_ptr(), off.data_ptr(), B, B, out.data_ptr()))
+    assert L.emb_lookup_ranged(eng._h, bad, (C.c_uint64 * 1)(0), 1, None) == pel.lib.EMB_ERR_INVALID
+    eng.close()

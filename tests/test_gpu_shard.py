@@ -54,13 +54,17 @@ ONE_RANK = dict(rows=[7, 300, 5000, 64, 2000, 900], dim=16, bags=37, max_len=5,
                 kinds=["replicated", "whole", "row_split", "replicated", "row_split", "whole"])
 
 
-@pytest.mark.parametrize("variant", ["ragged", "one-hot", "fixed-pooling", "int64", "f16-dim64"])
+@pytest.mark.parametrize("variant", ["ragged", "one-hot", "one-hot-direct", "fixed-pooling", "int64", "f16-dim64", "f16-direct"])
 def test_shard_one_rank_every_placement(variant, tmp_path):
     """A world of one rank (no communicator): replicated, whole and row-split tables in one call, ragged bags (empty ones
     included), depth 0 (forward) and depths 2 / 3 (submit / wait / flush) -- every table bit for bit the oracle's."""
     cfg = dict(ONE_RANK)
     if variant == "one-hot":
         cfg.update(max_len=1, fixed=True)
+    elif variant == "one-hot-direct":       # unchecked shard + one index per bag: the row-split tables take the direct path
+        cfg.update(max_len=1, fixed=True, check=False, expect_direct=True)
+    elif variant == "f16-direct":
+        cfg.update(max_len=1, fixed=True, check=False, expect_direct=True, f16=True, dim=64)
     elif variant == "fixed-pooling":
         cfg.update(max_len=4, fixed=True)
     elif variant == "int64":
@@ -95,7 +99,8 @@ def test_shard_rccl_ranks_on_one_gpu(variant, world, tmp_path):
         assert all(st["stats_depth2"]["bytes_to_self"] > 0 for st in res)
 
 
-@pytest.mark.parametrize("variant,world", [("ragged", 2), ("ragged", 3), ("one-hot", 4), ("whole-only", 2), ("empty-rank", 3)])
+@pytest.mark.parametrize("variant,world", [("ragged", 2), ("ragged", 3), ("one-hot", 4), ("one-hot-direct", 3), ("one-hot-direct-empty-rank", 2),
+                                           ("whole-only", 2), ("empty-rank", 3), ("ragged-three-chunk-arena", 2)])
 def test_shard_peer_stores_ranks_on_one_gpu(variant, world, tmp_path):
     """EMB_SHARD_PEER_STORES: the collective-free exchange with 2-4 PROCESSES on the one GPU (HIP IPC mappings of each
     other's arenas, handshake through the job's shared-memory segment; no RCCL communicator exists in these jobs).  The
@@ -106,13 +111,21 @@ def test_shard_peer_stores_ranks_on_one_gpu(variant, world, tmp_path):
                expect_kinds=["replicated", "whole", "row_split"], peer=True, peer_tag="t" + uuid.uuid4().hex[:12])
     if variant == "one-hot":
         cfg.update(max_len=1, fixed=True, dim=64, rep=64 * 64 * 4, split=3000 * 64 * 4)
+    elif variant.startswith("one-hot-direct"):      # no router, no counts, no un-router: every shard scans the peers' raw index arrays
+        cfg.update(max_len=1, fixed=True, check=False, expect_direct=True, dim=32, rep=64 * 32 * 4, split=3000 * 32 * 4)
+        if variant.endswith("empty-rank"):
+            cfg.update(empty_rank=1)
     elif variant == "whole-only":
         cfg.update(split=10 ** 12, expect_kinds=["replicated", "whole"], max_len=5, fixed=True)
     elif variant == "empty-rank":
         cfg.update(empty_rank=1)
+    elif variant == "ragged-three-chunk-arena":     # an arena of 2.5 GiB = three IPC mappings (one of more than 2 GiB never maps on this
+        cfg.update(arena_bytes=int(2.5 * (1 << 30)), arena_filler=[900 << 20, 600 << 20], depths=[0, 3])   # runtime); buffers land in chunks 1 and 2
     res = _run(cfg, world, tmp_path)
     for st in res:
         assert st["peer"]["world"] == world and st["stats_depth3"]["n_batches"] == 6 and st["stats_depth0"]["bytes_to_peers"] > 0
+        if variant == "ragged-three-chunk-arena":
+            assert st["peer"]["arena_bytes"] == int(2.5 * (1 << 30)) and st["peer"]["used"] > 1 << 30
 
 
 def test_shard_peer_stores_missing_rank_times_out_nonzero(tmp_path):
