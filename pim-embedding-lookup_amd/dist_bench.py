@@ -393,7 +393,7 @@ def run_sharded(args, hbm_peak_gbs: float, ctx, rep_bytes: int, mode: str):
             kernels["unrouter_GBps"] = kernels["unrouter_bytes"] / (k_un * 1e-6) / 1e9
         if k_route > 0:
             kernels["router_GBps"] = kernels["router_bytes"] / (k_route * 1e-6) / 1e9
-        traffic = sharded_traffic_entry(args, mode, world)
+        traffic = sharded_traffic_entry(args, mode, world, direct)
         if world == 1:       # every table is looked up here: compulsory table bytes of one step = every DISTINCT row once
             uniq = sum(int(np.unique(idx_host[0][t]).shape[0]) for t in range(T)) * dim * elem
         result = ({
@@ -452,11 +452,11 @@ def run_sharded(args, hbm_peak_gbs: float, ctx, rep_bytes: int, mode: str):
     return result
 
 
-def sharded_traffic_entry(args, mode, world):
-    """profiles/traffic.json entry of this sharded command (world-1 PMC passes of the served lookup, the router and the
+def sharded_traffic_entry(args, mode, world, direct=False):
+    """profiles/traffic.json entry of this sharded command (world-1 PMC passes of the ROUTED step's fused lookup, router and
     un-router; see profiles/collect_dist_pmc.sh), or None."""
-    if world != 1 or args.batch is not None:
-        return None          # the counters were collected with one rank: another rank count serves other pieces
+    if world != 1 or args.batch is not None or direct:
+        return None          # the counters were collected with one rank on the routed path: other pieces / other kernels otherwise
     if getattr(args, "workload", "c2") == "c4" and abs(float(getattr(args, "rows_scale", 1.0) or 1.0) - 0.125) > 1e-9:
         return None          # (C4 is profiled at one of 8 ranks' share of the rows)
     key = "dist-%s-%s-l%d" % (getattr(args, "workload", "c2"), mode, int(getattr(args, "pooling", None) or 0) or 1)

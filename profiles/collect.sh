@@ -10,6 +10,7 @@ out=$root/gpurun_out/profiles_${round}
 mkdir -p "$scratch" "$out"
 cd /tmp && export TMPDIR=/tmp
 steps_stats=${STEPS_STATS:-200}
+echo "[collect $key] kernel-trace pass"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$scratch/stats" -- python3 "$root/bench.py" --no-cpu-baseline \
     --steps "$steps_stats" --warmup 20 "$@" > "$scratch/bench_under_stats.log" 2>&1 || { echo "stats pass failed for $key"; tail -5 "$scratch/bench_under_stats.log"; exit 1; }
 cp "$(find "$scratch/stats" -name '*kernel_stats.csv' | head -1)" "$out/${key}_kernel_stats.csv"
@@ -17,9 +18,11 @@ grep '^{' "$scratch/bench_under_stats.log" | tail -1 > "$out/${key}_bench_under_
 pass=0
 for counters in "FETCH_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" "TCC_HIT_sum TCC_MISS_sum" "WRITE_SIZE"; do
     pass=$((pass + 1))
+    echo "[collect $key] PMC pass $pass: $counters"
     timeout -k 10 600 rocprofv3 --pmc $counters --output-format csv -d "$scratch/pmc$pass" -- python3 "$root/bench.py" --no-cpu-baseline \
         --steps 24 --warmup 8 --prewarm-ms 0 "$@" > "$scratch/pmc$pass.log" 2>&1 || { echo "pmc pass $pass failed for $key"; tail -5 "$scratch/pmc$pass.log"; exit 1; }
 done
 python3 "$root/profiles/pmc_summary.py" "$scratch" bag_sum > "$out/${key}_pmc_summary.txt"
 (cd "$root" && python3 -c "import json, bench; print(json.dumps(bench.library_identity()))") > "$out/${key}_identity.json"
+rm -rf "$scratch"        # (counter CSVs of the big workloads exceed what gpurun copies back)
 echo "== $key"; head -3 "$out/${key}_kernel_stats.csv" | cut -c1-260; cat "$out/${key}_pmc_summary.txt"

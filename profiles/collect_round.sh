@@ -1,0 +1,13 @@
+#!/bin/bash
+# Everything profiles/traffic.json and DESIGN.md's tables are made from, on the round's FINAL build (entries are tied to the
+# library / source hashes: profiles/make_traffic.py).  usage: bash profiles/collect_round.sh r04 <part>     part = a | b | c | d
+round=$1; part=$2
+case $part in
+a) bash profiles/collect.sh $round c2 && bash profiles/collect.sh $round c2-zipf --index-dist zipf && \
+   bash profiles/collect.sh $round c4 --workload c4 && bash profiles/collect.sh $round c4-l32 --workload c4 --pooling 32 && \
+   bash profiles/collect_dist_pmc.sh $round dist-c4-rows-l1 --workload c4 --rows-scale 0.125 --replicate-mb 64 && \
+   bash profiles/collect_dist_pmc.sh $round dist-c4-rows-l32 --workload c4 --rows-scale 0.125 --replicate-mb 64 --pooling 32 ;;
+b) STEPS_STATS=60 bash profiles/collect.sh $round c3 --workload c3 && STEPS_STATS=30 bash profiles/collect.sh $round c3-uniform --workload c3 --index-dist uniform ;;
+c) STEPS_STATS=60 bash profiles/collect.sh $round c5 --workload c5 ;;
+d) bash tools/run_all_benches.sh gpurun_out/profiles_$round/benches ;;
+esac

@@ -630,11 +630,14 @@ def test_c_programs_against_the_abi(pel):
     libdir = os.path.dirname(pel.LIB_PATH)
     ex = os.path.join(libdir, "native_example")
     hb = os.path.join(libdir, "emb_host_bench")
-    if not (os.path.exists(ex) and os.path.exists(hb)):
+    if not (os.path.exists(ex) and os.path.exists(hb) and os.path.exists(os.path.join(libdir, "shard_example"))):
         subprocess.check_call(["make", "-s", "-C", os.path.join(os.path.dirname(libdir), "csrc"), "-f",
                                "Makefile.tools"])
     r = subprocess.run([ex], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "mismatches: 0" in r.stdout, r.stdout + r.stderr
+    # the sharded lookup as one call per batch (replicated + whole + row-split tables, a refused bad index) and the request queue
+    r = subprocess.run([os.path.join(libdir, "shard_example")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "mismatches: 0" in r.stdout and "3 requests in 1 launch" in r.stdout, r.stdout + r.stderr
     r = subprocess.run([hb, "4", "16", "20000", "65", "7", "5"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "Validation result: true" in r.stdout, r.stdout + r.stderr
 
