@@ -124,3 +124,33 @@ def test_marshal_helper_is_built_and_refuses_what_it_does_not_handle():
     assert m.pack(ctypes.addressof(buf), [0], [i, i], [o, o], None, tables) is None             # lengths differ
     key = m.fill_pooled(ctypes.addressof(buf), 2, 4096, 16)
     assert isinstance(key, bytes) and len(key) == 96
+
+
+def test_round4_struct_layouts_match_the_header(pel, tmp_path):
+    """The structs of the sharded call, the transfer list and their stats as a C compiler lays them out (a small program
+    over include/pimemb.h prints sizeof / offsetof) against the ctypes mirrors in lib.py -- field for field."""
+    L = pel.lib
+    specs = {"emb_comm_op": L.EmbCommOp, "emb_shard_table": L.EmbShardTable, "emb_shard_input": L.EmbShardInput,
+             "emb_shard_config": L.EmbShardConfig, "emb_shard_stats": L.EmbShardStats, "emb_lookup_desc": L.EmbLookupDesc,
+             "emb_route_table": L.EmbRouteTable}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "pimemb.h"', 'int main(void){']
+    for cname, ct in specs.items():
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in ct._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines.append("return 0;}")
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, ct in specs.items():
+        assert int(got[cname]) == C.sizeof(ct), cname
+        for fname, _ in ct._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(ct, fname).offset, f"{cname}.{fname}"
+    # placement / flag constants
+    text = open(HEADER).read()
+    for name, val in (("EMB_PLACE_REPLICATED", L.EMB_PLACE_REPLICATED), ("EMB_PLACE_WHOLE", L.EMB_PLACE_WHOLE), ("EMB_PLACE_ROWS", L.EMB_PLACE_ROWS),
+                      ("EMB_SHARD_SELF_VIA_COMM", L.EMB_SHARD_SELF_VIA_COMM), ("EMB_SHARD_CHECK_SERVED", L.EMB_SHARD_CHECK_SERVED),
+                      ("EMB_SHARD_PEER_STORES", L.EMB_SHARD_PEER_STORES), ("EMB_SHARD_NO_DIRECT", L.EMB_SHARD_NO_DIRECT)):
+        assert re.search(r"#define %s %du\b" % (name, val), text), name
