@@ -270,7 +270,9 @@ int emb_device_of(emb_engine *e, int32_t *device);
  *                   blocks until the flush that carried the request has finished and copies its rows into the caller's
  *                   buffers (every waiter copies its own request: threads unpack in parallel).
  * All tables of a queue share one (dtype, dim) -- every reference preset does (NR_COLS); other shapes: emb_lookup_batched.
- * A host-space request must be waited for before the fourth flush after its own (its staging is reused then).  No event is
+ * A host-space request's rows stay in the queue's staging until emb_queue_wait has copied them out: the fourth flush after
+ * its own blocks (up to 30 s, then fails) while any request of that flush is uncollected, so a front end that flushes faster
+ * than its clients collect is held back instead of overwriting rows.  No event is
  * recorded per flush (an event between two kernels costs GPU time): a host queue's kernel is followed by a one-thread kernel that
  * stores the flush number into a pinned word its waiters poll; a device queue's results are simply complete in stream order
  * behind the flush (emb_queue_wait on a device queue synchronises the flush's stream). */

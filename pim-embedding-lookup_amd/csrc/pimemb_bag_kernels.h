@@ -708,6 +708,8 @@ bag_sum_wavebatch_kernel(const DevDesc *__restrict__ descs, uint32_t chunks_arg,
 // the requester's output: no router, no counts, no un-router.  Bags outside the range are left untouched (another shard
 // writes them).  A separate kernel, so the tuned wave-batch launch is not touched: 64 bags per wavefront -- lane l loads
 // bag l's index (coalesced), lane groups pull theirs by shuffle, eight gathers in flight per lane, predicated stores.
+// (Tried: ONE batch of gathers per wavefront -- 16 bags at dim 128 instead of 64, four times the wavefronts: 38 us against 31
+// for the C4 share's 6 tables x 16 384 bags; the launch is bound by its fixed costs at that size, not by occupancy.)
 // Descriptor: indices uint32[n_bags], offsets unused, pad_[0] = row_lo.
 template <int DT, int LPR, class Cfg>
 __global__ void __launch_bounds__(Cfg::kBlock)

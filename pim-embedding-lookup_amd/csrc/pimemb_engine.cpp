@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -1017,7 +1018,6 @@ int emb_lookup_ranged(emb_engine *e, const emb_lookup_desc *descs, const uint64_
     if (!descs || !row_lo) return fail(EMB_ERR_INVALID, "emb_lookup_ranged: NULL argument");
     DeviceGuard g(e->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const uint32_t bpt = pimemb::onehot_ranged_bags_per_tile();
     // one launch per (dtype, dim) among the descriptors (every BASELINE config and reference preset has one)
     std::map<std::pair<int, uint32_t>, std::vector<uint32_t>> by_shape;
     for (uint32_t i = 0; i < n_descs; i++) {
@@ -1036,6 +1036,7 @@ int emb_lookup_ranged(emb_engine *e, const emb_lookup_desc *descs, const uint64_
         std::vector<DevDesc> img;
         uint32_t max_tiles = 0;
         const Table &t0 = e->tables[descs[kv.second[0]].table_id];
+        const uint32_t bpt = pimemb::onehot_ranged_bags_per_tile(t0.geom);
         for (uint32_t i : kv.second) {
             const emb_lookup_desc &u = descs[i];
             const Table &t = e->tables[u.table_id];
@@ -1421,6 +1422,7 @@ constexpr size_t kQueueBlock = 1u << 20;   // pinned staging is handed out from 
 struct QueueRequest {
     uint32_t first_desc = 0, n_descs = 0;
     std::vector<pimemb::CopyPiece> out;     // host queues: staging -> caller's buffers, done by emb_queue_wait
+    bool collected = false;                 // emb_queue_wait has copied its rows out
 };
 
 struct QueueGen {
@@ -1433,6 +1435,7 @@ struct QueueGen {
     size_t block_at = 0, block_used = 0;
     hipStream_t stream = nullptr;           // the stream its flush went to
     bool in_flight = false;
+    uint32_t collected = 0;                 // host queues: requests whose rows have been copied out (emb_queue_wait)
 };
 
 }  // namespace
@@ -1442,6 +1445,7 @@ struct emb_queue {
     emb_index_type itype = EMB_IDX_U32;
     emb_memspace space = EMB_MEM_DEVICE;
     std::mutex mu;
+    std::condition_variable cv;             // a host queue's generation is recycled only when all its requests were collected
     QueueGen gen[kQueueGens];
     int open = 0;
     uint64_t next_ticket = 0, n_flushes = 0;
@@ -1623,9 +1627,19 @@ int emb_queue_flush(emb_queue *q, void *stream, uint32_t *n_requests) {
     emb_engine *e = q->e;
     DeviceGuard dg(e->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    std::lock_guard<std::mutex> lk(q->mu);
+    std::unique_lock<std::mutex> lk(q->mu);
     QueueGen &g = q->gen[q->open];
     if (g.reqs.empty()) return EMB_OK;
+    // The generation this flush will open next still holds, in a host queue's staging, the rows of the requests flushed four
+    // flushes ago until their waiters have copied them out: it is recycled only then.  A front end that flushes faster than
+    // its clients collect is held back HERE, before anything of this flush is launched (requests that arrive meanwhile
+    // still join it), instead of overwriting rows.
+    const int next = (q->open + 1) % kQueueGens;
+    QueueGen &nx = q->gen[next];
+    if (nx.in_flight && q->space == EMB_MEM_HOST &&
+        !q->cv.wait_for(lk, std::chrono::seconds(30), [&] { return nx.collected >= nx.reqs.size(); }))
+        return fail(EMB_ERR_INVALID, "emb_queue_flush: %zu request(s) of flush %llu were never waited for (emb_queue_wait): their staging "
+                    "cannot be reused", nx.reqs.size() - nx.collected, (unsigned long long)nx.flush_no);
     // requests were tiled for the lane-group kernel as they came in; a flush that adds up to a big one-hot launch runs the
     // wave-batch kernel instead (choose_kernel's rule for any launch): its tiles are larger, so the counts are redone
     KernelKind kind = q->kind;
@@ -1660,18 +1674,10 @@ int emb_queue_flush(emb_queue *q, void *stream, uint32_t *n_requests) {
     e->n_bags.fetch_add(g.bags, std::memory_order_relaxed);
     e->n_indices.fetch_add(g.idx, std::memory_order_relaxed);
     if (n_requests) *n_requests = (uint32_t)g.reqs.size();
-    // open the next generation; a host queue's staging of four flushes ago must have been read before it is written again
-    q->open = (q->open + 1) % kQueueGens;
-    QueueGen &nx = q->gen[q->open];
-    if (nx.in_flight && q->space == EMB_MEM_HOST) {
-        volatile unsigned long long *w = q->done + 8 * q->open;
-        for (uint64_t spin = 0; *w < nx.flush_no; spin++)
-            if (spin > 2000000) {
-                HIP_TRY(hipStreamSynchronize(nx.stream));
-                break;
-            }
-    }
+    // open the next generation (its previous occupants were collected: checked before this flush launched anything)
+    q->open = next;
     nx.in_flight = false;
+    nx.collected = 0;
     nx.descs.clear();
     nx.reqs.clear();
     nx.max_tiles = 0;
@@ -1687,6 +1693,7 @@ int emb_queue_wait(emb_queue *q, uint64_t ticket) {
     volatile unsigned long long *w = nullptr;
     uint64_t flush_no = 0;
     hipStream_t stream = nullptr;
+    int gen_at = -1;
     {
         std::lock_guard<std::mutex> lk(q->mu);
         if (ticket >= q->next_ticket) return fail(EMB_ERR_INVALID, "emb_queue_wait: ticket %llu was never handed out", (unsigned long long)ticket);
@@ -1698,10 +1705,12 @@ int emb_queue_wait(emb_queue *q, uint64_t ticket) {
         if (at < 0) return fail(EMB_ERR_INVALID, "emb_queue_wait: request %llu is no longer tracked (wait before the fourth flush after its own)", (unsigned long long)ticket);
         if (at == q->open) return fail(EMB_ERR_INVALID, "emb_queue_wait: request %llu has not been flushed yet", (unsigned long long)ticket);
         QueueGen &g = q->gen[at];
+        if (g.reqs[ticket - g.first_ticket].collected) return EMB_OK;      // (waited for before)
         out = g.reqs[ticket - g.first_ticket].out;
         w = q->done + 8 * at;
         flush_no = g.flush_no;
         stream = g.stream;
+        gen_at = at;
     }
     DeviceGuard dg(q->e->device);
     if (q->space == EMB_MEM_HOST) {
@@ -1711,6 +1720,15 @@ int emb_queue_wait(emb_queue *q, uint64_t ticket) {
         for (const pimemb::CopyPiece &c : out) memcpy(c.dst, c.src, c.bytes);
     } else {
         HIP_TRY(hipStreamSynchronize(stream));      // (device queues: results are complete in stream order; this is the blunt form)
+    }
+    {       // the generation cannot have been recycled meanwhile: it still held this uncollected request
+        std::lock_guard<std::mutex> lk(q->mu);
+        QueueGen &g = q->gen[gen_at];
+        QueueRequest &r = g.reqs[ticket - g.first_ticket];
+        if (!r.collected) {
+            r.collected = true;
+            if (++g.collected >= g.reqs.size()) q->cv.notify_all();
+        }
     }
     return EMB_OK;
 }

@@ -55,7 +55,7 @@ hipError_t launch_bag_sum_hot(const DevDesc *d_descs, uint32_t n_descs, uint32_t
 // DevDesc::pad_[0]); other bags are left untouched.  uint32 indices, 16-byte-multiple rows up to 1 KiB.
 hipError_t launch_onehot_ranged(const DevDesc *d_descs, uint32_t n_descs, uint32_t max_tiles, emb_dtype dtype,
                                 const LaunchGeom &g, hipStream_t stream);
-uint32_t onehot_ranged_bags_per_tile();
+uint32_t onehot_ranged_bags_per_tile(const LaunchGeom &g);
 
 // Scatter an int32 column (device buffer, nr_rows entries) into column `col` of a row-major
 // [nr_rows][dim] int32 table: the inverse of alloc_buffers' split (emb_host.h:116-118).

@@ -1050,7 +1050,7 @@ hipError_t launch_onehot_ranged(const DevDesc *d_descs, uint32_t n_descs, uint32
     }
     return hipErrorInvalidValue;
 }
-uint32_t onehot_ranged_bags_per_tile() { return 64u * (WaveCfg::kBlock / 64); }
+uint32_t onehot_ranged_bags_per_tile(const LaunchGeom &g) { (void)g; return 64u * (WaveCfg::kBlock / 64); }
 
 hipError_t launch_scatter_column(int32_t *table, const int32_t *column, uint64_t nr_rows,
                                  uint32_t dim, uint32_t col, hipStream_t stream) {
