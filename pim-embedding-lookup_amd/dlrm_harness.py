@@ -92,6 +92,70 @@ class EmbeddingBagCollection:
         self.engine.close()
 
 
+class ShardedEmbeddingBagCollection:
+    """The same `apply_emb(lS_o, lS_i) -> list of [B, m]` contract with the tables SHARDED over the ranks of one node
+    (one process per GPU; every rank passes its own bags and gets its own pooled rows): `plan_shards` places each table --
+    replicated, whole on an owner, or split by row range -- and every call is ONE library call (`emb_shard_lookup`).  The
+    reference's lookup() likewise serves all its devices from one call (emb_host.h:258-270, 297, 312-321).
+
+        comm = sharding.native_comm(engine, rank, world)   (RCCL; or peer=sharding.PeerGroup(...) for the peer-store exchange)
+        ebc = ShardedEmbeddingBagCollection(ln_emb, m, rank, world, comm=comm)
+        ly = ebc.apply_emb(lS_o, lS_i)                     # COLLECTIVE: every rank, every batch
+
+    weights: per table [n, m] arrays (every rank passes the same; each keeps its shards), or None: W[k][r][c] from a hash
+    of (k, r, c) in DLRM's U(-sqrt(1/n), sqrt(1/n)) range, so that ranks agree without exchanging anything."""
+
+    def __init__(self, ln_emb, m_spa: int, rank: int, world: int, comm=None, peer=None, device: int = 0, weights=None, seed: int = 0,
+                 replicate_bytes: int = 64 << 20, pooling: float = 1.0, trusted_inputs: bool = False, engine=None):
+        import torch
+        from . import sharding
+        self.torch = torch
+        self.device = torch.device("cuda", device)
+        self.ln_emb, self.m, self.rank, self.world = [int(n) for n in ln_emb], int(m_spa), int(rank), int(world)
+        self.plan = sharding.plan_shards(self.ln_emb, self.m, 4, world, replicate_bytes=replicate_bytes, pooling=pooling)
+        self.engine = engine if engine is not None else EmbeddingEngine(device=device, max_tables=len(self.plan.units) + 1)
+        self._own_engine = engine is None
+        self.sharded = sharding.ShardedEmbeddingBags(self.plan, self.engine, rank, comm, depth=0, check=not trusted_inputs, peer=peer)
+
+        def rows_of(t, lo, hi):
+            if weights is not None:
+                return torch.as_tensor(np.asarray(weights[t][lo:hi]), dtype=torch.float32)
+            a = float(np.float32(2.0 * np.sqrt(1.0 / self.ln_emb[t])))
+            out = torch.empty((hi - lo, self.m), dtype=torch.float32, device=self.device)
+            for r0 in range(lo, hi, 1 << 22):
+                r1 = min(r0 + (1 << 22), hi)
+                e = torch.arange(r0 * self.m, r1 * self.m, dtype=torch.int64, device=self.device)
+                h = (e * 2654435761 + (t + 1) * 40503 + seed * 7919) % 2147483647
+                out[r0 - lo:r1 - lo] = ((h.to(torch.float32) / 2147483647.0 - 0.5) * a).reshape(r1 - r0, self.m)
+            return out
+
+        self.sharded.load_tables(rows_of)
+
+    def apply_emb(self, lS_o, lS_i):
+        """lS_o[k], lS_i[k]: this rank's offsets / indices of table k (torch CUDA tensors, int64 or int32).  Returns this
+        rank's ly: [B, m] fp32 per table.  With a PeerGroup the tensors of tables other ranks hold are copied into the
+        group's arena first (peers gather from them in place)."""
+        if len(lS_o) != len(self.ln_emb) or len(lS_i) != len(self.ln_emb):
+            raise ValueError("need one (offsets, indices) pair per table")
+        peer = self.sharded.peer
+        if peer is not None:
+            t = self.torch
+
+            def to_arena(x):
+                y = peer.empty(x.shape, t.int32)
+                y.copy_(self.sharded._u32(x))
+                return y
+            lS_o, lS_i = [to_arena(o) for o in lS_o], [to_arena(i) for i in lS_i]
+        return self.sharded.forward(list(lS_o), list(lS_i))
+
+    forward = __call__ = apply_emb
+
+    def close(self):
+        self.sharded.close()
+        if self._own_engine:
+            self.engine.close()
+
+
 def random_batch(rng, ln_emb, batch: int, num_indices_per_lookup: int, fixed: bool, device=None):
     """DLRM's synthetic generator [EXT]: per sample and table, `num_indices_per_lookup` indices
     (fixed) or 1..num_indices_per_lookup (random), uniform over the table."""

@@ -141,6 +141,19 @@ def test_shard_peer_stores_missing_rank_times_out_nonzero(tmp_path):
     assert "did not" in p.stdout + p.stderr or "within" in p.stdout + p.stderr
 
 
+@pytest.mark.parametrize("transport", ["rccl", "peer"])
+def test_sharded_apply_emb_harness_two_ranks(transport, tmp_path):
+    """dlrm_harness.ShardedEmbeddingBagCollection: the `apply_emb(lS_o, lS_i)` contract over the sharded call (int64 tensors as
+    DLRM passes them, ragged bags, the planner's placement), two ranks over RCCL and over peer stores, against the oracle."""
+    import uuid
+    cfg = dict(rows=[7, 300, 5000, 64, 2000, 1500], dim=16, rep=64 * 16 * 4, split=3000 * 16 * 4, bags=19, max_len=5, depths=[0], batches=1,
+               harness=True)
+    if transport == "peer":
+        cfg.update(peer=True, peer_tag="t" + uuid.uuid4().hex[:12])
+    res = _run(cfg, 2, tmp_path)
+    assert all("replicated" in st["harness"] for st in res)
+
+
 def test_shard_bad_index_raises_on_the_serving_rank_and_nobody_hangs(tmp_path):
     """A row id outside its table, passed by rank 0: the rank that SERVES it (the last shard of a row-split table) raises
     IndexError after the batch has gone through all its stages; every rank finishes."""
