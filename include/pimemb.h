@@ -463,6 +463,8 @@ int emb_peer_destroy(emb_peer *p);   /* call emb_peer_barrier first: a peer may 
  * with nothing to look up submits n_bags = 0).  Lookups that recur byte for byte (same buffers, same lengths: static batch
  * slots) are served by prepared plans from their second sighting on.
  *
+ * Threading: one caller thread per shard object (the reference assumes a single caller too, emb_host.h:32-33); several shard
+ * objects may share an engine.
  * Indices and offsets are uint32 (the reference's width, emb_host.h:234); every table has `dim` columns; a batch has the
  * same number of bags for every table (the reference's MAX_NR_BATCHES).  At most 64 row-split tables per shard object. */
 typedef struct emb_shard emb_shard;

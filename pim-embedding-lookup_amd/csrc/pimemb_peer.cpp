@@ -97,7 +97,7 @@ struct emb_peer {
     char *shm = nullptr;           // host mapping of the segment
     char *shm_dev = nullptr;       // the same bytes as the GPU addresses them
     size_t shm_bytes = 0;
-    bool registered = false, creator = false;
+    bool registered = false, creator = false, unlinked = false;
     std::vector<char *> chunks;    // this rank's arena
     uint64_t arena_bytes = 0, arena_used = 0;
     bool fine_grained = false;
@@ -283,7 +283,10 @@ int emb_peer_create(emb_engine *e, const char *job_tag, int32_t rank, int32_t wo
         *out = nullptr;
         return bail(rc);
     }
-    if (p->creator) (void)shm_unlink(p->shm_name.c_str());      // every rank holds its mapping: the name can go (nothing is left behind)
+    if (p->creator) {       // every rank holds its mapping: the name can go (nothing is left behind)
+        (void)shm_unlink(p->shm_name.c_str());
+        p->unlinked = true;
+    }
     return EMB_OK;
 }
 
@@ -338,6 +341,7 @@ int emb_peer_destroy(emb_peer *p) {
     if (p->registered) (void)hipHostUnregister(p->shm);
     if (p->shm) (void)munmap(p->shm, p->shm_bytes);
     if (p->fd >= 0) (void)close(p->fd);
+    if (p->creator && !p->unlinked && !p->shm_name.empty()) (void)shm_unlink(p->shm_name.c_str());   // a set-up that failed half-way leaves no segment behind
     (void)hipGetLastError();
     delete p;
     return EMB_OK;
