@@ -17,7 +17,8 @@
  * Here: table management (emb_alloc_table / emb_load_* / emb_set_hot_rows / emb_destroy) must not run
  * concurrently with lookups on the same engine.  Lookups may be issued from several threads:
  * host-pointer calls are serialised inside the engine (they share one staging buffer),
- * device-pointer calls and emb_plan_launch only enqueue work on the caller's stream.  populate_mram /
+ * device-pointer calls and emb_plan_launch only enqueue work on the caller's stream (plan-less calls draw their launch
+ * images from a pool of eight rings picked by the calling thread: threads do not queue up behind one engine mutex).  populate_mram /
  * lookup serialise themselves.  emb_last_error() is thread-local.
  *
  * Paths cited as upmem/... are relative to the reference checkout.
@@ -253,6 +254,9 @@ int emb_copy_to_device(emb_engine *e, void *dst_device, const void *src_host, si
 int emb_copy_to_host(emb_engine *e, void *dst_host, const void *src_device, size_t bytes);
 int emb_memset_device(emb_engine *e, void *dst_device, int value, size_t bytes);
 int emb_synchronize(emb_engine *e, void *stream);
+/* A HIP stream (non-blocking) for callers without a HIP binding: one per serving thread keeps their launches independent. */
+int emb_stream_create(emb_engine *e, void **stream);
+int emb_stream_destroy(emb_engine *e, void *stream);
 int emb_device_of(emb_engine *e, int32_t *device);
 
 /* ------------------------------------------------------------------------------------------ */

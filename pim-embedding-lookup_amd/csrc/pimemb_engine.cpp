@@ -18,6 +18,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -26,6 +27,9 @@
 #include "pimemb_internal.h"
 #include "pimemb_xcd_map.h"
 
+namespace pimemb {
+hipError_t launch_store_word(volatile unsigned long long *dst, unsigned long long value, hipStream_t stream);   // pimemb_kernels.hip
+}
 using pimemb::DevDesc;
 using pimemb::KernelKind;
 using pimemb::LaunchGeom;
@@ -84,6 +88,11 @@ struct DescSlot {
 };
 constexpr int kSlots = 4;
 constexpr size_t kSlotBytes = 256u << 10;
+constexpr int kRingPool = 8;
+inline int ring_of_thread() {
+    static const bool one = getenv("PIMEMB_RING_POOL") && atoi(getenv("PIMEMB_RING_POOL")) == 1;   // A/B: every thread on ring 0 = one lock, as in round 3
+    return one ? 0 : (int)(std::hash<std::thread::id>()(std::this_thread::get_id()) % (size_t)kRingPool);
+}
 struct ImageRing {              // the engine has one (under its mutex); a request queue has its own (under the queue's lock)
     DescSlot slots[kSlots];
     int next_slot = 0;
@@ -120,7 +129,11 @@ struct emb_engine {
     std::mutex host_mu;  // serialises host-pointer calls (they share one staging buffer) -- held for the whole call
     pimemb::HostCopier copier;   // packs inputs / unpacks results of host-pointer calls (used under host_mu)
     hipEvent_t pipe_ev[4] = {};  // pipelined zero-copy calls: "tables of part k are done"
-    ImageRing ring;
+    // Launch images of transient calls: a small POOL of rings, each under its own lock, picked by the calling thread -- a
+    // launch holds its ring's lock across image copy + enqueue, so threads of a serving process no longer queue up behind ONE
+    // engine-wide mutex (round 3: launch_resolved held `mu`); `mu` is left with the tables, the map cache and the staging
+    ImageRing ring[kRingPool];
+    std::mutex ring_mu[kRingPool];
     std::vector<XmapCacheEntry> xmap_cache;
     uint64_t xmap_clock = 0;
     // staging for EMB_MEM_HOST calls
@@ -135,6 +148,8 @@ struct emb_engine {
     std::mutex val_mu;          // checked calls take turns (their findings are read as deltas of one device counter); `mu` is
                                 // held only while such a call enqueues, not while it waits for its result
     volatile unsigned long long *val_result = nullptr;   // two pinned, device-visible words the validation kernels report into
+    volatile unsigned long long *host_done = nullptr;    // host-pointer calls (under host_mu): "the kernel of call host_seq is done"
+    unsigned long long host_seq = 0;
     // stats
     std::atomic<uint64_t> n_lookup_calls{0}, n_kernel_launches{0}, n_bags{0}, n_indices{0};
     std::atomic<uint64_t> n_by_kind[5] = {};
@@ -480,10 +495,11 @@ HostProfile g_prof;
 int launch_resolved(emb_engine *e, Resolved &r, emb_index_type itype, hipStream_t s,
                     bool descriptors_in_host_memory = false) {
     if (r.descs.empty()) return EMB_OK;
-    std::lock_guard<std::mutex> lk(e->mu);
+    const int rk = ring_of_thread();
+    std::lock_guard<std::mutex> lk(e->ring_mu[rk]);
     const double p0 = g_prof.on ? now_us() : 0;
     char *h = nullptr, *d = nullptr;
-    int rc = take_image_space(e->ring, r.image.size(), s, &h, &d);
+    int rc = take_image_space(e->ring[rk], r.image.size(), s, &h, &d);
     if (rc) return rc;
     const double p1 = g_prof.on ? now_us() : 0;
     memcpy(h, r.image.data(), r.image.size());
@@ -707,7 +723,25 @@ int lookup_host(emb_engine *e, const emb_lookup_desc *descs, uint32_t n, emb_ind
         }
     }
     const double t4 = now_us();
-    HIP_TRY(hipStreamSynchronize(s));
+    if (hs.zero_copy && !timed) {
+        // a small zero-copy call: the rows land in pinned memory by the kernel's own stores, so all the host needs to know is
+        // "the kernel is done" -- a one-thread kernel behind it stores a sequence number into a pinned word and the host
+        // polls it (hipStreamSynchronize wakes several microseconds late for a launch this short)
+        if (!e->host_done) {
+            void *p = nullptr;
+            HIP_TRY(hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocCoherent));
+            e->host_done = static_cast<volatile unsigned long long *>(p);
+            *e->host_done = 0;
+        }
+        const unsigned long long seq = ++e->host_seq;
+        HIP_TRY(pimemb::launch_store_word(e->host_done, seq, s));
+        bool done = false;
+        for (int spin = 0; spin < 400000 && !(done = *e->host_done == seq); spin++) {
+        }
+        if (!done) HIP_TRY(hipStreamSynchronize(s));
+    } else {
+        HIP_TRY(hipStreamSynchronize(s));
+    }
     if (staged_out) {
         std::vector<pimemb::CopyPiece> unpack;
         unpack.reserve(n);
@@ -780,8 +814,10 @@ int emb_create(const emb_config *cfg, emb_engine **out) {
         // tools/transient_probe.py: 20.6 vs 22.4 us per C2-shaped call, 5.6 vs 8.7 us at 2048 bags per
         // table); PIMEMB_DESC_MODE=copy stages them into HBM with an in-stream copy instead
         const char *m = getenv("PIMEMB_DESC_MODE");
-        e->ring.desc_mode = (m && m[0] == 'c') ? 0 : 1;
-        e->ring.slot_flags = hipHostMallocMapped | hipHostMallocCoherent;
+        for (ImageRing &rg : e->ring) {
+            rg.desc_mode = (m && m[0] == 'c') ? 0 : 1;
+            rg.slot_flags = hipHostMallocMapped | hipHostMallocCoherent;
+        }
     }
     uint32_t max_tables = (cfg && cfg->max_tables) ? cfg->max_tables : 1024;
     e->tables.resize(max_tables);
@@ -806,7 +842,7 @@ int emb_destroy(emb_engine *e) {
         clear_hot(t);
         if (t.rows) (void)hipFree(t.rows);
     }
-    e->ring.release();
+    for (ImageRing &rg : e->ring) rg.release();
     for (XmapCacheEntry &c : e->xmap_cache) (void)hipFree(c.d_map);
     for (hipEvent_t ev : e->pipe_ev)
         if (ev) (void)hipEventDestroy(ev);
@@ -814,6 +850,7 @@ int emb_destroy(emb_engine *e) {
     if (e->d_stage) (void)hipFree(e->d_stage);
     if (e->d_val) (void)hipFree(e->d_val);
     if (e->val_result) (void)hipHostFree(const_cast<unsigned long long *>(e->val_result));
+    if (e->host_done) (void)hipHostFree(const_cast<unsigned long long *>(e->host_done));
     delete e;
     return EMB_OK;
 }
@@ -1057,9 +1094,10 @@ int emb_lookup_ranged(emb_engine *e, const emb_lookup_desc *descs, const uint64_
             bags += u.n_bags;
         }
         if (img.size() > 65535u) return fail(EMB_ERR_UNSUPPORTED, "emb_lookup_ranged: more than 65535 descriptors of one shape");
-        std::lock_guard<std::mutex> lk(e->mu);
+        const int rk = ring_of_thread();
+        std::lock_guard<std::mutex> lk(e->ring_mu[rk]);
         char *h = nullptr, *d = nullptr;
-        int rc = take_image_space(e->ring, img.size() * sizeof(DevDesc), s, &h, &d);
+        int rc = take_image_space(e->ring[rk], img.size() * sizeof(DevDesc), s, &h, &d);
         if (rc) return rc;
         memcpy(h, img.data(), img.size() * sizeof(DevDesc));
         const DevDesc *dev_img = reinterpret_cast<const DevDesc *>(h);
@@ -1196,7 +1234,9 @@ static int checked_launch(emb_engine *e, Resolved &r, emb_index_type itype, hipS
     unsigned long long seq = 0;
     volatile unsigned long long *result = nullptr;
     {
-        std::lock_guard<std::mutex> lk(e->mu);        // enqueue only; released before the wait below
+        // (d_val, val_result and the val_* bookkeeping are only touched under val_mu, held above)
+        const int rk = ring_of_thread();
+        std::lock_guard<std::mutex> lk(e->ring_mu[rk]);        // enqueue only; released before the wait below
         if (!e->d_val) {
             HIP_TRY(hipMalloc((void **)&e->d_val, sizeof(pimemb::ValidateCtl)));
             HIP_TRY(hipMemset(e->d_val, 0, sizeof(pimemb::ValidateCtl)));
@@ -1208,7 +1248,7 @@ static int checked_launch(emb_engine *e, Resolved &r, emb_index_type itype, hipS
         }
         result = e->val_result;
         char *h = nullptr, *d = nullptr;
-        int rc = take_image_space(e->ring, r.image.size(), s, &h, &d);
+        int rc = take_image_space(e->ring[rk], r.image.size(), s, &h, &d);
         if (rc) return rc;
         memcpy(h, r.image.data(), r.image.size());
         result[0] = result[1] = 0;
@@ -1246,7 +1286,6 @@ static int checked_launch(emb_engine *e, Resolved &r, emb_index_type itype, hipS
     if (!done) {
         HIP_TRY(hipStreamSynchronize(s));
         if (result[1] != seq) {
-            std::lock_guard<std::mutex> lk(e->mu);
             resync_validation(e, s);
             return fail(EMB_ERR_DEVICE, "validation kernel did not report");
         }
@@ -1395,6 +1434,23 @@ int emb_memset_device(emb_engine *e, void *dst_device, int value, size_t bytes) 
     if (!bytes) return EMB_OK;
     DeviceGuard g(e->device);
     HIP_TRY(hipMemset(dst_device, value, bytes));
+    return EMB_OK;
+}
+
+int emb_stream_create(emb_engine *e, void **stream) {
+    if (!e || !stream) return fail(EMB_ERR_INVALID, "engine or stream is NULL");
+    DeviceGuard g(e->device);
+    hipStream_t st = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    *stream = st;
+    return EMB_OK;
+}
+
+int emb_stream_destroy(emb_engine *e, void *stream) {
+    if (!e) return fail(EMB_ERR_INVALID, "engine is NULL");
+    if (!stream) return EMB_OK;
+    DeviceGuard g(e->device);
+    HIP_TRY(hipStreamDestroy(static_cast<hipStream_t>(stream)));
     return EMB_OK;
 }
 

@@ -148,6 +148,8 @@ SIGNATURES = {
     "emb_copy_to_host": (C.c_int, [_vp, _vp, _vp, _sz]),
     "emb_memset_device": (C.c_int, [_vp, _vp, C.c_int, _sz]),
     "emb_synchronize": (C.c_int, [_vp, _vp]),
+    "emb_stream_create": (C.c_int, [_vp, _pp]),
+    "emb_stream_destroy": (C.c_int, [_vp, _vp]),
     "emb_device_of": (C.c_int, [_vp, C.POINTER(_i32)]),
     "emb_route_bags_sizes": (C.c_int, [_u32, _u64, _u64, _u32, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64),
                                        C.POINTER(_u64)]),
