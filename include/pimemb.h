@@ -185,8 +185,13 @@ int emb_lookup_batched(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_d
  * tables: every shard scans the requester's raw index array and stores only the rows it holds, straight into the
  * requester's output -- each bag has exactly one shard, so there is nothing to route and nothing to add up
  * (emb_dpu_lookup.c:113-114 is the gather being served; the reference's column shards likewise all read the same index list,
- * emb_host.h:258-263).  offsets must be NULL and fixed_pooling 1; rows are 16-byte multiples up to 1 KiB. */
+ * emb_host.h:258-263).  offsets must be NULL and fixed_pooling 1; rows are 16-byte multiples up to 1 KiB.  A WHOLE table is
+ * the range row_lo = 0: whole tables and shards of one row width share ONE launch of the tuned one-hot kernel (an index
+ * outside the table then leaves its bag untouched instead of reading out of bounds). */
 int emb_lookup_ranged(emb_engine *e, const emb_lookup_desc *descs, const uint64_t *row_lo, uint32_t n_descs, void *stream);
+/* The same as a prepared launch (emb_plan_launch / emb_plan_destroy as for any plan): for a sharded step whose buffers recur. */
+int emb_plan_create_ranged(emb_engine *e, const emb_lookup_desc *descs, const uint64_t *row_lo, uint32_t n_descs,
+                           emb_plan **out);
 
 /* Prepared lookup over DEVICE buffers: descriptors are resolved and uploaded once, every launch is
  * then a single kernel enqueue (graph-capturable: no allocation, copy or sync inside).  The plan

@@ -544,7 +544,12 @@ bag_sum_anydim_vec_kernel(const DevDesc *__restrict__ descs, uint32_t dim, uint3
 }
 
 // ---- v2: wave batches of 64 bags, coalesced bounds, shuffle-distributed, one-hot fast path -------
-template <typename IdxT, int DT, int LPR, class Cfg>
+// RANGED (the sharded lookup's direct path, pimemb_shard.cpp): one index per bag, and a descriptor serves only the bags
+// whose row falls into [row_lo, row_lo + nr_rows) (row_lo in DevDesc::pad_[0]): out[b] = W[idx[b] - row_lo]; the other bags
+// are left untouched -- another shard of the table writes them, straight into the same output.  A shard scans the
+// requester's RAW index array (its own, or a peer's through its mapping): no router, no counts, no un-router.  A whole
+// table is the range [0, nr_rows), so replicated tables and shards share ONE launch of the tuned kernel.
+template <typename IdxT, int DT, int LPR, class Cfg, bool RANGED = false>
 __global__ void __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves)
 bag_sum_wavebatch_kernel(const DevDesc *__restrict__ descs, uint32_t chunks_arg,
                          const uint32_t *__restrict__ xmap) {
@@ -573,6 +578,8 @@ bag_sum_wavebatch_kernel(const DevDesc *__restrict__ descs, uint32_t chunks_arg,
     const uint32_t out_stride = chunks * Ops::kFloatsPerLane;
     const char *__restrict__ wsub = weights + sub * 16u;
     const bool lane_live = sub < chunks;
+    uint64_t row_lo = 0;
+    if constexpr (RANGED) row_lo = dp->pad_[0];
 
     if (tile < n_tiles) {
         const uint64_t step_base = ((uint64_t)tile * kWaves + wave) * (64u * NB);
@@ -626,6 +633,11 @@ bag_sum_wavebatch_kernel(const DevDesc *__restrict__ descs, uint32_t chunks_arg,
                 } else {
                     if (len[q]) my[q] = load_meta<Cfg::kNtMeta>(indices + st[q]);
                 }
+                if constexpr (RANGED) {     // row ids relative to this shard; a bag of another shard counts as empty
+                    const uint64_t r = (uint64_t)my[q] - row_lo;       // (wraps far out of range below row_lo)
+                    if (r > last_row) len[q] = 0;
+                    my[q] = (IdxT)r;
+                }
             }
 #pragma unroll
             for (uint32_t j0 = 0; j0 < ROUNDS; j0 += RU) {
@@ -646,8 +658,10 @@ bag_sum_wavebatch_kernel(const DevDesc *__restrict__ descs, uint32_t chunks_arg,
 #pragma unroll
                     for (uint32_t jj = 0; jj < RU; jj++) {
                         const uint64_t bag = step_base + 64u * q + (j0 + jj) * BPR + grp;
+                        // (RANGED: only the bags this shard holds the row of are written)
+                        const bool wr = RANGED ? has[q][jj] : bag < n_bags;
                         if constexpr (!Ops::kGroupStore) {
-                            if (bag < n_bags && lane_live) {
+                            if (wr && lane_live) {
                                 typename Ops::Acc acc = Ops::zero();
                                 if (has[q][jj]) Ops::add(acc, v[q][jj]);
                                 Ops::template store<Cfg::kNtStore>(
@@ -657,12 +671,13 @@ bag_sum_wavebatch_kernel(const DevDesc *__restrict__ descs, uint32_t chunks_arg,
                             typename Ops::Acc acc = Ops::zero();
                             if (has[q][jj] && lane_live) Ops::add(acc, v[q][jj]);
                             store_row<Ops, Cfg, LPR>(acc, out + bag * out_stride, sub, grp, chunks,
-                                                     bag < n_bags && lane_live);
+                                                     wr && lane_live);
                         }
                     }
             }
             return;
         }
+        if constexpr (RANGED) return;      // (the host hands a ranged launch fixed_pooling 1 only: every step is one-hot)
 
         // general step: each round, a lane group walks its bag in index order
 #pragma unroll 1
@@ -696,70 +711,6 @@ bag_sum_wavebatch_kernel(const DevDesc *__restrict__ descs, uint32_t chunks_arg,
                 }
                 if constexpr (Ops::kGroupStore)
                     store_row<Ops, Cfg, LPR>(acc, out + bag * out_stride, sub, grp, chunks, bag < n_bags && lane_live);
-            }
-        }
-    }
-}
-
-// ---- one index per bag, served by ROW RANGE: out[b] = W[idx[b] - row_lo] for the bags whose row this table holds --------
-// The sharded lookup's direct path for one-hot row-split tables (pimemb_shard.cpp): every shard scans the requester's RAW
-// index array -- in the requester's HBM, through a peer mapping, or its own -- and serves only the bags whose row falls into
-// its range [row_lo, row_lo + nr_rows); each bag has exactly one such shard, so the rows go straight to their final place in
-// the requester's output: no router, no counts, no un-router.  Bags outside the range are left untouched (another shard
-// writes them).  A separate kernel, so the tuned wave-batch launch is not touched: 64 bags per wavefront -- lane l loads
-// bag l's index (coalesced), lane groups pull theirs by shuffle, eight gathers in flight per lane, predicated stores.
-// (Tried: ONE batch of gathers per wavefront -- 16 bags at dim 128 instead of 64, four times the wavefronts: 38 us against 31
-// for the C4 share's 6 tables x 16 384 bags; the launch is bound by its fixed costs at that size, not by occupancy.)
-// Descriptor: indices uint32[n_bags], offsets unused, pad_[0] = row_lo.
-template <int DT, int LPR, class Cfg>
-__global__ void __launch_bounds__(Cfg::kBlock)
-bag_onehot_ranged_kernel(const DevDesc *__restrict__ descs, uint32_t chunks) {
-    using Ops = RowOps<DT>;
-    constexpr uint32_t kWaves = Cfg::kBlock / 64;
-    constexpr uint32_t BPR = 64 / LPR, ROUNDS = LPR;
-    constexpr uint32_t RU = (ROUNDS < 8u) ? ROUNDS : 8u;
-    const DevDesc *dp = descs + blockIdx.y;
-    const uint32_t tile = blockIdx.x;
-    if (tile >= dp->n_tiles) return;
-    const char *__restrict__ weights = static_cast<const char *>(dp->weights);
-    const uint32_t *__restrict__ indices = static_cast<const uint32_t *>(dp->indices);
-    float *__restrict__ out = dp->out;
-    const uint64_t n_bags = dp->n_bags, nr_rows = dp->nr_rows, row_lo = dp->pad_[0];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t sub = lane & (LPR - 1), grp = lane / LPR;
-    const uint32_t row_bytes = chunks * 16u, out_stride = chunks * Ops::kFloatsPerLane;
-    const char *__restrict__ wsub = weights + sub * 16u;
-    const bool lane_live = sub < chunks;
-    const uint64_t step_base = ((uint64_t)tile * kWaves + wave) * 64u;
-    if (step_base >= n_bags) return;  // wave-uniform
-    const uint64_t mb = step_base + lane;
-    uint32_t rel = 0, mine = 0;
-    if (mb < n_bags) {
-        const uint64_t r = (uint64_t)load_meta<false>(indices + mb) - row_lo;     // wraps far out of range below row_lo
-        mine = r < nr_rows ? 1u : 0u;
-        rel = (uint32_t)r;
-    }
-#pragma unroll
-    for (uint32_t j0 = 0; j0 < ROUNDS; j0 += RU) {
-        u32x4 v[RU];
-        bool has[RU];
-#pragma unroll
-        for (uint32_t jj = 0; jj < RU; jj++) {
-            const uint32_t src = (j0 + jj) * BPR + grp;
-            const uint64_t r = shfl_u32(rel, src);
-            has[jj] = shfl_u32(mine, src) != 0u;
-            v[jj] = u32x4{0u, 0u, 0u, 0u};
-            if (has[jj] && lane_live) v[jj] = load_row<false>(wsub + r * row_bytes);
-        }
-#pragma unroll
-        for (uint32_t jj = 0; jj < RU; jj++) {
-            const uint64_t bag = step_base + (j0 + jj) * BPR + grp;
-            typename Ops::Acc acc = Ops::zero();
-            if (has[jj] && lane_live) Ops::add(acc, v[jj]);
-            if constexpr (!Ops::kGroupStore) {
-                if (has[jj] && lane_live) Ops::template store<Cfg::kNtStore>(acc, out + bag * out_stride + sub * Ops::kFloatsPerLane);
-            } else {   // all lanes take part in the group store's shuffles
-                store_row<Ops, Cfg, LPR>(acc, out + bag * out_stride, sub, grp, chunks, has[jj] && lane_live);
             }
         }
     }

@@ -184,6 +184,7 @@ struct PlanGroup {
     uint32_t hot_wgs = 0;            // KERNEL_HOT: persistent workgroups per descriptor
     uint32_t hot_lds = 0;            // KERNEL_HOT: dynamic LDS bytes (largest hot set of the group)
     uint32_t *cached_xmap = nullptr; // transient launches: map owned by the engine's cache (not in the image)
+    bool ranged = false;             // descriptors serve a row range each (emb_lookup_ranged / emb_plan_create_ranged)
     size_t desc_off = 0, xmap_off = 0;  // byte offsets of this group's pieces in the launch image
     std::vector<uint32_t> xmap_words;
 };
@@ -312,10 +313,13 @@ int cached_xcd_map(emb_engine *e, PlanGroup &g, uint32_t bpt, const std::vector<
 
 // st_indices / st_offsets / st_out: if non-null, per-descriptor device pointers that replace the
 // caller's (the staged copies of a host-pointer call).
+// row_lo: if non-null, a RANGED launch -- descriptor i serves only the bags whose row falls into
+// [row_lo[i], row_lo[i] + the table's rows); one index per bag, uint32 indices, the wave-batch kernels.
 int resolve(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs, emb_index_type itype,
             const std::vector<const void *> *st_indices, const std::vector<const void *> *st_offsets,
-            const std::vector<float *> *st_out, Resolved *r, bool cache_maps = false) {
+            const std::vector<float *> *st_out, Resolved *r, bool cache_maps = false, const uint64_t *row_lo = nullptr) {
     if (itype != EMB_IDX_U32 && itype != EMB_IDX_I64) return fail(EMB_ERR_INVALID, "bad index type");
+    if (row_lo && itype != EMB_IDX_U32) return fail(EMB_ERR_INVALID, "ranged lookups take uint32 indices");
     std::map<std::pair<int, uint32_t>, std::vector<uint32_t>> by_shape;
     for (uint32_t i = 0; i < n_descs; i++) {
         const emb_lookup_desc &u = descs[i];
@@ -331,6 +335,12 @@ int resolve(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs, emb_i
                 return fail(EMB_ERR_INVALID, "desc %u: fixed_pooling*n_bags != n_indices", i);
         }
         const Table &t = e->tables[u.table_id];
+        if (row_lo) {
+            if (u.offsets != nullptr || u.fixed_pooling != 1)
+                return fail(EMB_ERR_INVALID, "ranged lookup: desc %u: one index per bag only (offsets NULL, fixed_pooling 1)", i);
+            if (t.geom.scalar_lanes)
+                return fail(EMB_ERR_UNSUPPORTED, "ranged lookup: desc %u: rows must be 16-byte multiples up to 1 KiB", i);
+        }
         by_shape[{(int)t.dtype, t.dim}].push_back(i);
     }
     const size_t isz = index_size(itype);
@@ -346,6 +356,8 @@ int resolve(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs, emb_i
             group_idx += descs[i].n_indices;
         }
         g.kind = pimemb::choose_kernel(group_bags, group_idx, g.geom);
+        g.ranged = row_lo != nullptr;
+        if (g.ranged && g.kind == pimemb::KERNEL_GROUP) g.kind = pimemb::KERNEL_WAVEBATCH;    // (small launches too: the predicate lives there)
         if (g.kind == pimemb::KERNEL_GROUP) {   // pooled launch over tables with a hot-row set: LDS-staged kernel
             for (uint32_t i : kv.second) {
                 const Table &t = e->tables[descs[i].table_id];
@@ -371,6 +383,7 @@ int resolve(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs, emb_i
             d.nr_rows = t.nr_rows;
             d.fixed_pooling = u.offsets ? 0u : u.fixed_pooling;
             d.n_tiles = (uint32_t)tiles;
+            if (row_lo) d.pad_[0] = row_lo[i];
             if (g.kind == pimemb::KERNEL_HOT) {
                 d.hot_rows = t.hot_rows;
                 d.hot_hash = t.hot_hash;
@@ -432,7 +445,7 @@ int launch_groups(emb_engine *e, const std::vector<PlanGroup> &groups, emb_index
             HIP_TRY(pimemb::launch_bag_sum_hot(g.d_descs, g.n, g.hot_wgs, g.hot_lds, g.dtype, itype, g.geom, s));
         else
             HIP_TRY(pimemb::launch_bag_sum(g.d_descs, g.n, g.max_tiles, g.dtype, itype, g.geom, g.kind, g.d_xmap,
-                                           g.xgrid, g.xdirect, s));
+                                           g.xgrid, g.xdirect, s, g.ranged));
         e->n_kernel_launches.fetch_add(1, std::memory_order_relaxed);
         e->n_by_kind[g.kind].fetch_add(1, std::memory_order_relaxed);
     }
@@ -1054,75 +1067,39 @@ int emb_lookup_ranged(emb_engine *e, const emb_lookup_desc *descs, const uint64_
     if (n_descs == 0) return EMB_OK;
     if (!descs || !row_lo) return fail(EMB_ERR_INVALID, "emb_lookup_ranged: NULL argument");
     DeviceGuard g(e->device);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    // one launch per (dtype, dim) among the descriptors (every BASELINE config and reference preset has one)
-    std::map<std::pair<int, uint32_t>, std::vector<uint32_t>> by_shape;
-    for (uint32_t i = 0; i < n_descs; i++) {
-        const emb_lookup_desc &u = descs[i];
-        if (u.table_id >= e->tables.size() || e->tables[u.table_id].rows == nullptr)
-            return fail(EMB_ERR_INVALID, "emb_lookup_ranged: desc %u: table %u is not loaded", i, u.table_id);
-        if (u.offsets != nullptr || u.fixed_pooling != 1 || u.n_indices != u.n_bags)
-            return fail(EMB_ERR_INVALID, "emb_lookup_ranged: desc %u: one index per bag only (offsets NULL, fixed_pooling 1)", i);
-        if (u.n_bags && (!u.indices || !u.pooled)) return fail(EMB_ERR_INVALID, "emb_lookup_ranged: desc %u: NULL buffer", i);
-        const Table &t = e->tables[u.table_id];
-        if (t.geom.scalar_lanes) return fail(EMB_ERR_UNSUPPORTED, "emb_lookup_ranged: desc %u: rows must be 16-byte multiples up to 1 KiB", i);
-        by_shape[{(int)t.dtype, t.dim}].push_back(i);
-    }
-    uint64_t bags = 0;
-    for (auto &kv : by_shape) {
-        std::vector<DevDesc> img;
-        uint32_t max_tiles = 0;
-        const Table &t0 = e->tables[descs[kv.second[0]].table_id];
-        const uint32_t bpt = pimemb::onehot_ranged_bags_per_tile(t0.geom);
-        for (uint32_t i : kv.second) {
-            const emb_lookup_desc &u = descs[i];
-            const Table &t = e->tables[u.table_id];
-            const uint64_t tiles = (u.n_bags + bpt - 1) / bpt;
-            if (tiles > 0x0fffffffull) return fail(EMB_ERR_UNSUPPORTED, "emb_lookup_ranged: desc %u: too many bags", i);
-            DevDesc d{};
-            d.weights = t.rows;
-            d.indices = u.indices;
-            d.out = u.pooled;
-            d.n_idx = u.n_bags;
-            d.n_bags = u.n_bags;
-            d.nr_rows = t.nr_rows;
-            d.fixed_pooling = 1;
-            d.n_tiles = (uint32_t)tiles;
-            d.pad_[0] = row_lo[i];
-            if (d.n_tiles > max_tiles) max_tiles = d.n_tiles;
-            img.push_back(d);
-            bags += u.n_bags;
-        }
-        if (img.size() > 65535u) return fail(EMB_ERR_UNSUPPORTED, "emb_lookup_ranged: more than 65535 descriptors of one shape");
-        const int rk = ring_of_thread();
-        std::lock_guard<std::mutex> lk(e->ring_mu[rk]);
-        char *h = nullptr, *d = nullptr;
-        int rc = take_image_space(e->ring[rk], img.size() * sizeof(DevDesc), s, &h, &d);
-        if (rc) return rc;
-        memcpy(h, img.data(), img.size() * sizeof(DevDesc));
-        const DevDesc *dev_img = reinterpret_cast<const DevDesc *>(h);
-        if (d != nullptr) {
-            HIP_TRY(hipMemcpyAsync(d, h, img.size() * sizeof(DevDesc), hipMemcpyHostToDevice, s));
-            dev_img = reinterpret_cast<const DevDesc *>(d);
-        }
-        HIP_TRY(pimemb::launch_onehot_ranged(dev_img, (uint32_t)img.size(), max_tiles, t0.dtype, t0.geom, s));
-        e->n_kernel_launches.fetch_add(1, std::memory_order_relaxed);
-        e->n_by_kind[pimemb::KERNEL_WAVEBATCH].fetch_add(1, std::memory_order_relaxed);
-    }
+    Resolved r;
+    int rc = resolve(e, descs, n_descs, EMB_IDX_U32, nullptr, nullptr, nullptr, &r, /*cache_maps=*/true, row_lo);
+    if (rc) return rc;
+    rc = launch_resolved(e, r, EMB_IDX_U32, static_cast<hipStream_t>(stream));
+    if (rc) return rc;
     e->n_lookup_calls.fetch_add(1, std::memory_order_relaxed);
-    e->n_bags.fetch_add(bags, std::memory_order_relaxed);
-    e->n_indices.fetch_add(bags, std::memory_order_relaxed);
+    e->n_bags.fetch_add(r.n_bags, std::memory_order_relaxed);
+    e->n_indices.fetch_add(r.n_indices, std::memory_order_relaxed);
     return EMB_OK;
+}
+
+static int plan_create(emb_engine *e, const emb_lookup_desc *descs, const uint64_t *row_lo, uint32_t n_descs,
+                       emb_index_type itype, emb_plan **out);
+
+int emb_plan_create_ranged(emb_engine *e, const emb_lookup_desc *descs, const uint64_t *row_lo, uint32_t n_descs,
+                           emb_plan **out) {
+    if (!row_lo) return fail(EMB_ERR_INVALID, "emb_plan_create_ranged: row_lo is NULL");
+    return plan_create(e, descs, row_lo, n_descs, EMB_IDX_U32, out);
 }
 
 int emb_plan_create(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs,
                     emb_index_type itype, emb_plan **out) {
+    return plan_create(e, descs, nullptr, n_descs, itype, out);
+}
+
+static int plan_create(emb_engine *e, const emb_lookup_desc *descs, const uint64_t *row_lo, uint32_t n_descs,
+                       emb_index_type itype, emb_plan **out) {
     if (!e || !out) return fail(EMB_ERR_INVALID, "engine or out is NULL");
     *out = nullptr;
     if (!descs || n_descs == 0) return fail(EMB_ERR_INVALID, "plan needs at least one descriptor");
     DeviceGuard g(e->device);
     Resolved r;
-    int rc = resolve(e, descs, n_descs, itype, nullptr, nullptr, nullptr, &r);
+    int rc = resolve(e, descs, n_descs, itype, nullptr, nullptr, nullptr, &r, false, row_lo);
     if (rc) return rc;
     emb_plan *p = new (std::nothrow) emb_plan();
     if (!p) return fail(EMB_ERR_NOMEM, "out of host memory");

@@ -45,17 +45,14 @@ KernelKind choose_kernel(uint64_t total_bags, uint64_t total_indices, const Laun
 hipError_t launch_bag_sum(const DevDesc *d_descs, uint32_t n_descs, uint32_t max_tiles,
                           emb_dtype dtype, emb_index_type itype, const LaunchGeom &g,
                           KernelKind kind, const uint32_t *d_xmap, uint32_t xgrid, bool xdirect,
-                          hipStream_t stream);
+                          hipStream_t stream, bool ranged = false);
 
 // Pooled launch with hot rows in LDS: `wgs` persistent workgroups per descriptor, `lds_bytes` of dynamic LDS.
 hipError_t launch_bag_sum_hot(const DevDesc *d_descs, uint32_t n_descs, uint32_t wgs, uint32_t lds_bytes,
                               emb_dtype dtype, emb_index_type itype, const LaunchGeom &g, hipStream_t stream);
 
-// One index per bag, served by row range: out[b] = W[idx[b] - row_lo] for the bags whose row the table holds (row_lo in
-// DevDesc::pad_[0]); other bags are left untouched.  uint32 indices, 16-byte-multiple rows up to 1 KiB.
-hipError_t launch_onehot_ranged(const DevDesc *d_descs, uint32_t n_descs, uint32_t max_tiles, emb_dtype dtype,
-                                const LaunchGeom &g, hipStream_t stream);
-uint32_t onehot_ranged_bags_per_tile(const LaunchGeom &g);
+// ranged (wave-batch kinds, uint32 indices, one index per bag): a descriptor serves only the bags whose row falls into
+// [row_lo, row_lo + nr_rows) -- row_lo in DevDesc::pad_[0] -- as out[b] = W[idx[b] - row_lo]; other bags are left untouched.
 
 // Scatter an int32 column (device buffer, nr_rows entries) into column `col` of a row-major
 // [nr_rows][dim] int32 table: the inverse of alloc_buffers' split (emb_host.h:116-118).

@@ -49,11 +49,20 @@ constexpr int kBlock = 256;  // helper kernels below
 
 template <typename IdxT, int DT, int L>
 void launch_one(const DevDesc *d, uint32_t n, uint32_t max_tiles, const LaunchGeom &g_in, KernelKind kind,
-                const uint32_t *xmap, uint32_t xgrid, bool xdirect, hipStream_t s) {
+                const uint32_t *xmap, uint32_t xgrid, bool xdirect, bool ranged, hipStream_t s) {
     const dim3 grid = xmap ? dim3(xgrid, 1, 1) : dim3(max_tiles, n, 1);
     struct { uint32_t chunks; } g{g_in.chunks | ((xmap && xdirect) ? kXmapDirect : 0u)};
     using One = typename WaveCfgOf<DT>::One;
     using Two = typename WaveCfgOf<DT>::Two;
+    if (ranged) {      // launch_bag_sum lets uint32 indices and the two wave-batch kinds through only
+        if constexpr (sizeof(IdxT) == 4) {
+            if (kind == KERNEL_WAVEBATCH)
+                hipLaunchKernelGGL((bag_sum_wavebatch_kernel<IdxT, DT, L, One, true>), grid, dim3(One::kBlock), 0, s, d, g.chunks, xmap);
+            else if constexpr (L <= 4)
+                hipLaunchKernelGGL((bag_sum_wavebatch_kernel<IdxT, DT, L, Two, true>), grid, dim3(Two::kBlock), 0, s, d, g.chunks, xmap);
+        }
+        return;
+    }
     if (kind == KERNEL_WAVEBATCH) {
         hipLaunchKernelGGL((bag_sum_wavebatch_kernel<IdxT, DT, L, One>), grid, dim3(One::kBlock), 0, s, d, g.chunks, xmap);
     } else if (kind == KERNEL_WAVEBATCH2) {
@@ -68,11 +77,11 @@ void launch_one(const DevDesc *d, uint32_t n, uint32_t max_tiles, const LaunchGe
 
 template <typename IdxT, int DT>
 hipError_t launch_lpr(const DevDesc *d, uint32_t n, uint32_t max_tiles, const LaunchGeom &g,
-                      KernelKind kind, const uint32_t *xmap, uint32_t xgrid, bool xdirect, hipStream_t s) {
+                      KernelKind kind, const uint32_t *xmap, uint32_t xgrid, bool xdirect, bool ranged, hipStream_t s) {
     switch (g.lanes_per_row) {
 #define PIMEMB_CASE(L)                                                          \
     case L:                                                                     \
-        launch_one<IdxT, DT, L>(d, n, max_tiles, g, kind, xmap, xgrid, xdirect, s); \
+        launch_one<IdxT, DT, L>(d, n, max_tiles, g, kind, xmap, xgrid, xdirect, ranged, s); \
         break;
         PIMEMB_CASE(1)
         PIMEMB_CASE(2)
@@ -91,14 +100,14 @@ hipError_t launch_lpr(const DevDesc *d, uint32_t n, uint32_t max_tiles, const La
 template <typename IdxT>
 hipError_t launch_dtype(const DevDesc *d, uint32_t n, uint32_t max_tiles, emb_dtype dtype,
                         const LaunchGeom &g, KernelKind kind, const uint32_t *xmap, uint32_t xgrid,
-                        bool xdirect, hipStream_t s) {
+                        bool xdirect, bool ranged, hipStream_t s) {
     switch (dtype) {
         case EMB_F32:
-            return launch_lpr<IdxT, EMB_F32>(d, n, max_tiles, g, kind, xmap, xgrid, xdirect, s);
+            return launch_lpr<IdxT, EMB_F32>(d, n, max_tiles, g, kind, xmap, xgrid, xdirect, ranged, s);
         case EMB_F16:
-            return launch_lpr<IdxT, EMB_F16>(d, n, max_tiles, g, kind, xmap, xgrid, xdirect, s);
+            return launch_lpr<IdxT, EMB_F16>(d, n, max_tiles, g, kind, xmap, xgrid, xdirect, ranged, s);
         case EMB_FIXED32:
-            return launch_lpr<IdxT, EMB_FIXED32>(d, n, max_tiles, g, kind, xmap, xgrid, xdirect, s);
+            return launch_lpr<IdxT, EMB_FIXED32>(d, n, max_tiles, g, kind, xmap, xgrid, xdirect, ranged, s);
     }
     return hipErrorInvalidValue;
 }
@@ -995,17 +1004,20 @@ KernelKind choose_kernel(uint64_t total_bags, uint64_t total_indices, const Laun
 hipError_t launch_bag_sum(const DevDesc *d_descs, uint32_t n_descs, uint32_t max_tiles,
                           emb_dtype dtype, emb_index_type itype, const LaunchGeom &g,
                           KernelKind kind, const uint32_t *d_xmap, uint32_t xgrid, bool xdirect,
-                          hipStream_t stream) {
+                          hipStream_t stream, bool ranged) {
     if (n_descs == 0 || max_tiles == 0) return hipSuccess;
     if (d_xmap == nullptr && n_descs > 65535u) return hipErrorInvalidValue;
+    if (ranged && (itype != EMB_IDX_U32 || (kind != KERNEL_WAVEBATCH && kind != KERNEL_WAVEBATCH2) ||
+                   (kind == KERNEL_WAVEBATCH2 && g.lanes_per_row > 4)))
+        return hipErrorInvalidValue;
     if (kind == KERNEL_ANYDIM) {
         if (g.scalar_lanes == 0 || d_xmap != nullptr) return hipErrorInvalidValue;
         return itype == EMB_IDX_U32 ? launch_anydim<uint32_t>(d_descs, n_descs, max_tiles, dtype, g, stream)
                                     : launch_anydim<int64_t>(d_descs, n_descs, max_tiles, dtype, g, stream);
     }
     if (itype == EMB_IDX_U32)
-        return launch_dtype<uint32_t>(d_descs, n_descs, max_tiles, dtype, g, kind, d_xmap, xgrid, xdirect, stream);
-    return launch_dtype<int64_t>(d_descs, n_descs, max_tiles, dtype, g, kind, d_xmap, xgrid, xdirect, stream);
+        return launch_dtype<uint32_t>(d_descs, n_descs, max_tiles, dtype, g, kind, d_xmap, xgrid, xdirect, ranged, stream);
+    return launch_dtype<int64_t>(d_descs, n_descs, max_tiles, dtype, g, kind, d_xmap, xgrid, xdirect, false, stream);
 }
 
 hipError_t launch_bag_sum_hot(const DevDesc *d_descs, uint32_t n_descs, uint32_t wgs, uint32_t lds_bytes,
@@ -1015,42 +1027,6 @@ hipError_t launch_bag_sum_hot(const DevDesc *d_descs, uint32_t n_descs, uint32_t
     return itype == EMB_IDX_U32 ? launch_hot_dtype<uint32_t>(d_descs, n_descs, wgs, lds_bytes, dtype, g, stream)
                                 : launch_hot_dtype<int64_t>(d_descs, n_descs, wgs, lds_bytes, dtype, g, stream);
 }
-
-// One index per bag, served by row range (bag_onehot_ranged_kernel): descriptors carry row_lo in pad_[0]; 2-D grid.
-template <int DT>
-hipError_t launch_ranged_lpr(const DevDesc *d, uint32_t n, uint32_t max_tiles, const LaunchGeom &g, hipStream_t s) {
-    const dim3 grid(max_tiles, n, 1), block(WaveCfg::kBlock);
-    switch (g.lanes_per_row) {
-#define PIMEMB_CASE(L)                                                                                         \
-    case L:                                                                                                    \
-        hipLaunchKernelGGL((bag_onehot_ranged_kernel<DT, L, WaveCfg>), grid, block, 0, s, d, g.chunks);        \
-        break;
-        PIMEMB_CASE(1)
-        PIMEMB_CASE(2)
-        PIMEMB_CASE(4)
-        PIMEMB_CASE(8)
-        PIMEMB_CASE(16)
-        PIMEMB_CASE(32)
-        PIMEMB_CASE(64)
-#undef PIMEMB_CASE
-        default:
-            return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-}
-
-hipError_t launch_onehot_ranged(const DevDesc *d_descs, uint32_t n_descs, uint32_t max_tiles, emb_dtype dtype,
-                                const LaunchGeom &g, hipStream_t stream) {
-    if (n_descs == 0 || max_tiles == 0) return hipSuccess;
-    if (n_descs > 65535u || g.scalar_lanes) return hipErrorInvalidValue;
-    switch (dtype) {
-        case EMB_F32: return launch_ranged_lpr<EMB_F32>(d_descs, n_descs, max_tiles, g, stream);
-        case EMB_F16: return launch_ranged_lpr<EMB_F16>(d_descs, n_descs, max_tiles, g, stream);
-        case EMB_FIXED32: return launch_ranged_lpr<EMB_FIXED32>(d_descs, n_descs, max_tiles, g, stream);
-    }
-    return hipErrorInvalidValue;
-}
-uint32_t onehot_ranged_bags_per_tile(const LaunchGeom &g) { (void)g; return 64u * (WaveCfg::kBlock / 64); }
 
 hipError_t launch_scatter_column(int32_t *table, const int32_t *column, uint64_t nr_rows,
                                  uint32_t dim, uint32_t col, hipStream_t stream) {

@@ -156,6 +156,7 @@ struct emb_shard {
     DevBuf work;                                     // scratch of one route call (ordered on the caller's stream)
     struct CachedPlan {
         std::vector<emb_lookup_desc> key;
+        std::vector<uint64_t> key_lo;                // row ranges of a ranged launch (empty: an ordinary one)
         emb_plan *plan = nullptr;
         uint64_t last_use = 0, seen = 0;
     };
@@ -172,7 +173,9 @@ struct emb_shard {
     Batch *local_of = nullptr;
     bool kernel_timing = false;
     bool allow_direct = true;                        // PIMEMB_SHARD_DIRECT=0 switches the direct one-hot path off (A/B, rehearsal)
+    bool merge_direct = true;                        // PIMEMB_SHARD_DIRECT_MERGE=0: the direct path's lookup stays a launch of its own (A/B)
     std::vector<uint64_t> row_lo;                    // scratch
+    std::vector<emb_lookup_desc> rdescs;             // scratch: the direct path's descriptors (one per source and row-split table)
 };
 
 namespace {
@@ -264,10 +267,12 @@ inline uint32_t *recv_whole(const emb_shard *s, const Batch &b) { return b.count
 // One fused lookup over s->descs on the caller's stream.  A call that recurs byte for byte (same tables, same buffers, same
 // lengths: static batch slots, fixed-size whole-table pieces) is served by a prepared plan from its second sighting on --
 // one kernel enqueue, no descriptor resolution.  A plan holds addresses, never values.  Checked lookups never use plans.
-int fused_lookup(emb_shard *s, Batch &b, bool cacheable) {
+// ranged: s->row_lo holds a row range start per descriptor (emb_lookup_ranged: one index per bag; a whole table is row_lo 0).
+int fused_lookup(emb_shard *s, Batch &b, bool cacheable, bool ranged = false) {
     const uint32_t n = (uint32_t)s->descs.size();
     if (n == 0) return EMB_OK;
-    if (s->check_served) {
+    if (ranged && s->row_lo.size() != n) return fail(EMB_ERR_INVALID, "emb_shard: internal: %u descriptors, %zu row ranges", n, s->row_lo.size());
+    if (s->check_served && !ranged) {
         uint64_t bad = 0;
         int rc = emb_lookup_batched_checked(s->e, s->descs.data(), n, EMB_IDX_U32, EMB_MEM_DEVICE, s->cs, &bad);
         if (rc == EMB_ERR_RANGE) {          // nothing was gathered: the pieces pool to zero rows, the batch still completes
@@ -282,7 +287,9 @@ int fused_lookup(emb_shard *s, Batch &b, bool cacheable) {
         s->plan_clock++;
         emb_shard::CachedPlan *hit = nullptr, *victim = nullptr;
         for (emb_shard::CachedPlan &c : s->plans) {
-            if (c.key.size() == n && memcmp(c.key.data(), s->descs.data(), n * sizeof(emb_lookup_desc)) == 0) hit = &c;
+            if (c.key.size() == n && c.key_lo.size() == (ranged ? n : 0u) && memcmp(c.key.data(), s->descs.data(), n * sizeof(emb_lookup_desc)) == 0 &&
+                (!ranged || memcmp(c.key_lo.data(), s->row_lo.data(), n * 8) == 0))
+                hit = &c;
             if (!victim || c.last_use < victim->last_use) victim = &c;
         }
         if (hit) {
@@ -292,7 +299,8 @@ int fused_lookup(emb_shard *s, Batch &b, bool cacheable) {
                 (void)emb_plan_destroy(hit->plan);
                 hit->plan = nullptr;
             }
-            if (++hit->seen >= 2 && emb_plan_create(s->e, s->descs.data(), n, EMB_IDX_U32, &hit->plan) == EMB_OK)
+            if (++hit->seen >= 2 && (ranged ? emb_plan_create_ranged(s->e, s->descs.data(), s->row_lo.data(), n, &hit->plan)
+                                            : emb_plan_create(s->e, s->descs.data(), n, EMB_IDX_U32, &hit->plan)) == EMB_OK)
                 return emb_plan_launch(hit->plan, s->cs);
         } else {
             if (s->plans.size() < 16) {
@@ -303,10 +311,13 @@ int fused_lookup(emb_shard *s, Batch &b, bool cacheable) {
                 victim->plan = nullptr;
             }
             victim->key.assign(s->descs.begin(), s->descs.end());
+            victim->key_lo.clear();
+            if (ranged) victim->key_lo.assign(s->row_lo.begin(), s->row_lo.end());
             victim->seen = 1;
             victim->last_use = s->plan_clock;
         }
     }
+    if (ranged) return emb_lookup_ranged(s->e, s->descs.data(), s->row_lo.data(), n, s->cs);
     return emb_lookup_batched(s->e, s->descs.data(), n, EMB_IDX_U32, EMB_MEM_DEVICE, s->cs);
 }
 
@@ -653,6 +664,7 @@ int stage_serve(emb_shard *s, Batch &b) {
         s->local_of = nullptr;
     }
     uint64_t alg = 0, n_sub = 0, n_idx = 0;
+    uint32_t n_piece_descs = 0;
     // row pieces: source s asked for sub-bags of my shard of table k -- an ordinary lookup each
     uint64_t in_at = 0, out_at = 0, served_at = 0, back_at = 0;
     for (uint32_t p = 0; p < N; p++) {
@@ -681,6 +693,7 @@ int stage_serve(emb_shard *s, Batch &b) {
                 d.n_bags = ns;
                 d.pooled = rows_dst + row * dim;
                 s->descs.push_back(d);
+                n_piece_descs++;
                 alg += ni * ((uint64_t)dim * s->elem_bytes[s->rows[k]] + 4) + ns * (4 + (uint64_t)dim * 4);
                 n_sub += ns;
                 n_idx += ni;
@@ -741,18 +754,12 @@ int stage_serve(emb_shard *s, Batch &b) {
         }
     }
     g_hp.lap(10);
-    if (!s->descs.empty()) {
-        EMB_TRY(tick(s, b, 2, false));
-        EMB_TRY(fused_lookup(s, b, /*cacheable=*/Kr == 0));      // (row pieces change size with every batch: nothing recurs)
-        EMB_TRY(tick(s, b, 2, true));
-        if (fused_with && b.deferred_rc != EMB_OK) fused_with->deferred_rc = b.deferred_rc;
-    }
     s->st.served_algorithmic_bytes += alg;
     s->st.served_sub_bags += n_sub;
     s->st.served_indices += n_idx;
     // sources that handed their one-index-per-bag row-split tables over directly: scan their raw index arrays, serve the bags
     // whose row this shard holds, straight into their outputs
-    s->descs.clear();
+    s->rdescs.clear();
     s->row_lo.clear();
     for (uint32_t p = 0; p < N; p++) {
         const PeerFrom &f = b.from[p];
@@ -773,14 +780,36 @@ int stage_serve(emb_shard *s, Batch &b) {
                 if (!d.indices || !d.pooled) return fail(EMB_ERR_INVALID, "emb_shard: rank %u posted buffer offsets outside its arena", p);
                 s->st.bytes_to_peers += f.n_bags * 4;       // (+ the rows this shard stores: their number is not known on the host)
             }
-            s->descs.push_back(d);
+            s->rdescs.push_back(d);
             s->row_lo.push_back((uint64_t)s->rank * s->tabs[t].rows_per_shard);
         }
     }
-    if (!s->descs.empty()) {
+    // ... in the SAME launch as everything else this call looks up when that is one index per bag as well (a whole table is
+    // the range starting at row 0): the tuned one-hot kernel once, over replicated tables, whole tables and shards alike
+    bool one_launch = !s->rdescs.empty() && !s->descs.empty() && !s->check_served && s->merge_direct;
+    if (one_launch)
+        for (const emb_lookup_desc &d : s->descs)
+            if (d.offsets != nullptr || d.fixed_pooling != 1) { one_launch = false; break; }
+    if (one_launch) {
+        s->row_lo.insert(s->row_lo.begin(), s->descs.size(), 0ull);
+        s->descs.insert(s->descs.end(), s->rdescs.begin(), s->rdescs.end());
+        s->rdescs.clear();
         EMB_TRY(tick(s, b, 4, false));
-        EMB_TRY(emb_lookup_ranged(s->e, s->descs.data(), s->row_lo.data(), (uint32_t)s->descs.size(), s->cs));
+        EMB_TRY(fused_lookup(s, b, /*cacheable=*/n_piece_descs == 0, /*ranged=*/true));
         EMB_TRY(tick(s, b, 4, true));
+    } else {
+        if (!s->descs.empty()) {
+            EMB_TRY(tick(s, b, 2, false));
+            EMB_TRY(fused_lookup(s, b, /*cacheable=*/n_piece_descs == 0));      // (row pieces change size with every batch: nothing recurs)
+            EMB_TRY(tick(s, b, 2, true));
+            if (fused_with && b.deferred_rc != EMB_OK) fused_with->deferred_rc = b.deferred_rc;
+        }
+        if (!s->rdescs.empty()) {
+            s->descs.swap(s->rdescs);
+            EMB_TRY(tick(s, b, 4, false));
+            EMB_TRY(fused_lookup(s, b, /*cacheable=*/true, /*ranged=*/true));
+            EMB_TRY(tick(s, b, 4, true));
+        }
     }
     if (s->peer_mode) {        // behind the lookup (its kernel boundary completes the stores into the peers' HBM): "served"
         pimemb::PeerDoneArgs da{};
@@ -934,6 +963,7 @@ int emb_shard_create(emb_engine *e, emb_comm *comm, const emb_shard_config *cfg,
     }
     if (const char *t = getenv("PIMEMB_SHARD_TIMEOUT_S")) s->timeout_s = atof(t) > 0 ? atof(t) : s->timeout_s;
     if (const char *t = getenv("PIMEMB_SHARD_DIRECT")) s->allow_direct = t[0] != '0';
+    if (const char *t = getenv("PIMEMB_SHARD_DIRECT_MERGE")) s->merge_direct = t[0] != '0';
     if (cfg->flags & (EMB_SHARD_NO_DIRECT | EMB_SHARD_CHECK_SERVED)) s->allow_direct = false;    // (the ranged lookup validates nothing: a checked shard routes)
     s->tabs.assign(cfg->tables, cfg->tables + cfg->n_tables);
     s->whole_of.assign((size_t)world, {});

@@ -1808,3 +1808,77 @@ def test_lookup_ranged_serves_only_its_row_range(pel, oracle, dim, dtype):
     bad = (pel.lib.EmbLookupDesc * 1)(pel.lib.EmbLookupDesc(0, 0, d_idx.data_ptr(), off.data_ptr(), B, B, out.data_ptr()))
     assert L.emb_lookup_ranged(eng._h, bad, (C.c_uint64 * 1)(0), 1, None) == pel.lib.EMB_ERR_INVALID
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,dtype,B", [(16, np.float32, 150_001), (16, np.float32, 9001), (128, np.float32, 33_000),
+                                         (64, np.float16, 40_000), (32, "fixed32", 20_011)])
+def test_ranged_launch_mixes_whole_tables_and_shards(pel, oracle, dim, dtype, B):
+    """ONE ranged launch over whole tables (the range starting at row 0) and the shards of row-split tables, as the sharded
+    lookup's direct path issues it: the small (64-bag tiles), the large (two batches per wavefront, XCD map) and the fp16 /
+    fixed-point forms of the one-hot kernel -- transient (emb_lookup_ranged) and prepared (emb_plan_create_ranged) -- every
+    bag equal to the oracle's, every bag of another shard untouched, an index outside a whole table leaves its bag alone."""
+    import ctypes as C
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(11)
+    fixed = dtype == "fixed32"
+    whole_rows, split_rows, N, me = [700, 12_345], [50_021, 9_973], 4, 2
+    n_tab = len(whole_rows) + len(split_rows)
+
+    def make(n):
+        if fixed:
+            return rng.integers(-2 ** 30, 2 ** 30, size=(n, dim)).astype(np.int32)
+        return (rng.standard_normal((n, dim)) * 0.1).astype(dtype)
+
+    tabs = [make(n) for n in whole_rows + split_rows]
+    eng = pel.EmbeddingEngine(device=0, max_tables=8)
+    per = [-(-n // N) for n in split_rows]
+    for t, n in enumerate(whole_rows):
+        eng.load_table(t, tabs[t], dtype=pel.EMB_FIXED32 if fixed else None)
+    for k, n in enumerate(split_rows):          # this "rank" holds shard `me` of every row-split table
+        t = len(whole_rows) + k
+        eng.load_table(t, tabs[t][me * per[k]:min((me + 1) * per[k], n)], dtype=pel.EMB_FIXED32 if fixed else None)
+    idx = [rng.integers(0, n, size=B).astype(np.uint32) for n in whole_rows + split_rows]
+    idx[1][5] = whole_rows[1] + 77                      # outside a whole table: nothing is read, the bag stays as it was
+    d_idx = [torch.from_numpy(i.view(np.int32)).to(dev) for i in idx]
+    L = pel.lib.load()
+    descs = (pel.lib.EmbLookupDesc * n_tab)()
+    lo = (C.c_uint64 * n_tab)()
+    for prepared in (False, True):
+        outs = [torch.full((B, dim), float("nan"), device=dev) for _ in range(n_tab)]
+        for t in range(n_tab):
+            descs[t] = pel.lib.EmbLookupDesc(t, 1, d_idx[t].data_ptr(), None, B, B, outs[t].data_ptr())
+            lo[t] = 0 if t < len(whole_rows) else me * per[t - len(whole_rows)]
+        launches = eng.stats()["n_kernel_launches"]
+        if prepared:
+            plan = C.c_void_p()
+            pel.lib.check(L.emb_plan_create_ranged(eng._h, descs, lo, n_tab, C.byref(plan)))
+            pel.lib.check(L.emb_plan_launch(plan, None))
+        else:
+            pel.lib.check(L.emb_lookup_ranged(eng._h, descs, lo, n_tab, None))
+        torch.cuda.synchronize()
+        assert eng.stats()["n_kernel_launches"] == launches + 1          # one row width: one launch
+        for t in range(n_tab):
+            got = outs[t].cpu().numpy()
+            n = (whole_rows + split_rows)[t]
+            if t < len(whole_rows):
+                mine = idx[t] < n
+                rel = np.minimum(idx[t], n - 1)
+                src = tabs[t]
+            else:
+                k = t - len(whole_rows)
+                mine = (idx[t] >= me * per[k]) & (idx[t] < min((me + 1) * per[k], n))
+                rel = np.where(mine, idx[t], 0)
+                src = tabs[t]
+            if fixed:             # the oracle over one-index bags of the rows in question
+                want = oracle.c_lookup_fixed32(src, rel.astype(np.uint32), np.arange(B, dtype=np.uint32))
+            else:
+                want = oracle.c_bag_sum(src.astype(np.float32), rel.astype(np.int64), np.arange(B, dtype=np.int64))
+            assert np.array_equal(got[mine], want[mine]), (t, prepared)
+            assert np.isnan(got[~mine]).all(), (t, prepared)
+            assert mine.sum() > 0
+        if prepared:
+            pel.lib.check(L.emb_plan_destroy(plan))
+    assert not (idx[1] < whole_rows[1])[5]
+    eng.close()
