@@ -1,0 +1,210 @@
+// TEST INFRASTRUCTURE -- never linked into libpimemb.so, never shipped.
+//
+// A stand-in for the HIP runtime so the HOST side of the library (csrc/pimemb_engine.cpp, pimemb_shard.cpp,
+// pimemb_compat.cpp and the host half of pimemb_kernels.hip, all compiled with `--cuda-host-only`) can run on a CPU-only
+// box under ThreadSanitizer / AddressSanitizer (tests/test_host_side_sanitizers.py).  What it provides:
+//   * "device" and pinned memory = calloc'd host memory (so ASan sees every overrun of a launch image or a staging buffer),
+//     copies = memcpy, streams / events = small heap objects, everything synchronous;
+//   * kernel launches are NO-OPS -- no lookup is computed here, nothing a test could mistake for a result -- except the
+//     few SIGNALLING kernels whose words the host code waits for: store_word, publish_words, zero_words, validate (counts
+//     out-of-range indices: its verdict steers host control flow) and validate_publish.  They run synchronously inside
+//     hipLaunchKernel, found by the name the compiler registers for them.
+// What the host-logic check asserts is therefore only return codes, tickets, ordering and that the sanitizers stay silent.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "pimemb_internal.h"
+
+namespace {
+
+std::mutex &reg_mu() { static std::mutex m; return m; }
+std::map<const void *, std::string> &registry() { static std::map<const void *, std::string> r; return r; }
+
+struct CallCfg { dim3 grid, block; size_t shmem; hipStream_t stream; };
+thread_local std::vector<CallCfg> t_cfg;
+
+struct FakeStream { int id; };
+struct FakeEvent { int recorded; };
+
+template <typename T> T arg(void **args, int i) { return *static_cast<T *>(args[i]); }
+
+struct PublishSrcMirror { const uint32_t *p[3]; uint32_t n[3]; };     // pimemb_kernels.hip: PublishSrc
+
+template <typename IdxT>
+void emulate_validate(void **args, dim3 grid) {
+    using pimemb::DevDesc;
+    DevDesc *descs = arg<DevDesc *>(args, 0);
+    const uint32_t n_descs = arg<uint32_t>(args, 1);
+    pimemb::ValidateCtl *ctl = arg<pimemb::ValidateCtl *>(args, 2);
+    const unsigned long long target = arg<unsigned long long>(args, 3);
+    unsigned long long *result = const_cast<unsigned long long *>(arg<volatile unsigned long long *>(args, 4));
+    const unsigned long long seq = arg<unsigned long long>(args, 5);
+    const int poison = arg<int>(args, 6);
+    unsigned long long bad = 0;
+    for (uint32_t d = 0; d < n_descs; d++) {
+        const DevDesc &dd = descs[d];
+        const IdxT *idx = static_cast<const IdxT *>(dd.indices), *off = static_cast<const IdxT *>(dd.offsets);
+        for (uint64_t i = 0; i < dd.n_idx; i++)
+            if (idx[i] < 0 || (uint64_t)idx[i] >= dd.nr_rows) bad++;
+        if (off) {
+            for (uint64_t b = 0; b < dd.n_bags; b++) {
+                const uint64_t nxt = (b + 1 < dd.n_bags) ? (uint64_t)off[b + 1] : dd.n_idx;
+                if (off[b] < 0 || (uint64_t)off[b] > nxt || nxt > dd.n_idx) bad++;
+            }
+        } else if ((uint64_t)dd.fixed_pooling * dd.n_bags != dd.n_idx) {
+            bad++;
+        }
+    }
+    __atomic_fetch_add(&ctl->bad, bad, __ATOMIC_RELAXED);         // (the kernel's adds are atomics too)
+    if (bad && poison)
+        for (uint32_t d = 0; d < n_descs; d++) descs[d].n_tiles = 0;
+    if (target != 0) {
+        const unsigned long long t = __atomic_add_fetch(&ctl->tickets, (unsigned long long)grid.x * grid.y, __ATOMIC_ACQ_REL);
+        if (t == target) {
+            __atomic_store_n(&result[0], __atomic_load_n(&ctl->bad, __ATOMIC_RELAXED), __ATOMIC_RELAXED);
+            __atomic_store_n(&result[1], seq, __ATOMIC_RELEASE);
+        }
+    }
+}
+
+void emulate(const std::string &name, void **args, dim3 grid) {
+    if (name.find("store_word_kernel") != std::string::npos) {
+        unsigned long long *w = const_cast<unsigned long long *>(arg<volatile unsigned long long *>(args, 0));
+        __atomic_store_n(w, arg<unsigned long long>(args, 1), __ATOMIC_RELEASE);
+    } else if (name.find("zero_words_kernel") != std::string::npos) {
+        memset(arg<uint32_t *>(args, 0), 0, (size_t)arg<uint32_t>(args, 1) * 4);
+    } else if (name.find("publish_words_kernel") != std::string::npos) {
+        const PublishSrcMirror src = arg<PublishSrcMirror>(args, 0);
+        uint32_t *dst = arg<uint32_t *>(args, 1);
+        uint32_t at = 0;
+        for (int j = 0; j < 3; j++) {
+            if (src.p[j]) memcpy(dst + at, src.p[j], (size_t)src.n[j] * 4);
+            at += src.n[j];
+        }
+        unsigned long long *flag = const_cast<unsigned long long *>(arg<volatile unsigned long long *>(args, 2));
+        __atomic_store_n(flag, arg<unsigned long long>(args, 3), __ATOMIC_RELEASE);
+    } else if (name.find("validate_publish_kernel") != std::string::npos) {
+        const pimemb::ValidateCtl *ctl = arg<const pimemb::ValidateCtl *>(args, 0);
+        unsigned long long *result = const_cast<unsigned long long *>(arg<volatile unsigned long long *>(args, 1));
+        __atomic_store_n(&result[0], __atomic_load_n(&ctl->bad, __ATOMIC_RELAXED), __ATOMIC_RELAXED);
+        __atomic_store_n(&result[1], arg<unsigned long long>(args, 2), __ATOMIC_RELEASE);
+    } else if (name.find("validate_kernelIjE") != std::string::npos) {
+        emulate_validate<uint32_t>(args, grid);
+    } else if (name.find("validate_kernelIlE") != std::string::npos) {
+        emulate_validate<int64_t>(args, grid);
+    }
+    // every other kernel (the lookups, the router, the un-router, the column scatter, the peer mailbox kernels): nothing
+}
+
+}  // namespace
+
+extern "C" {
+
+unsigned char pimemb_stub_fatbin[16] = {0};      // what the kernels object's __hip_fatbin_<hash> is pointed at when linking
+
+void **__hipRegisterFatBinary(const void *) {
+    static void *handle = nullptr;
+    return &handle;
+}
+void __hipUnregisterFatBinary(void **) {}
+void __hipRegisterFunction(void **, const void *host_fn, char *, const char *device_name, unsigned int, void *, void *, void *,
+                           void *, int *) {
+    std::lock_guard<std::mutex> lk(reg_mu());
+    registry()[host_fn] = device_name ? device_name : "";
+}
+void __hipRegisterVar(void **, void *, char *, const char *, int, size_t, int, int) {}
+
+hipError_t __hipPushCallConfiguration(dim3 grid, dim3 block, size_t shmem, hipStream_t stream) {
+    t_cfg.push_back(CallCfg{grid, block, shmem, stream});
+    return hipSuccess;
+}
+hipError_t __hipPopCallConfiguration(dim3 *grid, dim3 *block, size_t *shmem, hipStream_t *stream) {
+    if (t_cfg.empty()) return hipErrorInvalidValue;
+    const CallCfg c = t_cfg.back();
+    t_cfg.pop_back();
+    *grid = c.grid; *block = c.block; *shmem = c.shmem; *stream = c.stream;
+    return hipSuccess;
+}
+
+hipError_t hipLaunchKernel(const void *fn, dim3 grid, dim3 block, void **args, size_t, hipStream_t) {
+    if (grid.x == 0 || grid.y == 0 || grid.z == 0 || block.x == 0 || block.x * block.y * block.z > 1024u) return hipErrorInvalidConfiguration;
+    std::string name;
+    {
+        std::lock_guard<std::mutex> lk(reg_mu());
+        auto it = registry().find(fn);
+        if (it == registry().end()) return hipErrorInvalidDeviceFunction;
+        name = it->second;
+    }
+    emulate(name, args, grid);
+    return hipSuccess;
+}
+
+hipError_t hipGetLastError(void) { return hipSuccess; }
+const char *hipGetErrorString(hipError_t) { return "stub"; }
+hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidDevice; }
+hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
+
+hipError_t hipMalloc(void **p, size_t n) {
+    *p = calloc(n ? n : 1, 1);
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+hipError_t hipHostMalloc(void **p, size_t n, unsigned int) {
+    *p = calloc(n ? n : 1, 1);
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { if (n) memcpy(d, s, n); return hipSuccess; }
+hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { if (n) memcpy(d, s, n); return hipSuccess; }
+hipError_t hipMemset(void *d, int v, size_t n) { if (n) memset(d, v, n); return hipSuccess; }
+hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { if (n) memset(d, v, n); return hipSuccess; }
+
+hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned int) {
+    *s = reinterpret_cast<hipStream_t>(new FakeStream{1});
+    return hipSuccess;
+}
+hipError_t hipStreamDestroy(hipStream_t s) { delete reinterpret_cast<FakeStream *>(s); return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned int) { return hipSuccess; }
+
+hipError_t hipEventCreate(hipEvent_t *e) { *e = reinterpret_cast<hipEvent_t>(new FakeEvent{0}); return hipSuccess; }
+hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
+hipError_t hipEventDestroy(hipEvent_t e) { delete reinterpret_cast<FakeEvent *>(e); return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t) {
+    __atomic_store_n(&reinterpret_cast<FakeEvent *>(e)->recorded, 1, __ATOMIC_RELAXED);
+    return hipSuccess;
+}
+hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.001f; return hipSuccess; }
+
+}  // extern "C"
+
+// ---- what csrc/pimemb_peer.cpp needs for a group of ONE process (an IPC handle is the pointer itself) ------------------------
+extern "C" {
+hipError_t hipExtMallocWithFlags(void **p, size_t n, unsigned int) { return hipMalloc(p, n); }
+hipError_t hipHostRegister(void *, size_t, unsigned int) { return hipSuccess; }
+hipError_t hipHostUnregister(void *) { return hipSuccess; }
+hipError_t hipHostGetDevicePointer(void **dev, void *host, unsigned int) { *dev = host; return hipSuccess; }
+hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t *h, void *p) {
+    memset(h, 0, sizeof(*h));
+    memcpy(h, &p, sizeof(p));
+    return hipSuccess;
+}
+hipError_t hipIpcOpenMemHandle(void **p, hipIpcMemHandle_t h, unsigned int) {
+    memcpy(p, &h, sizeof(*p));
+    return hipSuccess;
+}
+hipError_t hipIpcCloseMemHandle(void *) { return hipSuccess; }
+}

@@ -1,0 +1,343 @@
+// TEST INFRASTRUCTURE: the HOST side of libpimemb's sources over tests/cpp/hip_runtime_stub.cpp (kernels are no-ops there),
+// under ThreadSanitizer / AddressSanitizer + UBSan -- see tests/test_host_side_sanitizers.py.  Through the public C ABI only.
+// Checks return codes, tickets and ordering; no lookup result exists here to be looked at.
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <unistd.h>
+#include <vector>
+
+#include "pimemb.h"
+
+#define CHECK(x)                                                                                          \
+    do {                                                                                                  \
+        int rc_ = (x);                                                                                    \
+        if (rc_ != EMB_OK) {                                                                              \
+            fprintf(stderr, "%s:%d: %s -> %d (%s)\n", __FILE__, __LINE__, #x, rc_, emb_last_error());     \
+            exit(1);                                                                                      \
+        }                                                                                                 \
+    } while (0)
+#define EXPECT(c)                                                                       \
+    do {                                                                                \
+        if (!(c)) {                                                                     \
+            fprintf(stderr, "%s:%d: expected %s\n", __FILE__, __LINE__, #c);            \
+            exit(1);                                                                    \
+        }                                                                               \
+    } while (0)
+
+namespace {
+
+constexpr uint32_t kTables = 6, kDim = 16, kRows = 1000;
+
+struct Rng {
+    uint64_t s;
+    uint32_t next() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (uint32_t)(s >> 11); }
+};
+
+emb_engine *make_engine(uint32_t flags) {
+    emb_config cfg{};
+    cfg.device = 0;
+    cfg.max_tables = kTables + 4;
+    cfg.flags = flags;
+    emb_engine *e = nullptr;
+    CHECK(emb_create(&cfg, &e));
+    std::vector<float> rows((size_t)kRows * kDim, 0.5f);
+    for (uint32_t t = 0; t < kTables; t++) CHECK(emb_load_table(e, t, kRows, kDim, EMB_F32, rows.data(), EMB_MEM_HOST));
+    return e;
+}
+
+// ---- several caller threads on one engine: transient launches, plans, host-pointer calls, checked calls -------------------
+void engine_threads() {
+    emb_engine *e = make_engine(0);
+    std::atomic<int> range_errors{0};
+    auto worker = [&](int tid) {
+        Rng rng{0x9E3779B97F4A7C15ull * (uint64_t)(tid + 1)};
+        void *stream = nullptr;
+        CHECK(emb_stream_create(e, &stream));
+        const uint32_t B = 64 + 13 * (uint32_t)tid;
+        std::vector<std::vector<uint32_t>> idx(kTables), off(kTables);
+        std::vector<std::vector<float>> out(kTables);
+        std::vector<void *> d_idx(kTables), d_off(kTables), d_out(kTables);
+        for (uint32_t t = 0; t < kTables; t++) {
+            off[t].resize(B);
+            uint32_t at = 0;
+            for (uint32_t b = 0; b < B; b++) { off[t][b] = at; at += rng.next() % 4; }
+            idx[t].resize(at);
+            for (auto &v : idx[t]) v = rng.next() % kRows;
+            out[t].assign((size_t)B * kDim, 0.f);
+            CHECK(emb_device_alloc(e, at * 4 + 4, &d_idx[t]));
+            CHECK(emb_device_alloc(e, B * 4, &d_off[t]));
+            CHECK(emb_device_alloc(e, (size_t)B * kDim * 4, &d_out[t]));
+            CHECK(emb_copy_to_device(e, d_idx[t], idx[t].data(), at * 4));
+            CHECK(emb_copy_to_device(e, d_off[t], off[t].data(), B * 4));
+        }
+        std::vector<emb_lookup_desc> dev(kTables), host(kTables);
+        for (uint32_t t = 0; t < kTables; t++) {
+            dev[t] = emb_lookup_desc{t, 0, d_idx[t], d_off[t], idx[t].size(), B, static_cast<float *>(d_out[t])};
+            host[t] = emb_lookup_desc{t, 0, idx[t].data(), off[t].data(), idx[t].size(), B, out[t].data()};
+        }
+        emb_plan *plan = nullptr;
+        CHECK(emb_plan_create(e, dev.data(), kTables, EMB_IDX_U32, &plan));
+        for (int it = 0; it < 200; it++) {
+            CHECK(emb_lookup_batched(e, dev.data(), kTables, EMB_IDX_U32, EMB_MEM_DEVICE, stream));
+            CHECK(emb_plan_launch(plan, stream));
+            if (it % 4 == 0) CHECK(emb_lookup_batched(e, host.data(), kTables, EMB_IDX_U32, EMB_MEM_HOST, nullptr));
+            if (it % 8 == 0) CHECK(emb_lookup(e, (uint32_t)tid % kTables, idx[0].data(), idx[0].size(), off[0].data(), B, out[0].data(),
+                                             EMB_IDX_U32, EMB_MEM_HOST, nullptr));
+            uint64_t bad = 0;
+            if (it % 16 == 5 && tid == 1) {         // ONE thread hands in a bad index now and then: only its call fails
+                uint32_t spoiled = kRows + 7;
+                CHECK(emb_copy_to_device(e, d_idx[2], &spoiled, 4));
+                int rc = emb_lookup_batched_checked(e, dev.data(), kTables, EMB_IDX_U32, EMB_MEM_DEVICE, stream, &bad);
+                EXPECT(rc == EMB_ERR_RANGE && bad == 1);
+                range_errors++;
+                CHECK(emb_copy_to_device(e, d_idx[2], idx[2].data(), 4));
+            } else if (idx[2].size()) {
+                CHECK(emb_lookup_batched_checked(e, dev.data(), kTables, EMB_IDX_U32, EMB_MEM_DEVICE, stream, &bad));
+                EXPECT(bad == 0);
+            }
+            if (it % 50 == 49) CHECK(emb_synchronize(e, stream));
+        }
+        CHECK(emb_synchronize(e, stream));
+        CHECK(emb_plan_destroy(plan));
+        for (uint32_t t = 0; t < kTables; t++) {
+            CHECK(emb_device_free(e, d_idx[t]));
+            CHECK(emb_device_free(e, d_off[t]));
+            CHECK(emb_device_free(e, d_out[t]));
+        }
+        CHECK(emb_stream_destroy(e, stream));
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < 4; t++) th.emplace_back(worker, t);
+    for (auto &t : th) t.join();
+    EXPECT(range_errors.load() > 0);
+    emb_stats st{};
+    CHECK(emb_get_stats(e, &st));
+    EXPECT(st.n_kernel_launches > 0 && st.n_lookup_calls > 0);
+    CHECK(emb_destroy(e));
+    printf("engine threads ok\n");
+}
+
+// ---- the request queue: adders, a free-running flusher, waiters that collect late ------------------------------------------
+void queue_threads() {
+    emb_engine *e = make_engine(0);
+    emb_queue *q = nullptr;
+    CHECK(emb_queue_create(e, EMB_IDX_U32, EMB_MEM_HOST, &q));
+    std::atomic<bool> stop{false};
+    std::atomic<uint64_t> flushed{0};
+    std::thread flusher([&] {
+        void *stream = nullptr;
+        CHECK(emb_stream_create(e, &stream));
+        while (!stop.load()) {
+            uint32_t n = 0;
+            CHECK(emb_queue_flush(q, stream, &n));
+            flushed += n;
+            std::this_thread::yield();
+        }
+        uint32_t n = 0;
+        CHECK(emb_queue_flush(q, stream, &n));
+        flushed += n;
+        CHECK(emb_synchronize(e, stream));
+        CHECK(emb_stream_destroy(e, stream));
+    });
+    constexpr int kClients = 3, kRequests = 400;
+    auto client = [&](int tid) {
+        Rng rng{77ull + (uint64_t)tid};
+        for (int r = 0; r < kRequests; r++) {
+            const uint32_t B = 1 + rng.next() % 8, n_t = 1 + rng.next() % kTables;
+            std::vector<std::vector<uint32_t>> idx(n_t), off(n_t);
+            std::vector<std::vector<float>> out(n_t);
+            std::vector<emb_lookup_desc> d(n_t);
+            for (uint32_t t = 0; t < n_t; t++) {
+                off[t].resize(B);
+                uint32_t at = 0;
+                for (uint32_t b = 0; b < B; b++) { off[t][b] = at; at += rng.next() % 3; }
+                idx[t].resize(at + 1);
+                for (auto &v : idx[t]) v = rng.next() % kRows;
+                out[t].assign((size_t)B * kDim, -1.f);
+                d[t] = emb_lookup_desc{t, 0, idx[t].data(), off[t].data(), at, B, out[t].data()};
+            }
+            uint64_t ticket = 0;
+            CHECK(emb_queue_add(q, d.data(), n_t, &ticket));
+            if (r % 7 == 3) std::this_thread::yield();      // collect late now and then: generations must be held for us
+            int rc;         // (a wait ahead of the flush that carries the request is refused, not blocked: the client tries again)
+            while ((rc = emb_queue_wait(q, ticket)) == EMB_ERR_INVALID && strstr(emb_last_error(), "not been flushed")) std::this_thread::yield();
+            CHECK(rc);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < kClients; t++) th.emplace_back(client, t);
+    for (auto &t : th) t.join();
+    stop = true;
+    flusher.join();
+    EXPECT(flushed.load() == (uint64_t)kClients * kRequests);
+    uint64_t never = 0;
+    EXPECT(emb_queue_wait(q, (uint64_t)kClients * kRequests + 5) == EMB_ERR_INVALID);
+    (void)never;
+    CHECK(emb_queue_destroy(q));
+
+    // a device queue from two threads + add_many
+    CHECK(emb_queue_create(e, EMB_IDX_U32, EMB_MEM_DEVICE, &q));
+    void *d_idx = nullptr, *d_out = nullptr;
+    CHECK(emb_device_alloc(e, 4096, &d_idx));
+    CHECK(emb_device_alloc(e, 64 * kDim * 4, &d_out));
+    auto adder = [&](int) {
+        for (int r = 0; r < 300; r++) {
+            emb_lookup_desc d[2] = {{0, 1, d_idx, nullptr, 8, 8, static_cast<float *>(d_out)}, {1, 2, d_idx, nullptr, 16, 8, static_cast<float *>(d_out)}};
+            uint32_t n[2] = {1, 1};
+            uint64_t first = 0;
+            CHECK(emb_queue_add_many(q, d, n, 2, &first));
+            if (r % 16 == 15) {
+                uint32_t got = 0;
+                CHECK(emb_queue_flush(q, nullptr, &got));
+            }
+        }
+    };
+    std::thread a(adder, 0), b(adder, 1);
+    a.join();
+    b.join();
+    uint32_t got = 0;
+    CHECK(emb_queue_flush(q, nullptr, &got));
+    CHECK(emb_queue_destroy(q));
+    CHECK(emb_device_free(e, d_idx));
+    CHECK(emb_device_free(e, d_out));
+    CHECK(emb_destroy(e));
+    printf("queue threads ok\n");
+}
+
+// ---- the sharded call with one rank: every placement, every depth, ragged and one-index batches, peer-store mode -----------
+void shard_one_rank(bool peer_mode) {
+    emb_engine *e = make_engine(0);
+    emb_peer *peer = nullptr;
+    if (peer_mode) {
+        char tag[64];
+        snprintf(tag, sizeof tag, "hostcheck-%d", (int)getpid());
+        CHECK(emb_peer_create(e, tag, 0, 1, 64ull << 20, &peer));
+    }
+    emb_shard_table tabs[kTables];
+    for (uint32_t t = 0; t < kTables; t++) {
+        tabs[t].placement = t < 2 ? EMB_PLACE_REPLICATED : (t < 4 ? EMB_PLACE_WHOLE : EMB_PLACE_ROWS);
+        tabs[t].owner = 0;
+        tabs[t].engine_table = t;
+        tabs[t].rows_per_shard = kRows;
+    }
+    auto dev_alloc = [&](size_t bytes) {
+        void *p = nullptr;
+        if (peer) CHECK(emb_peer_alloc(peer, bytes ? bytes : 4, &p));
+        else CHECK(emb_device_alloc(e, bytes ? bytes : 4, &p));
+        return p;
+    };
+    for (uint32_t depth = 0; depth <= 3; depth++) {
+        emb_shard_config cfg{};
+        cfg.n_tables = kTables;
+        cfg.dim = kDim;
+        cfg.depth = depth;
+        cfg.flags = peer ? EMB_SHARD_PEER_STORES : 0u;
+        cfg.tables = tabs;
+        cfg.peer = peer;
+        emb_shard *s = nullptr;
+        CHECK(emb_shard_create(e, nullptr, &cfg, &s));
+        CHECK(emb_shard_set_kernel_timing(s, depth == 2));
+        Rng rng{5ull + depth};
+        constexpr int kSlots = 8;
+        struct Slot { std::vector<void *> idx, off, out; };
+        std::vector<Slot> slots(kSlots);
+        const uint32_t Bmax = 96;
+        for (auto &sl : slots)
+            for (uint32_t t = 0; t < kTables; t++) {
+                sl.idx.push_back(dev_alloc(Bmax * 4 * 4));
+                sl.off.push_back(dev_alloc(Bmax * 4));
+                sl.out.push_back(dev_alloc((size_t)Bmax * kDim * 4));
+            }
+        std::vector<uint64_t> seqs;
+        for (int j = 0; j < 20; j++) {
+            Slot &sl = slots[j % kSlots];
+            const uint32_t B = (j == 7) ? 0u : 1 + rng.next() % Bmax;
+            const bool one_hot = j % 3 != 0;          // one index per bag: the direct path; else ragged bags: routed
+            emb_shard_input in[kTables];
+            for (uint32_t t = 0; t < kTables; t++) {
+                std::vector<uint32_t> off(B), idx;
+                for (uint32_t b = 0; b < B; b++) {
+                    off[b] = (uint32_t)idx.size();
+                    const uint32_t len = one_hot ? 1u : rng.next() % 4;
+                    for (uint32_t k = 0; k < len; k++) idx.push_back(rng.next() % kRows);
+                }
+                if (!idx.empty()) CHECK(emb_copy_to_device(e, sl.idx[t], idx.data(), idx.size() * 4));
+                if (B) CHECK(emb_copy_to_device(e, sl.off[t], off.data(), B * 4));
+                in[t] = emb_shard_input{static_cast<const uint32_t *>(sl.idx[t]), one_hot ? nullptr : static_cast<const uint32_t *>(sl.off[t]),
+                                        idx.size(), one_hot ? 1u : 0u, 0u, static_cast<float *>(sl.out[t])};
+            }
+            if (depth == 0 || j % 5 == 4) {
+                CHECK(emb_shard_lookup(s, in, B, nullptr));
+            } else {
+                uint64_t seq = 0;
+                CHECK(emb_shard_submit(s, in, B, nullptr, &seq));
+                seqs.push_back(seq);
+                if (seqs.size() > depth) {
+                    CHECK(emb_shard_wait(s, seqs.front(), nullptr));
+                    seqs.erase(seqs.begin());
+                }
+            }
+        }
+        CHECK(emb_shard_flush(s));
+        for (uint64_t q : seqs) CHECK(emb_shard_wait(s, q, nullptr));
+        emb_shard_stats st{};
+        CHECK(emb_shard_get_stats(s, &st, 1));
+        EXPECT(st.n_batches == 20);
+        uint32_t counts[64];
+        (void)emb_shard_sent_counts(s, 0, counts, 64);
+        CHECK(emb_shard_destroy(s));
+        if (!peer)
+            for (auto &sl : slots)
+                for (uint32_t t = 0; t < kTables; t++) {
+                    CHECK(emb_device_free(e, sl.idx[t]));
+                    CHECK(emb_device_free(e, sl.off[t]));
+                    CHECK(emb_device_free(e, sl.out[t]));
+                }
+        if (peer) break;       // (the arena is a bump allocator: one depth is what fits)
+    }
+    if (peer) {
+        CHECK(emb_peer_barrier(peer));
+        CHECK(emb_peer_destroy(peer));
+    }
+    CHECK(emb_destroy(e));
+    printf("shard one rank%s ok\n", peer_mode ? " (peer stores)" : "");
+}
+
+// ---- the reference's two entry points -------------------------------------------------------------------------------------
+void compat_calls() {
+    const uint32_t nt = 3, nc = 8, nb = 16, per = 4;
+    CHECK(emb_configure(nt, nc, nb, per));
+    std::vector<int32_t> col(500, 1000000);
+    struct dpu_set_t *set = nullptr;
+    for (uint32_t t = 0; t < nt; t++)
+        for (uint32_t c = 0; c < nc; c++) {
+            set = populate_mram(t, 500, c, col.data(), nullptr);
+            EXPECT(set != nullptr);
+        }
+    std::vector<std::vector<uint32_t>> idx(nt, std::vector<uint32_t>(nb * per, 3)), off(nt, std::vector<uint32_t>(nb));
+    std::vector<std::vector<float>> out(nt, std::vector<float>(nb * nc));
+    std::vector<uint32_t *> pi(nt), po(nt);
+    std::vector<float *> pr(nt);
+    for (uint32_t t = 0; t < nt; t++) {
+        for (uint32_t b = 0; b < nb; b++) off[t][b] = b * per;
+        pi[t] = idx[t].data(); po[t] = off[t].data(); pr[t] = out[t].data();
+    }
+    for (int it = 0; it < 5; it++) EXPECT(lookup(pi.data(), po.data(), pr.data(), set, 0) == nullptr);      // (an error would be printed: the test greps for it)
+    CHECK(emb_compat_reset());
+    printf("compat ok\n");
+}
+
+}  // namespace
+
+int main() {
+    engine_threads();
+    queue_threads();
+    shard_one_rank(false);
+    shard_one_rank(true);
+    compat_calls();
+    printf("host logic ok\n");
+    return 0;
+}
