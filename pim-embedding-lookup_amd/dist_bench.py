@@ -265,8 +265,14 @@ def run_sharded(args, hbm_peak_gbs: float, ctx, rep_bytes: int, mode: str):
     torch.cuda.synchronize()
 
     seqs = {}
-    consumer = torch.cuda.Stream(dev)      # where the pooled rows are consumed: NOT the stream the next inputs come from, or
-    hc = consumer.cuda_stream              # batch i+1 could not be routed before batch i-1 has been un-routed
+    # Where the pooled rows are consumed.  "same" (default): on the caller's stream, as DLRM's interaction layer consumes
+    # apply_emb's outputs -- stream order is the hand-over, emb_shard_wait has nothing to enqueue.  "other": a second stream
+    # (a consumer that overlaps with the next batches' lookups): emb_shard_wait then records an event behind the batch's last
+    # kernel and makes that stream wait for it -- one event between two kernels of the caller's stream per step, which
+    # costs GPU time of its own (a few us on this runtime) whatever the sharding does.
+    consumer_mode = os.environ.get("PIMEMB_BENCH_CONSUMER", "same")
+    consumer = torch.cuda.Stream(dev) if consumer_mode == "other" else None
+    hc = consumer.cuda_stream if consumer is not None else h
 
     def step(i):
         """One call per batch; the consumer's stream is made to wait for the batch that is `depth` submits old."""
@@ -411,6 +417,9 @@ def run_sharded(args, hbm_peak_gbs: float, ctx, rep_bytes: int, mode: str):
                        # one index per bag and no peer behind RCCL: row-split tables are not routed -- every shard scans the
                        # requesters' raw index arrays and serves the bags whose row it holds (PIMEMB_SHARD_DIRECT=0: always route)
                        "direct_one_hot_path": bool(direct),
+                       # where the loop consumes a finished batch: the caller's stream (stream order is the hand-over) or a second
+                       # stream (emb_shard_wait records an event between two kernels of the caller's stream every step)
+                       "consumer_stream": consumer_mode,
                        "placement": {"replicated": plan.kinds.count(sh.REPLICATED), "whole": len(whole), "row_split": len(split),
                                      "rules": sorted(set(n for n in plan.notes if n))},
                        "parallelism": "ONE library call per batch (emb_shard_submit, depth %d): whole tables travel straight out "
