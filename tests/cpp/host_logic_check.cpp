@@ -2,6 +2,10 @@
 // under ThreadSanitizer / AddressSanitizer + UBSan -- see tests/test_host_side_sanitizers.py.  Through the public C ABI only.
 // Checks return codes, tickets and ordering; no lookup result exists here to be looked at.
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -306,6 +310,138 @@ void shard_one_rank(bool peer_mode) {
     printf("shard one rank%s ok\n", peer_mode ? " (peer stores)" : "");
 }
 
+// ---- several ranks as THREADS over a stand-in for emb_comm (pimemb_comm.cpp, the RCCL binding, is not linked here) ----------
+// Sends are copied on the spot, receives wait for the matching send of the same pair (pieces of a pair match in order, as
+// grouped ncclSend / ncclRecv do) and insist on the same byte count: both sides' size arithmetic must agree.
+struct Hub {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<std::deque<std::vector<char>>> q;     // [src * world + dst]
+    int world;
+    explicit Hub(int w) : q((size_t)w * w), world(w) {}
+};
+}  // namespace
+struct emb_comm { int rank; Hub *hub; };
+extern "C" int emb_comm_rank(const emb_comm *c, int32_t *rank, int32_t *world) {
+    *rank = c->rank;
+    *world = c->hub->world;
+    return EMB_OK;
+}
+extern "C" int emb_comm_exchange(emb_comm *c, const emb_comm_op *ops, uint32_t n_ops, void *) {
+    Hub &h = *c->hub;
+    {
+        std::lock_guard<std::mutex> lk(h.mu);
+        for (uint32_t i = 0; i < n_ops; i++)
+            if (!ops[i].is_recv) {
+                const char *p = static_cast<const char *>(ops[i].ptr);
+                h.q[(size_t)c->rank * h.world + ops[i].peer].emplace_back(p, p + ops[i].bytes);
+            }
+    }
+    h.cv.notify_all();
+    for (uint32_t i = 0; i < n_ops; i++)
+        if (ops[i].is_recv) {
+            std::unique_lock<std::mutex> lk(h.mu);
+            auto &q = h.q[(size_t)ops[i].peer * h.world + c->rank];
+            if (!h.cv.wait_for(lk, std::chrono::seconds(60), [&] { return !q.empty(); })) {
+                fprintf(stderr, "rank %d: nothing arrived from rank %d\n", c->rank, ops[i].peer);
+                exit(1);
+            }
+            if (q.front().size() != ops[i].bytes) {
+                fprintf(stderr, "rank %d expects %llu bytes from rank %d, which sent %zu\n", c->rank, (unsigned long long)ops[i].bytes, ops[i].peer, q.front().size());
+                exit(1);
+            }
+            memcpy(ops[i].ptr, q.front().data(), ops[i].bytes);
+            q.pop_front();
+        }
+    return EMB_OK;
+}
+namespace {
+
+void shard_ranks_as_threads(int world) {
+    Hub hub(world);
+    std::atomic<int> finished{0};
+    auto rank_main = [&](int rank) {
+        emb_engine *e = make_engine(0);
+        emb_comm comm{rank, &hub};
+        emb_shard_table tabs[kTables];
+        for (uint32_t t = 0; t < kTables; t++) {
+            tabs[t].placement = t < 2 ? EMB_PLACE_REPLICATED : (t < 4 ? EMB_PLACE_WHOLE : EMB_PLACE_ROWS);
+            tabs[t].owner = (int32_t)(t % (uint32_t)world);
+            tabs[t].engine_table = t;
+            tabs[t].rows_per_shard = kRows;
+        }
+        for (uint32_t depth = 0; depth <= 3; depth++) {
+            emb_shard_config cfg{};
+            cfg.n_tables = kTables;
+            cfg.dim = kDim;
+            cfg.depth = depth;
+            cfg.tables = tabs;
+            emb_shard *s = nullptr;
+            CHECK(emb_shard_create(e, &comm, &cfg, &s));
+            Rng rng{1000ull * (uint64_t)(rank + 1) + depth};
+            constexpr int kSlots = 8;
+            const uint32_t Bmax = 64;
+            std::vector<std::vector<void *>> idx(kSlots), off(kSlots), out(kSlots);
+            for (int k = 0; k < kSlots; k++)
+                for (uint32_t t = 0; t < kTables; t++) {
+                    void *p = nullptr;
+                    CHECK(emb_device_alloc(e, Bmax * 4 * 4, &p)); idx[k].push_back(p);
+                    CHECK(emb_device_alloc(e, Bmax * 4, &p)); off[k].push_back(p);
+                    CHECK(emb_device_alloc(e, (size_t)Bmax * kDim * 4, &p)); out[k].push_back(p);
+                }
+            std::vector<uint64_t> seqs;
+            for (int j = 0; j < 16; j++) {
+                const uint32_t B = (j == 5 && rank == 1) ? 0u : 1 + rng.next() % Bmax;       // every rank has its OWN bags; one is empty once
+                const bool one_hot = j % 3 == 1;
+                emb_shard_input in[kTables];
+                for (uint32_t t = 0; t < kTables; t++) {
+                    std::vector<uint32_t> o(B), ix;
+                    for (uint32_t b = 0; b < B; b++) {
+                        o[b] = (uint32_t)ix.size();
+                        const uint32_t len = one_hot ? 1u : rng.next() % 4;
+                        for (uint32_t k = 0; k < len; k++) ix.push_back(rng.next() % (tabs[t].placement == EMB_PLACE_ROWS ? kRows * (uint32_t)world : kRows));
+                    }
+                    if (!ix.empty()) CHECK(emb_copy_to_device(e, idx[j % kSlots][t], ix.data(), ix.size() * 4));
+                    if (B) CHECK(emb_copy_to_device(e, off[j % kSlots][t], o.data(), B * 4));
+                    in[t] = emb_shard_input{static_cast<const uint32_t *>(idx[j % kSlots][t]), one_hot ? nullptr : static_cast<const uint32_t *>(off[j % kSlots][t]),
+                                            ix.size(), one_hot ? 1u : 0u, 0u, static_cast<float *>(out[j % kSlots][t])};
+                }
+                if (depth == 0) {
+                    CHECK(emb_shard_lookup(s, in, B, nullptr));
+                } else {
+                    uint64_t seq = 0;
+                    CHECK(emb_shard_submit(s, in, B, nullptr, &seq));
+                    seqs.push_back(seq);
+                    if (seqs.size() > depth) {
+                        CHECK(emb_shard_wait(s, seqs.front(), nullptr));
+                        seqs.erase(seqs.begin());
+                    }
+                }
+            }
+            CHECK(emb_shard_flush(s));
+            for (uint64_t q : seqs) CHECK(emb_shard_wait(s, q, nullptr));
+            emb_shard_stats st{};
+            CHECK(emb_shard_get_stats(s, &st, 0));
+            EXPECT(st.n_batches == 16 && st.bytes_to_peers > 0);
+            CHECK(emb_shard_destroy(s));
+            for (int k = 0; k < kSlots; k++)
+                for (uint32_t t = 0; t < kTables; t++) {
+                    CHECK(emb_device_free(e, idx[k][t]));
+                    CHECK(emb_device_free(e, off[k][t]));
+                    CHECK(emb_device_free(e, out[k][t]));
+                }
+        }
+        CHECK(emb_destroy(e));
+        finished++;
+    };
+    std::vector<std::thread> th;
+    for (int r = 0; r < world; r++) th.emplace_back(rank_main, r);
+    for (auto &t : th) t.join();
+    EXPECT(finished.load() == world);
+    for (auto &q : hub.q) EXPECT(q.empty());           // every piece sent was received
+    printf("shard %d ranks as threads ok\n", world);
+}
+
 // ---- the reference's two entry points -------------------------------------------------------------------------------------
 void compat_calls() {
     const uint32_t nt = 3, nc = 8, nb = 16, per = 4;
@@ -337,6 +473,8 @@ int main() {
     queue_threads();
     shard_one_rank(false);
     shard_one_rank(true);
+    shard_ranks_as_threads(2);
+    shard_ranks_as_threads(3);
     compat_calls();
     printf("host logic ok\n");
     return 0;
