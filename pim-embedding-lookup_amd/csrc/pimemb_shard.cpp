@@ -653,12 +653,11 @@ int stage_serve(emb_shard *s, Batch &b) {
         in_w += b.in_words[p];
         served += b.rows_served[p];
     }
-    // ONE launch for everything this call looks up: the replicated tables of the batch being submitted (if it is another
-    // batch: L(n) next to S(n - 2)) and every piece received for this one
+    // ONE launch for everything this call looks up: the replicated tables of the batch being submitted (another batch when
+    // pipelined: L(n) next to S(n - 2); this very batch at depth 0) and every piece received for this one
     Batch *fused_with = (s->local_of && s->local_of != &b) ? s->local_of : nullptr;
-    if (s->local_of == &b) EMB_TRY(launch_local(s));      // depth 0: the same batch -- its L goes first, on its own
     s->descs.clear();
-    if (fused_with) {
+    if (s->local_of) {
         s->descs.swap(s->local);
         s->local.clear();
         s->local_of = nullptr;

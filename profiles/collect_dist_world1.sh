@@ -22,6 +22,10 @@ run c2_rows_direct --shard-mode rows --replicate-mb 64 --steps 400 --warmup 40
 run c4_rows_L1_direct --workload c4 --rows-scale 0.125 --pooling 1 --replicate-mb 64 --steps 400 --warmup 40
 PIMEMB_SHARD_DIRECT=0 PIMEMB_SHARD_SELF_VIA_COMM=1 run c4_rows_L1_self_via_rccl --workload c4 --rows-scale 0.125 --pooling 1 --replicate-mb 64 --steps 400 --warmup 40
 run c4_rows_L1_peer --workload c4 --rows-scale 0.125 --pooling 1 --replicate-mb 64 --steps 400 --warmup 40 --exchange peer
+# ... and with depth 0 (every stage of a batch inside its own call: what the synchronous forward() / apply_emb harness runs)
+PIMEMB_SHARD_DEPTH=0 run c2_rows_direct_depth0 --shard-mode rows --replicate-mb 64 --steps 400 --warmup 40
+PIMEMB_SHARD_DEPTH=0 run c4_rows_L1_direct_depth0 --workload c4 --rows-scale 0.125 --pooling 1 --replicate-mb 64 --steps 400 --warmup 40
+PIMEMB_SHARD_DEPTH=0 PIMEMB_SHARD_DIRECT=0 run c4_rows_L1_depth0 --workload c4 --rows-scale 0.125 --pooling 1 --replicate-mb 64 --steps 400 --warmup 40
 # the same two direct legs with the loop's consumer on a SECOND stream (emb_shard_wait then records an event between two
 # kernels of the caller's stream every step: the cost of that hand-over, whatever the sharding does)
 PIMEMB_BENCH_CONSUMER=other run c2_rows_direct_other_stream --shard-mode rows --replicate-mb 64 --steps 400 --warmup 40
