@@ -460,6 +460,8 @@ int emb_peer_destroy(emb_peer *p);   /* call emb_peer_barrier first: a peer may 
  *   R(b) route + counts out | L(b) local lookup of the replicated tables        at submit(b)
  *   Q(b) host reads the counts, request pieces travel                           at submit(b + d_req)
  *   S(b) ONE fused lookup over every piece received; T(b) pooled rows return    at submit(b + d_serve)
+ *        (L of the batch submitted in that call rides in the same launch: L(b + d_serve) next to S(b) -- at depth 0 the
+ *        batch's own L(b) -- so a call enqueues one lookup kernel; on the direct path the shards' ranged lookups join it too)
  *   U(b) partial rows added in shard order into the caller's buffers            at submit(b + d_un)
  * with (d_req, d_serve, d_un) = (0, 0, 0) for depth 0, (0, 1, 1) for depth 1, (1, 2, 2) for depth 2 and (1, 2, 3) for depth 3:
  * from depth 2 on the counts a rank waits for were sent a whole call earlier, so the host wait is short; at depth 3 the
