@@ -318,6 +318,21 @@ def run_sharded(args, hbm_peak_gbs: float, ctx, rep_bytes: int, mode: str):
         drain()
         verify(it - 1, "pipelined")
 
+    # untimed pre-warm before the W warm-up steps, as in the replica leg and the single-GPU run (disclosed in config): a fresh
+    # process starts with idle clocks, and a recurring launch is served by a prepared plan only from its third sighting on
+    # (three rotations of the batch slots).  Rank 0's clock decides for everyone: submit / flush are collective.
+    prewarm_ms, n_pre, t_pre = float(getattr(args, "prewarm_ms", 250.0) or 0.0), 0, time.perf_counter()
+    while prewarm_ms > 0:
+        for _ in range(4 * NBATCH):
+            step(it)
+            it += 1
+        n_pre += 4 * NBATCH
+        drain()
+        go = torch.tensor([1 if time.perf_counter() - t_pre < prewarm_ms * 1e-3 else 0], dtype=torch.int32,
+                          device=dev if backend == "nccl" else "cpu")
+        dist.broadcast(go, 0)
+        if int(go.item()) == 0:
+            break
     for _ in range(args.warmup):
         step(it)
         it += 1
@@ -420,6 +435,7 @@ def run_sharded(args, hbm_peak_gbs: float, ctx, rep_bytes: int, mode: str):
                        # where the loop consumes a finished batch: the caller's stream (stream order is the hand-over) or a second
                        # stream (emb_shard_wait records an event between two kernels of the caller's stream every step)
                        "consumer_stream": consumer_mode,
+                       "prewarm_ms": prewarm_ms, "prewarm_steps": n_pre,
                        "placement": {"replicated": plan.kinds.count(sh.REPLICATED), "whole": len(whole), "row_split": len(split),
                                      "rules": sorted(set(n for n in plan.notes if n))},
                        "parallelism": "ONE library call per batch (emb_shard_submit, depth %d): whole tables travel straight out "
