@@ -160,7 +160,13 @@ struct emb_shard {
         emb_plan *plan = nullptr;
         uint64_t last_use = 0, seen = 0;
     };
-    std::vector<CachedPlan> plans;                   // recurring lookups (same buffers, same lengths): one emb_plan_launch
+    // recurring lookups (same buffers, same lengths): one emb_plan_launch.  A pipelined loop over R rotating batch slots has R
+    // steady-state launches (L(n) next to S(n - 2)) and as many again each time the pipeline fills and drains (L alone, S
+    // alone): room for all of them, or the first call after a flush rebuilds -- and, evicting, waits for the device (seen:
+    // 0.5 ms in the first submit of a 20-step timed region with 16 entries and 8 slots).
+    static constexpr size_t kPlanCache = 64;
+    std::vector<CachedPlan> plans;
+    std::vector<emb_plan *> retired;                 // evicted plans: destroyed with the shard (emb_plan_destroy waits for the device)
     uint64_t plan_clock = 0;
     Batch ring[kRing];
     uint64_t next_seq = 0;
@@ -303,12 +309,16 @@ int fused_lookup(emb_shard *s, Batch &b, bool cacheable, bool ranged = false) {
                                             : emb_plan_create(s->e, s->descs.data(), n, EMB_IDX_U32, &hit->plan)) == EMB_OK)
                 return emb_plan_launch(hit->plan, s->cs);
         } else {
-            if (s->plans.size() < 16) {
+            if (s->plans.size() < emb_shard::kPlanCache) {
                 s->plans.emplace_back();
                 victim = &s->plans.back();
-            } else if (victim->plan) {       // (destroying a plan waits for the device: only signatures that stopped recurring get here)
-                (void)emb_plan_destroy(victim->plan);
+            } else if (victim->plan) {       // destroying a plan waits for the device: not here, between two launches
+                s->retired.push_back(victim->plan);
                 victim->plan = nullptr;
+                if (s->retired.size() > 4 * emb_shard::kPlanCache) {        // (a caller whose buffers never recur: pay the wait once in a long while)
+                    for (emb_plan *p : s->retired) (void)emb_plan_destroy(p);
+                    s->retired.clear();
+                }
             }
             victim->key.assign(s->descs.begin(), s->descs.end());
             victim->key_lo.clear();
@@ -1174,6 +1184,7 @@ int emb_shard_destroy(emb_shard *s) {
     (void)hipGetLastError();
     for (emb_shard::CachedPlan &c : s->plans)
         if (c.plan) (void)emb_plan_destroy(c.plan);
+    for (emb_plan *p : s->retired) (void)emb_plan_destroy(p);
     for (Batch &b : s->ring) {
         DevBuf *bufs[8] = {&b.req_send, &b.meta, &b.slotmap, &b.counts_in, &b.wc_send, &b.req_recv, &b.ret_send, &b.ret_recv};
         for (DevBuf *d : bufs)

@@ -323,10 +323,10 @@ def run_sharded(args, hbm_peak_gbs: float, ctx, rep_bytes: int, mode: str):
     # (three rotations of the batch slots).  Rank 0's clock decides for everyone: submit / flush are collective.
     prewarm_ms, n_pre, t_pre = float(getattr(args, "prewarm_ms", 250.0) or 0.0), 0, time.perf_counter()
     while prewarm_ms > 0:
-        for _ in range(4 * NBATCH):
+        for _ in range(4 * NBATCH + 1):        # (+ 1: the pipeline fills and drains at every slot phase in turn, as the timed region's will)
             step(it)
             it += 1
-        n_pre += 4 * NBATCH
+        n_pre += 4 * NBATCH + 1
         drain()
         go = torch.tensor([1 if time.perf_counter() - t_pre < prewarm_ms * 1e-3 else 0], dtype=torch.int32,
                           device=dev if backend == "nccl" else "cpu")
@@ -341,14 +341,21 @@ def run_sharded(args, hbm_peak_gbs: float, ctx, rep_bytes: int, mode: str):
     dist.barrier()
     torch.cuda.synchronize()
     check_every = int(os.environ.get("PIMEMB_VERIFY_EVERY", "0"))   # soak mode: verify inside the loop (times mean nothing then)
+    step_clock = [] if os.environ.get("PIMEMB_BENCH_STEP_TIMES") == "1" else None     # where a short timed region's time goes (stderr)
     t0 = time.perf_counter()
     for n in range(args.steps):
         step(it)
         it += 1
+        if step_clock is not None:
+            step_clock.append(time.perf_counter())
         if check_every and (n + 1) % check_every == 0:
             drain()
             verify(it - 1, "soak")
     drain()
+    if step_clock is not None and rank == 0:
+        t_end = time.perf_counter()
+        print("host us per submit: " + " ".join("%.1f" % ((b - a) * 1e6) for a, b in zip([t0] + step_clock[:-1], step_clock)) +
+              " | drain %.1f us" % ((t_end - step_clock[-1]) * 1e6), file=sys.stderr)
     wall_ev, wall_sync = job_times(torch, dist, t0, time.perf_counter(), backend != "nccl", dev)   # drain waited for this rank's K-th step
     st = S.stats(reset=True)
     n_verified = 0
