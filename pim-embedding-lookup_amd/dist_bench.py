@@ -362,7 +362,10 @@ def run_sharded(args, hbm_peak_gbs: float, ctx, rep_bytes: int, mode: str):
     for i in range(max(it - NBATCH, it - args.steps), it):         # what the timed loop left behind: EVERY rotating slot
         verify(i, "timed")
         n_verified += 1
-    last = (it - 1) % NBATCH
+    # The digests below are over ONE batch slot's outputs.  A slot's inputs never change, so what it holds does not depend on
+    # how many steps ran; the slot is the one a run without pre-warm ends on (NBATCH + 2 checked steps, W, K), so the digest
+    # of a command is the same whatever the (time-based) pre-warm did -- and comparable with earlier rounds' lines.
+    last = (NBATCH + 2 + args.warmup + args.steps - 1) % NBATCH
     dump_row_split(torch, S, plan, sh, gen, rank, world, dev, rows_list, T, B, L, dim, NBATCH, last, idx_host, slots[last]["outs"])
     digest = None
     digest_all = None
