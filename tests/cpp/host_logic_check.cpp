@@ -212,8 +212,8 @@ void queue_threads() {
 }
 
 // ---- the sharded call with one rank: every placement, every depth, ragged and one-index batches, peer-store mode -----------
-void shard_one_rank(bool peer_mode) {
-    emb_engine *e = make_engine(0);
+void shard_one_rank(bool peer_mode, emb_engine *shared = nullptr) {
+    emb_engine *e = shared ? shared : make_engine(0);
     emb_peer *peer = nullptr;
     if (peer_mode) {
         char tag[64];
@@ -306,8 +306,20 @@ void shard_one_rank(bool peer_mode) {
         CHECK(emb_peer_barrier(peer));
         CHECK(emb_peer_destroy(peer));
     }
+    if (!shared) {
+        CHECK(emb_destroy(e));
+        printf("shard one rank%s ok\n", peer_mode ? " (peer stores)" : "");
+    }
+}
+
+// several shard objects, each with its own caller thread, on ONE engine (pimemb.h: "several shard objects may share an engine")
+void shards_sharing_an_engine() {
+    emb_engine *e = make_engine(0);
+    std::vector<std::thread> th;
+    for (int t = 0; t < 3; t++) th.emplace_back([e] { shard_one_rank(false, e); });
+    for (auto &t : th) t.join();
     CHECK(emb_destroy(e));
-    printf("shard one rank%s ok\n", peer_mode ? " (peer stores)" : "");
+    printf("three shard objects on one engine ok\n");
 }
 
 // ---- several ranks as THREADS over a stand-in for emb_comm (pimemb_comm.cpp, the RCCL binding, is not linked here) ----------
@@ -473,6 +485,7 @@ int main() {
     queue_threads();
     shard_one_rank(false);
     shard_one_rank(true);
+    shards_sharing_an_engine();
     shard_ranks_as_threads(2);
     shard_ranks_as_threads(3);
     compat_calls();
