@@ -1882,3 +1882,79 @@ def test_ranged_launch_mixes_whole_tables_and_shards(pel, oracle, dim, dtype, B)
             pel.lib.check(L.emb_plan_destroy(plan))
     assert not (idx[1] < whole_rows[1])[5]
     eng.close()
+
+
+@pytest.mark.gpu
+def test_shard_objects_from_two_threads_share_an_engine(pel, oracle):
+    """include/pimemb.h: one caller thread per shard object, several shard objects may share an engine.  Two threads, each with
+    its own ShardedEmbeddingBags (world of one rank: replicated / whole / row-split tables) and its own stream on ONE engine,
+    run routed and direct batches at different depths at the same time; every table of every batch equals the oracle's."""
+    import threading
+    from importlib import import_module
+    import torch
+    sh = import_module("pim-embedding-lookup_amd.sharding")
+    dev = torch.device("cuda", 0)
+    rows, dim = [700, 30_000, 9_000, 20_000, 50], 16
+    kinds = [sh.REPLICATED, sh.ROW_SPLIT, sh.WHOLE, sh.ROW_SPLIT, sh.REPLICATED]
+    units = [sh.Unit(t, -1 if k == sh.REPLICATED else 0, 0, rows[t], t) for t, k in enumerate(kinds)]
+    plan = sh.ShardPlan(1, rows, dim, 4, kinds, units, [[t] for t in range(len(rows))])
+    tabs = [(np.random.default_rng(7 + t).standard_normal((n, dim)) * 0.1).astype(np.float32) for t, n in enumerate(rows)]
+    eng = pel.EmbeddingEngine(device=0, max_tables=len(rows) + 1)
+    for u in units:
+        eng.load_table(u.uid, tabs[u.table])
+    errors = []
+
+    def worker(tid):
+        try:
+            rng = np.random.default_rng(100 + tid)
+            stream = torch.cuda.Stream(dev)
+            with torch.cuda.stream(stream):
+                for depth in (0, 3, 1):
+                    S = sh.ShardedEmbeddingBags(plan, eng, 0, None, depth=depth, check=False)
+                    pending = []
+                    for j in range(30):
+                        nb = int(rng.integers(1, 4000))
+                        one_hot = j % 2 == tid % 2
+                        idx, off = [], []
+                        for n in rows:
+                            if one_hot:
+                                o, ni = np.arange(nb, dtype=np.int64), nb
+                            else:
+                                lens = rng.integers(0, 5, size=nb)
+                                o = np.zeros(nb, np.int64)
+                                o[1:] = np.cumsum(lens)[:-1]
+                                ni = int(lens.sum())
+                            off.append(o)
+                            idx.append(rng.integers(0, n, size=ni).astype(np.int64))
+                        d_i = [torch.from_numpy(i.astype(np.int32)).to(dev) for i in idx]
+                        d_o = [torch.from_numpy(o.astype(np.int32)).to(dev) for o in off]
+                        h = stream.cuda_stream
+                        if one_hot:
+                            seq, outs = S.submit(d_i, None, fixed_pooling=1, stream=h)
+                        else:
+                            seq, outs = S.submit(d_i, d_o, stream=h)
+                        pending.append((seq, outs, idx, off, (d_i, d_o)))
+                        if len(pending) > depth:
+                            q, o_, i_, f_, _keep = pending.pop(0)
+                            S.wait(q, h)
+                            stream.synchronize()
+                            for t in range(len(rows)):
+                                assert np.array_equal(o_[t].cpu().numpy(), oracle.c_bag_sum(tabs[t], i_[t], f_[t])), (tid, depth, j, t)
+                    S.flush()
+                    for q, o_, i_, f_, _keep in pending:
+                        S.wait(q, stream.cuda_stream)
+                        stream.synchronize()
+                        for t in range(len(rows)):
+                            assert np.array_equal(o_[t].cpu().numpy(), oracle.c_bag_sum(tabs[t], i_[t], f_[t])), (tid, depth, "drained", t)
+                    S.close()
+        except Exception:  # noqa: BLE001
+            import traceback
+            errors.append(traceback.format_exc())
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    eng.close()
+    assert not errors, errors[0]
