@@ -488,15 +488,20 @@ def run_sharded(args, hbm_peak_gbs: float, ctx, rep_bytes: int, mode: str):
 
 
 def sharded_traffic_entry(args, mode, world, direct=False):
-    """profiles/traffic.json entry of this sharded command (world-1 PMC passes of the ROUTED step's fused lookup, router and
-    un-router; see profiles/collect_dist_pmc.sh), or None."""
-    if world != 1 or args.batch is not None or direct:
-        return None          # the counters were collected with one rank on the routed path: other pieces / other kernels otherwise
+    """profiles/traffic.json entry of this sharded command (world-1 PMC passes: the ROUTED step's fused lookup, router and
+    un-router, or -- key suffix -direct -- the direct path's one ranged launch; see profiles/collect_dist_pmc.sh), or None."""
+    if world != 1 or args.batch is not None:
+        return None          # the counters were collected with one rank: other pieces / other kernels otherwise
+    rep_mb = getattr(args, "replicate_mb", None)
+    if rep_mb is not None and int(rep_mb) != 64:          # (not given: the auto leg, which shards tables above 64 MiB)
+        return None          # (... and with tables above 64 MiB sharded: another threshold is another placement)
     if getattr(args, "workload", "c2") == "c4" and abs(float(getattr(args, "rows_scale", 1.0) or 1.0) - 0.125) > 1e-9:
         return None          # (C4 is profiled at one of 8 ranks' share of the rows)
     key = "dist-%s-%s-l%d" % (getattr(args, "workload", "c2"), mode, int(getattr(args, "pooling", None) or 0) or 1)
     if getattr(args, "index_dist", None):
         key += "-" + args.index_dist
+    if direct:
+        key += "-direct"
     try:
         import bench
         return bench.measured_traffic(key, "bag_sum")

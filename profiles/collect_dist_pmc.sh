@@ -9,7 +9,10 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 scratch=$root/gpurun_out/prof_${round}/$key
 out=$root/gpurun_out/profiles_${round}
 mkdir -p "$scratch" "$out"
-export PIMEMB_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 PIMEMB_SHARD_DIRECT=0     # (the ROUTED step: router + fused lookup + un-router)
+export PIMEMB_FORCE_DIST=1 MASTER_ADDR=127.0.0.1
+# default: the ROUTED step (router + fused lookup + un-router); DIST_PMC_DIRECT=1: whatever the library picks -- the direct
+# one-hot path for one index per bag (ONE ranged launch per step), or a `whole` placement (ONE fused launch per step)
+if [ -z "$DIST_PMC_DIRECT" ]; then export PIMEMB_SHARD_DIRECT=0; fi
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$scratch/stats" -- python3 "$root/bench.py" --gpus 1 --no-cpu-baseline \
     --steps 200 --warmup 20 "$@" > "$scratch/bench_under_stats.log" 2>&1 || { echo "stats pass failed for $key"; tail -5 "$scratch/bench_under_stats.log"; exit 1; }
