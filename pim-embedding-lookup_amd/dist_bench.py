@@ -469,8 +469,9 @@ def run_sharded(args, hbm_peak_gbs: float, ctx, rep_bytes: int, mode: str):
                          "algorithmic_bytes": alg_bytes, "basis": "algorithmic bytes",
                          "note": "rank 0's lookup launch per step (replicated tables of the newest batch + every piece received for "
                                  "the batch being served: ONE fused launch), HIP events inside the library (emb_shard_set_kernel_timing) over %d extra steps after "
-                                 "the timed region; the whole step (routing, transfers, un-routing) against HBM and xGMI: "
-                                 "roofline.exchange" % nt,
+                                 "the timed region (the brackets cost GPU time themselves: where a step is ONE launch -- the direct path, whole tables "
+                                 "on their owner -- ms_per_step is the tighter bound on that launch); the whole step (routing, transfers, "
+                                 "un-routing) against HBM and xGMI: roofline.exchange" % nt,
                          "kernels": kernels, "exchange": fr},
         })
         if world == 1:
