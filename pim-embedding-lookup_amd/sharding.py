@@ -203,7 +203,10 @@ class ShardedEmbeddingBags:
         raise TypeError(f"indices/offsets must be int32 (uint32 bits) or int64 CUDA tensors, got {x.dtype}")
 
     def prepare(self, indices: Sequence, offsets: Sequence | None = None, fixed_pooling: int = 0, outs: Sequence | None = None):
-        """Descriptor array of one batch (reusable while the tensors stay where they are): (array, n_bags, outs, keep)."""
+        """Descriptor array of one batch (reusable while the tensors stay where they are): (array, n_bags, outs, keep).
+        outs=None allocates the pooled rows: a fresh torch tensor -- or, with a peer group, a fresh block of the ARENA, which is
+        a bump allocator (nothing is freed before PeerGroup.close): a long-running peer-store caller allocates its batch slots
+        once (PeerGroup.empty for indices, offsets and outs) and passes them in, as bench.py --exchange peer does."""
         t = self.torch
         if len(indices) != self.T or (offsets is not None and len(offsets) != self.T):
             raise ValueError("one index (and offset) tensor per table")
