@@ -7,8 +7,9 @@
 //     copies = memcpy, streams / events = small heap objects, everything synchronous;
 //   * kernel launches are NO-OPS -- no lookup is computed here, nothing a test could mistake for a result -- except the
 //     few SIGNALLING kernels whose words the host code waits for: store_word, publish_words, zero_words, validate (counts
-//     out-of-range indices: its verdict steers host control flow) and validate_publish.  They run synchronously inside
-//     hipLaunchKernel, found by the name the compiler registers for them.
+//     out-of-range indices: its verdict steers host control flow), validate_publish, and the routers' COUNTS (they size the
+//     sharded step's transfers; the request pieces themselves stay zero).  They run synchronously inside hipLaunchKernel,
+//     found by the name the compiler registers for them.
 // What the host-logic check asserts is therefore only return codes, tickets, ordering and that the sanitizers stay silent.
 #include <hip/hip_runtime.h>
 
@@ -75,6 +76,53 @@ void emulate_validate(void **args, dim3 grid) {
     }
 }
 
+// The routers' COUNTS (nothing else of their output: request pieces, slots and the rest of `meta` stay zero -- no lookup is
+// computed here): how many sub-bags and indices of every row-split table this rank asks every shard for, and the two peaks.
+// They size every transfer of the sharded step, so with them the host's offset arithmetic runs with real, ragged numbers
+// on every rank (tests/cpp/host_logic_check.cpp: ranks as threads; a receive insists on the byte count its peer sent).
+struct RouteBagTableMirror { const uint32_t *indices, *offsets; uint64_t n_indices; uint32_t fixed_pooling, rows_per_shard; };   // pimemb_kernels.hip
+struct RouteBagParamsMirror { RouteBagTableMirror t[pimemb::kRouteBagMaxTables]; };
+
+void emulate_route_counts(const RouteBagParamsMirror &rp, uint64_t n_bags, uint32_t N, uint32_t K, uint32_t *meta) {
+    auto pad4 = [](uint32_t v) { return (v + 3u) & ~3u; };
+    std::vector<uint32_t> words(N, 0), rows(N, 0);
+    for (uint32_t k = 0; k < K; k++) {
+        const RouteBagTableMirror &t = rp.t[k];
+        std::vector<uint32_t> n_sub(N, 0), n_idx(N, 0);
+        for (uint64_t b = 0; b < n_bags; b++) {
+            uint64_t p = t.offsets ? t.offsets[b] : b * t.fixed_pooling;
+            uint64_t e = t.offsets ? (b + 1 < n_bags ? (uint64_t)t.offsets[b + 1] : t.n_indices) : p + t.fixed_pooling;
+            if (e > t.n_indices) e = t.n_indices;
+            if (p > e) p = e;
+            std::vector<uint32_t> here(N, 0);
+            for (; p < e; p++) {
+                uint64_t d = t.indices[p] / t.rows_per_shard;
+                if (d >= N) d = N - 1;                         // the last shard takes anything beyond
+                here[d]++;
+            }
+            for (uint32_t d = 0; d < N; d++) {
+                n_idx[d] += here[d];
+                n_sub[d] += here[d] ? 1u : 0u;
+            }
+        }
+        for (uint32_t d = 0; d < N; d++) {
+            meta[(d * (K + 1) + k) * 2 + 0] = n_sub[d];
+            meta[(d * (K + 1) + k) * 2 + 1] = n_idx[d];
+            words[d] += pad4(n_sub[d]) + pad4(n_idx[d]);
+            rows[d] += n_sub[d];
+        }
+    }
+    uint32_t peak_w = 0, peak_r = 0;
+    for (uint32_t d = 0; d < N; d++) {
+        if (words[d] > peak_w) peak_w = words[d];
+        if (rows[d] > peak_r) peak_r = rows[d];
+    }
+    for (uint32_t d = 0; d < N; d++) {
+        meta[(d * (K + 1) + K) * 2 + 0] = peak_w;
+        meta[(d * (K + 1) + K) * 2 + 1] = peak_r;
+    }
+}
+
 void emulate(const std::string &name, void **args, dim3 grid) {
     if (name.find("store_word_kernel") != std::string::npos) {
         unsigned long long *w = const_cast<unsigned long long *>(arg<volatile unsigned long long *>(args, 0));
@@ -91,6 +139,13 @@ void emulate(const std::string &name, void **args, dim3 grid) {
         }
         unsigned long long *flag = const_cast<unsigned long long *>(arg<volatile unsigned long long *>(args, 2));
         __atomic_store_n(flag, arg<unsigned long long>(args, 3), __ATOMIC_RELEASE);
+    } else if (name.find("route_bags_place_kernel") != std::string::npos) {          // (rp, n_bags, n_shards, n_tables, work, slots, meta, send)
+        emulate_route_counts(arg<RouteBagParamsMirror>(args, 0), arg<uint64_t>(args, 1), arg<uint32_t>(args, 2), arg<uint32_t>(args, 3),
+                             arg<uint32_t *>(args, 6));
+    } else if (name.find("route_onehot_place_fused_kernel") != std::string::npos || name.find("route_onehot_place_kernel") != std::string::npos) {
+        // (rp, n_bags, n_shards, n_tables, n_blocks, slots, work, meta, send)
+        emulate_route_counts(arg<RouteBagParamsMirror>(args, 0), arg<uint64_t>(args, 1), arg<uint32_t>(args, 2), arg<uint32_t>(args, 3),
+                             arg<uint32_t *>(args, 7));
     } else if (name.find("validate_publish_kernel") != std::string::npos) {
         const pimemb::ValidateCtl *ctl = arg<const pimemb::ValidateCtl *>(args, 0);
         unsigned long long *result = const_cast<unsigned long long *>(arg<volatile unsigned long long *>(args, 1));

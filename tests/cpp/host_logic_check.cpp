@@ -324,7 +324,8 @@ void shards_sharing_an_engine() {
 
 // ---- several ranks as THREADS over a stand-in for emb_comm (pimemb_comm.cpp, the RCCL binding, is not linked here) ----------
 // Sends are copied on the spot, receives wait for the matching send of the same pair (pieces of a pair match in order, as
-// grouped ncclSend / ncclRecv do) and insist on the same byte count: both sides' size arithmetic must agree.
+// grouped ncclSend / ncclRecv do) and insist on the same byte count: both sides' size arithmetic must agree -- for the counts
+// messages, the whole-table transfers and, since the stub's routers count like the real ones, ragged row pieces both ways.
 struct Hub {
     std::mutex mu;
     std::condition_variable cv;
@@ -435,6 +436,7 @@ void shard_ranks_as_threads(int world) {
             emb_shard_stats st{};
             CHECK(emb_shard_get_stats(s, &st, 0));
             EXPECT(st.n_batches == 16 && st.bytes_to_peers > 0);
+            EXPECT(st.served_sub_bags > 0 && st.served_indices >= st.served_sub_bags);       // row pieces really travelled (the stub counts like the router)
             CHECK(emb_shard_destroy(s));
             for (int k = 0; k < kSlots; k++)
                 for (uint32_t t = 0; t < kTables; t++) {
