@@ -8,7 +8,7 @@
 //   * kernel launches are NO-OPS -- no lookup is computed here, nothing a test could mistake for a result -- except the
 //     few SIGNALLING kernels whose words the host code waits for: store_word, publish_words, zero_words, validate (counts
 //     out-of-range indices: its verdict steers host control flow), validate_publish, and the routers' COUNTS (they size the
-//     sharded step's transfers; the request pieces themselves stay zero).  They run synchronously inside hipLaunchKernel,
+//     sharded step's transfers; the request pieces themselves stay zero) and the two mailbox kernels of the peer-store mode.  They run synchronously inside hipLaunchKernel,
 //     found by the name the compiler registers for them.
 // What the host-logic check asserts is therefore only return codes, tickets, ordering and that the sanitizers stay silent.
 #include <hip/hip_runtime.h>
@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "pimemb_internal.h"
+#include "pimemb_peer.h"
 
 namespace {
 
@@ -112,6 +113,21 @@ void emulate_route_counts(const RouteBagParamsMirror &rp, uint64_t n_bags, uint3
             rows[d] += n_sub[d];
         }
     }
+    // ... and where destination d's piece starts (words) and where shard d's partial rows of table k will sit (rows):
+    // meta = counts[N][K+1][2] | base[N][K][2] | piece[N+1] | ret_row0[N][K] | mode   (pimemb_kernels.hip: meta_layout)
+    const uint32_t base = 2 * N * (K + 1), piece = base + 2 * N * K, row0 = piece + N + 1;
+    uint32_t w_at = 0, r_at = 0;
+    for (uint32_t d = 0; d < N; d++) {
+        meta[piece + d] = w_at;
+        w_at += words[d];
+        uint32_t r = r_at;
+        for (uint32_t k = 0; k < K; k++) {
+            meta[row0 + d * K + k] = r;
+            r += meta[(d * (K + 1) + k) * 2 + 0];
+        }
+        r_at += rows[d];
+    }
+    meta[piece + N] = w_at;
     uint32_t peak_w = 0, peak_r = 0;
     for (uint32_t d = 0; d < N; d++) {
         if (words[d] > peak_w) peak_w = words[d];
@@ -146,6 +162,32 @@ void emulate(const std::string &name, void **args, dim3 grid) {
         // (rp, n_bags, n_shards, n_tables, n_blocks, slots, work, meta, send)
         emulate_route_counts(arg<RouteBagParamsMirror>(args, 0), arg<uint64_t>(args, 1), arg<uint32_t>(args, 2), arg<uint32_t>(args, 3),
                              arg<uint32_t *>(args, 7));
+    } else if (name.find("peer_post_kernel") != std::string::npos) {          // (meta, n_row_tables, n_shards, PeerPostArgs, value): the mailbox message
+        const uint32_t *meta = arg<const uint32_t *>(args, 0);
+        const uint32_t Kr = arg<uint32_t>(args, 1), N = arg<uint32_t>(args, 2);
+        const pimemb::PeerPostArgs a = arg<pimemb::PeerPostArgs>(args, 3);
+        const unsigned long long value = arg<unsigned long long>(args, 4);
+        const uint32_t K1 = Kr ? Kr : 1, piece = 2 * N * (K1 + 1) + 2 * N * K1, row0 = piece + N + 1;
+        for (uint32_t p = 0; p < N; p++) {
+            if (a.box[p] == 0) continue;
+            pimemb::PeerMsg *box = reinterpret_cast<pimemb::PeerMsg *>(a.box[p]);
+            uint32_t at = 0;
+            if (Kr) {
+                const uint32_t n = 2 * (Kr + 1);
+                for (uint32_t i = 0; i < n; i++) box->words[i] = meta ? meta[(p * (Kr + 1)) * 2 + i] : 0u;
+                box->words[n] = meta ? meta[piece + p] : 0u;
+                box->words[n + 1] = meta ? meta[row0 + p * Kr] : 0u;
+                at = n + 2;
+            }
+            for (uint32_t i = 0; i < a.n_consts[p]; i++) box->words[at + i] = a.consts[p][i];
+        }
+        for (uint32_t p = 0; p < N; p++)
+            if (a.box[p] != 0)
+                __atomic_store_n(const_cast<unsigned long long *>(&reinterpret_cast<pimemb::PeerMsg *>(a.box[p])->posted), value, __ATOMIC_RELEASE);
+    } else if (name.find("peer_done_kernel") != std::string::npos) {          // (PeerDoneArgs, value)
+        const pimemb::PeerDoneArgs a = arg<pimemb::PeerDoneArgs>(args, 0);
+        for (uint32_t i = 0; i < a.n; i++)
+            __atomic_store_n(const_cast<unsigned long long *>(&reinterpret_cast<pimemb::PeerMsg *>(a.box[i])->served), arg<unsigned long long>(args, 1), __ATOMIC_RELEASE);
     } else if (name.find("validate_publish_kernel") != std::string::npos) {
         const pimemb::ValidateCtl *ctl = arg<const pimemb::ValidateCtl *>(args, 0);
         unsigned long long *result = const_cast<unsigned long long *>(arg<volatile unsigned long long *>(args, 1));

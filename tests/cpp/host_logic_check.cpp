@@ -456,6 +456,104 @@ void shard_ranks_as_threads(int world) {
     printf("shard %d ranks as threads ok\n", world);
 }
 
+// ---- the collective-free exchange with several ranks as threads: one peer group, an IPC handle is the pointer itself --------
+// (AddressSanitizer build only: the hosts poll mailbox words that a peer's KERNEL writes -- here another thread's stub -- with
+// plain volatile loads, which ThreadSanitizer rightly calls a race between threads and which is none between a GPU and a host)
+#if defined(__has_feature)
+#if __has_feature(thread_sanitizer)
+#define HOST_CHECK_TSAN 1
+#endif
+#endif
+void peer_ranks_as_threads(int world) {
+#ifdef HOST_CHECK_TSAN
+    (void)world;
+    printf("peer stores, %d ranks as threads: skipped under ThreadSanitizer\n", world);
+#else
+    char tag[64];
+    snprintf(tag, sizeof tag, "hostcheck-peers-%d-%d", (int)getpid(), world);
+    std::atomic<int> finished{0};
+    auto rank_main = [&](int rank) {
+        emb_engine *e = make_engine(0);
+        emb_peer *peer = nullptr;
+        CHECK(emb_peer_create(e, tag, rank, world, 512ull << 20, &peer));
+        emb_shard_table tabs[kTables];
+        for (uint32_t t = 0; t < kTables; t++) {
+            tabs[t].placement = t < 2 ? EMB_PLACE_REPLICATED : (t < 4 ? EMB_PLACE_WHOLE : EMB_PLACE_ROWS);
+            tabs[t].owner = (int32_t)(t % (uint32_t)world);
+            tabs[t].engine_table = t;
+            tabs[t].rows_per_shard = kRows;
+        }
+        const uint32_t Bmax = 64;
+        constexpr int kSlots = 8;
+        std::vector<std::vector<void *>> idx(kSlots), off(kSlots), out(kSlots);
+        for (int k = 0; k < kSlots; k++)
+            for (uint32_t t = 0; t < kTables; t++) {
+                void *p = nullptr;
+                CHECK(emb_peer_alloc(peer, Bmax * 4 * 4, &p)); idx[k].push_back(p);
+                CHECK(emb_peer_alloc(peer, Bmax * 4, &p)); off[k].push_back(p);
+                CHECK(emb_peer_alloc(peer, (size_t)Bmax * kDim * 4, &p)); out[k].push_back(p);
+            }
+        for (uint32_t depth = 0; depth <= 3; depth++) {
+            emb_shard_config cfg{};
+            cfg.n_tables = kTables;
+            cfg.dim = kDim;
+            cfg.depth = depth;
+            cfg.flags = EMB_SHARD_PEER_STORES;
+            cfg.tables = tabs;
+            cfg.peer = peer;
+            emb_shard *s = nullptr;
+            CHECK(emb_shard_create(e, nullptr, &cfg, &s));
+            Rng rng{77ull * (uint64_t)(rank + 1) + depth};
+            std::vector<uint64_t> seqs;
+            for (int j = 0; j < 24; j++) {
+                const uint32_t B = (j == 5 && rank == 1) ? 0u : 1 + rng.next() % Bmax;
+                const bool one_hot = j % 3 == 1;        // every rank alike: the direct path needs no agreement, but keeps the run simple to read
+                emb_shard_input in[kTables];
+                for (uint32_t t = 0; t < kTables; t++) {
+                    std::vector<uint32_t> o(B), ix;
+                    for (uint32_t b = 0; b < B; b++) {
+                        o[b] = (uint32_t)ix.size();
+                        const uint32_t len = one_hot ? 1u : rng.next() % 4;
+                        for (uint32_t k = 0; k < len; k++) ix.push_back(rng.next() % (tabs[t].placement == EMB_PLACE_ROWS ? kRows * (uint32_t)world : kRows));
+                    }
+                    if (!ix.empty()) CHECK(emb_copy_to_device(e, idx[j % kSlots][t], ix.data(), ix.size() * 4));
+                    if (B) CHECK(emb_copy_to_device(e, off[j % kSlots][t], o.data(), B * 4));
+                    in[t] = emb_shard_input{static_cast<const uint32_t *>(idx[j % kSlots][t]), one_hot ? nullptr : static_cast<const uint32_t *>(off[j % kSlots][t]),
+                                            ix.size(), one_hot ? 1u : 0u, 0u, static_cast<float *>(out[j % kSlots][t])};
+                }
+                if (depth == 0) {
+                    CHECK(emb_shard_lookup(s, in, B, nullptr));
+                } else {
+                    uint64_t seq = 0;
+                    CHECK(emb_shard_submit(s, in, B, nullptr, &seq));
+                    seqs.push_back(seq);
+                    if (seqs.size() > depth) {
+                        CHECK(emb_shard_wait(s, seqs.front(), nullptr));
+                        seqs.erase(seqs.begin());
+                    }
+                }
+            }
+            CHECK(emb_shard_flush(s));
+            for (uint64_t q : seqs) CHECK(emb_shard_wait(s, q, nullptr));
+            emb_shard_stats st{};
+            CHECK(emb_shard_get_stats(s, &st, 0));
+            EXPECT(st.n_batches == 24 && st.bytes_to_peers > 0 && st.served_sub_bags > 0);
+            CHECK(emb_peer_barrier(peer));         // nobody tears its shard down while a peer may still be gathering from this arena
+            CHECK(emb_shard_destroy(s));
+        }
+        CHECK(emb_peer_barrier(peer));
+        CHECK(emb_peer_destroy(peer));
+        CHECK(emb_destroy(e));
+        finished++;
+    };
+    std::vector<std::thread> th;
+    for (int r = 0; r < world; r++) th.emplace_back(rank_main, r);
+    for (auto &t : th) t.join();
+    EXPECT(finished.load() == world);
+    printf("peer stores, %d ranks as threads ok\n", world);
+#endif
+}
+
 // ---- the reference's two entry points -------------------------------------------------------------------------------------
 void compat_calls() {
     const uint32_t nt = 3, nc = 8, nb = 16, per = 4;
@@ -490,6 +588,8 @@ int main() {
     shards_sharing_an_engine();
     shard_ranks_as_threads(2);
     shard_ranks_as_threads(3);
+    peer_ranks_as_threads(2);
+    peer_ranks_as_threads(3);
     compat_calls();
     printf("host logic ok\n");
     return 0;

@@ -79,7 +79,8 @@ def test_library_host_logic_under_sanitizers(tmp_path, sanitizer):
     """The HOST side of the library's own sources -- engine (launch-image rings from several caller threads, plans,
     host-pointer calls, checked calls with one thread handing in bad indices), the request queue (adders, a free-running
     flusher, late collectors), the sharded call with one rank (every placement, depth 0-3, routed and direct batches,
-    peer-store mode) and with two / three ranks as threads over a stand-in for emb_comm, populate_mram / lookup -- compiled host-only (`--cuda-host-only`) and linked against
+    peer-store mode), with two / three ranks as threads over a stand-in for emb_comm and -- ASan leg -- in one peer group
+    (the collective-free exchange: the stub plays the mailbox kernels), populate_mram / lookup -- compiled host-only (`--cuda-host-only`) and linked against
     tests/cpp/hip_runtime_stub.cpp instead of the HIP runtime: kernels are no-ops there except the signalling ones, so what
     is checked is return codes, tickets, ordering and that ThreadSanitizer / AddressSanitizer + UBSan stay silent.  (Removing
     the launch-ring lock makes the TSan leg fail: tried.)  Nothing of this is linked into libpimemb.so."""
