@@ -34,12 +34,16 @@ def test_profile_key_of_a_command():
 def test_traffic_json_entries_are_backed_by_files():
     data = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     keys = [k for k in data if not k.startswith("_")]
-    assert {"c2", "c2-zipf", "c3", "c3-uniform", "c4", "c4-l32", "c5", "dist-c4-rows-l1", "dist-c4-rows-l32"} <= set(keys)
+    assert {"c2", "c2-zipf", "c3", "c3-uniform", "c4", "c4-l32", "c5", "dist-c4-rows-l1", "dist-c4-rows-l32",
+            "dist-c4-rows-l1-direct", "dist-c2-rows-l1-direct", "dist-c2-whole-l1"} <= set(keys)
     for k in keys:
         e = data[k]
         if e.get("round", "r00") >= "r04":          # entries collected from round 4 on are tied to a build and a kernel
             assert len(e["lib_sha256"]) == 64 and len(e["src_sha256"]) == 64 and "bag_sum" in e["kernel"], k
-        if k.startswith("dist-"):                   # the sharded step: lookup entry + router / un-router sub-entries, per step
+        one_launch = k.endswith("-direct") or "-whole-" in k     # direct one-hot path / whole tables: the step IS one lookup launch
+        if one_launch:
+            assert "router" not in e and "unrouter" not in e, k
+        elif k.startswith("dist-"):                 # the routed sharded step: lookup entry + router / un-router sub-entries, per step
             for sub in ("router", "unrouter"):
                 assert e[sub]["traffic_bytes_per_launch"] == e[sub]["read_bytes"] + e[sub]["write_bytes"] > 0
                 assert e[sub]["kernel_avg_ns"] > 0
