@@ -4,7 +4,7 @@
     shard objects re-created with a random pipeline depth and checking on / off, waits that lag by a random amount;
   * the request queue (`RequestQueue`): host and device queues, a random number of random small requests per flush;
   * `emb_lookup_ranged` over whole tables + the shards of row-split tables in one launch, N emulated shards.
-    python tests/soak_round4.py [seconds]      (lives under tests/: the oracle is its checker)"""
+    python tests/soak_round4.py [seconds [seed]]      (lives under tests/: the oracle is its checker)"""
 import ctypes as C
 import os
 import sys
@@ -22,7 +22,8 @@ from oracle import oracle  # noqa: E402  (tool, not product: the checker)
 sh = import_module("pim-embedding-lookup_amd.sharding")
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 dev = torch.device("cuda", 0)
-rng = np.random.default_rng(4)
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+rng = np.random.default_rng(seed)
 L = pel.lib.load()
 t_start = time.time()
 n_calls = {"shard": 0, "queue": 0, "ranged": 0}
@@ -214,4 +215,4 @@ while time.time() - t_start < budget:
     print("  %4.0f s: %s, %d bags checked" % (time.time() - t_start, n_calls, n_bags_checked), flush=True)
 torch.cuda.synchronize()
 eng.close()
-print("soak (round 4): %s calls, %d bags checked against the oracle in %.0f s -- all equal" % (n_calls, n_bags_checked, time.time() - t_start))
+print("soak (round 4, seed %d): %s calls, %d bags checked against the oracle in %.0f s -- all equal" % (seed, n_calls, n_bags_checked, time.time() - t_start))
