@@ -50,6 +50,10 @@ def parse_args():
     ap.add_argument("--nbatch", type=int, default=8, help="distinct index batches rotated through")
     ap.add_argument("--index-dist", choices=["uniform", "zipf"], default=None,
                     help="default: uniform for c2, zipf(1.2) for c3")
+    ap.add_argument("--index-order", choices=["drawn", "sorted"], default="drawn",
+                    help="N=1 experiment (REJECTED_EXPERIMENTS, round 5): 'sorted' hands every table's indices over in ascending row "
+                         "order -- the IDEAL outcome of any locality bucketing of a one-index-per-bag launch (every XCD then sees a "
+                         "disjoint row range, every distinct row is fetched by one L2 only) without paying for the bucketing")
     ap.add_argument("--workload", choices=["c1", "c2", "c3", "c4", "c5"], default="c2",
                     help="c1 = configs[0]'s shape on the GPU (the 26 Kaggle tables, mini-batch 1: launch latency); "
                          "c2 = BASELINE configs[1] (the metric's config, default); c3 = configs[2] scaled "
@@ -72,6 +76,9 @@ def parse_args():
                     help="N>1: big tables placed whole on owner ranks (default for c2: no routing kernel, no copy), split "
                          "by row range over all ranks with GPU-side request routing (balanced xGMI egress; default for c4), or "
                          "whatever the shard planner decides (plan)")
+    ap.add_argument("--checked", action="store_true",
+                    help="sharded legs: create the shard with EMB_SHARD_CHECK_SERVED (one-index batches keep the direct path and count "
+                         "what every shard serves; routed batches validate what they serve)")
     ap.add_argument("--exchange", choices=["rccl", "peer"], default="rccl",
                     help="N>1 sharded legs: how pieces travel between ranks -- grouped ncclSend/ncclRecv issued from C (rccl, default) "
                          "or the collective-free exchange (peer: HIP IPC mappings, the owner gathers a requester's indices in place "
@@ -136,6 +143,8 @@ def profile_key(args, spec):
     default_dist = {"c1": "uniform", "c2": "uniform", "c3": "zipf", "c4": "uniform", "c5": "mixed"}[args.workload]
     if spec["dist"] != default_dist:
         key += "-" + spec["dist"]
+    if getattr(args, "index_order", "drawn") != "drawn":
+        key += "-" + args.index_order
     return key
 
 
@@ -210,7 +219,21 @@ def unique_row_bytes(batch, row_bytes):
     return int(sum(np.unique(i).shape[0] for i in idx)) * row_bytes
 
 
-def roofline_object(alg_bytes, kernel_us, entry, uniq_bytes, meta_bytes=0):
+def unique_line_bytes(batch, row_bytes, line=128):
+    """The same at the granularity the memory system fetches at: every DISTINCT 128-byte line that holds a piece of a named
+    row, once (gfx950 has no 32 / 64-byte sector fetch: tools/sector_probe.hip).  For rows narrower than a line -- dim 16 fp32 =
+    64 B -- this, not unique_row_bytes, is the floor of the table traffic: two rows share a line only when they are neighbours."""
+    idx, _off = batch
+    total = 0
+    for i in idx:
+        if row_bytes >= line:        # (rows of k x 128 B are line-aligned: tables are 256-byte aligned allocations)
+            total += np.unique(i).shape[0] * -(-row_bytes // line)
+        else:                        # the line holding the row's first byte (64-byte rows never straddle)
+            total += np.unique(i.astype(np.int64) * row_bytes // line).shape[0]
+    return int(total) * line
+
+
+def roofline_object(alg_bytes, kernel_us, entry, uniq_bytes, meta_bytes=0, uniq_line_bytes=None):
     """HBM roofline of the dominant kernel, ONE basis on every line: `achieved` / `frac` = ALGORITHMIC bytes per launch
     (cache hits still count) / the launch's duration / the 8 TB/s peak.  A launch that is
     mostly served by L2 / Infinity Cache gathers more than the HBM delivers, so its `frac` can exceed 1: `cache_served`
@@ -241,6 +264,10 @@ def roofline_object(alg_bytes, kernel_us, entry, uniq_bytes, meta_bytes=0):
             r["read_over_unique_rows"] = max(entry["read_bytes"] - meta_bytes, 0) / uniq_bytes
     if uniq_bytes:
         r["unique_row_bytes"] = uniq_bytes
+    if uniq_line_bytes:            # the floor of the table traffic at line granularity; read / it = what bucketing could remove
+        r["unique_line_bytes"] = uniq_line_bytes
+        if entry and entry.get("read_bytes"):
+            r["read_over_unique_lines"] = max(entry["read_bytes"] - meta_bytes, 0) / uniq_line_bytes
     if r["frac"] > 1.0:
         r["basis"] = ("algorithmic bytes; above 1 because most rows were served by L2 / Infinity Cache -- not an HBM "
                       "utilisation" + ("; the HBM-side rate is frac_measured" if r.get("frac_measured") is not None else
@@ -255,7 +282,7 @@ def workload_spec(pel, args):
         dist = args.index_dist or "uniform"
         return dict(rows=pel.workloads.KAGGLE_ROWS, dim=pel.workloads.KAGGLE_DIM, B=B, L=1, dist=dist,
                     name="%s: 26 Criteo-Kaggle tables, dim 16 fp32, B=%d bags/table, L=1, u32 indices+offsets, "
-                         "%s indices" % (args.workload.upper(), B, dist))
+                         "%s indices%s" % (args.workload.upper(), B, dist, ", SORTED per table (ideal bucketing)" if getattr(args, "index_order", "drawn") == "sorted" else ""))
     if args.workload == "c5":
         T = args.tables or 64
         B = args.batch or 16384
@@ -286,7 +313,7 @@ def workload_spec(pel, args):
                      "B=%d bags/table, L=32, u32 indices+offsets, %s indices" % (T, B, dist))
 
 
-def make_batches(pel, spec, nbatch, seed=1):
+def make_batches(pel, spec, nbatch, seed=1, order="drawn"):
     rng = np.random.default_rng(seed)
     def gen(t):
         if spec["dist"] == "uniform" or (spec["dist"] == "mixed" and t % 2 == 1):
@@ -295,8 +322,10 @@ def make_batches(pel, spec, nbatch, seed=1):
     batches = []
     off = pel.workloads.fixed_offsets(spec["B"], spec["L"])
     for _ in range(nbatch):
-        batches.append(([gen(t)(rng, n, spec["B"] * spec["L"]) for t, n in enumerate(spec["rows"])],
-                        [off] * len(spec["rows"])))
+        idx = [gen(t)(rng, n, spec["B"] * spec["L"]) for t, n in enumerate(spec["rows"])]
+        if order == "sorted":      # the ideal outcome of a locality bucketing pre-pass (outputs permute with the bags)
+            idx = [np.sort(i) for i in idx]
+        batches.append((idx, [off] * len(spec["rows"])))
     return batches
 
 
@@ -441,7 +470,7 @@ def run_single(args):
     n_host = T if args.workload in ("c1", "c2") else 2        # c3: 5 GB per table, sample two on the host
     host_tables = make_tables_on_gpu(torch, eng, rows_list, dim, dev, keep_host=n_host if want_cpu else 0,
                                      dtype=spec.get("dtype", "f32"))
-    batches = make_batches(pel, spec, args.nbatch)
+    batches = make_batches(pel, spec, args.nbatch, order=args.index_order)
     if args.hot_rows > 0:
         for t in range(T):
             eng.set_hot_rows(t, pel.workloads.top_rows(batches[0][0][t], args.hot_rows, min_share=0.05))
@@ -559,7 +588,9 @@ def run_single(args):
         "roofline": roofline_object(alg_bytes, kernel_us, measured_traffic(profile_key(args, spec), dominant_kernel),
                                     unique_row_bytes(batches[0], dim * (2 if spec.get("dtype") == "f16" else 4))
                                     if spec["L"] > 1 or spec["dist"] != "uniform" else None,
-                                    meta_bytes=4 * (n_idx + n_bags)),
+                                    meta_bytes=4 * (n_idx + n_bags),
+                                    uniq_line_bytes=unique_line_bytes(batches[0], dim * (2 if spec.get("dtype") == "f16" else 4))
+                                    if spec["L"] == 1 and spec["dist"] != "uniform" else None),
     }
     if want_cpu:
         result["cpu_baseline"] = cpu_baseline(pel, host_tables, batches[0], args.cpu_seconds)

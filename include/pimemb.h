@@ -192,6 +192,20 @@ int emb_lookup_ranged(emb_engine *e, const emb_lookup_desc *descs, const uint64_
 /* The same as a prepared launch (emb_plan_launch / emb_plan_destroy as for any plan): for a sharded step whose buffers recur. */
 int emb_plan_create_ranged(emb_engine *e, const emb_lookup_desc *descs, const uint64_t *row_lo, uint32_t n_descs,
                            emb_plan **out);
+/* COUNTED ranged lookups: served[i] (DEVICE, may be NULL; the array itself may be NULL = emb_lookup_ranged) is a COUNTER
+ * descriptor i's launch ADDS the number of bags it served to: EMB_SERVED_LANES uint32 words, EMB_SERVED_STRIDE bytes apart
+ * (EMB_SERVED_BYTES in all; a wavefront adds to the lane of its workgroup -- atomics on one line would retire one by one),
+ * the count is the sum of the lanes.  The caller zeroes and reads them in stream order.  Each bag of a row-split table has exactly one shard holding its row, so the requester adds the
+ * counts of all shards up: a sum short of its bag count means an index that NO shard holds -- a bag left untouched, which a
+ * checked shard (EMB_SHARD_CHECK_SERVED) reports as EMB_ERR_RANGE on the requesting rank.  The reference never checks
+ * (emb_dpu_lookup.c:113: an out-of-range index is a wild MRAM read). */
+#define EMB_SERVED_LANES 64u
+#define EMB_SERVED_STRIDE 256u
+#define EMB_SERVED_BYTES (EMB_SERVED_LANES * EMB_SERVED_STRIDE)
+int emb_lookup_ranged_counted(emb_engine *e, const emb_lookup_desc *descs, const uint64_t *row_lo, uint32_t *const *served,
+                              uint32_t n_descs, void *stream);
+int emb_plan_create_ranged_counted(emb_engine *e, const emb_lookup_desc *descs, const uint64_t *row_lo,
+                                   uint32_t *const *served, uint32_t n_descs, emb_plan **out);
 
 /* Prepared lookup over DEVICE buffers: descriptors are resolved and uploaded once, every launch is
  * then a single kernel enqueue (graph-capturable: no allocation, copy or sync inside).  The plan

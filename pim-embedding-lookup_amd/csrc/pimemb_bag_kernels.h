@@ -546,7 +546,8 @@ bag_sum_anydim_vec_kernel(const DevDesc *__restrict__ descs, uint32_t dim, uint3
 // ---- v2: wave batches of 64 bags, coalesced bounds, shuffle-distributed, one-hot fast path -------
 // RANGED (the sharded lookup's direct path, pimemb_shard.cpp): one index per bag, and a descriptor serves only the bags
 // whose row falls into [row_lo, row_lo + nr_rows) (row_lo in DevDesc::pad_[0]): out[b] = W[idx[b] - row_lo]; the other bags
-// are left untouched -- another shard of the table writes them, straight into the same output.  A shard scans the
+// are left untouched -- another shard of the table writes them, straight into the same output (pad_[1], if not null: a
+// uint32 counter in HBM the launch adds the number of bags it served to).  A shard scans the
 // requester's RAW index array (its own, or a peer's through its mapping): no router, no counts, no un-router.  A whole
 // table is the range [0, nr_rows), so replicated tables and shards share ONE launch of the tuned kernel.
 template <typename IdxT, int DT, int LPR, class Cfg, bool RANGED = false>
@@ -579,7 +580,11 @@ bag_sum_wavebatch_kernel(const DevDesc *__restrict__ descs, uint32_t chunks_arg,
     const char *__restrict__ wsub = weights + sub * 16u;
     const bool lane_live = sub < chunks;
     uint64_t row_lo = 0;
-    if constexpr (RANGED) row_lo = dp->pad_[0];
+    uint32_t *served_ctr = nullptr;      // RANGED: where this descriptor's launch adds the number of bags it served (or null)
+    if constexpr (RANGED) {
+        row_lo = dp->pad_[0];
+        served_ctr = reinterpret_cast<uint32_t *>(dp->pad_[1]);
+    }
 
     if (tile < n_tiles) {
         const uint64_t step_base = ((uint64_t)tile * kWaves + wave) * (64u * NB);
@@ -637,6 +642,21 @@ bag_sum_wavebatch_kernel(const DevDesc *__restrict__ descs, uint32_t chunks_arg,
                     const uint64_t r = (uint64_t)my[q] - row_lo;       // (wraps far out of range below row_lo)
                     if (r > last_row) len[q] = 0;
                     my[q] = (IdxT)r;
+                }
+            }
+            if constexpr (RANGED) {
+                // Counted launch (a checked shard's direct path): the bags this wavefront serves, one atomic per wavefront,
+                // no return value.  The requester adds the counts of all shards up: a sum short of its bag count means an
+                // index no shard holds -- a bag left untouched (pimemb_shard.cpp: stage_unroute).
+                // A counter is EMB_SERVED_LANES words EMB_SERVED_STRIDE bytes apart, a workgroup adds to lane blockIdx % LANES:
+                // agent-scope atomics on ONE line retire one by one (~5.5 ns each: 8 000 wavefronts of the Kaggle launch on 26
+                // neighbouring words took 44 us against the lookup's 20), spread over lines they cost nothing measurable.
+                if (served_ctr != nullptr) {     // wave-uniform (a scalar load of the descriptor)
+                    uint32_t n = 0;
+#pragma unroll
+                    for (uint32_t q = 0; q < NB; q++) n += (uint32_t)__popcll(__ballot(len[q] != 0u));
+                    uint32_t *slot = served_ctr + (size_t)(blockIdx.x % EMB_SERVED_LANES) * (EMB_SERVED_STRIDE / 4u);
+                    if (lane == 0 && n) (void)__hip_atomic_fetch_add(slot, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
 #pragma unroll

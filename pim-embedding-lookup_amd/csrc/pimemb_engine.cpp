@@ -315,9 +315,12 @@ int cached_xcd_map(emb_engine *e, PlanGroup &g, uint32_t bpt, const std::vector<
 // caller's (the staged copies of a host-pointer call).
 // row_lo: if non-null, a RANGED launch -- descriptor i serves only the bags whose row falls into
 // [row_lo[i], row_lo[i] + the table's rows); one index per bag, uint32 indices, the wave-batch kernels.
+// served (ranged launches only): if non-null, served[i] (may be null) is a uint32 counter in HBM that descriptor i's
+// launch adds the number of bags it served to.
 int resolve(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs, emb_index_type itype,
             const std::vector<const void *> *st_indices, const std::vector<const void *> *st_offsets,
-            const std::vector<float *> *st_out, Resolved *r, bool cache_maps = false, const uint64_t *row_lo = nullptr) {
+            const std::vector<float *> *st_out, Resolved *r, bool cache_maps = false, const uint64_t *row_lo = nullptr,
+            uint32_t *const *served = nullptr) {
     if (itype != EMB_IDX_U32 && itype != EMB_IDX_I64) return fail(EMB_ERR_INVALID, "bad index type");
     if (row_lo && itype != EMB_IDX_U32) return fail(EMB_ERR_INVALID, "ranged lookups take uint32 indices");
     std::map<std::pair<int, uint32_t>, std::vector<uint32_t>> by_shape;
@@ -384,6 +387,7 @@ int resolve(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs, emb_i
             d.fixed_pooling = u.offsets ? 0u : u.fixed_pooling;
             d.n_tiles = (uint32_t)tiles;
             if (row_lo) d.pad_[0] = row_lo[i];
+            if (row_lo && served) d.pad_[1] = (uint64_t)(uintptr_t)served[i];
             if (g.kind == pimemb::KERNEL_HOT) {
                 d.hot_rows = t.hot_rows;
                 d.hot_hash = t.hot_hash;
@@ -1063,12 +1067,17 @@ int emb_lookup(emb_engine *e, uint32_t table_id, const void *indices, uint64_t n
 }
 
 int emb_lookup_ranged(emb_engine *e, const emb_lookup_desc *descs, const uint64_t *row_lo, uint32_t n_descs, void *stream) {
+    return emb_lookup_ranged_counted(e, descs, row_lo, nullptr, n_descs, stream);
+}
+
+int emb_lookup_ranged_counted(emb_engine *e, const emb_lookup_desc *descs, const uint64_t *row_lo, uint32_t *const *served,
+                              uint32_t n_descs, void *stream) {
     if (!e) return fail(EMB_ERR_INVALID, "engine is NULL");
     if (n_descs == 0) return EMB_OK;
     if (!descs || !row_lo) return fail(EMB_ERR_INVALID, "emb_lookup_ranged: NULL argument");
     DeviceGuard g(e->device);
     Resolved r;
-    int rc = resolve(e, descs, n_descs, EMB_IDX_U32, nullptr, nullptr, nullptr, &r, /*cache_maps=*/true, row_lo);
+    int rc = resolve(e, descs, n_descs, EMB_IDX_U32, nullptr, nullptr, nullptr, &r, /*cache_maps=*/true, row_lo, served);
     if (rc) return rc;
     rc = launch_resolved(e, r, EMB_IDX_U32, static_cast<hipStream_t>(stream));
     if (rc) return rc;
@@ -1078,28 +1087,34 @@ int emb_lookup_ranged(emb_engine *e, const emb_lookup_desc *descs, const uint64_
     return EMB_OK;
 }
 
-static int plan_create(emb_engine *e, const emb_lookup_desc *descs, const uint64_t *row_lo, uint32_t n_descs,
-                       emb_index_type itype, emb_plan **out);
+static int plan_create(emb_engine *e, const emb_lookup_desc *descs, const uint64_t *row_lo, uint32_t *const *served,
+                       uint32_t n_descs, emb_index_type itype, emb_plan **out);
 
 int emb_plan_create_ranged(emb_engine *e, const emb_lookup_desc *descs, const uint64_t *row_lo, uint32_t n_descs,
                            emb_plan **out) {
     if (!row_lo) return fail(EMB_ERR_INVALID, "emb_plan_create_ranged: row_lo is NULL");
-    return plan_create(e, descs, row_lo, n_descs, EMB_IDX_U32, out);
+    return plan_create(e, descs, row_lo, nullptr, n_descs, EMB_IDX_U32, out);
+}
+
+int emb_plan_create_ranged_counted(emb_engine *e, const emb_lookup_desc *descs, const uint64_t *row_lo, uint32_t *const *served,
+                                   uint32_t n_descs, emb_plan **out) {
+    if (!row_lo) return fail(EMB_ERR_INVALID, "emb_plan_create_ranged_counted: row_lo is NULL");
+    return plan_create(e, descs, row_lo, served, n_descs, EMB_IDX_U32, out);
 }
 
 int emb_plan_create(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs,
                     emb_index_type itype, emb_plan **out) {
-    return plan_create(e, descs, nullptr, n_descs, itype, out);
+    return plan_create(e, descs, nullptr, nullptr, n_descs, itype, out);
 }
 
-static int plan_create(emb_engine *e, const emb_lookup_desc *descs, const uint64_t *row_lo, uint32_t n_descs,
-                       emb_index_type itype, emb_plan **out) {
+static int plan_create(emb_engine *e, const emb_lookup_desc *descs, const uint64_t *row_lo, uint32_t *const *served,
+                       uint32_t n_descs, emb_index_type itype, emb_plan **out) {
     if (!e || !out) return fail(EMB_ERR_INVALID, "engine or out is NULL");
     *out = nullptr;
     if (!descs || n_descs == 0) return fail(EMB_ERR_INVALID, "plan needs at least one descriptor");
     DeviceGuard g(e->device);
     Resolved r;
-    int rc = resolve(e, descs, n_descs, itype, nullptr, nullptr, nullptr, &r, false, row_lo);
+    int rc = resolve(e, descs, n_descs, itype, nullptr, nullptr, nullptr, &r, false, row_lo, served);
     if (rc) return rc;
     emb_plan *p = new (std::nothrow) emb_plan();
     if (!p) return fail(EMB_ERR_NOMEM, "out of host memory");
@@ -1427,7 +1442,22 @@ int emb_stream_destroy(emb_engine *e, void *stream) {
     if (!e) return fail(EMB_ERR_INVALID, "engine is NULL");
     if (!stream) return EMB_OK;
     DeviceGuard g(e->device);
-    HIP_TRY(hipStreamDestroy(static_cast<hipStream_t>(stream)));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // Launch-image segments still open on this stream would later be closed with an event recorded ON it: drain the stream
+    // and retire them now, so no ring ever touches the handle again (take_image_space's "the caller destroyed that stream"
+    // branch remains for streams the caller made and destroyed with the runtime directly).
+    bool drained = false;
+    for (int rk = 0; rk < kRingPool; rk++) {
+        std::lock_guard<std::mutex> lk(e->ring_mu[rk]);
+        for (DescSlot &sl : e->ring[rk].slots)
+            if (sl.stream == st && sl.used && !sl.pending) {
+                if (!drained) HIP_TRY(hipStreamSynchronize(st));
+                drained = true;
+                sl.used = 0;
+                sl.stream = nullptr;
+            }
+    }
+    HIP_TRY(hipStreamDestroy(st));
     return EMB_OK;
 }
 
@@ -1497,7 +1527,7 @@ struct emb_queue {
 namespace {
 
 // `bytes` of the open generation's pinned staging, 16-byte aligned (host queues).  Blocks are kept for later flushes.
-char *queue_stage(QueueGen &g, size_t bytes) {
+char *queue_stage(QueueGen &g, size_t bytes, int device) {
     bytes = (bytes + 15) / 16 * 16;
     if (bytes > kQueueBlock) return nullptr;
     if (g.block_at < g.blocks.size() && g.block_used + bytes > kQueueBlock) {
@@ -1506,6 +1536,7 @@ char *queue_stage(QueueGen &g, size_t bytes) {
     }
     if (g.block_at >= g.blocks.size()) {
         void *p = nullptr;
+        DeviceGuard dg(device);      // (a client thread's current device need not be the engine's: the block is mapped for THAT GPU)
         if (hipHostMalloc(&p, kQueueBlock, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return nullptr;
         g.blocks.push_back(static_cast<char *>(p));
         g.block_used = 0;
@@ -1574,7 +1605,8 @@ int queue_add_locked(emb_queue *q, const emb_lookup_desc *descs, uint32_t n_desc
         d.n_tiles = (uint32_t)tiles;
         if (q->space == EMB_MEM_HOST) {       // stage the inputs now; the rows come back through the same pinned memory
             const size_t ib = u.n_indices * isz, ob = u.offsets ? u.n_bags * isz : 0, rb = u.n_bags * (size_t)t.dim * 4;
-            char *pi = ib ? queue_stage(g, ib) : nullptr, *po = ob ? queue_stage(g, ob) : nullptr, *pr = rb ? queue_stage(g, rb) : nullptr;
+            const int dev = q->e->device;
+            char *pi = ib ? queue_stage(g, ib, dev) : nullptr, *po = ob ? queue_stage(g, ob, dev) : nullptr, *pr = rb ? queue_stage(g, rb, dev) : nullptr;
             if ((ib && !pi) || (ob && !po) || (rb && !pr)) {
                 undo();
                 return fail(EMB_ERR_UNSUPPORTED, "emb_queue_add: desc %u: a buffer of more than 1 MiB -- not a small request: use emb_lookup_batched", i);

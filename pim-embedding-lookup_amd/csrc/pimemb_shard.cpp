@@ -126,6 +126,11 @@ struct Batch {
     std::vector<uint64_t> out_words, in_words, rows_back, rows_served;
     int deferred_rc = EMB_OK;
     bool direct = false;                // this batch's row-split tables skip router and un-router (see stage_route)
+    // checked shards: what the counted ranged launches served (see stage_serve / stage_unroute)
+    DevBuf chk_ctr;                     // HBM counters [N][Kr + M] (source p: its row-split tables, then the whole tables owned here) + [R] replicated, + the publish kernel's ticket
+    uint32_t *chk_host = nullptr;       // pinned: [R] replicated counts | [Kr + M] what this rank served ITSELF
+    unsigned long long *chk_flags = nullptr;   // pinned: [0] = seq + 1 behind the replicated counts, [1] behind the self counts
+    bool rep_counted = false, self_published = false;
     // optional kernel timing (emb_shard_set_kernel_timing): start / stop around R, L, S, U
     hipEvent_t tev[10] = {};
     bool timed[5] = {false, false, false, false, false}, harvest = false;
@@ -157,6 +162,7 @@ struct emb_shard {
     struct CachedPlan {
         std::vector<emb_lookup_desc> key;
         std::vector<uint64_t> key_lo;                // row ranges of a ranged launch (empty: an ordinary one)
+        std::vector<uint32_t *> key_ctr;             // ... and its served counters (a checked shard's counted launch)
         emb_plan *plan = nullptr;
         uint64_t last_use = 0, seen = 0;
     };
@@ -182,6 +188,10 @@ struct emb_shard {
     bool merge_direct = true;                        // PIMEMB_SHARD_DIRECT_MERGE=0: the direct path's lookup stays a launch of its own (A/B)
     std::vector<uint64_t> row_lo;                    // scratch
     std::vector<emb_lookup_desc> rdescs;             // scratch: the direct path's descriptors (one per source and row-split table)
+    // checked shards count what their ranged launches serve: one counter per descriptor, parallel to descs / local / rdescs
+    std::vector<uint32_t *> desc_ctr, local_ctr, rdesc_ctr;
+    uint32_t max_whole = 0;                          // most whole tables on one owner: the served counts' tail of a mailbox is Kr + max_whole words
+    char range_msg[200] = {0};                       // what a requester-side count mismatch said (emb_last_error of the deferred EMB_ERR_RANGE)
 };
 
 namespace {
@@ -270,6 +280,21 @@ inline uint32_t *sent_counts(const emb_shard *s, const Batch &b) { (void)s; retu
 inline uint32_t *recv_counts(const emb_shard *s, const Batch &b) { return b.counts_host + (size_t)s->N * (s->Kr + 1) * 2; }
 inline uint32_t *recv_whole(const emb_shard *s, const Batch &b) { return b.counts_host + (size_t)s->N * (s->Kr + 1) * 4; }
 
+// checked shards: the served-bag counter of source p's i-th piece (i < Kr: row-split table i; Kr + j: the j-th whole table
+// owned here), the counter of the r-th replicated table, and where the counts for a peer sit in its mailbox
+// (a counter = EMB_SERVED_LANES words spread over EMB_SERVED_BYTES: pimemb.h, emb_lookup_ranged_counted)
+constexpr size_t kCtrWords = EMB_SERVED_BYTES / 4;
+inline size_t n_counters(const emb_shard *s) { return (size_t)s->N * (s->Kr + s->M) + s->rep.size(); }
+inline uint32_t *ctr_of(const emb_shard *s, const Batch &b, uint32_t p, uint32_t i) { return static_cast<uint32_t *>(b.chk_ctr.p) + ((size_t)p * (s->Kr + s->M) + i) * kCtrWords; }
+inline uint32_t *ctr_rep(const emb_shard *s, const Batch &b, uint32_t r) { return static_cast<uint32_t *>(b.chk_ctr.p) + ((size_t)s->N * (s->Kr + s->M) + r) * kCtrWords; }
+inline uint32_t *ctr_ticket(const emb_shard *s, const Batch &b) { return static_cast<uint32_t *>(b.chk_ctr.p) + n_counters(s) * kCtrWords; }
+inline uint32_t served_tail(const emb_shard *s) { return pimemb::kPeerMsgWords - (s->Kr + s->max_whole); }
+inline bool all_one_hot(const std::vector<emb_lookup_desc> &v) {
+    for (const emb_lookup_desc &d : v)
+        if (d.offsets != nullptr || d.fixed_pooling != 1) return false;
+    return true;
+}
+
 // One fused lookup over s->descs on the caller's stream.  A call that recurs byte for byte (same tables, same buffers, same
 // lengths: static batch slots, fixed-size whole-table pieces) is served by a prepared plan from its second sighting on --
 // one kernel enqueue, no descriptor resolution.  A plan holds addresses, never values.  Checked lookups never use plans.
@@ -278,6 +303,8 @@ int fused_lookup(emb_shard *s, Batch &b, bool cacheable, bool ranged = false) {
     const uint32_t n = (uint32_t)s->descs.size();
     if (n == 0) return EMB_OK;
     if (ranged && s->row_lo.size() != n) return fail(EMB_ERR_INVALID, "emb_shard: internal: %u descriptors, %zu row ranges", n, s->row_lo.size());
+    const bool counted = ranged && s->check_served;      // a checked shard's ranged launch counts the bags it serves
+    if (counted && s->desc_ctr.size() != n) return fail(EMB_ERR_INVALID, "emb_shard: internal: %u descriptors, %zu counters", n, s->desc_ctr.size());
     if (s->check_served && !ranged) {
         uint64_t bad = 0;
         int rc = emb_lookup_batched_checked(s->e, s->descs.data(), n, EMB_IDX_U32, EMB_MEM_DEVICE, s->cs, &bad);
@@ -293,8 +320,10 @@ int fused_lookup(emb_shard *s, Batch &b, bool cacheable, bool ranged = false) {
         s->plan_clock++;
         emb_shard::CachedPlan *hit = nullptr, *victim = nullptr;
         for (emb_shard::CachedPlan &c : s->plans) {
-            if (c.key.size() == n && c.key_lo.size() == (ranged ? n : 0u) && memcmp(c.key.data(), s->descs.data(), n * sizeof(emb_lookup_desc)) == 0 &&
-                (!ranged || memcmp(c.key_lo.data(), s->row_lo.data(), n * 8) == 0))
+            if (c.key.size() == n && c.key_lo.size() == (ranged ? n : 0u) && c.key_ctr.size() == (counted ? n : 0u) &&
+                memcmp(c.key.data(), s->descs.data(), n * sizeof(emb_lookup_desc)) == 0 &&
+                (!ranged || memcmp(c.key_lo.data(), s->row_lo.data(), n * 8) == 0) &&
+                (!counted || memcmp(c.key_ctr.data(), s->desc_ctr.data(), n * sizeof(uint32_t *)) == 0))
                 hit = &c;
             if (!victim || c.last_use < victim->last_use) victim = &c;
         }
@@ -305,7 +334,7 @@ int fused_lookup(emb_shard *s, Batch &b, bool cacheable, bool ranged = false) {
                 (void)emb_plan_destroy(hit->plan);
                 hit->plan = nullptr;
             }
-            if (++hit->seen >= 2 && (ranged ? emb_plan_create_ranged(s->e, s->descs.data(), s->row_lo.data(), n, &hit->plan)
+            if (++hit->seen >= 2 && (ranged ? emb_plan_create_ranged_counted(s->e, s->descs.data(), s->row_lo.data(), counted ? s->desc_ctr.data() : nullptr, n, &hit->plan)
                                             : emb_plan_create(s->e, s->descs.data(), n, EMB_IDX_U32, &hit->plan)) == EMB_OK)
                 return emb_plan_launch(hit->plan, s->cs);
         } else {
@@ -323,11 +352,13 @@ int fused_lookup(emb_shard *s, Batch &b, bool cacheable, bool ranged = false) {
             victim->key.assign(s->descs.begin(), s->descs.end());
             victim->key_lo.clear();
             if (ranged) victim->key_lo.assign(s->row_lo.begin(), s->row_lo.end());
+            victim->key_ctr.clear();
+            if (counted) victim->key_ctr.assign(s->desc_ctr.begin(), s->desc_ctr.end());
             victim->seen = 1;
             victim->last_use = s->plan_clock;
         }
     }
-    if (ranged) return emb_lookup_ranged(s->e, s->descs.data(), s->row_lo.data(), n, s->cs);
+    if (ranged) return emb_lookup_ranged_counted(s->e, s->descs.data(), s->row_lo.data(), counted ? s->desc_ctr.data() : nullptr, n, s->cs);
     return emb_lookup_batched(s->e, s->descs.data(), n, EMB_IDX_U32, EMB_MEM_DEVICE, s->cs);
 }
 
@@ -337,6 +368,7 @@ int stage_route(emb_shard *s, Batch &b) {
     g_hp.start();
     b.req_recorded = b.ret_recorded = b.out_recorded = false;
     b.deferred_rc = EMB_OK;
+    b.rep_counted = b.self_published = false;
 
     // One index per bag and no peer behind RCCL (every peer is this rank itself or reachable by loads / stores): the
     // row-split tables need NO routing at all -- every shard scans the requester's raw index array and serves the bags whose
@@ -461,7 +493,7 @@ int stage_route(emb_shard *s, Batch &b) {
             const uint32_t nw = (uint32_t)s->whole_of[p].size();
             c[0] = (uint32_t)rs; c[1] = (uint32_t)(rs >> 32);
             c[2] = (uint32_t)rr; c[3] = (uint32_t)(rr >> 32);
-            c[4] = (uint32_t)b.n_bags; c[5] = nw; c[6] = b.direct ? 1u : 0u; c[7] = 0;
+            c[4] = (uint32_t)b.n_bags; c[5] = nw; c[6] = (b.direct ? 1u : 0u) | (s->check_served ? 2u : 0u); c[7] = 0;
             memcpy(c + kPeerConstHead, b.wc_host + (size_t)s->wc_off[p] * kWholeWords, (size_t)nw * kWholeWords * 4);
             uint32_t extra = 0;
             if (b.direct) {          // where this rank's raw index arrays and output buffers of the row-split tables sit
@@ -488,6 +520,7 @@ int stage_route(emb_shard *s, Batch &b) {
     // L(b): replicated tables, this rank's own bags -- described here, launched by launch_local / together with an older
     // batch's S (stage_serve)
     s->local.clear();
+    s->local_ctr.clear();
     s->local_of = nullptr;
     if (!s->rep.empty() && b.n_bags) {
         for (uint32_t t : s->rep) {
@@ -501,6 +534,7 @@ int stage_route(emb_shard *s, Batch &b) {
             d.n_bags = b.n_bags;
             d.pooled = u.pooled;
             s->local.push_back(d);
+            if (s->check_served) s->local_ctr.push_back(ctr_rep(s, b, (uint32_t)s->local_ctr.size()));
             s->st.local_algorithmic_bytes += u.n_indices * ((uint64_t)s->dim * s->elem_bytes[t] + 4) +
                                              (u.offsets ? b.n_bags * 4 : 0) + b.n_bags * (uint64_t)s->dim * 4;
         }
@@ -516,11 +550,26 @@ int launch_local(emb_shard *s) {
     if (s->local.empty()) return EMB_OK;
     Batch &b = *s->local_of;
     s->descs.swap(s->local);
+    s->desc_ctr.swap(s->local_ctr);
     s->local.clear();
+    s->local_ctr.clear();
     s->local_of = nullptr;
+    // a checked shard whose replicated tables all take one index per bag: the counted ranged launch (a whole table is the
+    // range from row 0) instead of validation kernel + host round trip; the requester -- this rank -- compares at U(b)
+    const bool counted = s->check_served && s->allow_direct && all_one_hot(s->descs);
+    if (counted) s->row_lo.assign(s->descs.size(), 0ull);
     EMB_TRY(tick(s, b, 1, false));
-    EMB_TRY(fused_lookup(s, b, true));
+    EMB_TRY(fused_lookup(s, b, true, /*ranged=*/counted));
     EMB_TRY(tick(s, b, 1, true));
+    if (counted) {
+        pimemb::ServedArgs sa{};
+        sa.seg[sa.n_seg++] = pimemb::ServedSeg{ctr_rep(s, b, 0), b.chk_host, (uint32_t)s->descs.size(), 0u};
+        sa.flag[sa.n_flag] = (unsigned long long)(uintptr_t)&b.chk_flags[0];
+        sa.value[sa.n_flag++] = b.seq + 1;
+        sa.ticket = ctr_ticket(s, b);
+        HIP_TRY(pimemb::launch_served_counts(sa, s->cs));
+        b.rep_counted = true;
+    }
     return EMB_OK;
 }
 
@@ -573,7 +622,10 @@ int stage_request(emb_shard *s, Batch &b) {
             if (w[at + 5] != M) return fail(EMB_ERR_INVALID, "emb_shard: rank %u posted %u whole-table entries, this rank owns %u (different placements?)", p, w[at + 5], M);
             if (M) memcpy(rwhole + (size_t)p * M * kWholeWords, w + at + kPeerConstHead, (size_t)M * kWholeWords * 4);
             b.from[p].n_bags = w[at + 4];
-            b.from[p].direct = w[at + 6] != 0;
+            b.from[p].direct = (w[at + 6] & 1u) != 0;
+            if (((w[at + 6] & 2u) != 0) != s->check_served)
+                return fail(EMB_ERR_INVALID, "emb_shard: rank %u created its shard %s EMB_SHARD_CHECK_SERVED, this rank %s it (the flags must agree)", p,
+                            (w[at + 6] & 2u) ? "with" : "without", s->check_served ? "with" : "without");
             if (b.from[p].direct) {
                 const uint32_t *r = w + at + kPeerConstHead + M * kWholeWords;
                 b.from[p].idx_off.resize(Kr);
@@ -667,11 +719,17 @@ int stage_serve(emb_shard *s, Batch &b) {
     // pipelined: L(n) next to S(n - 2); this very batch at depth 0) and every piece received for this one
     Batch *fused_with = (s->local_of && s->local_of != &b) ? s->local_of : nullptr;
     s->descs.clear();
+    s->desc_ctr.clear();
+    Batch *local_batch = s->local_of;       // whose replicated tables ride in this call's launch (this batch, a younger one, or none)
     if (s->local_of) {
         s->descs.swap(s->local);
+        s->desc_ctr.swap(s->local_ctr);
         s->local.clear();
+        s->local_ctr.clear();
         s->local_of = nullptr;
     }
+    const size_t n_local_descs = s->descs.size();
+    const bool counting = s->check_served;
     uint64_t alg = 0, n_sub = 0, n_idx = 0;
     uint32_t n_piece_descs = 0;
     // row pieces: source s asked for sub-bags of my shard of table k -- an ordinary lookup each
@@ -702,6 +760,7 @@ int stage_serve(emb_shard *s, Batch &b) {
                 d.n_bags = ns;
                 d.pooled = rows_dst + row * dim;
                 s->descs.push_back(d);
+                if (counting) s->desc_ctr.push_back(nullptr);      // (a routed piece has offsets: never part of a counted launch)
                 n_piece_descs++;
                 alg += ni * ((uint64_t)dim * s->elem_bytes[s->rows[k]] + 4) + ns * (4 + (uint64_t)dim * 4);
                 n_sub += ns;
@@ -756,6 +815,7 @@ int stage_serve(emb_shard *s, Batch &b) {
             }
             if (nb) {
                 s->descs.push_back(d);
+                if (counting) s->desc_ctr.push_back(ctr_of(s, b, p, Kr + j));
                 alg += ni * ((uint64_t)dim * s->elem_bytes[t] + 4) + (d.offsets ? nb * 4 : 0) + nb * (uint64_t)dim * 4;
                 n_sub += nb;
                 n_idx += ni;
@@ -769,6 +829,7 @@ int stage_serve(emb_shard *s, Batch &b) {
     // sources that handed their one-index-per-bag row-split tables over directly: scan their raw index arrays, serve the bags
     // whose row this shard holds, straight into their outputs
     s->rdescs.clear();
+    s->rdesc_ctr.clear();
     s->row_lo.clear();
     for (uint32_t p = 0; p < N; p++) {
         const PeerFrom &f = b.from[p];
@@ -790,18 +851,24 @@ int stage_serve(emb_shard *s, Batch &b) {
                 s->st.bytes_to_peers += f.n_bags * 4;       // (+ the rows this shard stores: their number is not known on the host)
             }
             s->rdescs.push_back(d);
+            if (counting) s->rdesc_ctr.push_back(ctr_of(s, b, p, k));
             s->row_lo.push_back((uint64_t)s->rank * s->tabs[t].rows_per_shard);
         }
     }
     // ... in the SAME launch as everything else this call looks up when that is one index per bag as well (a whole table is
     // the range starting at row 0): the tuned one-hot kernel once, over replicated tables, whole tables and shards alike
-    bool one_launch = !s->rdescs.empty() && !s->descs.empty() && !s->check_served && s->merge_direct;
-    if (one_launch)
-        for (const emb_lookup_desc &d : s->descs)
-            if (d.offsets != nullptr || d.fixed_pooling != 1) { one_launch = false; break; }
+    // (a checked shard's merged launch COUNTS what it serves -- the requesters compare at U(b) -- instead of validating first)
+    // ... and a checked shard with no peer behind RCCL takes the counted launch for ANY all-one-index call, row-split tables
+    // or not: counting costs nothing, validating first costs a kernel and a host round trip on the serving rank
+    bool no_comm = true;
+    for (uint32_t p = 0; p < N; p++) no_comm = no_comm && via(s, (int)p) != COMM;
+    const bool one_launch = !s->descs.empty() && s->merge_direct && all_one_hot(s->descs) &&
+                            (!s->rdescs.empty() || (counting && s->allow_direct && no_comm));
+    const bool ranged_launch = one_launch || !s->rdescs.empty();
     if (one_launch) {
         s->row_lo.insert(s->row_lo.begin(), s->descs.size(), 0ull);
         s->descs.insert(s->descs.end(), s->rdescs.begin(), s->rdescs.end());
+        s->desc_ctr.insert(s->desc_ctr.end(), s->rdesc_ctr.begin(), s->rdesc_ctr.end());
         s->rdescs.clear();
         EMB_TRY(tick(s, b, 4, false));
         EMB_TRY(fused_lookup(s, b, /*cacheable=*/n_piece_descs == 0, /*ranged=*/true));
@@ -815,12 +882,43 @@ int stage_serve(emb_shard *s, Batch &b) {
         }
         if (!s->rdescs.empty()) {
             s->descs.swap(s->rdescs);
+            s->desc_ctr.swap(s->rdesc_ctr);
             EMB_TRY(tick(s, b, 4, false));
             EMB_TRY(fused_lookup(s, b, /*cacheable=*/true, /*ranged=*/true));
             EMB_TRY(tick(s, b, 4, true));
         }
     }
-    if (s->peer_mode) {        // behind the lookup (its kernel boundary completes the stores into the peers' HBM): "served"
+    if (counting && (ranged_launch || s->peer_mode)) {
+        // checked: the counters of the counted launch go to whoever asked -- this rank's own pinned words, the tail of a
+        // peer's mailbox -- and the "served" words are raised behind them (this kernel instead of launch_peer_done).  What
+        // went through the checked (validating) launch instead is marked 0xffffffff: "not counted, validated by its server".
+        pimemb::ServedArgs sa{};
+        if (one_launch && n_local_descs && local_batch) {
+            sa.seg[sa.n_seg++] = pimemb::ServedSeg{ctr_rep(s, *local_batch, 0), local_batch->chk_host, (uint32_t)n_local_descs, 0u};
+            sa.flag[sa.n_flag] = (unsigned long long)(uintptr_t)&local_batch->chk_flags[0];
+            sa.value[sa.n_flag++] = local_batch->seq + 1;
+            local_batch->rep_counted = true;
+        }
+        for (uint32_t p = 0; p < N; p++) {
+            const Via how = via(s, (int)p);
+            if (how == COMM) continue;          // (no direct path, no counted launch with a peer behind RCCL)
+            const uint32_t n_counted = one_launch ? Kr + M : (b.from[p].direct ? Kr : 0u);
+            uint32_t *dst = b.chk_host + s->rep.size();
+            if (how == PEER) {
+                pimemb::PeerMsg *box = pimemb::peer_box_dev(s->peer, (int)p, s->rank, (uint32_t)(b.seq % pimemb::kPeerSlots));
+                dst = box->words + served_tail(s);
+                sa.flag[sa.n_flag] = (unsigned long long)(uintptr_t)&box->served;
+                sa.value[sa.n_flag++] = s->peer_tag + b.seq + 1;
+            } else {
+                sa.flag[sa.n_flag] = (unsigned long long)(uintptr_t)&b.chk_flags[1];
+                sa.value[sa.n_flag++] = b.seq + 1;
+                b.self_published = true;
+            }
+            sa.seg[sa.n_seg++] = pimemb::ServedSeg{ctr_of(s, b, p, 0), dst, n_counted, Kr + M - n_counted};
+        }
+        sa.ticket = ctr_ticket(s, b);
+        HIP_TRY(pimemb::launch_served_counts(sa, s->cs));
+    } else if (s->peer_mode) {        // behind the lookup (its kernel boundary completes the stores into the peers' HBM): "served"
         pimemb::PeerDoneArgs da{};
         for (uint32_t p = 0; p < N; p++)
             if (via(s, (int)p) == PEER)
@@ -859,6 +957,60 @@ int stage_serve(emb_shard *s, Batch &b) {
     return EMB_OK;
 }
 
+// Checked shards, on the REQUESTING rank: every bag of a one-index batch has exactly one server -- the replicated copy here, the
+// whole table's owner, or the one shard holding the row -- so the counts of the counted launches must add up to the batch's bag
+// count per table.  A sum short of it is an index no shard holds: a bag nobody wrote (the ranged lookup leaves it untouched).
+// Called at U(b): the launches that counted were enqueued one or more calls ago (depth 0: in this call), the peers' "served"
+// words have been polled; what is left is the wait for this rank's own publish kernels.
+int check_served_counts(emb_shard *s, Batch &b) {
+    const uint32_t N = (uint32_t)s->N, Kr = s->Kr;
+    const uint32_t R = (uint32_t)s->rep.size();
+    auto wait_flag = [&](volatile unsigned long long *w, const char *what) -> int {
+        const double t0 = now_us();
+        for (uint64_t spin = 0; *w != b.seq + 1; spin++)
+            if ((spin & 0xfff) == 0xfff && now_us() - t0 > s->timeout_s * 1e6)
+                return fail(EMB_ERR_DEVICE, "emb_shard: the served counts (%s) of batch %llu did not arrive within %.0f s", what, (unsigned long long)b.seq, s->timeout_s);
+        std::atomic_thread_fence(std::memory_order_acquire);
+        return EMB_OK;
+    };
+    const double t0 = now_us();
+    if (b.rep_counted) EMB_TRY(wait_flag(&b.chk_flags[0], "replicated tables"));
+    if (b.self_published) EMB_TRY(wait_flag(&b.chk_flags[1], "this rank's own pieces"));
+    s->st.us_host_wait_served += now_us() - t0;
+    auto bad = [&](uint32_t t, uint64_t got) {
+        if (b.deferred_rc == EMB_OK)
+            snprintf(s->range_msg, sizeof s->range_msg, "emb_shard: batch %llu, table %u: %llu of %llu bags were served -- the others name rows no rank holds "
+                     "(their pooled rows were left untouched)", (unsigned long long)b.seq, t, (unsigned long long)got, (unsigned long long)b.n_bags);
+        b.deferred_rc = EMB_ERR_RANGE;
+    };
+    // the word shard / owner q published for this rank's i-th piece (0xffffffff: not counted -- q validated it itself)
+    auto word_from = [&](uint32_t q, uint32_t i) -> uint32_t {
+        const Via how = via(s, (int)q);
+        if (how == SELF) return b.self_published ? b.chk_host[R + i] : 0xffffffffu;
+        if (how == PEER) return pimemb::peer_box(s->peer, s->rank, (int)q, (uint32_t)(b.seq % pimemb::kPeerSlots))->words[served_tail(s) + i];
+        return 0xffffffffu;
+    };
+    if (b.rep_counted)
+        for (uint32_t r = 0; r < R; r++)
+            if (b.chk_host[r] != b.n_bags) bad(s->rep[r], b.chk_host[r]);
+    for (uint32_t q = 0; q < N; q++)
+        for (uint32_t j = 0; j < s->whole_of[q].size(); j++) {
+            const uint32_t w = word_from(q, Kr + j);
+            if (w != 0xffffffffu && w != b.n_bags) bad(s->whole_of[q][j], w);
+        }
+    if (b.direct)
+        for (uint32_t k = 0; k < Kr; k++) {
+            uint64_t sum = 0;
+            for (uint32_t q = 0; q < N; q++) {
+                const uint32_t w = word_from(q, k);
+                if (w == 0xffffffffu) return fail(EMB_ERR_INVALID, "emb_shard: rank %u did not count what it served of batch %llu (different EMB_SHARD_* flags?)", q, (unsigned long long)b.seq);
+                sum += w;
+            }
+            if (sum != b.n_bags) bad(s->rows[k], sum);
+        }
+    return EMB_OK;
+}
+
 // ---- U(b): partial rows added in shard order, into the caller's buffers ------------------------------------------------------
 int stage_unroute(emb_shard *s, Batch &b) {
     g_hp.start();
@@ -873,6 +1025,7 @@ int stage_unroute(emb_shard *s, Batch &b) {
         s->st.us_host_wait_served += now_us() - t0;
     }
     if (b.ret_recorded) HIP_TRY(hipStreamWaitEvent(s->cs, b.ev_ret, 0));       // the rows are back (whole tables: already in place)
+    if (s->check_served && b.n_bags) EMB_TRY(check_served_counts(s, b));
     if (s->Kr && b.n_bags && !b.direct) {
         float *outs[pimemb::kRouteBagMaxTables];
         for (uint32_t k = 0; k < s->Kr; k++) outs[k] = b.in[s->rows[k]].pooled;
@@ -914,12 +1067,20 @@ int advance(emb_shard *s, const Lag &lag, bool everything) {
     EMB_TRY(launch_local(s));          // nothing was served in this call: L(n) alone
     for (uint64_t q = first; q < newest; q++) {
         Batch &b = s->ring[q % kRing];
-        if (b.seq == q && b.stage == SERVED && old_enough(q, lag.un)) EMB_TRY(stage_unroute(s, b));
+        if (b.seq == q && b.stage == SERVED && old_enough(q, lag.un)) {
+            EMB_TRY(stage_unroute(s, b));
+            if (b.deferred_rc != EMB_OK) deferred = b.deferred_rc;
+        }
     }
     return deferred;
 }
 
-int range_error() {
+int range_error(emb_shard *s) {
+    if (s->range_msg[0]) {          // found by this rank as the REQUESTER (served counts short of the bag count)
+        const int rc = fail(EMB_ERR_RANGE, "%s", s->range_msg);
+        s->range_msg[0] = 0;
+        return rc;
+    }
     return fail(EMB_ERR_RANGE, "emb_shard: a piece served by this rank named rows outside its table (pooled to zero rows)");
 }
 
@@ -973,7 +1134,7 @@ int emb_shard_create(emb_engine *e, emb_comm *comm, const emb_shard_config *cfg,
     if (const char *t = getenv("PIMEMB_SHARD_TIMEOUT_S")) s->timeout_s = atof(t) > 0 ? atof(t) : s->timeout_s;
     if (const char *t = getenv("PIMEMB_SHARD_DIRECT")) s->allow_direct = t[0] != '0';
     if (const char *t = getenv("PIMEMB_SHARD_DIRECT_MERGE")) s->merge_direct = t[0] != '0';
-    if (cfg->flags & (EMB_SHARD_NO_DIRECT | EMB_SHARD_CHECK_SERVED)) s->allow_direct = false;    // (the ranged lookup validates nothing: a checked shard routes)
+    if (cfg->flags & EMB_SHARD_NO_DIRECT) s->allow_direct = false;
     s->tabs.assign(cfg->tables, cfg->tables + cfg->n_tables);
     s->whole_of.assign((size_t)world, {});
     s->elem_bytes.assign(cfg->n_tables, 0);
@@ -1007,12 +1168,16 @@ int emb_shard_create(emb_engine *e, emb_comm *comm, const emb_shard_config *cfg,
             s->elem_bytes[t] = dt == EMB_F16 ? 2u : 4u;
         }
     }
+    // the ranged (direct-path / counted) launches run on the 16-byte lane-piece kernels only: rows of 16..1024 bytes in 16-byte steps
+    for (uint32_t t = 0; t < s->T; t++)
+        if (s->elem_bytes[t] && (((uint64_t)s->dim * s->elem_bytes[t]) % 16 != 0 || (uint64_t)s->dim * s->elem_bytes[t] > 1024)) s->allow_direct = false;
     if (s->rows.size() > pimemb::kRouteBagMaxTables) return bail(fail(EMB_ERR_UNSUPPORTED, "emb_shard_create: at most %u row-split tables", pimemb::kRouteBagMaxTables));
     if (world > 255) return bail(fail(EMB_ERR_UNSUPPORTED, "emb_shard_create: at most 255 ranks"));
+    for (const auto &w : s->whole_of) s->max_whole = std::max<uint32_t>(s->max_whole, (uint32_t)w.size());
     if (s->peer_mode) {
-        size_t most = 0;
-        for (const auto &w : s->whole_of) most = std::max(most, w.size());
-        if (2 * (s->rows.size() + 1) + 2 + kPeerConstHead + most * kWholeWords + 4 * s->rows.size() > pimemb::kPeerMsgWords)
+        const size_t most = s->max_whole;
+        // (a checked shard keeps the last Kr + max_whole words of a mailbox for the served counts)
+        if (2 * (s->rows.size() + 1) + 2 + kPeerConstHead + most * kWholeWords + 4 * s->rows.size() + (s->check_served ? s->rows.size() + most : 0) > pimemb::kPeerMsgWords)
             return bail(fail(EMB_ERR_UNSUPPORTED, "emb_shard_create: %zu whole tables on one owner do not fit a mailbox message (%u words)", most, pimemb::kPeerMsgWords));
     }
     s->Kr = (uint32_t)s->rows.size();
@@ -1051,6 +1216,18 @@ int emb_shard_create(emb_engine *e, emb_comm *comm, const emb_shard_config *cfg,
         }
         if (err == hipSuccess) err = hipMemset(b.counts_in.p, 0, N * ((s->Kr + 1) * 2 + (size_t)s->M * kWholeWords) * 4 + 64);
         if (err == hipSuccess) err = hipMalloc(&b.wc_send.p, (size_t)s->Wtot * kWholeWords * 4 + 64);
+        if (s->check_served) {       // served-bag counters (zero between uses: the publish kernel reads them with an exchange)
+            const size_t ctr_bytes = n_counters(s) * EMB_SERVED_BYTES + 256;       // (+ the publish kernel's ticket)
+            if (err == hipSuccess) err = hipMalloc(&b.chk_ctr.p, ctr_bytes);
+            if (err == hipSuccess) err = hipMemset(b.chk_ctr.p, 0, ctr_bytes);
+            p = nullptr;
+            if (err == hipSuccess) err = hipHostMalloc(&p, (s->rep.size() + s->Kr + (size_t)s->M) * 4 + 64, hipHostMallocMapped | hipHostMallocCoherent);
+            b.chk_host = static_cast<uint32_t *>(p);
+            p = nullptr;
+            if (err == hipSuccess) err = hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocCoherent);
+            b.chk_flags = static_cast<unsigned long long *>(p);
+            if (b.chk_flags) b.chk_flags[0] = b.chk_flags[1] = 0;
+        }
     }
     if (err != hipSuccess) {
         const int code = fail(err == hipErrorOutOfMemory ? EMB_ERR_NOMEM : EMB_ERR_DEVICE, "emb_shard_create: %s", hipGetErrorString(err));
@@ -1098,7 +1275,7 @@ int emb_shard_submit(emb_shard *s, const emb_shard_input *in, uint64_t n_bags, v
     if (seq) *seq = b.seq;
     rc = advance(s, kLag[s->depth], false);
     s->st.us_host_submit += now_us() - t0;
-    return rc == EMB_ERR_RANGE ? range_error() : rc;
+    return rc == EMB_ERR_RANGE ? range_error(s) : rc;
 }
 
 int emb_shard_flush(emb_shard *s) {
@@ -1108,7 +1285,7 @@ int emb_shard_flush(emb_shard *s) {
     DeviceGuard g(s->device);
     int rc = advance(s, kLag[0], true);     // requests of all, then lookups + returns of all, then un-routing: same order on every rank
     s->st.us_host_submit += now_us() - t0;
-    return rc == EMB_ERR_RANGE ? range_error() : rc;
+    return rc == EMB_ERR_RANGE ? range_error(s) : rc;
 }
 
 int emb_shard_wait(emb_shard *s, uint64_t seq, void *stream) {
@@ -1142,6 +1319,7 @@ int emb_shard_lookup(emb_shard *s, const emb_shard_input *in, uint64_t n_bags, v
 
 int emb_shard_get_stats(emb_shard *s, emb_shard_stats *out, int reset) {
     if (!s || !out) return fail(EMB_ERR_INVALID, "emb_shard_get_stats: NULL argument");
+    DeviceGuard g(s->device);          // (harvest waits for / reads timing events of the shard's GPU)
     for (Batch &b : s->ring)
         if (b.stage == DONE) harvest(s, b);
     *out = s->st;
@@ -1186,9 +1364,11 @@ int emb_shard_destroy(emb_shard *s) {
         if (c.plan) (void)emb_plan_destroy(c.plan);
     for (emb_plan *p : s->retired) (void)emb_plan_destroy(p);
     for (Batch &b : s->ring) {
-        DevBuf *bufs[8] = {&b.req_send, &b.meta, &b.slotmap, &b.counts_in, &b.wc_send, &b.req_recv, &b.ret_send, &b.ret_recv};
+        DevBuf *bufs[9] = {&b.req_send, &b.meta, &b.slotmap, &b.counts_in, &b.wc_send, &b.req_recv, &b.ret_send, &b.ret_recv, &b.chk_ctr};
         for (DevBuf *d : bufs)
             if (d->p && !d->arena) (void)hipFree(d->p);
+        if (b.chk_host) (void)hipHostFree(b.chk_host);
+        if (b.chk_flags) (void)hipHostFree(b.chk_flags);
         if (b.pc_host) (void)hipHostFree(b.pc_host);
         if (b.counts_host) (void)hipHostFree(b.counts_host);
         if (b.wc_host) (void)hipHostFree(b.wc_host);

@@ -239,7 +239,10 @@ def run_sharded(args, hbm_peak_gbs: float, ctx, rep_bytes: int, mode: str):
         peer = sh.PeerGroup(eng, "bench-" + box[0], rank, world, arena_bytes=arena)
     else:
         comm = sh.native_comm(eng, rank, world, always=via)
-    S = sh.ShardedEmbeddingBags(plan, eng, rank, comm, depth=depth, check=False, self_via_comm=via and not use_peer, peer=peer)
+    # --checked: EMB_SHARD_CHECK_SERVED -- what ShardedEmbeddingBags does by default for tensors it does not trust.  One-index
+    # batches keep the direct path and COUNT what every shard serves (the requester compares); routed batches validate first.
+    checked = bool(getattr(args, "checked", False))
+    S = sh.ShardedEmbeddingBags(plan, eng, rank, comm, depth=depth, check=checked, self_via_comm=via and not use_peer, peer=peer)
     S.load_tables(lambda t, lo, hi: table_values(torch, t, lo, hi, dim, dev))
     torch.cuda.empty_cache()
 
@@ -442,6 +445,7 @@ def run_sharded(args, hbm_peak_gbs: float, ctx, rep_bytes: int, mode: str):
                        # one index per bag and no peer behind RCCL: row-split tables are not routed -- every shard scans the
                        # requesters' raw index arrays and serves the bags whose row it holds (PIMEMB_SHARD_DIRECT=0: always route)
                        "direct_one_hot_path": bool(direct),
+                       "checked": checked,      # EMB_SHARD_CHECK_SERVED: served bags counted (direct path) / pieces validated (routed)
                        # where the loop consumes a finished batch: the caller's stream (stream order is the hand-over) or a second
                        # stream (emb_shard_wait records an event between two kernels of the caller's stream every step)
                        "consumer_stream": consumer_mode,

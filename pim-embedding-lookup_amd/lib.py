@@ -127,6 +127,8 @@ SIGNATURES = {
     "emb_queue_destroy": (C.c_int, [_vp]),
     "emb_lookup_ranged": (C.c_int, [_vp, C.POINTER(EmbLookupDesc), C.POINTER(_u64), _u32, _vp]),
     "emb_plan_create_ranged": (C.c_int, [_vp, C.POINTER(EmbLookupDesc), C.POINTER(_u64), _u32, C.POINTER(_vp)]),
+    "emb_lookup_ranged_counted": (C.c_int, [_vp, C.POINTER(EmbLookupDesc), C.POINTER(_u64), C.POINTER(_vp), _u32, _vp]),
+    "emb_plan_create_ranged_counted": (C.c_int, [_vp, C.POINTER(EmbLookupDesc), C.POINTER(_u64), C.POINTER(_vp), _u32, C.POINTER(_vp)]),
     "emb_plan_create": (C.c_int, [_vp, C.POINTER(EmbLookupDesc), _u32, C.c_int, _pp]),
     "emb_plan_launch": (C.c_int, [_vp, _vp]),
     "emb_plan_destroy": (C.c_int, [_vp]),

@@ -8,11 +8,15 @@
 //   * kernel launches are NO-OPS -- no lookup is computed here, nothing a test could mistake for a result -- except the
 //     few SIGNALLING kernels whose words the host code waits for: store_word, publish_words, zero_words, validate (counts
 //     out-of-range indices: its verdict steers host control flow), validate_publish, and the routers' COUNTS (they size the
-//     sharded step's transfers; the request pieces themselves stay zero) and the two mailbox kernels of the peer-store mode.  They run synchronously inside hipLaunchKernel,
+//     sharded step's transfers; the request pieces themselves stay zero), the two mailbox kernels of the peer-store mode, and the served-bag
+//     COUNTERS of a checked shard's counted ranged launch with the kernel that publishes them.  They run synchronously inside hipLaunchKernel,
 //     found by the name the compiler registers for them.
 // What the host-logic check asserts is therefore only return codes, tickets, ordering and that the sanitizers stay silent.
 #include <hip/hip_runtime.h>
+#include <sanitizer/common_interface_defs.h>
 
+#include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -33,8 +37,40 @@ std::map<const void *, std::string> &registry() { static std::map<const void *, 
 struct CallCfg { dim3 grid, block; size_t shmem; hipStream_t stream; };
 thread_local std::vector<CallCfg> t_cfg;
 
-struct FakeStream { int id; };
-struct FakeEvent { int recorded; };
+struct FakeStream { int device; };
+struct FakeEvent { int recorded; int device; };
+
+// ---- devices: the stub plays a node with several GPUs ----------------------------------------------------------------------
+// The current device is per THREAD and starts at 0, as in the real runtime -- a helper thread the library starts must select
+// its engine's device itself.  pimemb_stub_expect_device(d) arms a check: from then on every HIP call (but the three that
+// query / select devices and the error getters) must be made with device d current, on streams and events created on device d;
+// a call that is not counts as a violation and is named on stderr.  An engine / queue / shard / peer group created on device 1
+// by a thread whose current device stays 0 must come through its whole life without one (tests/cpp/host_logic_check.cpp).
+std::atomic<int> g_device_count{1}, g_expect_device{-1};
+std::atomic<long> g_violations{0}, g_tracked_calls{0};
+thread_local int t_device = 0;
+
+void track(const char *what, int object_device = -1) {
+    const int want = g_expect_device.load(std::memory_order_relaxed);
+    if (want < 0) return;
+    if (object_device == -2) object_device = -1;           // (a stale stream handle: refused by the call itself)
+    g_tracked_calls.fetch_add(1, std::memory_order_relaxed);
+    if (t_device != want || (object_device >= 0 && object_device != want)) {
+        if (g_violations.fetch_add(1) < 20 && getenv("PIMEMB_STUB_STACKS")) __sanitizer_print_stack_trace();     // (where from?)
+        if (g_violations.load() <= 20)
+            fprintf(stderr, "[hip stub] %s: device %d current%s, the engine under test lives on device %d\n", what, t_device,
+                    object_device >= 0 && object_device != want ? " (and the stream / event belongs to another device)" : "", want);
+    }
+}
+// live streams (a handle the caller destroyed is refused like the real runtime refuses it -- never dereferenced)
+std::mutex &stream_mu() { static std::mutex m; return m; }
+std::map<hipStream_t, int> &streams() { static std::map<hipStream_t, int> m; return m; }
+int stream_device(hipStream_t s) {
+    if (!s) return -1;
+    std::lock_guard<std::mutex> lk(stream_mu());
+    auto it = streams().find(s);
+    return it == streams().end() ? -2 : it->second;
+}
 
 template <typename T> T arg(void **args, int i) { return *static_cast<T *>(args[i]); }
 
@@ -139,8 +175,55 @@ void emulate_route_counts(const RouteBagParamsMirror &rp, uint64_t n_bags, uint3
     }
 }
 
+// The COUNTED ranged lookup of a checked shard's direct path: no row is gathered here, but the per-descriptor counters of
+// served bags steer host control flow (the requester compares their sum with its bag count), so they are produced: the
+// number of indices inside [row_lo, row_lo + nr_rows), added to the counter the descriptor names in pad_[1].
+void emulate_ranged_counts(void **args, dim3 grid) {
+    using pimemb::DevDesc;
+    const DevDesc *descs = arg<const DevDesc *>(args, 0);
+    const uint32_t chunks_arg = arg<uint32_t>(args, 1);
+    const uint32_t *xmap = arg<const uint32_t *>(args, 2);
+    std::vector<uint32_t> ids;
+    if (!xmap) {
+        for (uint32_t d = 0; d < grid.y; d++) ids.push_back(d);
+    } else if (chunks_arg & pimemb::kXmapDirect) {
+        for (uint32_t b = 0; b < grid.x; b++)
+            if (xmap[2 * b] != 0xffffffffu) ids.push_back(xmap[2 * b]);
+    } else {
+        uint32_t n_seg = 0;
+        for (uint32_t c = 0; c < 8; c++) n_seg += xmap[c];
+        for (uint32_t i = 0; i < n_seg; i++) ids.push_back(xmap[16 + 4 * i]);
+    }
+    std::sort(ids.begin(), ids.end());
+    ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+    for (uint32_t d : ids) {
+        const DevDesc &dd = descs[d];
+        uint32_t *ctr = reinterpret_cast<uint32_t *>(dd.pad_[1]);
+        if (!ctr || dd.n_tiles == 0) continue;
+        const uint32_t *idx = static_cast<const uint32_t *>(dd.indices);
+        uint32_t n = 0;
+        for (uint64_t b = 0; b < dd.n_bags; b++)
+            if ((uint64_t)idx[b] - dd.pad_[0] < dd.nr_rows) n++;
+        __atomic_fetch_add(ctr + (size_t)(d % EMB_SERVED_LANES) * (EMB_SERVED_STRIDE / 4), n, __ATOMIC_RELAXED);      // (any lane of the counter)
+    }
+}
+
 void emulate(const std::string &name, void **args, dim3 grid) {
-    if (name.find("store_word_kernel") != std::string::npos) {
+    if (name.find("bag_sum_wavebatch_kernel") != std::string::npos && name.find("EELb1EEEvPK") != std::string::npos) {
+        emulate_ranged_counts(args, grid);
+    } else if (name.find("served_counts_kernel") != std::string::npos) {
+        const pimemb::ServedArgs a = arg<pimemb::ServedArgs>(args, 0);
+        for (uint32_t i = 0; i < a.n_seg; i++) {
+            for (uint32_t j = 0; j < a.seg[i].n_counted; j++) {       // a counter = EMB_SERVED_LANES words, EMB_SERVED_STRIDE bytes apart
+                uint32_t sum = 0;
+                for (uint32_t l = 0; l < EMB_SERVED_LANES; l++)
+                    sum += __atomic_exchange_n(a.seg[i].ctr + (size_t)j * (EMB_SERVED_BYTES / 4) + (size_t)l * (EMB_SERVED_STRIDE / 4), 0u, __ATOMIC_RELAXED);
+                a.seg[i].dst[j] = sum;
+            }
+            for (uint32_t j = 0; j < a.seg[i].n_fill; j++) a.seg[i].dst[a.seg[i].n_counted + j] = 0xffffffffu;
+        }
+        for (uint32_t j = 0; j < a.n_flag; j++) __atomic_store_n(reinterpret_cast<unsigned long long *>(a.flag[j]), a.value[j], __ATOMIC_RELEASE);
+    } else if (name.find("store_word_kernel") != std::string::npos) {
         unsigned long long *w = const_cast<unsigned long long *>(arg<volatile unsigned long long *>(args, 0));
         __atomic_store_n(w, arg<unsigned long long>(args, 1), __ATOMIC_RELEASE);
     } else if (name.find("zero_words_kernel") != std::string::npos) {
@@ -231,7 +314,8 @@ hipError_t __hipPopCallConfiguration(dim3 *grid, dim3 *block, size_t *shmem, hip
     return hipSuccess;
 }
 
-hipError_t hipLaunchKernel(const void *fn, dim3 grid, dim3 block, void **args, size_t, hipStream_t) {
+hipError_t hipLaunchKernel(const void *fn, dim3 grid, dim3 block, void **args, size_t, hipStream_t stream) {
+    track("hipLaunchKernel", stream_device(stream));
     if (grid.x == 0 || grid.y == 0 || grid.z == 0 || block.x == 0 || block.x * block.y * block.z > 1024u) return hipErrorInvalidConfiguration;
     std::string name;
     {
@@ -246,62 +330,94 @@ hipError_t hipLaunchKernel(const void *fn, dim3 grid, dim3 block, void **args, s
 
 hipError_t hipGetLastError(void) { return hipSuccess; }
 const char *hipGetErrorString(hipError_t) { return "stub"; }
-hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
-hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
-hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidDevice; }
-hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
-
-hipError_t hipMalloc(void **p, size_t n) {
-    *p = calloc(n ? n : 1, 1);
-    return *p ? hipSuccess : hipErrorOutOfMemory;
-}
-hipError_t hipFree(void *p) { free(p); return hipSuccess; }
-hipError_t hipHostMalloc(void **p, size_t n, unsigned int) {
-    *p = calloc(n ? n : 1, 1);
-    return *p ? hipSuccess : hipErrorOutOfMemory;
-}
-hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
-hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { if (n) memcpy(d, s, n); return hipSuccess; }
-hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { if (n) memcpy(d, s, n); return hipSuccess; }
-hipError_t hipMemset(void *d, int v, size_t n) { if (n) memset(d, v, n); return hipSuccess; }
-hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { if (n) memset(d, v, n); return hipSuccess; }
-
-hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned int) {
-    *s = reinterpret_cast<hipStream_t>(new FakeStream{1});
+hipError_t hipGetDeviceCount(int *n) { *n = g_device_count.load(); return hipSuccess; }
+hipError_t hipGetDevice(int *d) { *d = t_device; return hipSuccess; }
+hipError_t hipSetDevice(int d) {
+    if (d < 0 || d >= g_device_count.load()) return hipErrorInvalidDevice;
+    t_device = d;
     return hipSuccess;
 }
-hipError_t hipStreamDestroy(hipStream_t s) { delete reinterpret_cast<FakeStream *>(s); return hipSuccess; }
-hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
-hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
-hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned int) { return hipSuccess; }
+hipError_t hipDeviceSynchronize(void) { track("hipDeviceSynchronize"); return hipSuccess; }
 
-hipError_t hipEventCreate(hipEvent_t *e) { *e = reinterpret_cast<hipEvent_t>(new FakeEvent{0}); return hipSuccess; }
+hipError_t hipMalloc(void **p, size_t n) {
+    track("hipMalloc");
+    *p = calloc(n ? n : 1, 1);
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+hipError_t hipFree(void *p) { track("hipFree"); free(p); return hipSuccess; }
+hipError_t hipHostMalloc(void **p, size_t n, unsigned int) {
+    track("hipHostMalloc");
+    *p = calloc(n ? n : 1, 1);
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+hipError_t hipHostFree(void *p) { track("hipHostFree"); free(p); return hipSuccess; }
+hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { track("hipMemcpy"); if (n) memcpy(d, s, n); return hipSuccess; }
+hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t st) { track("hipMemcpyAsync", stream_device(st)); if (n) memcpy(d, s, n); return hipSuccess; }
+hipError_t hipMemset(void *d, int v, size_t n) { track("hipMemset"); if (n) memset(d, v, n); return hipSuccess; }
+hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t st) { track("hipMemsetAsync", stream_device(st)); if (n) memset(d, v, n); return hipSuccess; }
+
+hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned int) {
+    track("hipStreamCreateWithFlags");
+    *s = reinterpret_cast<hipStream_t>(new FakeStream{t_device});
+    std::lock_guard<std::mutex> lk(stream_mu());
+    streams()[*s] = t_device;
+    return hipSuccess;
+}
+hipError_t hipStreamDestroy(hipStream_t s) {
+    const int dev = stream_device(s);
+    if (dev == -2) return hipErrorInvalidHandle;
+    track("hipStreamDestroy", dev);
+    {
+        std::lock_guard<std::mutex> lk(stream_mu());
+        streams().erase(s);
+    }
+    delete reinterpret_cast<FakeStream *>(s);
+    return hipSuccess;
+}
+hipError_t hipStreamSynchronize(hipStream_t s) { track("hipStreamSynchronize", stream_device(s)); return hipSuccess; }
+hipError_t hipStreamQuery(hipStream_t s) { track("hipStreamQuery", stream_device(s)); return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t, unsigned int) { track("hipStreamWaitEvent", stream_device(s)); return hipSuccess; }
+
+hipError_t hipEventCreate(hipEvent_t *e) { track("hipEventCreate"); *e = reinterpret_cast<hipEvent_t>(new FakeEvent{0, t_device}); return hipSuccess; }
 hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
-hipError_t hipEventDestroy(hipEvent_t e) { delete reinterpret_cast<FakeEvent *>(e); return hipSuccess; }
-hipError_t hipEventRecord(hipEvent_t e, hipStream_t) {
+hipError_t hipEventDestroy(hipEvent_t e) { track("hipEventDestroy", reinterpret_cast<FakeEvent *>(e)->device); delete reinterpret_cast<FakeEvent *>(e); return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) {
+    const int sdev = stream_device(s);
+    if (sdev == -2) return hipErrorInvalidHandle;          // a destroyed stream
+    track("hipEventRecord", reinterpret_cast<FakeEvent *>(e)->device);
+    // (the real runtime refuses an event of one device on a stream of another)
+    if (s && sdev != reinterpret_cast<FakeEvent *>(e)->device) return hipErrorInvalidHandle;
     __atomic_store_n(&reinterpret_cast<FakeEvent *>(e)->recorded, 1, __ATOMIC_RELAXED);
     return hipSuccess;
 }
-hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
-hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
-hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.001f; return hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t e) { track("hipEventSynchronize", reinterpret_cast<FakeEvent *>(e)->device); return hipSuccess; }
+hipError_t hipEventQuery(hipEvent_t e) { track("hipEventQuery", reinterpret_cast<FakeEvent *>(e)->device); return hipSuccess; }
+hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { track("hipEventElapsedTime"); *ms = 0.001f; return hipSuccess; }
+
+// ---- test controls (tests/cpp/host_logic_check.cpp) ----
+void pimemb_stub_set_device_count(int n) { g_device_count.store(n); }
+void pimemb_stub_expect_device(int d) { g_expect_device.store(d); }
+long pimemb_stub_violations(void) { return g_violations.load(); }
+long pimemb_stub_tracked_calls(void) { return g_tracked_calls.load(); }
 
 }  // extern "C"
 
 // ---- what csrc/pimemb_peer.cpp needs for a group of ONE process (an IPC handle is the pointer itself) ------------------------
 extern "C" {
 hipError_t hipExtMallocWithFlags(void **p, size_t n, unsigned int) { return hipMalloc(p, n); }
-hipError_t hipHostRegister(void *, size_t, unsigned int) { return hipSuccess; }
-hipError_t hipHostUnregister(void *) { return hipSuccess; }
-hipError_t hipHostGetDevicePointer(void **dev, void *host, unsigned int) { *dev = host; return hipSuccess; }
+hipError_t hipHostRegister(void *, size_t, unsigned int) { track("hipHostRegister"); return hipSuccess; }
+hipError_t hipHostUnregister(void *) { track("hipHostUnregister"); return hipSuccess; }
+hipError_t hipHostGetDevicePointer(void **dev, void *host, unsigned int) { track("hipHostGetDevicePointer"); *dev = host; return hipSuccess; }
 hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t *h, void *p) {
+    track("hipIpcGetMemHandle");
     memset(h, 0, sizeof(*h));
     memcpy(h, &p, sizeof(p));
     return hipSuccess;
 }
 hipError_t hipIpcOpenMemHandle(void **p, hipIpcMemHandle_t h, unsigned int) {
+    track("hipIpcOpenMemHandle");
     memcpy(p, &h, sizeof(*p));
     return hipSuccess;
 }
-hipError_t hipIpcCloseMemHandle(void *) { return hipSuccess; }
+hipError_t hipIpcCloseMemHandle(void *) { track("hipIpcCloseMemHandle"); return hipSuccess; }
 }

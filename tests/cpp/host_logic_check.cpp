@@ -13,6 +13,8 @@
 #include <unistd.h>
 #include <vector>
 
+#include <hip/hip_runtime.h>      // (hipGetDevice of the stub: "is the caller's current device untouched?")
+
 #include "pimemb.h"
 
 #define CHECK(x)                                                                                          \
@@ -34,27 +36,34 @@
 namespace {
 
 constexpr uint32_t kTables = 6, kDim = 16, kRows = 1000;
+constexpr uint32_t kMaxTables = 26;
+
+// test controls of tests/cpp/hip_runtime_stub.cpp (several devices, "which device was current at every HIP call")
+extern "C" void pimemb_stub_set_device_count(int n);
+extern "C" void pimemb_stub_expect_device(int d);
+extern "C" long pimemb_stub_violations(void);
+extern "C" long pimemb_stub_tracked_calls(void);
 
 struct Rng {
     uint64_t s;
     uint32_t next() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (uint32_t)(s >> 11); }
 };
 
-emb_engine *make_engine(uint32_t flags) {
+emb_engine *make_engine(uint32_t flags, int device = 0, uint32_t n_tables = kTables) {
     emb_config cfg{};
-    cfg.device = 0;
-    cfg.max_tables = kTables + 4;
+    cfg.device = device;
+    cfg.max_tables = n_tables + 4;
     cfg.flags = flags;
     emb_engine *e = nullptr;
     CHECK(emb_create(&cfg, &e));
     std::vector<float> rows((size_t)kRows * kDim, 0.5f);
-    for (uint32_t t = 0; t < kTables; t++) CHECK(emb_load_table(e, t, kRows, kDim, EMB_F32, rows.data(), EMB_MEM_HOST));
+    for (uint32_t t = 0; t < n_tables; t++) CHECK(emb_load_table(e, t, kRows, kDim, EMB_F32, rows.data(), EMB_MEM_HOST));
     return e;
 }
 
 // ---- several caller threads on one engine: transient launches, plans, host-pointer calls, checked calls -------------------
-void engine_threads() {
-    emb_engine *e = make_engine(0);
+void engine_threads(int device = 0, int n_threads = 4) {
+    emb_engine *e = make_engine(0, device);
     std::atomic<int> range_errors{0};
     auto worker = [&](int tid) {
         Rng rng{0x9E3779B97F4A7C15ull * (uint64_t)(tid + 1)};
@@ -114,7 +123,7 @@ void engine_threads() {
         CHECK(emb_stream_destroy(e, stream));
     };
     std::vector<std::thread> th;
-    for (int t = 0; t < 4; t++) th.emplace_back(worker, t);
+    for (int t = 0; t < n_threads; t++) th.emplace_back(worker, t);
     for (auto &t : th) t.join();
     EXPECT(range_errors.load() > 0);
     emb_stats st{};
@@ -125,8 +134,8 @@ void engine_threads() {
 }
 
 // ---- the request queue: adders, a free-running flusher, waiters that collect late ------------------------------------------
-void queue_threads() {
-    emb_engine *e = make_engine(0);
+void queue_threads(int device = 0) {
+    emb_engine *e = make_engine(0, device);
     emb_queue *q = nullptr;
     CHECK(emb_queue_create(e, EMB_IDX_U32, EMB_MEM_HOST, &q));
     std::atomic<bool> stop{false};
@@ -211,104 +220,154 @@ void queue_threads() {
     printf("queue threads ok\n");
 }
 
-// ---- the sharded call with one rank: every placement, every depth, ragged and one-index batches, peer-store mode -----------
-void shard_one_rank(bool peer_mode, emb_engine *shared = nullptr) {
-    emb_engine *e = shared ? shared : make_engine(0);
-    emb_peer *peer = nullptr;
-    if (peer_mode) {
-        char tag[64];
-        snprintf(tag, sizeof tag, "hostcheck-%d", (int)getpid());
-        CHECK(emb_peer_create(e, tag, 0, 1, 64ull << 20, &peer));
-    }
-    emb_shard_table tabs[kTables];
-    for (uint32_t t = 0; t < kTables; t++) {
-        tabs[t].placement = t < 2 ? EMB_PLACE_REPLICATED : (t < 4 ? EMB_PLACE_WHOLE : EMB_PLACE_ROWS);
-        tabs[t].owner = 0;
+// ---- the sharded call -------------------------------------------------------------------------------------------------------
+// Placement mixes: SMALL = the six tables of the earlier rounds (2 replicated, 2 whole, 2 row-split); C4 = the mix the planner
+// gives BASELINE configs[3] at 8 ranks (26 tables: 20 replicated, 6 split by row range); C5 = configs[4]'s (every table
+// whole on an owner rank, two per rank at world 8).
+enum Mix { MIX_SMALL = 0, MIX_C4 = 1, MIX_C5 = 2 };
+uint32_t tables_of(Mix m) { return m == MIX_SMALL ? kTables : (m == MIX_C4 ? 26u : 16u); }
+void fill_tables(Mix m, int world, emb_shard_table *tabs) {
+    const uint32_t n = tables_of(m);
+    for (uint32_t t = 0; t < n; t++) {
+        tabs[t].owner = (int32_t)(t % (uint32_t)world);
         tabs[t].engine_table = t;
         tabs[t].rows_per_shard = kRows;
+        if (m == MIX_SMALL) tabs[t].placement = t < 2 ? EMB_PLACE_REPLICATED : (t < 4 ? EMB_PLACE_WHOLE : EMB_PLACE_ROWS);
+        else if (m == MIX_C4) tabs[t].placement = (t == 0 || t == 9 || t == 10 || t == 19 || t == 20 || t == 21) ? EMB_PLACE_ROWS : EMB_PLACE_REPLICATED;
+        else tabs[t].placement = EMB_PLACE_WHOLE;
     }
+}
+
+// One rank's life with a shard object: `steps` batches of its OWN (ragged / one-index / empty) bags through submit / wait /
+// flush or the synchronous call, for every depth in `depths`.  comm: the RCCL stand-in (or NULL); peer: the peer group (or
+// NULL).  checked: EMB_SHARD_CHECK_SERVED -- and, where a one-index batch takes the direct path (one rank, or peer stores),
+// rank 0 hands in ONE index no shard holds at step `bad_step`: exactly that rank gets EMB_ERR_RANGE, nobody hangs, the
+// batches after it are clean.
+struct Drive {
+    emb_engine *e; int rank, world; Mix mix; emb_comm *comm; emb_peer *peer; bool checked; std::vector<uint32_t> depths; int steps;
+};
+void drive_shard(const Drive &D) {
+    emb_engine *e = D.e;
+    const uint32_t T = tables_of(D.mix);
+    emb_shard_table tabs[kMaxTables];
+    fill_tables(D.mix, D.world, tabs);
+    const bool direct_possible = D.comm == nullptr;      // (no peer behind RCCL: one rank, or peer stores)
     auto dev_alloc = [&](size_t bytes) {
         void *p = nullptr;
-        if (peer) CHECK(emb_peer_alloc(peer, bytes ? bytes : 4, &p));
+        if (D.peer) CHECK(emb_peer_alloc(D.peer, bytes ? bytes : 4, &p));
         else CHECK(emb_device_alloc(e, bytes ? bytes : 4, &p));
         return p;
     };
-    for (uint32_t depth = 0; depth <= 3; depth++) {
+    const uint32_t Bmax = 64;
+    constexpr int kSlots = 8;
+    std::vector<std::vector<void *>> idx(kSlots), off(kSlots), out(kSlots);
+    for (int k = 0; k < kSlots; k++)
+        for (uint32_t t = 0; t < T; t++) {
+            idx[k].push_back(dev_alloc(Bmax * 4 * 4));
+            off[k].push_back(dev_alloc(Bmax * 4));
+            out[k].push_back(dev_alloc((size_t)Bmax * kDim * 4));
+        }
+    for (uint32_t depth : D.depths) {
         emb_shard_config cfg{};
-        cfg.n_tables = kTables;
+        cfg.n_tables = T;
         cfg.dim = kDim;
         cfg.depth = depth;
-        cfg.flags = peer ? EMB_SHARD_PEER_STORES : 0u;
+        cfg.flags = (D.peer ? EMB_SHARD_PEER_STORES : 0u) | (D.checked ? EMB_SHARD_CHECK_SERVED : 0u);
         cfg.tables = tabs;
-        cfg.peer = peer;
+        cfg.peer = D.peer;
         emb_shard *s = nullptr;
-        CHECK(emb_shard_create(e, nullptr, &cfg, &s));
+        CHECK(emb_shard_create(e, D.comm, &cfg, &s));
         CHECK(emb_shard_set_kernel_timing(s, depth == 2));
-        Rng rng{5ull + depth};
-        constexpr int kSlots = 8;
-        struct Slot { std::vector<void *> idx, off, out; };
-        std::vector<Slot> slots(kSlots);
-        const uint32_t Bmax = 96;
-        for (auto &sl : slots)
-            for (uint32_t t = 0; t < kTables; t++) {
-                sl.idx.push_back(dev_alloc(Bmax * 4 * 4));
-                sl.off.push_back(dev_alloc(Bmax * 4));
-                sl.out.push_back(dev_alloc((size_t)Bmax * kDim * 4));
-            }
+        Rng rng{1000ull * (uint64_t)(D.rank + 1) + depth + 17ull * (uint64_t)D.mix};
         std::vector<uint64_t> seqs;
-        for (int j = 0; j < 20; j++) {
-            Slot &sl = slots[j % kSlots];
-            const uint32_t B = (j == 7) ? 0u : 1 + rng.next() % Bmax;
-            const bool one_hot = j % 3 != 0;          // one index per bag: the direct path; else ragged bags: routed
-            emb_shard_input in[kTables];
-            for (uint32_t t = 0; t < kTables; t++) {
-                std::vector<uint32_t> off(B), idx;
+        const int bad_step = (D.checked && direct_possible) ? 9 : -1;        // (9 % 4 == 1: a one-index batch)
+        int range_seen = 0;
+        auto note = [&](int rc) {           // a deferred EMB_ERR_RANGE may surface at the submit that un-routes the batch, or at the flush
+            if (rc == EMB_ERR_RANGE) range_seen++;
+            else CHECK(rc);
+        };
+        for (int j = 0; j < D.steps; j++) {
+            const int sl = j % kSlots;
+            const uint32_t B = (j == 5 && D.rank == 1) ? 0u : 1 + rng.next() % Bmax;       // every rank has its OWN bags; one is empty once
+            const bool one_hot = j % 2 == 1;
+            emb_shard_input in[kMaxTables];
+            for (uint32_t t = 0; t < T; t++) {
+                std::vector<uint32_t> o(B), ix;
+                const uint32_t range = tabs[t].placement == EMB_PLACE_ROWS ? kRows * (uint32_t)D.world : kRows;
                 for (uint32_t b = 0; b < B; b++) {
-                    off[b] = (uint32_t)idx.size();
+                    o[b] = (uint32_t)ix.size();
                     const uint32_t len = one_hot ? 1u : rng.next() % 4;
-                    for (uint32_t k = 0; k < len; k++) idx.push_back(rng.next() % kRows);
+                    for (uint32_t k = 0; k < len; k++) ix.push_back(rng.next() % range);
                 }
-                if (!idx.empty()) CHECK(emb_copy_to_device(e, sl.idx[t], idx.data(), idx.size() * 4));
-                if (B) CHECK(emb_copy_to_device(e, sl.off[t], off.data(), B * 4));
-                in[t] = emb_shard_input{static_cast<const uint32_t *>(sl.idx[t]), one_hot ? nullptr : static_cast<const uint32_t *>(sl.off[t]),
-                                        idx.size(), one_hot ? 1u : 0u, 0u, static_cast<float *>(sl.out[t])};
+                if (j == bad_step && D.rank == 0 && t == T - 1 && B) ix[B / 2] = range + 5;      // a row nobody holds (last table: row-split / whole)
+                if (!ix.empty()) CHECK(emb_copy_to_device(e, idx[sl][t], ix.data(), ix.size() * 4));
+                if (B) CHECK(emb_copy_to_device(e, off[sl][t], o.data(), B * 4));
+                in[t] = emb_shard_input{static_cast<const uint32_t *>(idx[sl][t]), one_hot ? nullptr : static_cast<const uint32_t *>(off[sl][t]),
+                                        ix.size(), one_hot ? 1u : 0u, 0u, static_cast<float *>(out[sl][t])};
             }
-            if (depth == 0 || j % 5 == 4) {
-                CHECK(emb_shard_lookup(s, in, B, nullptr));
+            if (depth == 0 || j % 7 == 6) {
+                note(emb_shard_lookup(s, in, B, nullptr));
+                seqs.clear();
             } else {
                 uint64_t seq = 0;
-                CHECK(emb_shard_submit(s, in, B, nullptr, &seq));
+                note(emb_shard_submit(s, in, B, nullptr, &seq));
                 seqs.push_back(seq);
                 if (seqs.size() > depth) {
                     CHECK(emb_shard_wait(s, seqs.front(), nullptr));
                     seqs.erase(seqs.begin());
                 }
             }
+            if (j == bad_step) {            // every rank alike: flush is collective
+                note(emb_shard_flush(s));
+                for (uint64_t q : seqs) CHECK(emb_shard_wait(s, q, nullptr));
+                seqs.clear();
+                if (D.rank == 0) {
+                    EXPECT(range_seen == 1);
+                    EXPECT(strstr(emb_last_error(), "bags were served") != nullptr);
+                } else {
+                    EXPECT(range_seen == 0);
+                }
+            }
         }
         CHECK(emb_shard_flush(s));
         for (uint64_t q : seqs) CHECK(emb_shard_wait(s, q, nullptr));
+        EXPECT(range_seen == (bad_step >= 0 && bad_step < D.steps && D.rank == 0 ? 1 : 0));
         emb_shard_stats st{};
-        CHECK(emb_shard_get_stats(s, &st, 1));
-        EXPECT(st.n_batches == 20);
-        uint32_t counts[64];
-        (void)emb_shard_sent_counts(s, 0, counts, 64);
+        CHECK(emb_shard_get_stats(s, &st, 0));
+        EXPECT(st.n_batches == (uint64_t)D.steps);
+        if (D.world > 1) EXPECT(st.bytes_to_peers > 0);
+        if (D.world > 1 && D.mix != MIX_C5 && D.comm) EXPECT(st.served_sub_bags > 0 && st.served_indices >= st.served_sub_bags);   // row pieces really travelled (the stub counts like the router)
+        uint32_t counts[2 * 64 * 8];
+        (void)emb_shard_sent_counts(s, 0, counts, 2 * 64 * 8);
+        if (D.peer) CHECK(emb_peer_barrier(D.peer));         // nobody tears its shard down while a peer may still be gathering from this arena
         CHECK(emb_shard_destroy(s));
-        if (!peer)
-            for (auto &sl : slots)
-                for (uint32_t t = 0; t < kTables; t++) {
-                    CHECK(emb_device_free(e, sl.idx[t]));
-                    CHECK(emb_device_free(e, sl.off[t]));
-                    CHECK(emb_device_free(e, sl.out[t]));
-                }
-        if (peer) break;       // (the arena is a bump allocator: one depth is what fits)
     }
+    if (!D.peer)
+        for (int k = 0; k < kSlots; k++)
+            for (uint32_t t = 0; t < T; t++) {
+                CHECK(emb_device_free(e, idx[k][t]));
+                CHECK(emb_device_free(e, off[k][t]));
+                CHECK(emb_device_free(e, out[k][t]));
+            }
+}
+
+// ---- one rank: every placement, every depth, ragged and one-index batches, peer-store mode, checked ---------------------------
+void shard_one_rank(bool peer_mode, bool checked, emb_engine *shared = nullptr, int device = 0) {
+    emb_engine *e = shared ? shared : make_engine(0, device);
+    emb_peer *peer = nullptr;
+    if (peer_mode) {
+        char tag[64];
+        snprintf(tag, sizeof tag, "hostcheck-%d-%d", (int)getpid(), (int)checked);
+        CHECK(emb_peer_create(e, tag, 0, 1, 64ull << 20, &peer));
+    }
+    drive_shard(Drive{e, 0, 1, MIX_SMALL, nullptr, peer, checked, {0, 1, 2, 3}, 20});
     if (peer) {
         CHECK(emb_peer_barrier(peer));
         CHECK(emb_peer_destroy(peer));
     }
     if (!shared) {
         CHECK(emb_destroy(e));
-        printf("shard one rank%s ok\n", peer_mode ? " (peer stores)" : "");
+        printf("shard one rank%s%s ok\n", peer_mode ? " (peer stores)" : "", checked ? " (checked)" : "");
     }
 }
 
@@ -316,7 +375,7 @@ void shard_one_rank(bool peer_mode, emb_engine *shared = nullptr) {
 void shards_sharing_an_engine() {
     emb_engine *e = make_engine(0);
     std::vector<std::thread> th;
-    for (int t = 0; t < 3; t++) th.emplace_back([e] { shard_one_rank(false, e); });
+    for (int t = 0; t < 3; t++) th.emplace_back([e, t] { shard_one_rank(false, t == 1, e); });
     for (auto &t : th) t.join();
     CHECK(emb_destroy(e));
     printf("three shard objects on one engine ok\n");
@@ -355,7 +414,7 @@ extern "C" int emb_comm_exchange(emb_comm *c, const emb_comm_op *ops, uint32_t n
         if (ops[i].is_recv) {
             std::unique_lock<std::mutex> lk(h.mu);
             auto &q = h.q[(size_t)ops[i].peer * h.world + c->rank];
-            if (!h.cv.wait_for(lk, std::chrono::seconds(60), [&] { return !q.empty(); })) {
+            if (!h.cv.wait_for(lk, std::chrono::seconds(120), [&] { return !q.empty(); })) {
                 fprintf(stderr, "rank %d: nothing arrived from rank %d\n", c->rank, ops[i].peer);
                 exit(1);
             }
@@ -370,81 +429,13 @@ extern "C" int emb_comm_exchange(emb_comm *c, const emb_comm_op *ops, uint32_t n
 }
 namespace {
 
-void shard_ranks_as_threads(int world) {
+void shard_ranks_as_threads(int world, Mix mix, bool checked, std::vector<uint32_t> depths) {
     Hub hub(world);
     std::atomic<int> finished{0};
     auto rank_main = [&](int rank) {
-        emb_engine *e = make_engine(0);
+        emb_engine *e = make_engine(0, 0, tables_of(mix));
         emb_comm comm{rank, &hub};
-        emb_shard_table tabs[kTables];
-        for (uint32_t t = 0; t < kTables; t++) {
-            tabs[t].placement = t < 2 ? EMB_PLACE_REPLICATED : (t < 4 ? EMB_PLACE_WHOLE : EMB_PLACE_ROWS);
-            tabs[t].owner = (int32_t)(t % (uint32_t)world);
-            tabs[t].engine_table = t;
-            tabs[t].rows_per_shard = kRows;
-        }
-        for (uint32_t depth = 0; depth <= 3; depth++) {
-            emb_shard_config cfg{};
-            cfg.n_tables = kTables;
-            cfg.dim = kDim;
-            cfg.depth = depth;
-            cfg.tables = tabs;
-            emb_shard *s = nullptr;
-            CHECK(emb_shard_create(e, &comm, &cfg, &s));
-            Rng rng{1000ull * (uint64_t)(rank + 1) + depth};
-            constexpr int kSlots = 8;
-            const uint32_t Bmax = 64;
-            std::vector<std::vector<void *>> idx(kSlots), off(kSlots), out(kSlots);
-            for (int k = 0; k < kSlots; k++)
-                for (uint32_t t = 0; t < kTables; t++) {
-                    void *p = nullptr;
-                    CHECK(emb_device_alloc(e, Bmax * 4 * 4, &p)); idx[k].push_back(p);
-                    CHECK(emb_device_alloc(e, Bmax * 4, &p)); off[k].push_back(p);
-                    CHECK(emb_device_alloc(e, (size_t)Bmax * kDim * 4, &p)); out[k].push_back(p);
-                }
-            std::vector<uint64_t> seqs;
-            for (int j = 0; j < 16; j++) {
-                const uint32_t B = (j == 5 && rank == 1) ? 0u : 1 + rng.next() % Bmax;       // every rank has its OWN bags; one is empty once
-                const bool one_hot = j % 3 == 1;
-                emb_shard_input in[kTables];
-                for (uint32_t t = 0; t < kTables; t++) {
-                    std::vector<uint32_t> o(B), ix;
-                    for (uint32_t b = 0; b < B; b++) {
-                        o[b] = (uint32_t)ix.size();
-                        const uint32_t len = one_hot ? 1u : rng.next() % 4;
-                        for (uint32_t k = 0; k < len; k++) ix.push_back(rng.next() % (tabs[t].placement == EMB_PLACE_ROWS ? kRows * (uint32_t)world : kRows));
-                    }
-                    if (!ix.empty()) CHECK(emb_copy_to_device(e, idx[j % kSlots][t], ix.data(), ix.size() * 4));
-                    if (B) CHECK(emb_copy_to_device(e, off[j % kSlots][t], o.data(), B * 4));
-                    in[t] = emb_shard_input{static_cast<const uint32_t *>(idx[j % kSlots][t]), one_hot ? nullptr : static_cast<const uint32_t *>(off[j % kSlots][t]),
-                                            ix.size(), one_hot ? 1u : 0u, 0u, static_cast<float *>(out[j % kSlots][t])};
-                }
-                if (depth == 0) {
-                    CHECK(emb_shard_lookup(s, in, B, nullptr));
-                } else {
-                    uint64_t seq = 0;
-                    CHECK(emb_shard_submit(s, in, B, nullptr, &seq));
-                    seqs.push_back(seq);
-                    if (seqs.size() > depth) {
-                        CHECK(emb_shard_wait(s, seqs.front(), nullptr));
-                        seqs.erase(seqs.begin());
-                    }
-                }
-            }
-            CHECK(emb_shard_flush(s));
-            for (uint64_t q : seqs) CHECK(emb_shard_wait(s, q, nullptr));
-            emb_shard_stats st{};
-            CHECK(emb_shard_get_stats(s, &st, 0));
-            EXPECT(st.n_batches == 16 && st.bytes_to_peers > 0);
-            EXPECT(st.served_sub_bags > 0 && st.served_indices >= st.served_sub_bags);       // row pieces really travelled (the stub counts like the router)
-            CHECK(emb_shard_destroy(s));
-            for (int k = 0; k < kSlots; k++)
-                for (uint32_t t = 0; t < kTables; t++) {
-                    CHECK(emb_device_free(e, idx[k][t]));
-                    CHECK(emb_device_free(e, off[k][t]));
-                    CHECK(emb_device_free(e, out[k][t]));
-                }
-        }
+        drive_shard(Drive{e, rank, world, mix, &comm, nullptr, checked, depths, 16});
         CHECK(emb_destroy(e));
         finished++;
     };
@@ -453,7 +444,7 @@ void shard_ranks_as_threads(int world) {
     for (auto &t : th) t.join();
     EXPECT(finished.load() == world);
     for (auto &q : hub.q) EXPECT(q.empty());           // every piece sent was received
-    printf("shard %d ranks as threads ok\n", world);
+    printf("shard %d ranks as threads, mix %d%s ok\n", world, (int)mix, checked ? ", checked" : "");
 }
 
 // ---- the collective-free exchange with several ranks as threads: one peer group, an IPC handle is the pointer itself --------
@@ -464,83 +455,19 @@ void shard_ranks_as_threads(int world) {
 #define HOST_CHECK_TSAN 1
 #endif
 #endif
-void peer_ranks_as_threads(int world) {
+void peer_ranks_as_threads(int world, Mix mix, bool checked, std::vector<uint32_t> depths) {
 #ifdef HOST_CHECK_TSAN
-    (void)world;
+    (void)mix; (void)checked; (void)depths;
     printf("peer stores, %d ranks as threads: skipped under ThreadSanitizer\n", world);
 #else
     char tag[64];
-    snprintf(tag, sizeof tag, "hostcheck-peers-%d-%d", (int)getpid(), world);
+    snprintf(tag, sizeof tag, "hostcheck-peers-%d-%d-%d-%d", (int)getpid(), world, (int)mix, (int)checked);
     std::atomic<int> finished{0};
     auto rank_main = [&](int rank) {
-        emb_engine *e = make_engine(0);
+        emb_engine *e = make_engine(0, 0, tables_of(mix));
         emb_peer *peer = nullptr;
-        CHECK(emb_peer_create(e, tag, rank, world, 512ull << 20, &peer));
-        emb_shard_table tabs[kTables];
-        for (uint32_t t = 0; t < kTables; t++) {
-            tabs[t].placement = t < 2 ? EMB_PLACE_REPLICATED : (t < 4 ? EMB_PLACE_WHOLE : EMB_PLACE_ROWS);
-            tabs[t].owner = (int32_t)(t % (uint32_t)world);
-            tabs[t].engine_table = t;
-            tabs[t].rows_per_shard = kRows;
-        }
-        const uint32_t Bmax = 64;
-        constexpr int kSlots = 8;
-        std::vector<std::vector<void *>> idx(kSlots), off(kSlots), out(kSlots);
-        for (int k = 0; k < kSlots; k++)
-            for (uint32_t t = 0; t < kTables; t++) {
-                void *p = nullptr;
-                CHECK(emb_peer_alloc(peer, Bmax * 4 * 4, &p)); idx[k].push_back(p);
-                CHECK(emb_peer_alloc(peer, Bmax * 4, &p)); off[k].push_back(p);
-                CHECK(emb_peer_alloc(peer, (size_t)Bmax * kDim * 4, &p)); out[k].push_back(p);
-            }
-        for (uint32_t depth = 0; depth <= 3; depth++) {
-            emb_shard_config cfg{};
-            cfg.n_tables = kTables;
-            cfg.dim = kDim;
-            cfg.depth = depth;
-            cfg.flags = EMB_SHARD_PEER_STORES;
-            cfg.tables = tabs;
-            cfg.peer = peer;
-            emb_shard *s = nullptr;
-            CHECK(emb_shard_create(e, nullptr, &cfg, &s));
-            Rng rng{77ull * (uint64_t)(rank + 1) + depth};
-            std::vector<uint64_t> seqs;
-            for (int j = 0; j < 24; j++) {
-                const uint32_t B = (j == 5 && rank == 1) ? 0u : 1 + rng.next() % Bmax;
-                const bool one_hot = j % 3 == 1;        // every rank alike: the direct path needs no agreement, but keeps the run simple to read
-                emb_shard_input in[kTables];
-                for (uint32_t t = 0; t < kTables; t++) {
-                    std::vector<uint32_t> o(B), ix;
-                    for (uint32_t b = 0; b < B; b++) {
-                        o[b] = (uint32_t)ix.size();
-                        const uint32_t len = one_hot ? 1u : rng.next() % 4;
-                        for (uint32_t k = 0; k < len; k++) ix.push_back(rng.next() % (tabs[t].placement == EMB_PLACE_ROWS ? kRows * (uint32_t)world : kRows));
-                    }
-                    if (!ix.empty()) CHECK(emb_copy_to_device(e, idx[j % kSlots][t], ix.data(), ix.size() * 4));
-                    if (B) CHECK(emb_copy_to_device(e, off[j % kSlots][t], o.data(), B * 4));
-                    in[t] = emb_shard_input{static_cast<const uint32_t *>(idx[j % kSlots][t]), one_hot ? nullptr : static_cast<const uint32_t *>(off[j % kSlots][t]),
-                                            ix.size(), one_hot ? 1u : 0u, 0u, static_cast<float *>(out[j % kSlots][t])};
-                }
-                if (depth == 0) {
-                    CHECK(emb_shard_lookup(s, in, B, nullptr));
-                } else {
-                    uint64_t seq = 0;
-                    CHECK(emb_shard_submit(s, in, B, nullptr, &seq));
-                    seqs.push_back(seq);
-                    if (seqs.size() > depth) {
-                        CHECK(emb_shard_wait(s, seqs.front(), nullptr));
-                        seqs.erase(seqs.begin());
-                    }
-                }
-            }
-            CHECK(emb_shard_flush(s));
-            for (uint64_t q : seqs) CHECK(emb_shard_wait(s, q, nullptr));
-            emb_shard_stats st{};
-            CHECK(emb_shard_get_stats(s, &st, 0));
-            EXPECT(st.n_batches == 24 && st.bytes_to_peers > 0 && st.served_sub_bags > 0);
-            CHECK(emb_peer_barrier(peer));         // nobody tears its shard down while a peer may still be gathering from this arena
-            CHECK(emb_shard_destroy(s));
-        }
+        CHECK(emb_peer_create(e, tag, rank, world, 96ull << 20, &peer));
+        drive_shard(Drive{e, rank, world, mix, nullptr, peer, checked, depths, 24});
         CHECK(emb_peer_barrier(peer));
         CHECK(emb_peer_destroy(peer));
         CHECK(emb_destroy(e));
@@ -550,8 +477,67 @@ void peer_ranks_as_threads(int world) {
     for (int r = 0; r < world; r++) th.emplace_back(rank_main, r);
     for (auto &t : th) t.join();
     EXPECT(finished.load() == world);
-    printf("peer stores, %d ranks as threads ok\n", world);
+    printf("peer stores, %d ranks as threads, mix %d%s ok\n", world, (int)mix, checked ? ", checked" : "");
 #endif
+}
+
+// ---- a node with several GPUs: everything on device 1 while the calling threads' current device stays 0 ------------------------
+// The stub counts every HIP call made with another device current (or on a stream / event of another device).  Engine (four
+// caller threads), request queues (host + device, with the flusher and client threads), the sharded call with one rank
+// (routed, direct, checked, peer stores) and a two-rank peer group: no violation, and the callers' current device is untouched.
+void everything_on_device_one() {
+    pimemb_stub_set_device_count(2);
+    int cur = -1;
+    EXPECT(hipGetDevice(&cur) == hipSuccess && cur == 0);
+    pimemb_stub_expect_device(1);
+    const long before = pimemb_stub_tracked_calls();
+    engine_threads(1, 2);
+    queue_threads(1);
+    shard_one_rank(false, false, nullptr, 1);
+    shard_one_rank(false, true, nullptr, 1);
+    shard_one_rank(true, true, nullptr, 1);
+#ifndef HOST_CHECK_TSAN
+    {       // two peer-store ranks as threads, both engines on device 1 (the stub has one address space)
+        char tag[64];
+        snprintf(tag, sizeof tag, "hostcheck-dev1-%d", (int)getpid());
+        auto rank_main = [&](int rank) {
+            emb_engine *e = make_engine(0, 1, tables_of(MIX_SMALL));
+            emb_peer *peer = nullptr;
+            CHECK(emb_peer_create(e, tag, rank, 2, 96ull << 20, &peer));
+            drive_shard(Drive{e, rank, 2, MIX_SMALL, nullptr, peer, true, {0, 3}, 16});
+            CHECK(emb_peer_barrier(peer));
+            CHECK(emb_peer_destroy(peer));
+            CHECK(emb_destroy(e));
+            int c = -1;
+            EXPECT(hipGetDevice(&c) == hipSuccess && c == 0);      // a rank thread's own current device was never changed for good
+        };
+        std::thread a(rank_main, 0), b(rank_main, 1);
+        a.join();
+        b.join();
+    }
+#endif
+    {       // ranks behind the RCCL stand-in
+        Hub hub(2);
+        auto rank_main = [&](int rank) {
+            emb_engine *e = make_engine(0, 1, tables_of(MIX_SMALL));
+            emb_comm comm{rank, &hub};
+            drive_shard(Drive{e, rank, 2, MIX_SMALL, &comm, nullptr, false, {0, 3}, 16});
+            CHECK(emb_destroy(e));
+        };
+        std::thread a(rank_main, 0), b(rank_main, 1);
+        a.join();
+        b.join();
+    }
+    EXPECT(hipGetDevice(&cur) == hipSuccess && cur == 0);
+    const long calls = pimemb_stub_tracked_calls() - before, bad = pimemb_stub_violations();
+    pimemb_stub_expect_device(-1);
+    pimemb_stub_set_device_count(1);
+    if (bad) {
+        fprintf(stderr, "%ld HIP calls were made with the wrong device current\n", bad);
+        exit(1);
+    }
+    EXPECT(calls > 10000);
+    printf("everything on device 1: %ld HIP calls, every one with device 1 current ok\n", calls);
 }
 
 // ---- the reference's two entry points -------------------------------------------------------------------------------------
@@ -580,17 +566,33 @@ void compat_calls() {
 
 }  // namespace
 
-int main() {
-    engine_threads();
-    queue_threads();
-    shard_one_rank(false);
-    shard_one_rank(true);
-    shards_sharing_an_engine();
-    shard_ranks_as_threads(2);
-    shard_ranks_as_threads(3);
-    peer_ranks_as_threads(2);
-    peer_ranks_as_threads(3);
-    compat_calls();
+int main(int argc, char **argv) {
+    const bool only_world8 = argc > 1 && strcmp(argv[1], "world8") == 0;
+    if (!only_world8) {
+        engine_threads();
+        queue_threads();
+        shard_one_rank(false, false);
+        shard_one_rank(false, true);
+        shard_one_rank(true, false);
+        shard_one_rank(true, true);
+        shards_sharing_an_engine();
+        shard_ranks_as_threads(2, MIX_SMALL, false, {0, 1, 2, 3});
+        shard_ranks_as_threads(3, MIX_SMALL, true, {0, 1, 2, 3});
+        peer_ranks_as_threads(2, MIX_SMALL, true, {0, 1, 2, 3});
+        peer_ranks_as_threads(3, MIX_SMALL, false, {0, 1, 2, 3});
+        everything_on_device_one();
+        compat_calls();
+    }
+    // world 8 -- the sizes that change there (counts[N][K+1][2], mailboxes [dst][src][slot], N * K descriptors, slots (d << 24))
+    // walked with the C4 placement mix (20 replicated / 6 row-split), the C5 mix (every table whole on an owner) and the small one
+    shard_ranks_as_threads(8, MIX_C4, false, {0, 3});
+    shard_ranks_as_threads(8, MIX_C4, true, {2});
+    shard_ranks_as_threads(8, MIX_C5, false, {0, 3});
+    shard_ranks_as_threads(8, MIX_SMALL, false, {1, 3});
+    peer_ranks_as_threads(8, MIX_C4, false, {0, 3});
+    peer_ranks_as_threads(8, MIX_C4, true, {0, 3});
+    peer_ranks_as_threads(8, MIX_C5, true, {0, 2});
+    peer_ranks_as_threads(8, MIX_SMALL, true, {1, 3});
     printf("host logic ok\n");
     return 0;
 }

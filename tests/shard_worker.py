@@ -193,6 +193,15 @@ def main():
                 except IndexError:
                     raised = True
                 status["raised_depth%d" % depth] = raised
+                if cfg.get("good_after_bad"):      # the shard object is still usable: a clean batch after the refused one, against the oracle
+                    torch.cuda.synchronize()
+                    g = make_batch(rng, rows, cfg["bags"] + 1, max(1, cfg["max_len"]), True)
+                    outs = S.forward(None, [to_dev(i) for i in g[0]], fixed_pooling=max(1, cfg["max_len"])) if depth == 0 else None
+                    if depth:
+                        q, outs = S.submit([to_dev(i) for i in g[0]], None, fixed_pooling=max(1, cfg["max_len"]))
+                        S.flush()
+                        S.wait(q)
+                    check(outs, g, "clean batch after a refused one")
             torch.cuda.synchronize()
             S.close()
         if cfg.get("harness"):        # the apply_emb-shaped module over the sharded call: its own engine, the same communicator

@@ -163,3 +163,31 @@ def test_shard_bad_index_raises_on_the_serving_rank_and_nobody_hangs(tmp_path):
     for depth in (0, 2, 3):
         raised = [st["raised_depth%d" % depth] for st in res]
         assert raised == [False, False, True], raised
+
+
+@pytest.mark.parametrize("table", [0, 1, 2])
+def test_checked_direct_path_reports_unserved_bags_one_rank(table, tmp_path):
+    """A CHECKED shard keeps the direct path for one-index batches (round 4: it fell back to routing) and COUNTS what every
+    launch serves: an index outside its table -- replicated (0), whole (1) or row-split (2) -- is served by nobody, the
+    requester's sum falls short of its bag count and the call raises IndexError (EMB_ERR_RANGE); a clean batch afterwards is
+    the oracle's, bit for bit.  expect_direct: the kernel brackets show the ranged launch and no router / un-router."""
+    cfg = dict(ONE_RANK, max_len=1, fixed=True, check=True, expect_direct=True, bad_index={"rank": 0, "table": table}, batches=3,
+               good_after_bad=True)
+    res = _run(cfg, 1, tmp_path)
+    for depth in (0, 2, 3):
+        assert res[0]["raised_depth%d" % depth] is True
+
+
+@pytest.mark.parametrize("table,world", [(2, 2), (1, 2), (0, 2), (2, 3)])
+def test_checked_direct_path_reports_unserved_bags_peer_store_ranks(table, world, tmp_path):
+    """The same over peer stores with 2-3 processes on the one GPU: every shard counts the bags it serves of every requester's
+    raw index array, the counts return in the tail of the requester's mailbox next to the "served" word, and the REQUESTING
+    rank (rank 0 handed in the bad index) raises -- nobody else does, nobody hangs, the next batch is clean on every rank."""
+    import uuid
+    cfg = dict(rows=[7, 300, 5000, 64, 2000, 1500], dim=32, rep=64 * 32 * 4, split=3000 * 32 * 4, bags=29, max_len=1, fixed=True,
+               expect_kinds=["replicated", "whole", "row_split"], peer=True, peer_tag="t" + uuid.uuid4().hex[:12], check=True,
+               expect_direct=True, bad_index={"rank": 0, "table": table}, batches=3, good_after_bad=True)
+    res = _run(cfg, world, tmp_path)
+    for depth in (0, 2, 3):
+        raised = [st["raised_depth%d" % depth] for st in res]
+        assert raised == [True] + [False] * (world - 1), (depth, raised)
