@@ -79,10 +79,13 @@ def parse_args():
     ap.add_argument("--checked", action="store_true",
                     help="sharded legs: create the shard with EMB_SHARD_CHECK_SERVED (one-index batches keep the direct path and count "
                          "what every shard serves; routed batches validate what they serve)")
-    ap.add_argument("--exchange", choices=["rccl", "peer"], default="rccl",
-                    help="N>1 sharded legs: how pieces travel between ranks -- grouped ncclSend/ncclRecv issued from C (rccl, default) "
-                         "or the collective-free exchange (peer: HIP IPC mappings, the owner gathers a requester's indices in place "
-                         "and stores pooled rows straight into its HBM; handshake through a shared-memory segment, no RCCL in the data path)")
+    ap.add_argument("--exchange", choices=["rccl", "peer", "both"], default=None,
+                    help="N>1 sharded legs: how pieces travel between ranks -- grouped ncclSend/ncclRecv issued from C (rccl), "
+                         "the collective-free exchange (peer: HIP IPC mappings, the owner gathers a requester's indices in place "
+                         "and stores pooled rows straight into its HBM; handshake through a shared-memory segment, no RCCL in the data path), "
+                         "or BOTH in one run (the default for N > 1): the RCCL leg is value_exchange, the peer-store leg is brought up under a "
+                         "deadline afterwards and reported as value_exchange_peer -- or {skipped: reason} if it cannot come up, which does not "
+                         "fail the run; both legs are verified against the same expected rows and must leave the same bits.  N = 1: rccl")
     ap.add_argument("--collective", choices=["native"], default="native",
                     help="kept for command-line compatibility: the sharded legs' transfers are always grouped ncclSend/ncclRecv "
                          "issued from the C side (emb_comm_exchange inside emb_shard_*)")

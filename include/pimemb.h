@@ -334,7 +334,8 @@ int emb_queue_destroy(emb_queue *q);
  *                                           d).  counts[d] is the message for peer d and goes out FIRST; from the K+1
  *                                           entries it receives from every peer a rank sizes the payload AND learns the
  *                                           job-wide largest piece, so all ranks agree on how many rounds a transfer
- *                                           that is too large for one collective takes (sharding.py)
+ *                                           that is too large for one RCCL group takes (emb_comm_exchange cuts every pair's
+ *                                           bytes into <= 512-MiB pieces on both ends from the same byte count)
  *                        base  [N][K][2]  = word offsets in `send` of that request's offsets / indices arrays
  *                        piece [N+1]      = word offset of destination d's piece (piece[N] = words in all)
  *                        ret_row0[N][K]   = first partial row of (d, k) in the returned rows (see below)
@@ -397,8 +398,9 @@ int emb_route_serve_descs(const uint32_t *received, uint32_t n_tables, uint32_t 
  * torch.distributed.broadcast), every rank calls emb_comm_create.  RCCL is resolved at run time
  * (EMB_ERR_UNSUPPORTED if librccl.so cannot be found).  The reference's counterpart is the broadcast
  * push / gather pull of dpu_push_xfer (emb_host.h:258-287, :321).  Exercised with one rank and with
- * three / four ranks over RCCL's socket transport (several ranks on one GPU), never over xGMI; bench.py uses
- * torch.distributed unless --collective native is given. */
+ * two to four ranks over RCCL's socket transport (several ranks on one GPU), never over xGMI.  It is the ONLY transport of the
+ * RCCL-mode sharded step: emb_shard_* issues every transfer through emb_comm_exchange, and bench.py's N > 1 legs call
+ * emb_shard_* -- torch.distributed carries the bootstrap (this id), the barriers and the job clock, never payload. */
 typedef struct emb_comm emb_comm;
 int emb_comm_unique_id(void *id128);
 int emb_comm_create(emb_engine *e, const void *id128, int32_t rank, int32_t world, emb_comm **out);

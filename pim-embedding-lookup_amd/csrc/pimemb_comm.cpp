@@ -13,7 +13,8 @@
 // STATUS: exercised with one rank (self send/recv) and with three and four ranks sharing the development box's one GPU
 // (every rank claiming a host of its own, so RCCL connects them through its socket transport:
 // tests/test_gpu_sharding.py::test_rccl_several_ranks_on_one_gpu[native-*], all tables verified on every rank); never
-// over xGMI.  bench.py keeps torch.distributed as the default (--collective torch).
+// over xGMI.  It is the only transport of the RCCL-mode sharded step (emb_shard_* -> emb_comm_exchange); bench.py's N > 1
+// legs call emb_shard_*, torch.distributed carries the bootstrap, the barriers and the job clock only.
 #include <dlfcn.h>
 
 #include <cstdio>

@@ -940,10 +940,11 @@ hipError_t launch_peer_done(const PeerDoneArgs &args, unsigned long long value, 
 // Checked shards: the counters of a counted ranged launch -> their requesters, then the flags (pimemb_peer.h: ServedArgs).
 // Wavefront w of the grid takes counters w, w + W, ... of the concatenated segments: lane l swaps lane-word l of the counter
 // for zero, the wavefront adds the 64 values up, lane 0 stores the sum.
-__global__ void __launch_bounds__(kBlock)
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
 served_counts_kernel(ServedArgs a) {
     static_assert(EMB_SERVED_LANES == 64, "one lane of a wavefront per lane of a counter");
-    const uint32_t lane = threadIdx.x & 63u, wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), n_waves = gridDim.x * (kBlock / 64);
+    const uint32_t lane = threadIdx.x & 63u, wave = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6), n_waves = gridDim.x * (BLOCK / 64);
     uint32_t total = 0;
     for (uint32_t i = 0; i < a.n_seg; i++) total += a.seg[i].n_counted + a.seg[i].n_fill;
     for (uint32_t g = wave; g < total; g += n_waves) {
@@ -985,10 +986,15 @@ hipError_t launch_served_counts(const ServedArgs &args, hipStream_t stream) {
     if (args.n_seg > kServedSegs || args.n_flag > kServedSegs) return hipErrorInvalidValue;
     uint32_t n = 0;
     for (uint32_t i = 0; i < args.n_seg; i++) n += args.seg[i].n_counted + args.seg[i].n_fill;
-    uint32_t grid = (n + (kBlock / 64) - 1) / (kBlock / 64);        // a wavefront per counter, up to 64 workgroups
-    grid = grid < 1 ? 1 : (grid > 64 ? 64 : grid);
-    if (grid > 1 && args.ticket == nullptr) grid = 1;
-    hipLaunchKernelGGL(served_counts_kernel, dim3(grid), dim3(kBlock), 0, stream, args);
+    // up to 64 counters (26 tables on one rank: the Kaggle / Terabyte shapes): ONE workgroup of 16 wavefronts -- no ticket, one
+    // fence; more (512 tables, many peers): a wavefront per counter over up to 64 workgroups, the last one raises the flags
+    if (n <= 64 || args.ticket == nullptr) {
+        hipLaunchKernelGGL(served_counts_kernel<1024>, dim3(1), dim3(1024), 0, stream, args);
+    } else {
+        uint32_t grid = (n + (kBlock / 64) - 1) / (kBlock / 64);
+        grid = grid > 64 ? 64 : grid;
+        hipLaunchKernelGGL(served_counts_kernel<kBlock>, dim3(grid), dim3(kBlock), 0, stream, args);
+    }
     return hipGetLastError();
 }
 

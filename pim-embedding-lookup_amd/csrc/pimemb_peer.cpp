@@ -23,6 +23,9 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -84,6 +87,61 @@ struct DeviceGuard {
     }
     ~DeviceGuard() {
         if (switched) (void)hipSetDevice(prev);
+    }
+};
+
+// hipIpcOpenMemHandle has no deadline of its own, and on this runtime it has been seen never to return (an allocation above
+// 2 GiB: see the chunk note above; what it does with a different threshold across real devices is unknown).  A rank stuck in
+// it cannot report an error -- the call never comes back -- so a watchdog thread ENDS THE PROCESS with a message naming the
+// rank, the peer and the chunk once a mapping call has been out for longer than the group's timeout: the launcher sees a
+// non-zero exit instead of a job that hangs until its own limit.  (A fresh failure: nothing is re-executed.)
+struct MapWatchdog {
+    std::mutex mu;
+    std::condition_variable cv;
+    bool done = false;
+    int rank = 0, peer = -1;
+    unsigned chunk = 0;
+    double call_t0 = 0.0;       // 0: no mapping call is out
+    double limit_s;
+    std::string unlink_name;    // the job's segment (whoever ends the job takes the name with it: nothing is left behind in /dev/shm)
+    std::thread th;
+    MapWatchdog(int rank_, double limit, const std::string &unlink) : rank(rank_), limit_s(limit), unlink_name(unlink) {
+        th = std::thread([this] {
+            std::unique_lock<std::mutex> lk(mu);
+            while (!done) {
+                cv.wait_for(lk, std::chrono::milliseconds(50));
+                if (!done && call_t0 > 0.0 && now_s() - call_t0 > limit_s) {
+                    fprintf(stderr, "emb_peer_create: rank %d: hipIpcOpenMemHandle of rank %d's arena (chunk %u) has not returned within %.0f s -- "
+                            "the runtime cannot map that allocation (seen for IPC mappings above 2 GiB on ROCm 7.0 / 7.2); this process "
+                            "is ended so the job fails instead of hanging (PIMEMB_SHARD_TIMEOUT_S sets the limit)\n", rank, peer, chunk, limit_s);
+                    fflush(stderr);
+                    if (!unlink_name.empty()) (void)shm_unlink(unlink_name.c_str());
+                    // PIMEMB_PEER_WATCHDOG=report: a caller with a deadline of its own (bench.py's peer-store leg) ends the
+                    // process itself -- with the numbers it already has
+                    const char *mode = getenv("PIMEMB_PEER_WATCHDOG");
+                    if (mode && mode[0] == 'r') return;
+                    _exit(70);
+                }
+            }
+        });
+    }
+    void enter(int p, unsigned c) {
+        std::lock_guard<std::mutex> lk(mu);
+        peer = p;
+        chunk = c;
+        call_t0 = now_s();
+    }
+    void leave() {
+        std::lock_guard<std::mutex> lk(mu);
+        call_t0 = 0.0;
+    }
+    ~MapWatchdog() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            done = true;
+        }
+        cv.notify_all();
+        th.join();
     }
 };
 
@@ -236,13 +294,22 @@ int emb_peer_create(emb_engine *e, const char *job_tag, int32_t rank, int32_t wo
             }
             ok = err == hipSuccess;
         }
-        if (!ok) {          // (a runtime that cannot allocate / export fine-grained memory: ordinary memory instead, once)
+        if (!ok) {
             (void)hipGetLastError();
             for (char *c : p->chunks) (void)hipFree(c);
             p->chunks.clear();
             if (!p->fine_grained)
                 return bail(fail(err == hipErrorOutOfMemory ? EMB_ERR_NOMEM : EMB_ERR_DEVICE, "emb_peer_create: %llu bytes of arena: %s (HSA_ENABLE_IPC_MODE_LEGACY=0 set?)",
                                  (unsigned long long)arena_bytes, hipGetErrorString(err)));
+            // A runtime that cannot allocate / export fine-grained memory.  Ordinary (coarse-grained) memory is a stand-in only
+            // where no second agent stores into it: with peers, rows another GPU stored into this rank's arena are not
+            // guaranteed visible to this GPU's kernels at a kernel boundary -- so the fallback is taken silently for a group of
+            // ONE rank only; with peers it must be asked for (PIMEMB_PEER_ARENA=coarse: same-device rehearsals), else refused.
+            if (world > 1)
+                return bail(fail(EMB_ERR_UNSUPPORTED, "emb_peer_create: this runtime cannot allocate / export fine-grained device memory (%s); a peer group of %d ranks "
+                                 "will not fall back to ordinary memory by itself -- stores of another GPU into it are not guaranteed visible. Use the RCCL "
+                                 "exchange, or set PIMEMB_PEER_ARENA=coarse to take ordinary memory knowingly (ranks sharing one device)",
+                                 hipGetErrorString(err), world));
             p->fine_grained = false;
         }
     }
@@ -260,6 +327,7 @@ int emb_peer_create(emb_engine *e, const char *job_tag, int32_t rank, int32_t wo
     p->base[(size_t)rank] = p->chunks;
     p->peer_bytes[(size_t)rank] = arena_bytes;
     const double t0 = now_s();
+    std::unique_ptr<MapWatchdog> dog(world > 1 ? new MapWatchdog(rank, p->timeout_s, p->shm_name) : nullptr);
     for (int r = 0; r < world; r++) {
         if (r == rank) continue;
         RankInfo *ri = pimemb::peer_rank_info(p, r);
@@ -269,7 +337,9 @@ int emb_peer_create(emb_engine *e, const char *job_tag, int32_t rank, int32_t wo
         }
         for (uint32_t c = 0; c < ri->n_chunks; c++) {
             void *mapped = nullptr;
+            dog->enter(r, c);
             err = hipIpcOpenMemHandle(&mapped, ri->handle[c], hipIpcMemLazyEnablePeerAccess);
+            dog->leave();
             if (err != hipSuccess) return bail(fail(EMB_ERR_DEVICE, "emb_peer_create: hipIpcOpenMemHandle of rank %d's arena (chunk %u): %s", r, c, hipGetErrorString(err)));
             p->base[(size_t)r].push_back(static_cast<char *>(mapped));
         }

@@ -215,13 +215,24 @@ def run_sharded(args, hbm_peak_gbs: float, ctx, rep_bytes: int, mode: str):
     T = len(rows_list)
     NBATCH = max(6, args.nbatch)
     depth = int(os.environ.get("PIMEMB_SHARD_DEPTH", "3"))
-    if mode == "whole":
-        plan = sh.plan_shards(rows_list, dim, elem, world, replicate_bytes=rep_bytes, split_bytes=1 << 62)
-    elif mode == "rows":
-        plan = sh.plan_shards(rows_list, dim, elem, world, replicate_bytes=rep_bytes, split_bytes=rep_bytes, pooling=1.0,
-                              split_single_rank=True)
-    else:
-        plan = sh.plan_shards(rows_list, dim, elem, world, replicate_bytes=rep_bytes, pooling=float(L), split_single_rank=True)
+    def make_plan(rows_):
+        if mode == "whole":
+            return sh.plan_shards(rows_, dim, elem, world, replicate_bytes=rep_bytes, split_bytes=1 << 62)
+        if mode == "rows":
+            return sh.plan_shards(rows_, dim, elem, world, replicate_bytes=rep_bytes, split_bytes=rep_bytes, pooling=1.0, split_single_rank=True)
+        return sh.plan_shards(rows_, dim, elem, world, replicate_bytes=rep_bytes, pooling=float(L), split_single_rank=True)
+    # Pre-flight: tables + batch slots + the library's staging against THIS GPU's HBM, on the worst rank -- before anything is
+    # allocated.  A layout that does not fit is shrunk (rows, uniformly) and the line says so; C5 at 8 ranks needs it.
+    transport = "peer" if getattr(args, "exchange", "rccl") == "peer" else "rccl"
+    checked = bool(getattr(args, "checked", False))
+    hbm_total = int(torch.cuda.get_device_properties(dev).total_memory)
+    fit_scale, rows_list, plan, hbm_need = sh.fit_to_hbm(rows_list, hbm_total, make_plan,
+                                                          lambda p_, r_: sh.hbm_budget(p_, r_, B, L, NBATCH, depth, transport, checked))
+    if fit_scale < 1.0:
+        label += " (rows x %.3f more: tables + batch slots + staging must fit %.0f GB of HBM)" % (fit_scale, hbm_total / 1e9)
+        if rank == 0:
+            print("[dist_bench] the layout as configured needs more than this GPU's HBM on its fullest rank: rows scaled by %.3f" % fit_scale,
+                  file=sys.stderr)
     split = [t for t, k in enumerate(plan.kinds) if k == sh.ROW_SPLIT]
     whole = [t for t, k in enumerate(plan.kinds) if k == sh.WHOLE]
     rps = {t: -(-rows_list[t] // world) for t in split}
@@ -236,12 +247,12 @@ def run_sharded(args, hbm_peak_gbs: float, ctx, rep_bytes: int, mode: str):
             dist.broadcast_object_list(box, src=0)         # one job tag for the shared-memory segment
         n_split = sum(1 for k in plan.kinds if k == sh.ROW_SPLIT)
         arena = int(1.25 * NBATCH * T * B * (L * 4 + dim * 4)) + 8 * 2 * n_split * B * (L * 8 + min(L, world) * dim * 4 * 2) + (256 << 20)
+        arena = int(os.environ.get("PIMEMB_BENCH_PEER_ARENA_BYTES", arena))         # (test hook: an arena nobody can allocate)
         peer = sh.PeerGroup(eng, "bench-" + box[0], rank, world, arena_bytes=arena)
     else:
         comm = sh.native_comm(eng, rank, world, always=via)
     # --checked: EMB_SHARD_CHECK_SERVED -- what ShardedEmbeddingBags does by default for tensors it does not trust.  One-index
     # batches keep the direct path and COUNT what every shard serves (the requester compares); routed batches validate first.
-    checked = bool(getattr(args, "checked", False))
     S = sh.ShardedEmbeddingBags(plan, eng, rank, comm, depth=depth, check=checked, self_via_comm=via and not use_peer, peer=peer)
     S.load_tables(lambda t, lo, hi: table_values(torch, t, lo, hi, dim, dev))
     torch.cuda.empty_cache()
@@ -403,6 +414,7 @@ def run_sharded(args, hbm_peak_gbs: float, ctx, rep_bytes: int, mode: str):
     kernel_us, alg_bytes = k_local + k_serve + k_direct, int(serve_bytes + local_bytes)
     direct = k_direct > 0 and k_route == 0
 
+    free_b, total_b = torch.cuda.mem_get_info(dev)        # what the GPU holds now, all processes on it: next to the pre-flight's estimate
     result = None
     if rank == 0:
         ach = alg_bytes / (kernel_us * 1e-6) / 1e9 if kernel_us > 0 else 0.0
@@ -446,6 +458,9 @@ def run_sharded(args, hbm_peak_gbs: float, ctx, rep_bytes: int, mode: str):
                        # requesters' raw index arrays and serves the bags whose row it holds (PIMEMB_SHARD_DIRECT=0: always route)
                        "direct_one_hot_path": bool(direct),
                        "checked": checked,      # EMB_SHARD_CHECK_SERVED: served bags counted (direct path) / pieces validated (routed)
+                       # what the fullest rank holds, GB (sharding.hbm_budget, computed before anything was allocated)
+                       "hbm_budget_GB": {k: round(v / 1e9, 3) for k, v in hbm_need.items()}, "hbm_total_GB": round(hbm_total / 1e9, 1),
+                       "rows_scale_to_fit": fit_scale, "hbm_in_use_GB_measured": round((total_b - free_b) / 1e9, 3),
                        # where the loop consumes a finished batch: the caller's stream (stream order is the hand-over) or a second
                        # stream (emb_shard_wait records an event between two kernels of the caller's stream every step)
                        "consumer_stream": consumer_mode,
@@ -699,7 +714,15 @@ def run(args, hbm_peak_gbs: float) -> None:
     auto = getattr(args, "replicate_mb", None) is None
     mode = getattr(args, "shard_mode", None) or ("rows" if getattr(args, "workload", "c2") == "c4" else "whole")
 
-    def shard_leg(a, peak, c, rep):
+    # --exchange: rccl | peer | both.  "both" (the default for N > 1): the sharded leg runs over RCCL first -- that is
+    # value_exchange, and a failure there fails the run -- then once more over peer stores, under a deadline (peer_leg below).
+    exchange = getattr(args, "exchange", None) or ("both" if world > 1 else "rccl")
+    first_transport = "peer" if exchange == "peer" else "rccl"
+
+    def shard_leg(a, peak, c, rep, transport=None):
+        import copy
+        a = copy.copy(a)
+        a.exchange = transport or first_transport
         return run_sharded(a, peak, c, rep, mode)
     state = {"printed": False, "dog": None, "primary": None}
 
@@ -758,7 +781,10 @@ def run(args, hbm_peak_gbs: float) -> None:
                 result["sharded_exchange"]["config"] = sec["config"]["workload"] + "; " + sec["config"]["parallelism"]
                 # the same numbers inside the two objects a SCALE record keeps (config / roofline) ...
                 result["config"]["exchange"] = dict(sec["config"]["exchange"], steps=sec["steps"],
-                                                    what="secondary leg of the same run: " + sec["config"]["workload"])
+                                                    what="secondary leg of the same run: " + sec["config"]["workload"],
+                                                    transport=sec["config"]["exchange_transport"],
+                                                    last_step_sharded_outputs_sha1=sec["config"].get("last_step_sharded_outputs_sha1"))
+                result["exchange_transport"] = sec["config"]["exchange_transport"]
                 result["roofline"]["exchange"] = sec["roofline"]["exchange"]
                 # ... and at the TOP LEVEL: `value` is the replica curve (every table on every rank, no data-path transfer:
                 # it scales with N by construction), `value_exchange` the all-to-all curve north_star asks for -- the five
@@ -771,7 +797,103 @@ def run(args, hbm_peak_gbs: float) -> None:
         result = shard_leg(args, hbm_peak_gbs, ctx, rep_mb << 20)
         if rank == 0 and result is not None:       # the primary leg IS the exchange: one number, two names
             result["value_exchange"], result["ms_per_step_exchange"], result["exchange_mode"] = result["value"], result["ms_per_step"], mode
+            result["exchange_transport"] = result["config"]["exchange_transport"]
+    secondary = auto and total_bytes <= hbm // 4          # the sharded leg was the run's secondary leg (fewer steps)
+    if exchange == "both" and not (secondary and getattr(args, "no_exchange_leg", False)):
+        peer_leg(args, (64 if auto else int(args.replicate_mb)) << 20, result, emit, finish, ctx, shard_leg, hbm_peak_gbs, secondary)
     emit(finish(result))
+    # teardown under a deadline: a peer leg that lost a rank must not keep the survivors in a barrier nobody will complete
+    bye = threading.Timer(float(os.environ.get("PIMEMB_TEARDOWN_TIMEOUT", "60")), lambda: os._exit(0))
+    bye.daemon = True
+    bye.start()
     dist.barrier()
     dist.destroy_process_group()
+    bye.cancel()
     run_dog.cancel()
+
+
+def peer_leg(args, rep_bytes, result, emit, finish, ctx, shard_leg, hbm_peak_gbs, secondary):
+    """--exchange both: the sharded leg once more over PEER STORES, after the RCCL leg has been timed and verified.  The faster
+    design on one GPU (58 vs 144 us per step at world 1, round 4) has never crossed a link: whenever a multi-GPU node runs
+    this file, ONE run measures both transports.  Reported on the same line as value_exchange_peer / ms_per_step_exchange_peer
+    / exchange_transport_peer (+ config.exchange_peer, roofline.exchange_peer), verified against the same expected rows, and
+    its outputs must carry the RCCL leg's digest (exchange_same_bits).
+
+    What can go wrong here must not cost the RCCL numbers.  A peer leg that cannot come up -- no fine-grained arena
+    (emb_peer_create refuses to fall back silently), an IPC mapping that does not return (the library's watchdog reports, this
+    leg's deadline ends the wait), a rank that lost its peers -- is recorded as {"skipped": reason}: the line is printed, the
+    exit status stays 0.  A peer leg that comes up and leaves WRONG rows fails the run like any parity failure."""
+    import copy
+    import threading
+    import torch
+    import torch.distributed as dist
+    rank, world, dev, backend = ctx["rank"], ctx["world"], ctx["dev"], ctx["backend"]
+    limit = float(os.environ.get("PIMEMB_PEER_LEG_TIMEOUT", "150"))
+
+    def record(obj):
+        if rank == 0 and result is not None:
+            result["exchange_peer"] = obj
+            result["config"]["exchange_peer"] = obj
+    def expire():
+        record({"skipped": "no result within %.0f s: a rank is stuck in the peer group's set-up or in a wait for a peer (stderr has the library's message)" % limit})
+        emit(finish(result))
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
+    dog = threading.Timer(limit, expire)
+    dog.daemon = True
+    dog.start()
+    a3 = copy.copy(args)
+    if secondary:            # the same W / K as the RCCL leg it is compared with (the digest is over the slot the loop ends on)
+        a3.steps, a3.warmup = min(args.steps, 400), min(args.warmup, 40)
+    saved = {k: os.environ.get(k) for k in ("PIMEMB_SHARD_TIMEOUT_S", "PIMEMB_PEER_WATCHDOG")}
+    os.environ["PIMEMB_SHARD_TIMEOUT_S"] = os.environ.get("PIMEMB_PEER_LEG_WAIT_S", "30")      # a missing peer ends a wait after this long
+    os.environ["PIMEMB_PEER_WATCHDOG"] = "report"            # a mapping call that hangs: say so, this leg's deadline ends the process (status 0)
+    status, note, out = 0, "", None
+    try:
+        out = shard_leg(a3, hbm_peak_gbs, ctx, rep_bytes, "peer")
+    except AssertionError as ex:                # a leg that came up and left wrong rows is a parity failure, not a skip
+        status, note = (2 if ("differs from the expected" in str(ex) or "more than 1e-6" in str(ex)) else 1), "%s: %s" % (type(ex).__name__, ex)
+    except BaseException as ex:  # noqa: BLE001
+        import traceback
+        traceback.print_exc()
+        status, note = 1, "%s: %s" % (type(ex).__name__, ex)
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+    worst = torch.tensor([status], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(worst, op=dist.ReduceOp.MAX)          # every rank ends this leg the same way (under the same deadline)
+    worst = int(worst.item())
+    dog.cancel()
+    if worst == 2:
+        record({"failed": note or "another rank's peer-store outputs differ from the expected rows", "verified": False})
+        if rank == 0 and result is not None:
+            result["verified"] = False
+        emit(finish(result))
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(1)
+    if worst == 1:
+        record({"skipped": note or "another rank could not bring the peer-store leg up (its stderr says why)"})
+        return
+    if rank == 0 and result is not None and out is not None:
+        same = out["config"].get("last_step_sharded_outputs_sha1") == result["config"].get("last_step_sharded_outputs_sha1",
+                                                                                         (result["config"].get("exchange") or {}).get("last_step_sharded_outputs_sha1"))
+        obj = {"value": out["value"], "ms_per_step": out["ms_per_step"], "ms_per_step_event": out["ms_per_step_event"], "steps": out["steps"],
+               "verified": True, "transport": out["config"]["exchange_transport"], "direct_one_hot_path": out["config"]["direct_one_hot_path"],
+               "bytes_out_per_rank_per_step": out["config"]["exchange"]["bytes_out_per_rank_per_step"],
+               "host_us_per_step": out["config"]["exchange"]["host_us_per_step"],
+               "last_step_sharded_outputs_sha1": out["config"].get("last_step_sharded_outputs_sha1"), "same_bits_as_rccl_leg": bool(same)}
+        record(obj)
+        result["roofline"]["exchange_peer"] = out["roofline"]["exchange"]
+        result["value_exchange_peer"] = out["value"]
+        result["ms_per_step_exchange_peer"] = out["ms_per_step"]
+        result["exchange_transport_peer"] = out["config"]["exchange_transport"]
+        result["exchange_same_bits"] = bool(same)
+        if not same:
+            result["verified"] = False
+            emit(finish(result))
+            sys.stdout.flush()
+            os._exit(1)

@@ -130,6 +130,86 @@ def plan_shards(rows: Sequence[int], dim: int, elem_bytes: int, world: int,
     return plan
 
 
+def hbm_budget(plan: ShardPlan, rank: int, bags: int, pooling: int, n_slots: int = 8, depth: int = 3, transport: str = "rccl",
+               checked: bool = False, balance: float = 1.0) -> dict:
+    """HBM one rank needs for a sharded job, by category, in bytes -- host arithmetic only (emb_route_bags_sizes through the C
+    ABI), so that a layout can be checked against 288 GB BEFORE an 8-GPU node is booked (and by bench.py before it allocates):
+
+      tables     what the rank holds: its shards, its whole tables, every replicated table;
+      batches    the caller's `n_slots` rotating batch slots: indices (uint32) + pooled rows of ALL tables for its own bags
+                 (peer stores: carved from the arena instead -- counted there);
+      staging    the library's ring of 6 batch slots (pimemb_shard.cpp kRing), grow-only with 25 % headroom: routed requests,
+                 slot maps, what arrives from the peers (request pieces, whole tables' index arrays) and what goes back (partial
+                 rows, pooled rows of whole tables owned here) -- the last two only over RCCL: with peer stores the owner gathers
+                 and stores in place; only slots that can be live at `depth` are ever touched (depth + 2, at most 6);
+      plans      64 cached plans (emb_shard's kPlanCache): descriptors (128 B) + the XCD map (8 B per workgroup);
+      counters   a checked shard's served-bag counters (16 KiB per descriptor and ring slot);
+      arena      peer stores: what emb_peer_create allocates (bench.py's formula).
+
+    `balance` scales what a rank RECEIVES: 1.0 = every shard gets 1/world of the row-split requests (uniform indices), world =
+    every index of every rank names rows of this one shard (the worst skew)."""
+    from . import lib as _l
+    import ctypes as C
+    N, T, dim, elem = plan.world, len(plan.rows), plan.dim, plan.elem_bytes
+    B, L = int(bags), int(pooling)
+    split = [t for t, k in enumerate(plan.kinds) if k == ROW_SPLIT]
+    whole_here = [t for t, k in enumerate(plan.kinds) if k == WHOLE and plan.units[plan.units_of_table[t][0]].owner == rank]
+    whole_else = [t for t, k in enumerate(plan.kinds) if k == WHOLE and plan.units[plan.units_of_table[t][0]].owner != rank]
+    rep = [t for t, k in enumerate(plan.kinds) if k == REPLICATED]
+    Kr, M = len(split), len(whole_here)
+    grow = lambda b: int(b + b // 4 + 256)          # pimemb_shard.cpp ensure()
+    live = min(6, depth + 2)
+    out = {"tables": plan.bytes_on(rank)}
+    per_slot = T * B * L * 4 + T * B * dim * 4
+    out["batches"] = 0 if transport == "peer" else n_slots * per_slot
+    stg = 0
+    one_hot_direct = L == 1 and (transport == "peer" or N == 1)           # the direct path: nothing is routed, nothing staged
+    if Kr and not one_hot_direct:
+        sb, mb, lb, wb = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _l.check(_l.load().emb_route_bags_sizes(Kr, max(B, 1), Kr * B * L, N, C.byref(sb), C.byref(mb), C.byref(lb), C.byref(wb)))
+        sub = min(L, N)                                # partial rows a bag can come back as
+        stg += live * (grow(sb.value) + grow(mb.value) + grow(lb.value)) + grow(wb.value)
+        stg += live * grow(Kr * B * sub * dim * 4)                                              # ret_recv
+        if transport != "peer":                        # pieces arrive in / leave from staging only when RCCL carries them
+            recv_idx = int(balance * Kr * B * L)                                                # indices this shard is asked for, all sources
+            recv_sub = int(min(balance * Kr * B * sub, recv_idx))
+            stg += live * (grow((recv_idx + recv_sub) * 4 + 64 * N * Kr) + grow(recv_sub * dim * 4))     # req_recv, ret_send
+    if M and transport != "peer" and N > 1:            # whole tables owned here: the other ranks' index arrays in, their pooled rows out
+        stg += live * (grow((N - 1) * M * B * (L + 1) * 4) + grow((N - 1) * M * B * dim * 4))
+    out["staging"] = stg
+    n_desc = N * (Kr + M) + len(rep)
+    tiles = -(-B // 64)
+    out["plans"] = 64 * (n_desc * 128 + (n_desc * tiles + 8 * n_desc) * 8)
+    out["counters"] = live * n_desc * 16384 if checked else 0
+    out["arena"] = 0
+    if transport == "peer":
+        out["arena"] = int(1.25 * n_slots * T * B * (L * 4 + dim * 4)) + 8 * 2 * Kr * B * (L * 8 + min(L, N) * dim * 4 * 2) + (256 << 20)
+    out["total"] = sum(out.values())
+    return out
+
+
+def fit_to_hbm(rows: Sequence[int], hbm_bytes: int, make_plan: Callable[[Sequence[int]], ShardPlan], budget_of: Callable[[ShardPlan, int], dict],
+               headroom: float = 0.94):
+    """Largest uniform row scale <= 1 at which the worst rank's hbm_budget stays within headroom x hbm_bytes:
+    (scale, rows, plan, worst budget).  make_plan(rows) -> ShardPlan; budget_of(plan, rank) -> hbm_budget dict.  BASELINE
+    configs[4] (512 x 50M x dim 64 fp16) does not fit 8 x 288 GB as written; at 30M rows the TABLES fit (245.8 GB per rank) but
+    tables + the batch slots + the RCCL staging of 64 whole tables per owner do not (289 GB): the bench shrinks the rows by a few
+    per cent more and says so, instead of running out of memory half-way through its first real 8-GPU run."""
+    scale, cur = 1.0, [int(r) for r in rows]
+    for _ in range(8):
+        plan = make_plan(cur)
+        worst = max((budget_of(plan, r) for r in range(plan.world)), key=lambda d: d["total"])
+        if worst["total"] <= headroom * hbm_bytes:
+            return scale, cur, plan, worst
+        room = headroom * hbm_bytes - (worst["total"] - worst["tables"])
+        if room <= 0:
+            raise MemoryError("the batch slots and staging buffers alone (%.1f GB) exceed %.0f %% of %.1f GB of HBM: fewer bags per batch or "
+                              "fewer rotating slots" % ((worst["total"] - worst["tables"]) / 1e9, headroom * 100, hbm_bytes / 1e9))
+        scale *= 0.995 * room / worst["tables"]
+        cur = [max(1, int(r * scale)) for r in rows]
+    raise MemoryError("no row scale found that fits %.1f GB" % (hbm_bytes / 1e9))
+
+
 # ------------------------------------------------------------------------------------------------
 class ShardedEmbeddingBags:
     """`apply_emb` over tables sharded across the ranks of one node: forward(lS_o, lS_i) -> [B, dim] per table, ONE

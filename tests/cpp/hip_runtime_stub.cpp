@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <unistd.h>
 #include <map>
 #include <mutex>
 #include <string>
@@ -404,7 +405,15 @@ long pimemb_stub_tracked_calls(void) { return g_tracked_calls.load(); }
 
 // ---- what csrc/pimemb_peer.cpp needs for a group of ONE process (an IPC handle is the pointer itself) ------------------------
 extern "C" {
-hipError_t hipExtMallocWithFlags(void **p, size_t n, unsigned int) { return hipMalloc(p, n); }
+// two behaviours of real runtimes the peer group must survive (pimemb_peer.cpp): no fine-grained device memory, and an IPC
+// mapping call that never returns
+std::atomic<int> g_no_finegrained{0}, g_ipc_open_hangs{0};
+void pimemb_stub_no_finegrained(int on) { g_no_finegrained.store(on); }
+void pimemb_stub_ipc_open_hangs(int on) { g_ipc_open_hangs.store(on); }
+hipError_t hipExtMallocWithFlags(void **p, size_t n, unsigned int) {
+    if (g_no_finegrained.load()) { track("hipExtMallocWithFlags"); return hipErrorNotSupported; }
+    return hipMalloc(p, n);
+}
 hipError_t hipHostRegister(void *, size_t, unsigned int) { track("hipHostRegister"); return hipSuccess; }
 hipError_t hipHostUnregister(void *) { track("hipHostUnregister"); return hipSuccess; }
 hipError_t hipHostGetDevicePointer(void **dev, void *host, unsigned int) { track("hipHostGetDevicePointer"); *dev = host; return hipSuccess; }
@@ -416,6 +425,7 @@ hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t *h, void *p) {
 }
 hipError_t hipIpcOpenMemHandle(void **p, hipIpcMemHandle_t h, unsigned int) {
     track("hipIpcOpenMemHandle");
+    while (g_ipc_open_hangs.load()) usleep(1000);       // "never returns" (until the process ends)
     memcpy(p, &h, sizeof(*p));
     return hipSuccess;
 }

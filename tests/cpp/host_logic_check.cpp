@@ -43,6 +43,8 @@ extern "C" void pimemb_stub_set_device_count(int n);
 extern "C" void pimemb_stub_expect_device(int d);
 extern "C" long pimemb_stub_violations(void);
 extern "C" long pimemb_stub_tracked_calls(void);
+extern "C" void pimemb_stub_no_finegrained(int on);
+extern "C" void pimemb_stub_ipc_open_hangs(int on);
 
 struct Rng {
     uint64_t s;
@@ -540,6 +542,76 @@ void everything_on_device_one() {
     printf("everything on device 1: %ld HIP calls, every one with device 1 current ok\n", calls);
 }
 
+// ---- the peer group's two exposures -------------------------------------------------------------------
+// (a) a runtime without fine-grained device memory: a group of one rank falls back to ordinary memory (nobody else stores into
+//     it), a group with peers refuses -- unless ordinary memory was asked for by name (PIMEMB_PEER_ARENA=coarse).
+void peer_group_without_finegrained_memory() {
+    pimemb_stub_no_finegrained(1);
+    emb_engine *e = make_engine(0);
+    emb_peer *peer = nullptr;
+    char tag[64];
+    snprintf(tag, sizeof tag, "hostcheck-nofg-%d", (int)getpid());
+    CHECK(emb_peer_create(e, tag, 0, 1, 8ull << 20, &peer));
+    int32_t fg = 1;
+    CHECK(emb_peer_info(peer, nullptr, nullptr, nullptr, nullptr, nullptr, &fg));
+    EXPECT(fg == 0);
+    CHECK(emb_peer_destroy(peer));
+    std::atomic<int> refused{0}, taken{0};
+    auto join2 = [&](const char *suffix, bool expect_ok) {
+        char t2[96];
+        snprintf(t2, sizeof t2, "%s-%s", tag, suffix);
+        auto rank_main = [&, expect_ok](int rank) {
+            emb_engine *e2 = make_engine(0);
+            emb_peer *p2 = nullptr;
+            const int rc = emb_peer_create(e2, t2, rank, 2, 8ull << 20, &p2);
+            if (expect_ok) {
+                CHECK(rc);
+                int32_t f = 1;
+                CHECK(emb_peer_info(p2, nullptr, nullptr, nullptr, nullptr, nullptr, &f));
+                EXPECT(f == 0);
+                taken++;
+                CHECK(emb_peer_barrier(p2));
+                CHECK(emb_peer_destroy(p2));
+            } else {
+                EXPECT(rc == EMB_ERR_UNSUPPORTED && p2 == nullptr && strstr(emb_last_error(), "PIMEMB_PEER_ARENA=coarse") != nullptr);
+                refused++;
+            }
+            CHECK(emb_destroy(e2));
+        };
+        std::thread a(rank_main, 0), b(rank_main, 1);
+        a.join();
+        b.join();
+    };
+    join2("refuse", false);
+    EXPECT(refused.load() == 2);
+    setenv("PIMEMB_PEER_ARENA", "coarse", 1);
+    join2("coarse", true);
+    unsetenv("PIMEMB_PEER_ARENA");
+    EXPECT(taken.load() == 2);
+    CHECK(emb_destroy(e));
+    pimemb_stub_no_finegrained(0);
+    printf("peer group without fine-grained memory ok\n");
+}
+
+// (b) hipIpcOpenMemHandle that never returns: the watchdog ends the PROCESS with a non-zero status and a message naming rank,
+//     peer and chunk (run as `host_logic_check ipc-hang` by the test, which expects exactly that)
+[[noreturn]] void peer_group_ipc_mapping_hangs() {
+    setenv("PIMEMB_SHARD_TIMEOUT_S", "1", 1);
+    pimemb_stub_ipc_open_hangs(1);
+    char tag[64];
+    snprintf(tag, sizeof tag, "hostcheck-hang-%d", (int)getpid());
+    auto rank_main = [&](int rank) {
+        emb_engine *e = make_engine(0);
+        emb_peer *peer = nullptr;
+        (void)emb_peer_create(e, tag, rank, 2, 8ull << 20, &peer);
+        fprintf(stderr, "emb_peer_create returned although the mapping call hangs\n");
+    };
+    std::thread a(rank_main, 0), b(rank_main, 1);
+    a.join();
+    b.join();
+    exit(0);        // (not reached: the watchdog ends the process first)
+}
+
 // ---- the reference's two entry points -------------------------------------------------------------------------------------
 void compat_calls() {
     const uint32_t nt = 3, nc = 8, nb = 16, per = 4;
@@ -567,6 +639,7 @@ void compat_calls() {
 }  // namespace
 
 int main(int argc, char **argv) {
+    if (argc > 1 && strcmp(argv[1], "ipc-hang") == 0) peer_group_ipc_mapping_hangs();
     const bool only_world8 = argc > 1 && strcmp(argv[1], "world8") == 0;
     if (!only_world8) {
         engine_threads();
@@ -581,6 +654,7 @@ int main(int argc, char **argv) {
         peer_ranks_as_threads(2, MIX_SMALL, true, {0, 1, 2, 3});
         peer_ranks_as_threads(3, MIX_SMALL, false, {0, 1, 2, 3});
         everything_on_device_one();
+        peer_group_without_finegrained_memory();
         compat_calls();
     }
     // world 8 -- the sizes that change there (counts[N][K+1][2], mailboxes [dst][src][slot], N * K descriptors, slots (d << 24))

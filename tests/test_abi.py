@@ -154,3 +154,20 @@ def test_round4_struct_layouts_match_the_header(pel, tmp_path):
                       ("EMB_SHARD_SELF_VIA_COMM", L.EMB_SHARD_SELF_VIA_COMM), ("EMB_SHARD_CHECK_SERVED", L.EMB_SHARD_CHECK_SERVED),
                       ("EMB_SHARD_PEER_STORES", L.EMB_SHARD_PEER_STORES), ("EMB_SHARD_NO_DIRECT", L.EMB_SHARD_NO_DIRECT)):
         assert re.search(r"#define %s %du\b" % (name, val), text), name
+
+
+def test_boundary_documents_do_not_name_a_retired_transport():
+    """The ABI header is the boundary document: the RCCL-mode sharded step has ONE transport --
+    emb_comm_exchange issued from C -- and bench.py has no torch.distributed data path any more.  The retired wording
+    ("--collective torch", "uses torch.distributed unless") must not come back in the header, the RCCL binding or the
+    integration notes."""
+    import re
+    retired = re.compile(r"--collective\s+torch|torch\.distributed\s+unless|keeps\s+torch\.distributed\s+as\s+the\s+default|all_to_all_rounds", re.S)
+    for rel in ("include/pimemb.h", "pim-embedding-lookup_amd/csrc/pimemb_comm.cpp", "pim-embedding-lookup_amd/csrc/pimemb_shard.cpp",
+                "INTEGRATION.md", "README.md"):
+        text = " ".join(open(os.path.join(ROOT, rel)).read().split())
+        m = retired.search(text)
+        assert m is None, f"{rel}: retired wording {m.group(0)!r}"
+    # ... and what bench.py ships agrees: --collective has the one choice
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'choices=["native"]' in bench and '"--collective"' in bench

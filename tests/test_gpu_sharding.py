@@ -634,6 +634,20 @@ def test_driver_torchrun_command_two_ranks():
     assert d["clock"] == "sync" and d["ms_per_step"] == d["ms_per_step_sync"] >= d["ms_per_step_event"] > 0
     assert d["config"]["exchange"]["verified"] is True and d["roofline"]["exchange"]["step_frac"] > 0
     assert len([l for l in res.stdout.splitlines() if l.strip()]) == 1          # nothing but the JSON line on the job's stdout
+    _assert_both_transports(d)
+
+
+def _assert_both_transports(d):
+    """Default flags at N > 1 = --exchange both: the RCCL leg is value_exchange, the peer-store leg of the
+    SAME run is value_exchange_peer, each verified against the same expected rows, and they leave the same bits."""
+    assert d["exchange_transport"].startswith("RCCL groups") and "peer stores" in d["exchange_transport_peer"]
+    assert d["value_exchange"] > 0 and d["value_exchange_peer"] > 0 and d["ms_per_step_exchange_peer"] > 0
+    xp = d["config"]["exchange_peer"]
+    assert xp["verified"] is True and xp["same_bits_as_rccl_leg"] is True and d["exchange_same_bits"] is True
+    assert xp["last_step_sharded_outputs_sha1"] == d["config"]["exchange"]["last_step_sharded_outputs_sha1"] is not None
+    assert "fine-grained" in xp["transport"] or "ordinary" in xp["transport"]          # which kind of arena the peers stored into
+    assert d["roofline"]["exchange_peer"]["step_frac"] > 0 and d["exchange_peer"] == xp
+    assert d["verified"] is True
 
 
 def test_driver_command_shape_four_ranks_on_one_gpu():
@@ -664,6 +678,7 @@ def test_driver_command_shape_four_ranks_on_one_gpu():
     assert c["exchange"]["verified"] is True and c["exchange"]["value"] > 0 and c["exchange"]["bytes_out_per_rank_per_step"] > 0
     assert d["roofline"]["exchange"]["step_frac"] > 0 and d["roofline"]["exchange"]["xgmi_frac"] > 0
     assert d["ms_per_step_sync"] >= d["ms_per_step_event"] > 0
+    _assert_both_transports(d)
     assert wall < 300, f"{wall:.0f} s for the rehearsal: too close to the driver's limit"
 
 
@@ -690,3 +705,20 @@ def test_peer_store_exchange_leaves_the_same_bits_as_rccl(leg):
             assert "NONE" in d["config"]["parallelism"] and d["roofline"]["exchange"]["host_wait_served_us_per_step"] >= 0
         got[ex] = d["config"]["last_step_sharded_outputs_sha1"]
     assert got["rccl"] == got["peer"] is not None
+
+
+@pytest.mark.parametrize("how", ["deadline", "cannot-come-up"])
+def test_peer_leg_that_cannot_come_up_is_skipped_not_failed(how):
+    """--exchange both: whatever happens to the peer-store leg must not cost the RCCL numbers.  deadline: the leg's deadline
+    passes (here at once: what a rank stuck in hipIpcOpenMemHandle or in a wait for a lost peer ends in); cannot-come-up:
+    emb_peer_create fails on every rank (an arena no GPU can hold stands in for "no fine-grained memory").  Either way: ONE
+    JSON line, rc 0, value_exchange of the RCCL leg intact and verified, exchange_peer = {"skipped": reason}."""
+    import json
+    env = {"PIMEMB_PEER_LEG_TIMEOUT": "0.01"} if how == "deadline" else {"PIMEMB_BENCH_PEER_ARENA_BYTES": str(1 << 50)}
+    res, lines = _bench_rccl_ranks(2, ["--steps", "6", "--warmup", "3", "--nbatch", "4", "--batch", "4099"], env_extra=env)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["verified"] is True and d["value_exchange"] > 0 and d["config"]["exchange"]["verified"] is True
+    assert "skipped" in d["exchange_peer"] and "value_exchange_peer" not in d
+    assert ("no result within" in d["exchange_peer"]["skipped"]) == (how == "deadline"), d["exchange_peer"]

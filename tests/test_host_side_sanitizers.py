@@ -79,8 +79,13 @@ def test_library_host_logic_under_sanitizers(tmp_path, sanitizer):
     """The HOST side of the library's own sources -- engine (launch-image rings from several caller threads, plans,
     host-pointer calls, checked calls with one thread handing in bad indices), the request queue (adders, a free-running
     flusher, late collectors), the sharded call with one rank (every placement, depth 0-3, routed and direct batches,
-    peer-store mode), with two / three ranks as threads over a stand-in for emb_comm and -- ASan leg -- in one peer group
-    (the collective-free exchange: the stub plays the mailbox kernels), populate_mram / lookup -- compiled host-only (`--cuda-host-only`) and linked against
+    peer-store mode, CHECKED shards whose counted direct path must name the one bad index on the requesting rank),
+    with 2 / 3 and with EIGHT ranks as threads over a stand-in for emb_comm (the C4 placement mix: 20 replicated / 6
+    row-split; the C5 mix: every table whole on an owner; ragged, one-index, empty batches) and -- ASan leg -- in one peer
+    group of 2 / 3 / 8 ranks (the collective-free exchange: the stub plays the mailbox kernels and the served counters),
+    EVERYTHING AGAIN ON DEVICE 1 of a two-device stub that counts every HIP call made with another device current (none may
+    be: engine, queues and their client / flusher threads, shards, peer groups), a runtime without fine-grained memory
+    (a group with peers refuses the silent fallback), populate_mram / lookup -- compiled host-only (`--cuda-host-only`) and linked against
     tests/cpp/hip_runtime_stub.cpp instead of the HIP runtime: kernels are no-ops there except the signalling ones, so what
     is checked is return codes, tickets, ordering and that ThreadSanitizer / AddressSanitizer + UBSan stay silent.  (Removing
     the launch-ring lock makes the TSan leg fail: tried.)  Nothing of this is linked into libpimemb.so."""
@@ -98,3 +103,25 @@ def test_library_host_logic_under_sanitizers(tmp_path, sanitizer):
     run = subprocess.run([str(out / "host_logic_check")], capture_output=True, text=True, timeout=900, env=env)
     assert run.returncode == 0 and "host logic ok" in run.stdout, run.stdout[-1000:] + run.stderr[-4000:]
     assert "pimemb:" not in run.stderr and "Sanitizer" not in run.stderr, run.stderr[-4000:]
+
+
+def test_peer_group_mapping_watchdog_ends_the_process(tmp_path):
+    """hipIpcOpenMemHandle has no deadline and has been seen never to return on this runtime (allocations above 2 GiB).  The
+    stub makes it hang for good: the watchdog of emb_peer_create must end the PROCESS with a non-zero status and a message
+    that names the rank, the peer and the chunk -- within the group's timeout, leaving no shared-memory segment behind."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    out = tmp_path / "obj"
+    build = subprocess.run(["bash", os.path.join(ROOT, "tests", "cpp", "build_host_logic_check.sh"), "address,undefined", str(out)],
+                           capture_output=True, text=True, timeout=900)
+    if build.returncode != 0 and "libclang_rt" in build.stderr and "No such file" in build.stderr:
+        pytest.skip("sanitizer runtime not installed: " + build.stderr[-200:])
+    assert build.returncode == 0, build.stderr[-3000:]
+    before = set(os.listdir("/dev/shm")) if os.path.isdir("/dev/shm") else set()
+    run = subprocess.run([str(out / "host_logic_check"), "ipc-hang"], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 70, (run.returncode, run.stderr[-2000:])
+    assert "hipIpcOpenMemHandle of rank" in run.stderr and "chunk 0" in run.stderr and "has not returned within" in run.stderr
+    assert "returned although" not in run.stderr
+    left = {n for n in (set(os.listdir("/dev/shm")) - before if os.path.isdir("/dev/shm") else set()) if n.startswith("pimemb-hostcheck-hang")}
+    assert not left, left

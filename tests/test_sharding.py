@@ -122,8 +122,10 @@ def _worker(rank, world, port, cfg, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         rows, dim, N = cfg["rows"], cfg["dim"], world
-        plan = sh.plan_shards(rows, dim, 4, world, replicate_bytes=cfg["rep"], split_bytes=cfg["split"])
+        plan = sh.plan_shards(rows, dim, 4, world, replicate_bytes=cfg["rep"], split_bytes=cfg["split"], pooling=cfg.get("plan_pooling", 1.0))
         assert set(plan.kinds) == set(cfg["expect_kinds"]), plan.kinds
+        if cfg.get("expect_row_split") is not None:
+            assert plan.kinds.count(sh.ROW_SPLIT) == cfg["expect_row_split"], plan.kinds
         tabs = [np.random.default_rng(100 + t).standard_normal((n, dim)).astype(np.float32) for t, n in enumerate(rows)]
         split = [t for t, k in enumerate(plan.kinds) if k == sh.ROW_SPLIT]
         whole_of = [[t for t, k in enumerate(plan.kinds) if k == sh.WHOLE and plan.units[plan.units_of_table[t][0]].owner == p]
@@ -293,6 +295,76 @@ def test_gloo_exchange_protocol_matches_single_process_oracle(cfg, world):
         p.join(timeout=60)
     for rank, status, info in res:
         assert status == "ok", f"rank {rank}:\n{info}"
+
+
+@pytest.mark.parametrize("pooling", [1, 32])
+def test_gloo_exchange_protocol_world_8_terabyte_placement(pel, pooling):
+    """World EIGHT: the planner's own placement of the 26 Terabyte-shaped tables (BASELINE configs[3]; rows
+    and the replication threshold scaled by 1/20000 so that eight CPU processes hold them) -- 4 row-split tables at one index per
+    bag, fewer at pooling 32 where the return-volume term keeps pooled tables whole -- through a real eight-process exchange:
+    counts[8][K+1][2] first, request pieces sized by the library's own arithmetic (emb_route_exchange_sizes), 8 x K serve
+    descriptors (emb_route_serve_descs), partial rows back and added in shard order; whole tables on eight owners.  Every table
+    of every rank against the single-process oracle.  The reference fans one lookup() out to all its devices the same way
+    (upmem/include/emb_host.h:155-160, 258-321)."""
+    import torch.multiprocessing as mp
+    scale = 1.0 / 20000
+    rows, dim, _, _ = pel.workloads.table_set("c4", rows_scale=scale)
+    sh = _sharding()
+    plan = sh.plan_shards(rows, dim, 4, 8, replicate_bytes=int((64 << 20) * scale), pooling=float(pooling))
+    n_split = plan.kinds.count(sh.ROW_SPLIT)
+    assert n_split == 4 if pooling == 1 else 0 < n_split < 4, plan.kinds
+    cfg = dict(rows=rows, dim=dim, rep=int((64 << 20) * scale), split=None, plan_pooling=float(pooling), bags=9, max_len=pooling,
+               expect_kinds=sorted(set(plan.kinds)), expect_row_split=n_split)
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, cfg, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = [q.get(timeout=420) for _ in procs]
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    for rank, status, info in res:
+        assert status == "ok", f"rank {rank}:\n{info}"
+
+
+def test_hbm_budget_of_the_8_rank_layouts_fits_288_gb(pel):
+    """per-rank HBM of BASELINE configs[3] (C4) and configs[4] (C5, 30M rows) at EIGHT ranks -- tables +
+    the caller's rotating batch slots (or the arena) + the library's staging ring + 64 cached plans + a checked shard's
+    counters -- against 288 GB, for both transports, by host arithmetic alone.  C4 is far inside.  C5's TABLES fit (245.8 GB a
+    rank) but tables + slots + the RCCL staging of 64 whole tables per owner do NOT (289 GB): bench.py's pre-flight
+    (sharding.fit_to_hbm) shrinks the rows a few per cent and the line says so -- checked here, before a node is booked."""
+    sh = _sharding()
+    HBM = 288 * 10**9
+    for name, L, elem in (("c4", 1, 4), ("c4", 32, 4), ("c5", 32, 2)):
+        rows, dim, B, _ = pel.workloads.table_set(name)
+        make = lambda rows_: sh.plan_shards(rows_, dim, elem, 8, replicate_bytes=64 << 20, pooling=float(L))   # noqa: E731
+        for transport in ("rccl", "peer"):
+            bud = lambda p_, r_: sh.hbm_budget(p_, r_, B, L, n_slots=8, depth=3, transport=transport, checked=True)   # noqa: E731
+            plan = make(rows)
+            worst = max((bud(plan, r) for r in range(8)), key=lambda d: d["total"])
+            assert worst["total"] == sum(v for k, v in worst.items() if k != "total") and worst["tables"] == max(plan.bytes_on(r) for r in range(8))
+            if name == "c4":
+                assert worst["total"] < 0.5 * HBM, (name, L, transport, worst)
+                assert sh.fit_to_hbm(rows, HBM, make, bud)[0] == 1.0
+            else:
+                assert 240e9 < worst["tables"] < 250e9
+                if transport == "rccl":
+                    assert worst["total"] > HBM, worst            # as configured it would run out of memory on the node
+                    assert worst["staging"] > 10e9 and worst["batches"] > 20e9
+                scale, rows2, plan2, worst2 = sh.fit_to_hbm(rows, HBM, make, bud)
+                assert 0.8 < scale <= 1.0 and worst2["total"] <= 0.94 * HBM and all(r2 <= r for r2, r in zip(rows2, rows))
+                assert (scale < 1.0) == (worst["total"] > 0.94 * HBM)
+    # the worst skew (every index of every rank names ONE shard's rows) at C4, pooling 32: still inside
+    rows, dim, B, _ = pel.workloads.table_set("c4")
+    plan = sh.plan_shards(rows, dim, 4, 8, replicate_bytes=64 << 20, pooling=1.0)
+    skew = max(sh.hbm_budget(plan, r, B, 32, transport="rccl", balance=8.0)["total"] for r in range(8))
+    assert skew < 0.6 * HBM
 
 
 def test_planner_return_volume_term(pel):
