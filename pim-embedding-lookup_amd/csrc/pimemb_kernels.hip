@@ -986,15 +986,12 @@ hipError_t launch_served_counts(const ServedArgs &args, hipStream_t stream) {
     if (args.n_seg > kServedSegs || args.n_flag > kServedSegs) return hipErrorInvalidValue;
     uint32_t n = 0;
     for (uint32_t i = 0; i < args.n_seg; i++) n += args.seg[i].n_counted + args.seg[i].n_fill;
-    // up to 64 counters (26 tables on one rank: the Kaggle / Terabyte shapes): ONE workgroup of 16 wavefronts -- no ticket, one
-    // fence; more (512 tables, many peers): a wavefront per counter over up to 64 workgroups, the last one raises the flags
-    if (n <= 64 || args.ticket == nullptr) {
-        hipLaunchKernelGGL(served_counts_kernel<1024>, dim3(1), dim3(1024), 0, stream, args);
-    } else {
-        uint32_t grid = (n + (kBlock / 64) - 1) / (kBlock / 64);
-        grid = grid > 64 ? 64 : grid;
-        hipLaunchKernelGGL(served_counts_kernel<kBlock>, dim3(grid), dim3(kBlock), 0, stream, args);
-    }
+    // a wavefront per counter over up to 64 workgroups of 4, the last one to finish raises the flags.  (ONE workgroup of 16
+    // wavefronts for the 26-table shapes -- no ticket, one fence -- was tried: +13 us per step against +6: profiles/r05/README.md)
+    uint32_t grid = (n + (kBlock / 64) - 1) / (kBlock / 64);
+    grid = grid < 1 ? 1 : (grid > 64 ? 64 : grid);
+    if (args.ticket == nullptr) grid = 1;
+    hipLaunchKernelGGL(served_counts_kernel<kBlock>, dim3(grid), dim3(kBlock), 0, stream, args);
     return hipGetLastError();
 }
 

@@ -26,9 +26,15 @@ run c4_rows_L1_peer --workload c4 --rows-scale 0.125 --pooling 1 --replicate-mb 
 PIMEMB_SHARD_DEPTH=0 run c2_rows_direct_depth0 --shard-mode rows --replicate-mb 64 --steps 400 --warmup 40
 PIMEMB_SHARD_DEPTH=0 run c4_rows_L1_direct_depth0 --workload c4 --rows-scale 0.125 --pooling 1 --replicate-mb 64 --steps 400 --warmup 40
 PIMEMB_SHARD_DEPTH=0 PIMEMB_SHARD_DIRECT=0 run c4_rows_L1_depth0 --workload c4 --rows-scale 0.125 --pooling 1 --replicate-mb 64 --steps 400 --warmup 40
+# CHECKED shards (EMB_SHARD_CHECK_SERVED, round 5): one-index batches keep the direct path and count what every launch serves
+run c2_rows_direct_checked --shard-mode rows --replicate-mb 64 --steps 400 --warmup 40 --checked
+run c4_rows_L1_direct_checked --workload c4 --rows-scale 0.125 --pooling 1 --replicate-mb 64 --steps 400 --warmup 40 --checked
+PIMEMB_SHARD_DEPTH=0 run c4_rows_L1_direct_checked_depth0 --workload c4 --rows-scale 0.125 --pooling 1 --replicate-mb 64 --steps 400 --warmup 40 --checked
+PIMEMB_SHARD_DIRECT=0 run c4_rows_L1_routed_checked --workload c4 --rows-scale 0.125 --pooling 1 --replicate-mb 64 --steps 400 --warmup 40 --checked
+run c4_rows_L1_peer_checked --workload c4 --rows-scale 0.125 --pooling 1 --replicate-mb 64 --steps 400 --warmup 40 --exchange peer --checked
 # the same two direct legs with the loop's consumer on a SECOND stream (emb_shard_wait then records an event between two
 # kernels of the caller's stream every step: the cost of that hand-over, whatever the sharding does)
 PIMEMB_BENCH_CONSUMER=other run c2_rows_direct_other_stream --shard-mode rows --replicate-mb 64 --steps 400 --warmup 40
 PIMEMB_BENCH_CONSUMER=other run c4_rows_L1_direct_other_stream --workload c4 --rows-scale 0.125 --pooling 1 --replicate-mb 64 --steps 400 --warmup 40
-python3 "$root/profiles/summarize_dist_world1.py" "$out" "$root/profiles/r03/dist_world1" > "$root/gpurun_out/profiles_${round}/dist_world1.md"
+python3 "$root/profiles/summarize_dist_world1.py" "$out" "$root/profiles/r04/dist_world1" > "$root/gpurun_out/profiles_${round}/dist_world1.md"
 cat "$root/gpurun_out/profiles_${round}/dist_world1.md"

@@ -15,13 +15,19 @@ PIMEMB_FORCE_DIST=1 PIMEMB_VERIFY_EVERY=37 run b python3 "$root/bench.py" --gpus
 echo "one rank, pooling 8, Zipf (a hot shard), verify every 37th step:" >> "$out"
 PIMEMB_FORCE_DIST=1 PIMEMB_VERIFY_EVERY=37 run c python3 "$root/bench.py" --gpus 1 --workload c4 --rows-scale 0.125 --pooling 8 --index-dist zipf --steps 3000 --nbatch 7 --replicate-mb 64 --no-cpu-baseline
 echo "three RCCL ranks on the one GPU (PIMEMB_RCCL_ONE_GPU=1: sockets over loopback), Kaggle tables, one index per bag, verify every 37th step:" >> "$out"
-PIMEMB_RCCL_ONE_GPU=1 PIMEMB_VERIFY_EVERY=37 run d python3 "$root/bench.py" --gpus 3 --shard-mode rows --replicate-mb 64 --batch 2003 --steps 600 --nbatch 7 --no-cpu-baseline
+PIMEMB_RCCL_ONE_GPU=1 PIMEMB_VERIFY_EVERY=37 run d python3 "$root/bench.py" --gpus 3 --shard-mode rows --replicate-mb 64 --batch 2003 --steps 600 --nbatch 7 --exchange rccl --no-cpu-baseline
 echo "three RCCL ranks, pooling 5, Zipf, verify every 37th step:" >> "$out"
-PIMEMB_RCCL_ONE_GPU=1 PIMEMB_VERIFY_EVERY=37 run e python3 "$root/bench.py" --gpus 3 --shard-mode rows --replicate-mb 64 --pooling 5 --index-dist zipf --batch 2003 --steps 600 --nbatch 7 --no-cpu-baseline
+PIMEMB_RCCL_ONE_GPU=1 PIMEMB_VERIFY_EVERY=37 run e python3 "$root/bench.py" --gpus 3 --shard-mode rows --replicate-mb 64 --pooling 5 --index-dist zipf --batch 2003 --steps 600 --nbatch 7 --exchange rccl --no-cpu-baseline
 echo "three ranks, peer stores (--exchange peer: no RCCL in the data path), one index per bag (direct path), verify every 37th step:" >> "$out"
 PIMEMB_RCCL_ONE_GPU=1 PIMEMB_VERIFY_EVERY=37 run f python3 "$root/bench.py" --gpus 3 --shard-mode rows --replicate-mb 64 --batch 2003 --steps 3000 --nbatch 7 --exchange peer --no-cpu-baseline
 echo "three ranks, peer stores, pooling 5, Zipf (routed), verify every 37th step:" >> "$out"
 PIMEMB_RCCL_ONE_GPU=1 PIMEMB_VERIFY_EVERY=37 run g python3 "$root/bench.py" --gpus 3 --shard-mode rows --replicate-mb 64 --pooling 5 --index-dist zipf --batch 2003 --steps 3000 --nbatch 7 --exchange peer --no-cpu-baseline
 echo "four ranks, peer stores, whole tables (one rank serves nothing), pooling 3, verify every 37th step:" >> "$out"
 PIMEMB_RCCL_ONE_GPU=1 PIMEMB_VERIFY_EVERY=37 run h python3 "$root/bench.py" --gpus 4 --shard-mode whole --replicate-mb 400 --pooling 3 --batch 2003 --steps 3000 --nbatch 7 --exchange peer --no-cpu-baseline
+echo "one rank, CHECKED shard (EMB_SHARD_CHECK_SERVED) on the direct path: every launch counts what it serves, the requester compares; verify every 37th step:" >> "$out"
+PIMEMB_FORCE_DIST=1 PIMEMB_VERIFY_EVERY=37 run i python3 "$root/bench.py" --gpus 1 --workload c4 --rows-scale 0.125 --pooling 1 --steps 3000 --nbatch 7 --replicate-mb 64 --checked --no-cpu-baseline
+echo "three ranks, peer stores, CHECKED, one index per bag (counts return through the mailboxes), verify every 37th step:" >> "$out"
+PIMEMB_RCCL_ONE_GPU=1 PIMEMB_VERIFY_EVERY=37 run j python3 "$root/bench.py" --gpus 3 --shard-mode rows --replicate-mb 64 --batch 2003 --steps 3000 --nbatch 7 --exchange peer --checked --no-cpu-baseline
+echo "two ranks, the driver's default flags (--exchange both: the RCCL leg, then the peer-store leg of the same run), verify every 37th step:" >> "$out"
+PIMEMB_RCCL_ONE_GPU=1 PIMEMB_VERIFY_EVERY=37 PIMEMB_PEER_LEG_TIMEOUT=400 run k python3 "$root/bench.py" --gpus 2 --shard-mode rows --replicate-mb 64 --batch 2003 --steps 600 --nbatch 7 --no-cpu-baseline
 cat "$out"
