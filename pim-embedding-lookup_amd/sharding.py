@@ -141,7 +141,7 @@ def hbm_budget(plan: ShardPlan, rank: int, bags: int, pooling: int, n_slots: int
       staging    the library's ring of 6 batch slots (pimemb_shard.cpp kRing), grow-only with 25 % headroom: routed requests,
                  slot maps, what arrives from the peers (request pieces, whole tables' index arrays) and what goes back (partial
                  rows, pooled rows of whole tables owned here) -- the last two only over RCCL: with peer stores the owner gathers
-                 and stores in place; only slots that can be live at `depth` are ever touched (depth + 2, at most 6);
+                 and stores in place; batches rotate through ALL six slots whatever the depth, and a slot keeps what it grew to;
       plans      64 cached plans (emb_shard's kPlanCache): descriptors (128 B) + the XCD map (8 B per workgroup);
       counters   a checked shard's served-bag counters (16 KiB per descriptor and ring slot);
       arena      peer stores: what emb_peer_create allocates (bench.py's formula).
@@ -158,7 +158,7 @@ def hbm_budget(plan: ShardPlan, rank: int, bags: int, pooling: int, n_slots: int
     rep = [t for t, k in enumerate(plan.kinds) if k == REPLICATED]
     Kr, M = len(split), len(whole_here)
     grow = lambda b: int(b + b // 4 + 256)          # pimemb_shard.cpp ensure()
-    live = min(6, depth + 2)
+    live = 6                                         # (batch seq uses slot seq % 6: every slot ends up with buffers of its own)
     out = {"tables": plan.bytes_on(rank)}
     per_slot = T * B * L * 4 + T * B * dim * 4
     out["batches"] = 0 if transport == "peer" else n_slots * per_slot
@@ -193,7 +193,7 @@ def fit_to_hbm(rows: Sequence[int], hbm_bytes: int, make_plan: Callable[[Sequenc
     """Largest uniform row scale <= 1 at which the worst rank's hbm_budget stays within headroom x hbm_bytes:
     (scale, rows, plan, worst budget).  make_plan(rows) -> ShardPlan; budget_of(plan, rank) -> hbm_budget dict.  BASELINE
     configs[4] (512 x 50M x dim 64 fp16) does not fit 8 x 288 GB as written; at 30M rows the TABLES fit (245.8 GB per rank) but
-    tables + the batch slots + the RCCL staging of 64 whole tables per owner do not (289 GB): the bench shrinks the rows by a few
+    tables + the batch slots + the RCCL staging of 64 whole tables per owner do not (293 GB): the bench shrinks the rows by a few
     per cent more and says so, instead of running out of memory half-way through its first real 8-GPU run."""
     scale, cur = 1.0, [int(r) for r in rows]
     for _ in range(8):

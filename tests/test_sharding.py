@@ -337,7 +337,7 @@ def test_hbm_budget_of_the_8_rank_layouts_fits_288_gb(pel):
     """per-rank HBM of BASELINE configs[3] (C4) and configs[4] (C5, 30M rows) at EIGHT ranks -- tables +
     the caller's rotating batch slots (or the arena) + the library's staging ring + 64 cached plans + a checked shard's
     counters -- against 288 GB, for both transports, by host arithmetic alone.  C4 is far inside.  C5's TABLES fit (245.8 GB a
-    rank) but tables + slots + the RCCL staging of 64 whole tables per owner do NOT (289 GB): bench.py's pre-flight
+    rank) but tables + slots + the RCCL staging of 64 whole tables per owner do NOT (293 GB): bench.py's pre-flight
     (sharding.fit_to_hbm) shrinks the rows a few per cent and the line says so -- checked here, before a node is booked."""
     sh = _sharding()
     HBM = 288 * 10**9
