@@ -226,8 +226,11 @@ def run_sharded(args, hbm_peak_gbs: float, ctx, rep_bytes: int, mode: str):
     transport = "peer" if getattr(args, "exchange", "rccl") == "peer" else "rccl"
     checked = bool(getattr(args, "checked", False))
     hbm_total = int(torch.cuda.get_device_properties(dev).total_memory)
-    fit_scale, rows_list, plan, hbm_need = sh.fit_to_hbm(rows_list, hbm_total, make_plan,
-                                                          lambda p_, r_: sh.hbm_budget(p_, r_, B, L, NBATCH, depth, transport, checked))
+    # (--exchange both: one layout for the two legs -- their outputs are compared bit for bit -- so the needier transport decides)
+    fit_for = ("rccl", "peer") if getattr(args, "exchange_both", False) else (transport,)
+    fit_scale, rows_list, plan, hbm_need = sh.fit_to_hbm(
+        rows_list, hbm_total, make_plan,
+        lambda p_, r_: max((sh.hbm_budget(p_, r_, B, L, NBATCH, depth, tr_, checked) for tr_ in fit_for), key=lambda d_: d_["total"]))
     if fit_scale < 1.0:
         label += " (rows x %.3f more: tables + batch slots + staging must fit %.0f GB of HBM)" % (fit_scale, hbm_total / 1e9)
         if rank == 0:
@@ -723,6 +726,7 @@ def run(args, hbm_peak_gbs: float) -> None:
         import copy
         a = copy.copy(a)
         a.exchange = transport or first_transport
+        a.exchange_both = exchange == "both"
         return run_sharded(a, peak, c, rep, mode)
     state = {"printed": False, "dog": None, "primary": None}
 
