@@ -85,6 +85,24 @@ def shard_phase(seconds):
                 idx.append(rng.integers(0, n, size=ni).astype(np.int64))
             d_i = [torch.from_numpy(i.astype(np.int32)).to(dev) for i in idx]
             d_o = [torch.from_numpy(o.astype(np.int32)).to(dev) for o in off]
+            if check and shape == 1 and nb and rng.integers(0, 8) == 0:
+                # round 5: a checked shard keeps the direct path and COUNTS what it serves -- one index no table row answers to
+                # (replicated, whole or row-split table alike) must be refused on this, the requesting, rank; the batches
+                # after it are clean
+                if depth:
+                    S.flush()
+                    collect(0)
+                t_bad = int(rng.integers(0, len(rows)))
+                spoiled = idx[t_bad].copy()
+                spoiled[int(rng.integers(0, nb))] = rows[t_bad] + int(rng.integers(0, 1000))
+                bad_i = list(d_i)
+                bad_i[t_bad] = torch.from_numpy(spoiled.astype(np.int32)).to(dev)
+                try:
+                    S.forward(None, bad_i, fixed_pooling=1)
+                    raise AssertionError(("an index beyond its table went through a checked shard", depth, t_bad, kinds[t_bad], nb))
+                except IndexError:
+                    n_calls["refused"] = n_calls.get("refused", 0) + 1
+                torch.cuda.synchronize()
             if depth == 0 or rng.integers(0, 6) == 0:
                 if depth:                 # the synchronous form in the middle of a pipelined run: drain first
                     S.flush()
