@@ -937,14 +937,17 @@ hipError_t launch_peer_done(const PeerDoneArgs &args, unsigned long long value, 
     return hipGetLastError();
 }
 
-// Checked shards: the counters of a counted ranged launch -> their requesters, then the flags (pimemb_peer.h: ServedArgs).
-// Wavefront w of the grid takes counters w, w + W, ... of the concatenated segments: lane l swaps lane-word l of the counter
-// for zero, the wavefront adds the 64 values up, lane 0 stores the sum.
-template <int BLOCK>
-__global__ void __launch_bounds__(BLOCK)
+// Checked shards: the counters of a counted ranged launch -> their requesters (pimemb_peer.h: ServedArgs).  Wavefront w of
+// the grid takes entries w, w + W, ... of the concatenated segments: lane l swaps lane-word l of the counter for zero, the
+// wavefront adds the 64 values up, lane 0 stores (tag << 32) | sum as one 8-byte word.
+__global__ void __launch_bounds__(kBlock)
 served_counts_kernel(ServedArgs a) {
     static_assert(EMB_SERVED_LANES == 64, "one lane of a wavefront per lane of a counter");
-    const uint32_t lane = threadIdx.x & 63u, wave = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6), n_waves = gridDim.x * (BLOCK / 64);
+    const uint32_t lane = threadIdx.x & 63u, wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), n_waves = gridDim.x * (kBlock / 64);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.n_flag) {        // "served": the lookup before this kernel has completed its stores
+        __threadfence_system();
+        for (uint32_t j = 0; j < a.n_flag; j++) *reinterpret_cast<volatile unsigned long long *>(a.flag[j]) = a.value[j];
+    }
     uint32_t total = 0;
     for (uint32_t i = 0; i < a.n_seg; i++) total += a.seg[i].n_counted + a.seg[i].n_fill;
     for (uint32_t g = wave; g < total; g += n_waves) {
@@ -954,30 +957,15 @@ served_counts_kernel(ServedArgs a) {
             i++;
         }
         const ServedSeg sg = a.seg[i];
+        uint32_t v = 0xffffffffu;
         if (c < sg.n_counted) {
             // (the launch before this one added with agent-scope atomics: read and zero the same way)
-            uint32_t v = __hip_atomic_exchange(sg.ctr + (size_t)c * (EMB_SERVED_BYTES / 4u) + (size_t)lane * (EMB_SERVED_STRIDE / 4u), 0u,
-                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v = __hip_atomic_exchange(sg.ctr + (size_t)c * (EMB_SERVED_BYTES / 4u) + (size_t)lane * (EMB_SERVED_STRIDE / 4u), 0u,
+                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off, 64);
-            if (lane == 0) sg.dst[c] = v;
-        } else if (lane == 0) {
-            sg.dst[c] = 0xffffffffu;
         }
-    }
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence_system();
-        bool last = true;
-        if (gridDim.x > 1) {
-            last = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
-            if (last) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (last) {
-            __threadfence_system();
-            for (uint32_t j = 0; j < a.n_flag; j++) *reinterpret_cast<volatile unsigned long long *>(a.flag[j]) = a.value[j];
-        }
+        if (lane == 0) *reinterpret_cast<volatile unsigned long long *>(sg.dst + c) = ((unsigned long long)sg.tag << 32) | v;
     }
 }
 
@@ -986,12 +974,9 @@ hipError_t launch_served_counts(const ServedArgs &args, hipStream_t stream) {
     if (args.n_seg > kServedSegs || args.n_flag > kServedSegs) return hipErrorInvalidValue;
     uint32_t n = 0;
     for (uint32_t i = 0; i < args.n_seg; i++) n += args.seg[i].n_counted + args.seg[i].n_fill;
-    // a wavefront per counter over up to 64 workgroups of 4, the last one to finish raises the flags.  (ONE workgroup of 16
-    // wavefronts for the 26-table shapes -- no ticket, one fence -- was tried: +13 us per step against +6: profiles/r05/README.md)
-    uint32_t grid = (n + (kBlock / 64) - 1) / (kBlock / 64);
-    grid = grid < 1 ? 1 : (grid > 64 ? 64 : grid);
-    if (args.ticket == nullptr) grid = 1;
-    hipLaunchKernelGGL(served_counts_kernel<kBlock>, dim3(grid), dim3(kBlock), 0, stream, args);
+    uint32_t grid = (n + (kBlock / 64) - 1) / (kBlock / 64);        // a wavefront per entry, up to 256 workgroups of 4
+    grid = grid < 1 ? 1 : (grid > 256 ? 256 : grid);
+    hipLaunchKernelGGL(served_counts_kernel, dim3(grid), dim3(kBlock), 0, stream, args);
     return hipGetLastError();
 }
 

@@ -58,24 +58,25 @@ hipError_t launch_peer_done(const PeerDoneArgs &args, unsigned long long value, 
 
 // Checked shards (EMB_SHARD_CHECK_SERVED): behind a COUNTED ranged launch, carry the per-descriptor served-bag counts
 // (emb_lookup_ranged_counted: EMB_SERVED_LANES words per counter) to whoever asked.  Segment i: n_counted counters, each summed
-// over its lanes -> one word of dst, the lanes zeroed for their next use (atomic exchanges), then n_fill words 0xffffffff ("not
-// counted here: the serving rank validated these pieces itself"); dst is pinned host memory of this rank (its own requests) or
-// the tail of a requester's mailbox.  Then, behind a system-scope fence, flag[j] = value[j]: this rank's pinned flag words and /
-// or the requesters' `served` words -- in peer-store mode this kernel stands in for launch_peer_done.  One segment per requester
-// + one for the replicated tables.  A wavefront per counter, several workgroups; the last one to finish (a ticket in HBM,
-// `ticket`: one zeroed uint32 the kernel leaves zero again) raises the flags.
+// over its lanes (the lanes zeroed for their next use: atomic exchanges), then n_fill "not counted here: the serving rank
+// validated these pieces itself" entries (count 0xffffffff).  Every entry is ONE self-describing 64-bit word, (tag << 32) | count,
+// stored with a single 8-byte store into pinned host memory of this rank (its own requests) or the tail of a requester's
+// mailbox: the reader polls the word until it carries the batch's tag -- no fence, no ticket, no flag on the counts' path (the
+// first version of this kernel published plain words behind two system-scope fences, a last-workgroup ticket and a flag: 6.5 us
+// per launch, profiles/r05/README.md).  The `served` words of peer-store mode (flag / value) are raised by workgroup 0 behind one
+// system-scope fence, as launch_peer_done does -- they speak for the lookup's stores, which the kernel boundary completed.
 struct ServedSeg {
-    uint32_t *ctr;      // first counter (HBM of this rank), counters EMB_SERVED_BYTES apart
-    uint32_t *dst;      // where the requester reads the counts
+    uint32_t *ctr;               // first counter (HBM of this rank), counters EMB_SERVED_BYTES apart
+    unsigned long long *dst;     // where the requester polls: one 64-bit word per entry
     uint32_t n_counted, n_fill;
+    uint32_t tag, pad;
 };
 constexpr uint32_t kServedSegs = 66;
 struct ServedArgs {
     ServedSeg seg[kServedSegs];
-    unsigned long long flag[kServedSegs];   // addresses of 64-bit flag words
+    unsigned long long flag[kServedSegs];   // addresses of 64-bit flag words (peer-store mode: the requesters' `served`)
     unsigned long long value[kServedSegs];
     uint32_t n_seg, n_flag;
-    uint32_t *ticket;
 };
 hipError_t launch_served_counts(const ServedArgs &args, hipStream_t stream);
 

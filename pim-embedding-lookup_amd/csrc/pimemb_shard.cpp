@@ -127,9 +127,8 @@ struct Batch {
     int deferred_rc = EMB_OK;
     bool direct = false;                // this batch's row-split tables skip router and un-router (see stage_route)
     // checked shards: what the counted ranged launches served (see stage_serve / stage_unroute)
-    DevBuf chk_ctr;                     // HBM counters [N][Kr + M] (source p: its row-split tables, then the whole tables owned here) + [R] replicated, + the publish kernel's ticket
-    uint32_t *chk_host = nullptr;       // pinned: [R] replicated counts | [Kr + M] what this rank served ITSELF
-    unsigned long long *chk_flags = nullptr;   // pinned: [0] = seq + 1 behind the replicated counts, [1] behind the self counts
+    DevBuf chk_ctr;                     // HBM counters [N][Kr + M] (source p: its row-split tables, then the whole tables owned here) + [R] replicated
+    unsigned long long *chk_host = nullptr;    // pinned, one self-describing word (tag << 32 | count) per entry: [R] replicated | [Kr + M] what this rank served ITSELF
     bool rep_counted = false, self_published = false;
     // optional kernel timing (emb_shard_set_kernel_timing): start / stop around R, L, S, U
     hipEvent_t tev[10] = {};
@@ -287,8 +286,12 @@ constexpr size_t kCtrWords = EMB_SERVED_BYTES / 4;
 inline size_t n_counters(const emb_shard *s) { return (size_t)s->N * (s->Kr + s->M) + s->rep.size(); }
 inline uint32_t *ctr_of(const emb_shard *s, const Batch &b, uint32_t p, uint32_t i) { return static_cast<uint32_t *>(b.chk_ctr.p) + ((size_t)p * (s->Kr + s->M) + i) * kCtrWords; }
 inline uint32_t *ctr_rep(const emb_shard *s, const Batch &b, uint32_t r) { return static_cast<uint32_t *>(b.chk_ctr.p) + ((size_t)s->N * (s->Kr + s->M) + r) * kCtrWords; }
-inline uint32_t *ctr_ticket(const emb_shard *s, const Batch &b) { return static_cast<uint32_t *>(b.chk_ctr.p) + n_counters(s) * kCtrWords; }
-inline uint32_t served_tail(const emb_shard *s) { return pimemb::kPeerMsgWords - (s->Kr + s->max_whole); }
+// a served-count entry is one 64-bit word, (tag << 32) | count: in a peer's mailbox they take the last 2 x (Kr + max_whole)
+// uint32 words (8-byte aligned: the message starts 64 bytes into the mailbox, kPeerMsgWords is even)
+inline uint32_t served_tail(const emb_shard *s) { return pimemb::kPeerMsgWords - 2u * (s->Kr + s->max_whole); }
+// the tag of batch seq's entries: distinct for every batch of this shard object (2^31 of them), and -- the group's n-th user of
+// the mailboxes folds n in -- not what an earlier user left behind in the same slot; never 0 (what zeroed memory holds)
+inline uint32_t served_tag(const emb_shard *s, uint64_t seq) { return 0x80000000u | ((uint32_t)(seq + 1) ^ ((uint32_t)(s->peer_tag >> 40) * 0x9E3779B1u)); }
 inline bool all_one_hot(const std::vector<emb_lookup_desc> &v) {
     for (const emb_lookup_desc &d : v)
         if (d.offsets != nullptr || d.fixed_pooling != 1) return false;
@@ -563,10 +566,7 @@ int launch_local(emb_shard *s) {
     EMB_TRY(tick(s, b, 1, true));
     if (counted) {
         pimemb::ServedArgs sa{};
-        sa.seg[sa.n_seg++] = pimemb::ServedSeg{ctr_rep(s, b, 0), b.chk_host, (uint32_t)s->descs.size(), 0u};
-        sa.flag[sa.n_flag] = (unsigned long long)(uintptr_t)&b.chk_flags[0];
-        sa.value[sa.n_flag++] = b.seq + 1;
-        sa.ticket = ctr_ticket(s, b);
+        sa.seg[sa.n_seg++] = pimemb::ServedSeg{ctr_rep(s, b, 0), b.chk_host, (uint32_t)s->descs.size(), 0u, served_tag(s, b.seq), 0u};
         HIP_TRY(pimemb::launch_served_counts(sa, s->cs));
         b.rep_counted = true;
     }
@@ -894,29 +894,25 @@ int stage_serve(emb_shard *s, Batch &b) {
         // went through the checked (validating) launch instead is marked 0xffffffff: "not counted, validated by its server".
         pimemb::ServedArgs sa{};
         if (one_launch && n_local_descs && local_batch) {
-            sa.seg[sa.n_seg++] = pimemb::ServedSeg{ctr_rep(s, *local_batch, 0), local_batch->chk_host, (uint32_t)n_local_descs, 0u};
-            sa.flag[sa.n_flag] = (unsigned long long)(uintptr_t)&local_batch->chk_flags[0];
-            sa.value[sa.n_flag++] = local_batch->seq + 1;
+            sa.seg[sa.n_seg++] = pimemb::ServedSeg{ctr_rep(s, *local_batch, 0), local_batch->chk_host, (uint32_t)n_local_descs, 0u,
+                                                   served_tag(s, local_batch->seq), 0u};
             local_batch->rep_counted = true;
         }
         for (uint32_t p = 0; p < N; p++) {
             const Via how = via(s, (int)p);
             if (how == COMM) continue;          // (no direct path, no counted launch with a peer behind RCCL)
             const uint32_t n_counted = one_launch ? Kr + M : (b.from[p].direct ? Kr : 0u);
-            uint32_t *dst = b.chk_host + s->rep.size();
+            unsigned long long *dst = b.chk_host + s->rep.size();
             if (how == PEER) {
                 pimemb::PeerMsg *box = pimemb::peer_box_dev(s->peer, (int)p, s->rank, (uint32_t)(b.seq % pimemb::kPeerSlots));
-                dst = box->words + served_tail(s);
+                dst = reinterpret_cast<unsigned long long *>(box->words + served_tail(s));
                 sa.flag[sa.n_flag] = (unsigned long long)(uintptr_t)&box->served;
                 sa.value[sa.n_flag++] = s->peer_tag + b.seq + 1;
             } else {
-                sa.flag[sa.n_flag] = (unsigned long long)(uintptr_t)&b.chk_flags[1];
-                sa.value[sa.n_flag++] = b.seq + 1;
                 b.self_published = true;
             }
-            sa.seg[sa.n_seg++] = pimemb::ServedSeg{ctr_of(s, b, p, 0), dst, n_counted, Kr + M - n_counted};
+            sa.seg[sa.n_seg++] = pimemb::ServedSeg{ctr_of(s, b, p, 0), dst, n_counted, Kr + M - n_counted, served_tag(s, b.seq), 0u};
         }
-        sa.ticket = ctr_ticket(s, b);
         HIP_TRY(pimemb::launch_served_counts(sa, s->cs));
     } else if (s->peer_mode) {        // behind the lookup (its kernel boundary completes the stores into the peers' HBM): "served"
         pimemb::PeerDoneArgs da{};
@@ -965,50 +961,62 @@ int stage_serve(emb_shard *s, Batch &b) {
 int check_served_counts(emb_shard *s, Batch &b) {
     const uint32_t N = (uint32_t)s->N, Kr = s->Kr;
     const uint32_t R = (uint32_t)s->rep.size();
-    auto wait_flag = [&](volatile unsigned long long *w, const char *what) -> int {
-        const double t0 = now_us();
-        for (uint64_t spin = 0; *w != b.seq + 1; spin++)
-            if ((spin & 0xfff) == 0xfff && now_us() - t0 > s->timeout_s * 1e6)
-                return fail(EMB_ERR_DEVICE, "emb_shard: the served counts (%s) of batch %llu did not arrive within %.0f s", what, (unsigned long long)b.seq, s->timeout_s);
-        std::atomic_thread_fence(std::memory_order_acquire);
-        return EMB_OK;
-    };
+    const uint32_t tag = served_tag(s, b.seq);
     const double t0 = now_us();
-    if (b.rep_counted) EMB_TRY(wait_flag(&b.chk_flags[0], "replicated tables"));
-    if (b.self_published) EMB_TRY(wait_flag(&b.chk_flags[1], "this rank's own pieces"));
-    s->st.us_host_wait_served += now_us() - t0;
+    int rc = EMB_OK;
+    // one entry: poll the self-describing word until it carries this batch's tag (the kernel that stores it was enqueued a
+    // call or more ago; a peer's: its "served" word has been seen, the entries are on their way), hand back the count
+    auto entry = [&](volatile unsigned long long *w, const char *what, uint32_t who) -> uint32_t {
+        for (uint64_t spin = 0;; spin++) {
+            const unsigned long long v = *w;
+            if ((uint32_t)(v >> 32) == tag) return (uint32_t)v;
+            if ((spin & 0xfff) == 0xfff && now_us() - t0 > s->timeout_s * 1e6) {
+                if (rc == EMB_OK)
+                    rc = fail(EMB_ERR_DEVICE, "emb_shard: the served counts of batch %llu (%s, rank %u) did not arrive within %.0f s", (unsigned long long)b.seq, what, who, s->timeout_s);
+                return 0xffffffffu;
+            }
+        }
+    };
     auto bad = [&](uint32_t t, uint64_t got) {
         if (b.deferred_rc == EMB_OK)
             snprintf(s->range_msg, sizeof s->range_msg, "emb_shard: batch %llu, table %u: %llu of %llu bags were served -- the others name rows no rank holds "
                      "(their pooled rows were left untouched)", (unsigned long long)b.seq, t, (unsigned long long)got, (unsigned long long)b.n_bags);
         b.deferred_rc = EMB_ERR_RANGE;
     };
-    // the word shard / owner q published for this rank's i-th piece (0xffffffff: not counted -- q validated it itself)
+    // what shard / owner q published for this rank's i-th piece (0xffffffff: not counted -- q validated it itself)
     auto word_from = [&](uint32_t q, uint32_t i) -> uint32_t {
         const Via how = via(s, (int)q);
-        if (how == SELF) return b.self_published ? b.chk_host[R + i] : 0xffffffffu;
-        if (how == PEER) return pimemb::peer_box(s->peer, s->rank, (int)q, (uint32_t)(b.seq % pimemb::kPeerSlots))->words[served_tail(s) + i];
+        if (how == SELF) return b.self_published ? entry(b.chk_host + R + i, "this rank's own pieces", q) : 0xffffffffu;
+        if (how == PEER) {
+            pimemb::PeerMsg *box = pimemb::peer_box(s->peer, s->rank, (int)q, (uint32_t)(b.seq % pimemb::kPeerSlots));
+            return entry(reinterpret_cast<volatile unsigned long long *>(box->words + served_tail(s)) + i, "a peer's", q);
+        }
         return 0xffffffffu;
     };
     if (b.rep_counted)
-        for (uint32_t r = 0; r < R; r++)
-            if (b.chk_host[r] != b.n_bags) bad(s->rep[r], b.chk_host[r]);
-    for (uint32_t q = 0; q < N; q++)
+        for (uint32_t r = 0; r < R; r++) {
+            const uint32_t w = entry(b.chk_host + r, "replicated tables", (uint32_t)s->rank);
+            if (rc == EMB_OK && w != b.n_bags) bad(s->rep[r], w);
+        }
+    for (uint32_t q = 0; q < N && rc == EMB_OK; q++)
         for (uint32_t j = 0; j < s->whole_of[q].size(); j++) {
             const uint32_t w = word_from(q, Kr + j);
-            if (w != 0xffffffffu && w != b.n_bags) bad(s->whole_of[q][j], w);
+            if (rc == EMB_OK && w != 0xffffffffu && w != b.n_bags) bad(s->whole_of[q][j], w);
         }
     if (b.direct)
-        for (uint32_t k = 0; k < Kr; k++) {
+        for (uint32_t k = 0; k < Kr && rc == EMB_OK; k++) {
             uint64_t sum = 0;
-            for (uint32_t q = 0; q < N; q++) {
+            for (uint32_t q = 0; q < N && rc == EMB_OK; q++) {
                 const uint32_t w = word_from(q, k);
-                if (w == 0xffffffffu) return fail(EMB_ERR_INVALID, "emb_shard: rank %u did not count what it served of batch %llu (different EMB_SHARD_* flags?)", q, (unsigned long long)b.seq);
+                if (rc == EMB_OK && w == 0xffffffffu)
+                    rc = fail(EMB_ERR_INVALID, "emb_shard: rank %u did not count what it served of batch %llu (different EMB_SHARD_* flags?)", q, (unsigned long long)b.seq);
                 sum += w;
             }
-            if (sum != b.n_bags) bad(s->rows[k], sum);
+            if (rc == EMB_OK && sum != b.n_bags) bad(s->rows[k], sum);
         }
-    return EMB_OK;
+    std::atomic_thread_fence(std::memory_order_acquire);
+    s->st.us_host_wait_served += now_us() - t0;
+    return rc;
 }
 
 // ---- U(b): partial rows added in shard order, into the caller's buffers ------------------------------------------------------
@@ -1176,8 +1184,8 @@ int emb_shard_create(emb_engine *e, emb_comm *comm, const emb_shard_config *cfg,
     for (const auto &w : s->whole_of) s->max_whole = std::max<uint32_t>(s->max_whole, (uint32_t)w.size());
     if (s->peer_mode) {
         const size_t most = s->max_whole;
-        // (a checked shard keeps the last Kr + max_whole words of a mailbox for the served counts)
-        if (2 * (s->rows.size() + 1) + 2 + kPeerConstHead + most * kWholeWords + 4 * s->rows.size() + (s->check_served ? s->rows.size() + most : 0) > pimemb::kPeerMsgWords)
+        // (a checked shard keeps the last 2 x (Kr + max_whole) words of a mailbox for the served counts)
+        if (2 * (s->rows.size() + 1) + 2 + kPeerConstHead + most * kWholeWords + 4 * s->rows.size() + (s->check_served ? 2 * (s->rows.size() + most) : 0) > pimemb::kPeerMsgWords)
             return bail(fail(EMB_ERR_UNSUPPORTED, "emb_shard_create: %zu whole tables on one owner do not fit a mailbox message (%u words)", most, pimemb::kPeerMsgWords));
     }
     s->Kr = (uint32_t)s->rows.size();
@@ -1217,16 +1225,14 @@ int emb_shard_create(emb_engine *e, emb_comm *comm, const emb_shard_config *cfg,
         if (err == hipSuccess) err = hipMemset(b.counts_in.p, 0, N * ((s->Kr + 1) * 2 + (size_t)s->M * kWholeWords) * 4 + 64);
         if (err == hipSuccess) err = hipMalloc(&b.wc_send.p, (size_t)s->Wtot * kWholeWords * 4 + 64);
         if (s->check_served) {       // served-bag counters (zero between uses: the publish kernel reads them with an exchange)
-            const size_t ctr_bytes = n_counters(s) * EMB_SERVED_BYTES + 256;       // (+ the publish kernel's ticket)
+            const size_t ctr_bytes = n_counters(s) * EMB_SERVED_BYTES + 256;
             if (err == hipSuccess) err = hipMalloc(&b.chk_ctr.p, ctr_bytes);
             if (err == hipSuccess) err = hipMemset(b.chk_ctr.p, 0, ctr_bytes);
             p = nullptr;
-            if (err == hipSuccess) err = hipHostMalloc(&p, (s->rep.size() + s->Kr + (size_t)s->M) * 4 + 64, hipHostMallocMapped | hipHostMallocCoherent);
-            b.chk_host = static_cast<uint32_t *>(p);
-            p = nullptr;
-            if (err == hipSuccess) err = hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocCoherent);
-            b.chk_flags = static_cast<unsigned long long *>(p);
-            if (b.chk_flags) b.chk_flags[0] = b.chk_flags[1] = 0;
+            const size_t n_entries = s->rep.size() + s->Kr + (size_t)s->M;
+            if (err == hipSuccess) err = hipHostMalloc(&p, n_entries * 8 + 64, hipHostMallocMapped | hipHostMallocCoherent);
+            b.chk_host = static_cast<unsigned long long *>(p);
+            if (b.chk_host) memset(b.chk_host, 0, n_entries * 8 + 64);           // (tag 0 is no batch's: served_tag)
         }
     }
     if (err != hipSuccess) {
@@ -1368,7 +1374,6 @@ int emb_shard_destroy(emb_shard *s) {
         for (DevBuf *d : bufs)
             if (d->p && !d->arena) (void)hipFree(d->p);
         if (b.chk_host) (void)hipHostFree(b.chk_host);
-        if (b.chk_flags) (void)hipHostFree(b.chk_flags);
         if (b.pc_host) (void)hipHostFree(b.pc_host);
         if (b.counts_host) (void)hipHostFree(b.counts_host);
         if (b.wc_host) (void)hipHostFree(b.wc_host);

@@ -144,7 +144,9 @@ def hbm_budget(plan: ShardPlan, rank: int, bags: int, pooling: int, n_slots: int
                  and stores in place; batches rotate through ALL six slots whatever the depth, and a slot keeps what it grew to;
       plans      64 cached plans (emb_shard's kPlanCache): descriptors (128 B) + the XCD map (8 B per workgroup);
       counters   a checked shard's served-bag counters (16 KiB per descriptor and ring slot);
-      arena      peer stores: what emb_peer_create allocates (bench.py's formula).
+      arena      peer stores: what emb_peer_create allocates (bench.py's formula);
+      runtime    3 GB flat: the HIP context, code objects, torch's allocator slack, RCCL's buffers -- the world-1 runs of
+                 profiles/r05/dist_world1.md hold 1.6 ... 4.3 GB more than the other terms add up to.
 
     `balance` scales what a rank RECEIVES: 1.0 = every shard gets 1/world of the row-split requests (uniform indices), world =
     every index of every rank names rows of this one shard (the worst skew)."""
@@ -184,6 +186,7 @@ def hbm_budget(plan: ShardPlan, rank: int, bags: int, pooling: int, n_slots: int
     out["arena"] = 0
     if transport == "peer":
         out["arena"] = int(1.25 * n_slots * T * B * (L * 4 + dim * 4)) + 8 * 2 * Kr * B * (L * 8 + min(L, N) * dim * 4 * 2) + (256 << 20)
+    out["runtime"] = 3 * 10**9
     out["total"] = sum(out.values())
     return out
 

@@ -214,16 +214,18 @@ void emulate(const std::string &name, void **args, dim3 grid) {
         emulate_ranged_counts(args, grid);
     } else if (name.find("served_counts_kernel") != std::string::npos) {
         const pimemb::ServedArgs a = arg<pimemb::ServedArgs>(args, 0);
-        for (uint32_t i = 0; i < a.n_seg; i++) {
-            for (uint32_t j = 0; j < a.seg[i].n_counted; j++) {       // a counter = EMB_SERVED_LANES words, EMB_SERVED_STRIDE bytes apart
-                uint32_t sum = 0;
-                for (uint32_t l = 0; l < EMB_SERVED_LANES; l++)
-                    sum += __atomic_exchange_n(a.seg[i].ctr + (size_t)j * (EMB_SERVED_BYTES / 4) + (size_t)l * (EMB_SERVED_STRIDE / 4), 0u, __ATOMIC_RELAXED);
-                a.seg[i].dst[j] = sum;
-            }
-            for (uint32_t j = 0; j < a.seg[i].n_fill; j++) a.seg[i].dst[a.seg[i].n_counted + j] = 0xffffffffu;
-        }
         for (uint32_t j = 0; j < a.n_flag; j++) __atomic_store_n(reinterpret_cast<unsigned long long *>(a.flag[j]), a.value[j], __ATOMIC_RELEASE);
+        for (uint32_t i = 0; i < a.n_seg; i++) {
+            for (uint32_t j = 0; j < a.seg[i].n_counted + a.seg[i].n_fill; j++) {     // an entry = (tag << 32) | count; a counter = EMB_SERVED_LANES words
+                uint32_t sum = 0xffffffffu;
+                if (j < a.seg[i].n_counted) {
+                    sum = 0;
+                    for (uint32_t l = 0; l < EMB_SERVED_LANES; l++)
+                        sum += __atomic_exchange_n(a.seg[i].ctr + (size_t)j * (EMB_SERVED_BYTES / 4) + (size_t)l * (EMB_SERVED_STRIDE / 4), 0u, __ATOMIC_RELAXED);
+                }
+                __atomic_store_n(a.seg[i].dst + j, ((unsigned long long)a.seg[i].tag << 32) | sum, __ATOMIC_RELEASE);
+            }
+        }
     } else if (name.find("store_word_kernel") != std::string::npos) {
         unsigned long long *w = const_cast<unsigned long long *>(arg<volatile unsigned long long *>(args, 0));
         __atomic_store_n(w, arg<unsigned long long>(args, 1), __ATOMIC_RELEASE);
