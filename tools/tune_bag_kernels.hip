@@ -97,12 +97,21 @@ struct Variant {
     bool direct = false;         // ... expanded to a per-workgroup table
     uint32_t xrounds = 4;
     bool checked = true;         // ablations are timing-only
+    bool ranged = false;         // the RANGED instantiation (every descriptor serves a row range; a whole table is the range from row 0)
+    bool split_mid = false;      // round-5 experiment: tables of 4 .. 32 MiB as 8 row-range descriptors, one per XCD class, so that
+                                 // each XCD's L2 keeps 1/8 of the table's rows across launches (every piece scans all the bags)
+    uint32_t n_desc = 26;
     uint32_t *d_xmap = nullptr;
     uint32_t xgrid = 0;
     std::vector<float> us;
 };
 
 static uint32_t g_direct_flag = 0;
+template <class Cfg, int LPR>
+void do_launch_ranged(const DevDesc *d, uint32_t n, uint32_t tiles, const uint32_t *xmap, uint32_t xgrid, hipStream_t s) {
+    dim3 grid = xmap ? dim3(xgrid, 1, 1) : dim3(tiles, n, 1), block(Cfg::kBlock, 1, 1);
+    hipLaunchKernelGGL((bag_sum_wavebatch_kernel<uint32_t, EMB_F32, LPR, Cfg, true>), grid, block, 0, s, d, (uint32_t)LPR | g_direct_flag, xmap);
+}
 template <class Cfg, bool WAVEBATCH, int LPR>
 void do_launch(const DevDesc *d, uint32_t n, uint32_t tiles, const uint32_t *xmap, uint32_t xgrid, hipStream_t s) {
     dim3 grid = xmap ? dim3(xgrid, 1, 1) : dim3(tiles, n, 1), block(Cfg::kBlock, 1, 1);
@@ -173,41 +182,59 @@ int main(int argc, char **argv) {
     add(make_variant<BagCfg<64, 8, true, false, 8, 8, 1, false, true>, true>("v2 b1 XCD segments", true), false);
     add(make_variant<BagCfg<64, 8, true, false, 8, 8, 1, false, true>, true>("v2 b1 XCD direct", true), true);
     add(make_variant<BagCfg<64, 4, true, false, 8, 8, 2, false, true>, true>("v2 blk64 b2 U4 XCD direct", true), true);
+    {   // round 5: the RANGED instantiation of the shipped kernel, whole tables (control) and with the 4 .. 32 MiB tables cut
+        // into 8 row ranges pinned to the 8 XCD classes
+        using Ship = BagCfg<128, 4, true, false, 8, 8, 2, false, true>;
+        Variant c = make_variant<Ship, true>("v2 SHIP RANGED whole tables", true);
+        c.fn = &do_launch_ranged<Ship, 4>; c.ranged = true; add(c, true);
+        Variant m = make_variant<Ship, true>("v2 SHIP RANGED mid tables x8 rows", true);
+        m.fn = &do_launch_ranged<Ship, 4>; m.ranged = true; m.split_mid = true; add(m, true);
+    }
     { Variant v; v.name = "ABLATION null kernel same grid"; v.fn = launch_null; v.checked = false; vars.push_back(v); }
     {
         Variant v; v.name = "ABLATION store-only (ntS)"; v.fn = launch_store_only; v.checked = false; vars.push_back(v);
         Variant g; g.name = "ABLATION gather-only"; g.fn = launch_gather_only; g.checked = false; vars.push_back(g);
     }
 
-    // descriptors per (variant, batch): n_tiles depends on the variant's tile size
+    // descriptors per (variant, batch): n_tiles depends on the variant's tile size; split_mid variants have more descriptors
     std::vector<std::vector<DevDesc *>> d_desc(vars.size(), std::vector<DevDesc *>(NB));
     std::vector<uint32_t> tiles(vars.size());
+    std::vector<std::vector<uint64_t>> desc_bytes(vars.size());
     for (size_t v = 0; v < vars.size(); v++) {
         tiles[v] = (B + vars[v].bags_per_tile - 1) / vars[v].bags_per_tile;
         for (int b = 0; b < NB; b++) {
-            std::vector<DevDesc> hd(T);
+            std::vector<DevDesc> hd;
+            desc_bytes[v].clear();
             for (uint32_t t = 0; t < T; t++) {
-                hd[t] = DevDesc{};
-                hd[t].weights = tables[t];
-                hd[t].indices = d_idx[b][t];
-                hd[t].offsets = d_off[b][t];
-                hd[t].out = d_out[b][t];
-                hd[t].n_idx = B;
-                hd[t].n_bags = B;
-                hd[t].nr_rows = kKaggleRows[t];
-                hd[t].fixed_pooling = 0;
-                hd[t].n_tiles = tiles[v];
+                const uint64_t bytes = kKaggleRows[t] * D * 4;
+                const uint32_t pieces = (vars[v].split_mid && bytes > (4ull << 20) && bytes <= (32ull << 20)) ? 8u : 1u;
+                const uint64_t rps = (kKaggleRows[t] + pieces - 1) / pieces;
+                for (uint32_t k = 0; k < pieces; k++) {
+                    const uint64_t lo = k * rps, hi = std::min<uint64_t>(kKaggleRows[t], lo + rps);
+                    DevDesc d{};
+                    d.weights = reinterpret_cast<const char *>(tables[t]) + lo * D * 4;
+                    d.indices = d_idx[b][t];
+                    d.offsets = d_off[b][t];
+                    d.out = d_out[b][t];
+                    d.n_idx = B;
+                    d.n_bags = B;
+                    d.nr_rows = hi - lo;
+                    d.fixed_pooling = 0;
+                    d.n_tiles = tiles[v];
+                    d.pad_[0] = lo;
+                    hd.push_back(d);
+                    desc_bytes[v].push_back((hi - lo) * D * 4);
+                }
             }
-            CK(hipMalloc((void **)&d_desc[v][b], sizeof(DevDesc) * T));
-            CK(hipMemcpy(d_desc[v][b], hd.data(), sizeof(DevDesc) * T, hipMemcpyHostToDevice));
+            vars[v].n_desc = (uint32_t)hd.size();
+            CK(hipMalloc((void **)&d_desc[v][b], sizeof(DevDesc) * hd.size()));
+            CK(hipMemcpy(d_desc[v][b], hd.data(), sizeof(DevDesc) * hd.size(), hipMemcpyHostToDevice));
         }
     }
     for (size_t v = 0; v < vars.size(); v++) {
         if (!vars[v].xcd) continue;
-        std::vector<uint32_t> nt(T, tiles[v]), words;
-        std::vector<uint64_t> bytes(T);
-        for (uint32_t t = 0; t < T; t++) bytes[t] = kKaggleRows[t] * D * 4;
-        vars[v].xgrid = build_xcd_map(nt, bytes, &words, vars[v].xrounds);
+        std::vector<uint32_t> nt(vars[v].n_desc, tiles[v]), words;
+        vars[v].xgrid = build_xcd_map(nt, desc_bytes[v], &words, vars[v].xrounds);
         if (vars[v].direct) {
             std::vector<uint32_t> d;
             expand_xcd_map(words, vars[v].xgrid, &d);
@@ -225,7 +252,7 @@ int main(int argc, char **argv) {
         if (!vars[v].checked) continue;
         for (uint32_t t = 0; t < T; t++) CK(hipMemsetAsync(d_out[0][t], 0xff, out_bytes, s));
         g_direct_flag = vars[v].direct ? kXmapDirect : 0u;
-        vars[v].fn(d_desc[v][0], T, tiles[v], vars[v].d_xmap, vars[v].xgrid, s);
+        vars[v].fn(d_desc[v][0], vars[v].n_desc, tiles[v], vars[v].d_xmap, vars[v].xgrid, s);
         CK(hipGetLastError());
         CK(hipStreamSynchronize(s));
         for (uint32_t t = 0; t < T; t++) {
@@ -245,7 +272,7 @@ int main(int argc, char **argv) {
         for (size_t v = 0; v < vars.size(); v++) {
             g_direct_flag = vars[v].direct ? kXmapDirect : 0u;
             CK(hipEventRecord(e0, s));
-            for (int i = 0; i < iters; i++) vars[v].fn(d_desc[v][i % NB], T, tiles[v], vars[v].d_xmap, vars[v].xgrid, s);
+            for (int i = 0; i < iters; i++) vars[v].fn(d_desc[v][i % NB], vars[v].n_desc, tiles[v], vars[v].d_xmap, vars[v].xgrid, s);
             CK(hipEventRecord(e1, s));
             CK(hipEventSynchronize(e1));
             float ms;
