@@ -466,7 +466,9 @@ int emb_peer_destroy(emb_peer *p);   /* call emb_peer_barrier first: a peer may 
  * rank itself or a peer-store peer), those tables are not routed at all -- every shard scans the requester's raw index array
  * and serves the bags whose row it holds straight into the requester's output (emb_lookup_ranged): no router, no counts, no
  * un-router.  Decided per batch and per rank; same bits (a one-index bag's pooled row IS the table row).  Not taken by a
- * shard created with EMB_SHARD_CHECK_SERVED (the ranged lookup validates nothing) or EMB_SHARD_NO_DIRECT.
+ * shard created with EMB_SHARD_NO_DIRECT, or whose rows are not 16-byte multiples up to 1 KiB.  A shard created with
+ * EMB_SHARD_CHECK_SERVED keeps it: its ranged launches COUNT the bags they serve (emb_lookup_ranged_counted) and the
+ * requesting rank compares the sums with its bag count (see the flag below).
  * Counts first, payload second: what a rank will send each peer (sub-bags and indices per table) leaves before the payload,
  * so nothing has a capacity that skewed indices could overflow.  The one host wait of a batch is for those counts.
  *
@@ -516,10 +518,18 @@ typedef struct emb_shard_input {      /* one per table, in table order */
 } emb_shard_input;
 #define EMB_SHARD_SELF_VIA_COMM 1u /* pieces a rank addresses to ITSELF go through RCCL like any other (rehearsal / A-B);
                                       default: they are served in place -- no transfer, no copy */
-#define EMB_SHARD_CHECK_SERVED 2u  /* the fused lookup of every batch validates the indices it serves first
-                                      (emb_lookup_batched_checked); a finding makes emb_shard_submit / _flush return
-                                      EMB_ERR_RANGE on the SERVING rank after the batch has gone through all its stages
-                                      (the offending pieces pool to zero rows), so no peer is left in a transfer */
+#define EMB_SHARD_CHECK_SERVED 2u  /* indices are not trusted (the reference never checks: emb_dpu_lookup.c:113).  Two mechanisms, chosen
+                                      per batch; every rank of the job must pass the flag alike (a mismatch is refused):
+                                      ROUTED batches -- the fused lookup validates what it serves first (emb_lookup_batched_checked);
+                                      a finding makes emb_shard_submit / _flush return EMB_ERR_RANGE on the SERVING rank after the batch
+                                      has gone through all its stages (the offending pieces pool to zero rows), so no peer is left in a
+                                      transfer.  ONE-INDEX batches on the direct path (and, with no peer behind RCCL, any call whose
+                                      lookups are all one index per bag) -- nothing is validated up front: every launch counts the bags
+                                      it serves, the counts travel back with the "served" handshake, and the REQUESTING rank compares:
+                                      each replicated / whole table must have served all its bags, the shards of a row-split table
+                                      must add up to the bag count.  A shortfall = an index no rank holds, whose bag was left
+                                      untouched: EMB_ERR_RANGE on the requesting rank when the batch completes (emb_last_error names
+                                      the table and the count); the other bags of the batch are correct, the next batch is unaffected */
 #define EMB_SHARD_PEER_STORES 4u   /* the collective-free exchange (needs emb_shard_config.peer): nothing travels through RCCL.  A
                                       rank posts what it asks each peer for -- counts and buffer addresses -- into the peer's
                                       mailbox; the owner's ONE fused lookup gathers the requester's indices IN PLACE (its mapped

@@ -1885,6 +1885,82 @@ def test_ranged_launch_mixes_whole_tables_and_shards(pel, oracle, dim, dtype, B)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dim,dtype,B", [(16, np.float32, 150_001), (16, np.float32, 4001), (128, np.float32, 33_000), (64, np.float16, 20_000)])
+def test_ranged_counted_launch_counts_exactly_the_bags_it_serves(pel, dim, dtype, B):
+    """emb_lookup_ranged_counted / emb_plan_create_ranged_counted through the C ABI (round 5): every descriptor's counter --
+    EMB_SERVED_LANES words EMB_SERVED_STRIDE bytes apart, the count is their sum -- grows by exactly the number of bags whose
+    index falls into the descriptor's row range: whole tables (with a few indices beyond the table: not served, not counted),
+    the N shards of a row-split table over the SAME raw index array (their counts add up to the bag count minus the indices no
+    shard holds), a NULL counter among them (that descriptor is not counted), the small and the two-batch geometry, transient
+    and prepared, twice in a row (counters accumulate: the caller zeroes them).  The rows themselves are the uncounted
+    launch's, bit for bit."""
+    import ctypes as C
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(23)
+    whole_rows, split_rows, N = [900, 20_011], 31_007, 4
+    per = -(-split_rows // N)
+    eng = pel.EmbeddingEngine(device=0, max_tables=8)
+    tabs = [(rng.standard_normal((n, dim)) * 0.1).astype(dtype) for n in whole_rows]
+    big = (rng.standard_normal((split_rows, dim)) * 0.1).astype(dtype)
+    for t, w in enumerate(tabs):
+        eng.load_table(t, w)
+    for d in range(N):
+        eng.load_table(2 + d, big[d * per:min((d + 1) * per, split_rows)])
+    idx = [rng.integers(0, n, size=B).astype(np.uint32) for n in whole_rows] + [rng.integers(0, split_rows, size=B).astype(np.uint32)]
+    idx[1][::97] = whole_rows[1] + 5                    # beyond a whole table
+    idx[2][::89] = N * per + 11                         # beyond the last shard
+    d_idx = [torch.from_numpy(i.view(np.int32)).to(dev) for i in idx]
+    n_desc = 2 + N
+    L = pel.lib.load()
+    lanes, stride = 64, 256
+    ctr = torch.zeros((n_desc, lanes * stride // 4), dtype=torch.int32, device=dev)
+    expect = [int((idx[0] < whole_rows[0]).sum()), int((idx[1] < whole_rows[1]).sum())] + \
+             [int(((idx[2] >= d * per) & (idx[2] < min((d + 1) * per, split_rows))).sum()) for d in range(N)]
+    assert sum(expect[2:]) == B - int((idx[2] >= split_rows).sum()) < B and expect[1] < B
+    descs = (pel.lib.EmbLookupDesc * n_desc)()
+    lo = (C.c_uint64 * n_desc)()
+    served = (C.c_void_p * n_desc)()
+    ref = None
+    for prepared in (False, True):
+        outs = [torch.full((B, dim), float("nan"), device=dev) for _ in range(3)]
+        for i in range(n_desc):
+            t = min(i, 2)
+            descs[i] = pel.lib.EmbLookupDesc(i, 1, d_idx[t].data_ptr(), None, B, B, outs[t].data_ptr())
+            lo[i] = 0 if i < 2 else (i - 2) * per
+            served[i] = ctr[i].data_ptr()
+        served[3] = None                                # the shard d = 1: not counted
+        ctr.zero_()
+        for rep_ in range(2):
+            if prepared:
+                plan = C.c_void_p()
+                pel.lib.check(L.emb_plan_create_ranged_counted(eng._h, descs, lo, served, n_desc, C.byref(plan)))
+                pel.lib.check(L.emb_plan_launch(plan, None))
+                torch.cuda.synchronize()
+                pel.lib.check(L.emb_plan_destroy(plan))
+            else:
+                pel.lib.check(L.emb_lookup_ranged_counted(eng._h, descs, lo, served, n_desc, None))
+            torch.cuda.synchronize()
+            got = ctr.view(n_desc, lanes, stride // 4)[:, :, 0].sum(dim=1).cpu().numpy().astype(np.int64)
+            want = np.array([e * (rep_ + 1) for e in expect], dtype=np.int64)
+            want[3] = 0
+            assert np.array_equal(got, want), (prepared, rep_, got, want)
+            assert int(ctr.view(n_desc, lanes, stride // 4)[:, :, 1:].abs().sum()) == 0        # nothing but the lane words is touched
+        rows = [o.cpu().numpy() for o in outs]
+        if ref is None:         # the uncounted launch over the same descriptors: the same rows, the same untouched bags
+            outs2 = [torch.full((B, dim), float("nan"), device=dev) for _ in range(3)]
+            for i in range(n_desc):
+                descs[i].pooled = outs2[min(i, 2)].data_ptr()
+            pel.lib.check(L.emb_lookup_ranged(eng._h, descs, lo, n_desc, None))
+            torch.cuda.synchronize()
+            ref = [o.cpu().numpy() for o in outs2]
+        for t in range(3):
+            assert np.array_equal(rows[t], ref[t], equal_nan=True), (prepared, t)
+        assert np.isnan(rows[1][::97]).all() and np.isnan(rows[2][::89]).all() and not np.isnan(rows[0]).any()
+    eng.close()
+
+
+@pytest.mark.gpu
 def test_shard_objects_from_two_threads_share_an_engine(pel, oracle):
     """include/pimemb.h: one caller thread per shard object, several shard objects may share an engine.  Two threads, each with
     its own ShardedEmbeddingBags (world of one rank: replicated / whole / row-split tables) and its own stream on ONE engine,
