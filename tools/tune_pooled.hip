@@ -264,6 +264,74 @@ bag_sum_stream_kernel(const DevDesc *__restrict__ descs, uint32_t chunks, uint32
     }
 }
 
+// ---- v5 (round-5 experiment): the table's K HOTTEST rows in REGISTERS ------------------------------------------------
+// Zipf(1.2) over 10 M rows names its hottest row in 18.5 % of all gathers, the top two in 26.5 %, the top four in 35 %.  Those
+// gathers hit the L1, but an L1 hit still goes through the texture-address unit and the L1's 64 B/clk -- the two things the
+// pooled Zipf launch is bound by.  Here every lane keeps its 16-byte piece of the K hottest rows of
+// the descriptor's table in 4 K registers (row ids in DevDesc::pad_[2..3], rows = the first K of the compact hot copy the
+// engine already keeps for the LDS path); a gather whose row id equals one of them is a register select, its lanes are
+// masked out of the load.  Same bits: the register copy holds the table's own bits, the adds stay in index order.
+template <typename IdxT, int DT, int LPR, class Cfg, int K>
+__global__ void __launch_bounds__(Cfg::kBlock)
+bag_sum_reghot_kernel(const DevDesc *__restrict__ descs, uint32_t chunks_arg, const uint32_t *__restrict__ xmap) {
+    using Ops = RowOps<DT>;
+    constexpr uint32_t kWaves = Cfg::kBlock / 64;
+    constexpr uint32_t BPW = 64 / LPR;
+    constexpr uint32_t BAGS_PER_TILE = BPW * kWaves;
+    uint32_t desc_i, tile;
+    if (!decode_block(xmap, chunks_arg & kXmapDirect, &desc_i, &tile)) return;
+    const uint32_t chunks = chunks_arg & ~kXmapDirect;
+    const DevDesc *dp = descs + desc_i;
+    const char *__restrict__ weights = static_cast<const char *>(dp->weights);
+    const IdxT *__restrict__ indices = static_cast<const IdxT *>(dp->indices);
+    const IdxT *__restrict__ offsets = static_cast<const IdxT *>(dp->offsets);
+    float *__restrict__ out = dp->out;
+    const uint64_t n_idx = dp->n_idx, n_bags = dp->n_bags, last_row = dp->nr_rows - 1;
+    const uint32_t fixed_pooling = dp->fixed_pooling, n_tiles = dp->n_tiles;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t sub = lane & (LPR - 1), grp = lane / LPR;
+    const uint32_t row_bytes = chunks * 16u;
+    const uint32_t out_stride = chunks * Ops::kFloatsPerLane;
+    const char *__restrict__ wsub = weights + sub * 16u;
+    if (tile >= n_tiles) return;
+    const uint64_t bag = (uint64_t)tile * BAGS_PER_TILE + wave * BPW + grp;
+    const bool live = sub < chunks;
+    if (bag >= n_bags) return;
+    // the K hottest rows of this table: ids (0xffffffff = none) and this lane's piece of each
+    uint32_t hid[K];
+    u32x4 hrow[K];
+    const uint32_t *ids = reinterpret_cast<const uint32_t *>(&dp->pad_[2]);
+    const u32x4 *hot = static_cast<const u32x4 *>(dp->hot_rows);
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        hid[k] = ((uint32_t)k < dp->n_hot) ? ids[k] : 0xffffffffu;
+        hrow[k] = (hid[k] != 0xffffffffu && live) ? hot[(uint32_t)k * chunks + sub] : u32x4{0u, 0u, 0u, 0u};
+    }
+    uint64_t p, e;
+    if (offsets != nullptr) {
+        p = (uint64_t)load_meta<Cfg::kNtMeta>(offsets + bag);
+        e = (bag + 1 < n_bags) ? (uint64_t)load_meta<Cfg::kNtMeta>(offsets + bag + 1) : n_idx;
+    } else {
+        p = bag * fixed_pooling;
+        e = p + fixed_pooling;
+    }
+    typename Ops::Acc acc = Ops::zero();
+    walk_bag<IdxT, LPR, Cfg, Ops>(indices, p, e, sub, grp, live, acc, NoProbe{},
+                                  [&](uint64_t r, uint32_t) -> u32x4 {
+                                      u32x4 v = {0u, 0u, 0u, 0u};
+                                      bool hit = false;
+#pragma unroll
+                                      for (int k = 0; k < K; k++)
+                                          if ((uint32_t)r == hid[k]) {
+                                              v = hrow[k];
+                                              hit = true;
+                                          }
+                                      if (!hit) v = load_row<Cfg::kNtRow>(wsub + clamp_row<Cfg::kClamp, IdxT>(r, last_row) * row_bytes);
+                                      return v;
+                                  });
+    store_row<Ops, Cfg, LPR>(acc, out + bag * out_stride, sub, grp, chunks, live);
+}
+
 }  // namespace pimemb
 
 #define CK(x)                                                                              \
@@ -309,6 +377,7 @@ struct Variant {
     bool xcd = false;
     uint64_t cacheable = kXcdCacheableBytes;
     uint32_t hot = 0;        // hot rows per table staged in LDS (0 = not the hot kernel)
+    bool reghot = false;     // ... kept in registers instead (bag_sum_reghot_kernel): ordinary grid, no LDS
     uint32_t wgs = 0;        // persistent workgroups per table (hot kernel)
     size_t lds = 0;
     uint32_t *d_xmap = nullptr;
@@ -339,6 +408,22 @@ Variant make_hot(const char *name, uint32_t hot, uint32_t wgs) {
     v.fn = &do_launch_hot<Cfg>;
     v.hot = hot;
     v.wgs = wgs;
+    return v;
+}
+
+template <class Cfg, int K>
+void do_launch_reghot(const DevDesc *d, uint32_t n, uint32_t tiles, const uint32_t *xmap, uint32_t xgrid, hipStream_t s) {
+    dim3 grid = xmap ? dim3(xgrid, 1, 1) : dim3(tiles, n, 1), block(Cfg::kBlock, 1, 1);
+    hipLaunchKernelGGL((bag_sum_reghot_kernel<uint32_t, EMB_F32, LPR, Cfg, K>), grid, block, 0, s, d, (uint32_t)LPR, xmap);
+}
+template <class Cfg, int K>
+Variant make_reghot(const char *name) {
+    Variant v;
+    v.name = name;
+    v.bags_per_tile = (64u / LPR) * (Cfg::kBlock / 64);
+    v.fn = &do_launch_reghot<Cfg, K>;
+    v.hot = K;
+    v.reghot = true;
     return v;
 }
 
@@ -439,6 +524,14 @@ int main(int argc, char **argv) {
         vars.push_back(make_hot<BagCfg<512, 8, true, false, 8, 1, 1, false, false, true>>("v3 hot100 blk512", 100, 2 * wg));
         vars.push_back(make_hot<BagCfg<512, 8, true, false, 8, 1, 1, true, false, true>>("v3 hot100 blk512, misses nt", 100, 2 * wg));
     }
+    if (getenv("TUNE_REGHOT")) {   // round 5: the K hottest rows in registers
+        using G8 = BagCfg<256, 8, true, false, 8, 1, 1, false, false, true>;
+        vars.push_back(make_reghot<G8, 1>("v5 reghot K=1"));
+        vars.push_back(make_reghot<G8, 2>("v5 reghot K=2"));
+        vars.push_back(make_reghot<G8, 4>("v5 reghot K=4"));
+        vars.push_back(make_reghot<BagCfg<256, 8, true, false, 8, 1, 1, false, false, false>, 2>("v5 reghot K=2 no idxshfl"));
+        vars.push_back(make_hot<BagCfg<1024, 8, true, false, 8, 1, 1, false, false, true>>("v3 hot32 (LDS) for reference", 32, std::max(1u, 8192u / T)));
+    }
     if (getenv("TUNE_HOT_SWEEP")) {   // how many hot rows, how many persistent workgroups
         static char names[64][64];
         int ni = 0;
@@ -472,6 +565,11 @@ build_done:
             std::vector<uint64_t> ids(vars[v].hot);
             for (uint32_t k = 0; k < vars[v].hot; k++) ids[k] = ((uint64_t)k * 2654435761ull + 12345ull + t) % rows;
             HotSet hs = build_hot_set(ids.data(), vars[v].hot, rows, D * 4, 62 * 1024);
+            if (vars[v].reghot) {          // registers: no hash, the compact copy = the K hottest rows in rank order
+                hs.rows.assign(ids.begin(), ids.end());
+                hs.hash.assign(2, ~0ull);
+                hs.log2size = 1;
+            }
             hot_n[v][t] = (uint32_t)hs.rows.size();
             hot_log2[v][t] = hs.log2size;
             vars[v].lds = std::max(vars[v].lds, hs.lds_bytes(D * 4));
@@ -503,6 +601,11 @@ build_done:
                 hd[t].n_bags = B;
                 hd[t].nr_rows = rows;
                 hd[t].n_tiles = tiles[v];
+                if (vars[v].reghot) {
+                    uint32_t *ids32 = reinterpret_cast<uint32_t *>(&hd[t].pad_[2]);
+                    for (uint32_t k = 0; k < 4; k++)
+                        ids32[k] = k < vars[v].hot ? (uint32_t)(((uint64_t)k * 2654435761ull + 12345ull + t) % rows) : 0xffffffffu;
+                }
                 if (vars[v].hot) {
                     hd[t].hot_rows = hot_dev[v][t];
                     hd[t].hot_hash = hash_dev[v][t];
