@@ -19,8 +19,12 @@ Infinity Cache (working set per rotation > 1 GB).
 N > 1 (one process per GPU, torch.distributed over RCCL; pim-embedding-lookup_amd/dist_bench.py): each
 rank owns B bags per table (weak scaling, global batch N * B).  Tables are replicated while the whole
 set fits a quarter of one GPU's HBM -- the Kaggle tables do, so the metric's config needs no exchange --
-and sharded by table id / row range with all_to_all(indices in, pooled rows out) otherwise
-(SURVEY.md section 8 row E); the sharded exchange is measured in the same run as a secondary leg.
+and sharded by table id / row range with indices in / pooled rows out otherwise (ONE
+library call per batch, emb_shard_*); the sharded exchange is measured in the same run as a secondary leg -- over BOTH
+transports by default (--exchange both): grouped ncclSend / ncclRecv issued from C (value_exchange), then the
+collective-free peer-store exchange (value_exchange_peer, or exchange_peer = {"skipped": reason} if it cannot come up),
+same expected rows, same bits.  Before a sharded leg allocates anything it adds up the fullest rank's HBM
+(sharding.hbm_budget) and shrinks a layout that does not fit (config.rows_scale_to_fit).
 """
 from __future__ import annotations
 
