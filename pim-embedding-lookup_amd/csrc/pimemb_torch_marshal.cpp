@@ -14,6 +14,11 @@
 //       cache; stream: torch's current stream on that device (hipStream_t as an int).
 //   fill_pooled(desc_addr, n, base_ptr, dim) -> key
 //       pooled pointers of n records laid out back to back from base_ptr (one allocation, one view per table).
+//   pack_shard(input_addr, indices, offsets | None, outs, fixed_pooling, dim) -> None | (n_bags, device, stream)
+//       the same for the SHARDED call: len(indices) emb_shard_input records (40 bytes each) at input_addr.  int32 (uint32 bits)
+//       1-D contiguous CUDA tensors only -- int64 ids must be narrowed first, which the Python path does; offsets None =
+//       fixed_pooling indices per bag; every table the same number of bags; outs float32 contiguous of n_bags x dim.
+//       ShardedEmbeddingBags.prepare spends ~1.2 us per table in Python without it (32 us for 26 tables against a 60-us step).
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
 
@@ -112,9 +117,63 @@ PyObject *fill_pooled(PyObject *, PyObject *args) {
     return PyBytes_FromStringAndSize(reinterpret_cast<const char *>(d), n * (Py_ssize_t)sizeof(Desc));
 }
 
+struct ShardInput {        // emb_shard_input (include/pimemb.h), 40 bytes
+    uint64_t indices, offsets, n_indices;
+    uint32_t fixed_pooling, reserved;
+    uint64_t pooled;
+};
+static_assert(sizeof(ShardInput) == 40, "emb_shard_input layout");
+
+PyObject *pack_shard(PyObject *, PyObject *args) {
+    unsigned long long addr = 0;
+    PyObject *indices, *offsets, *outs;
+    long fixed_pooling = 0, dim = 0;
+    if (!PyArg_ParseTuple(args, "KOOOll", &addr, &indices, &offsets, &outs, &fixed_pooling, &dim)) return nullptr;
+    if (!PyList_Check(indices) || !(PyList_Check(outs) || PyTuple_Check(outs)) || dim <= 0) Py_RETURN_NONE;
+    const Py_ssize_t n = PyList_GET_SIZE(indices);
+    const bool have_off = offsets != Py_None;
+    if (n == 0 || PySequence_Fast_GET_SIZE(outs) != n || (have_off && (!PyList_Check(offsets) || PyList_GET_SIZE(offsets) != n))) Py_RETURN_NONE;
+    if (!have_off && fixed_pooling <= 0) Py_RETURN_NONE;
+    ShardInput *d = reinterpret_cast<ShardInput *>(static_cast<uintptr_t>(addr));
+    c10::DeviceIndex dev = -1;
+    uint64_t n_bags = 0;
+    for (Py_ssize_t k = 0; k < n; k++) {
+        const at::Tensor *ia = as_tensor(PyList_GET_ITEM(indices, k));
+        const at::Tensor *oa = have_off ? as_tensor(PyList_GET_ITEM(offsets, k)) : nullptr;
+        const at::Tensor *ua = as_tensor(PySequence_Fast_GET_ITEM(outs, k));
+        if (!ia || !ua || (have_off && !oa)) Py_RETURN_NONE;
+        if (ia->scalar_type() != c10::ScalarType::Int || !ia->is_cuda() || ia->dim() != 1 || !ia->is_contiguous()) Py_RETURN_NONE;
+        if (k == 0) dev = ia->device().index();
+        if (ia->device().index() != dev) Py_RETURN_NONE;
+        uint64_t nb;
+        if (have_off) {
+            if (oa->scalar_type() != c10::ScalarType::Int || !oa->is_cuda() || oa->device().index() != dev || oa->dim() != 1 || !oa->is_contiguous())
+                Py_RETURN_NONE;
+            nb = (uint64_t)oa->numel();
+        } else {
+            if ((uint64_t)ia->numel() % (uint64_t)fixed_pooling) Py_RETURN_NONE;
+            nb = (uint64_t)ia->numel() / (uint64_t)fixed_pooling;
+        }
+        if (k == 0) n_bags = nb;
+        if (nb != n_bags) Py_RETURN_NONE;                   // (the Python path words the error)
+        if (ua->scalar_type() != c10::ScalarType::Float || !ua->is_cuda() || ua->device().index() != dev || !ua->is_contiguous() ||
+            (uint64_t)ua->numel() != n_bags * (uint64_t)dim)
+            Py_RETURN_NONE;
+        d[k].indices = (uint64_t)(uintptr_t)ia->const_data_ptr();
+        d[k].offsets = have_off ? (uint64_t)(uintptr_t)oa->const_data_ptr() : 0;
+        d[k].n_indices = (uint64_t)ia->numel();
+        d[k].fixed_pooling = have_off ? 0u : (uint32_t)fixed_pooling;
+        d[k].reserved = 0;
+        d[k].pooled = (uint64_t)(uintptr_t)ua->const_data_ptr();
+    }
+    const unsigned long long stream = (unsigned long long)(uintptr_t)c10::hip::getCurrentHIPStream(dev).stream();
+    return Py_BuildValue("(KiK)", (unsigned long long)n_bags, (int)dev, stream);
+}
+
 PyMethodDef methods[] = {
     {"pack", pack, METH_VARARGS, "lists of torch tensors -> emb_lookup_desc records (see the file header)"},
     {"fill_pooled", fill_pooled, METH_VARARGS, "pooled pointers laid out back to back from one allocation"},
+    {"pack_shard", pack_shard, METH_VARARGS, "lists of torch tensors -> emb_shard_input records (see the file header)"},
     {nullptr, nullptr, 0, nullptr}};
 
 PyModuleDef module = {PyModuleDef_HEAD_INIT, "_pimemb_marshal", "torch tensor lists -> emb_lookup_desc records", -1, methods,
