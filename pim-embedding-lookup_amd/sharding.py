@@ -282,8 +282,21 @@ class ShardedEmbeddingBags:
         if x.dtype == t.int32:
             return x if x.is_contiguous() else x.contiguous()
         if x.dtype == t.int64:          # out-of-range ids must not wrap into range: they become 0xffffffff
-            return (x.clamp(-1, 0xffffffff) & 0xffffffff).to(t.int32)
+            return x.clamp(-1, 0xffffffff).to(t.int32)          # (the cast keeps the low 32 bits)
         raise TypeError(f"indices/offsets must be int32 (uint32 bits) or int64 CUDA tensors, got {x.dtype}")
+
+    def _u32_list(self, xs):
+        """The per-table tensors as uint32 bits.  int32 tensors pass through; a list of int64 CUDA tensors is narrowed in ONE
+        pass over their concatenation (cat + clamp + and + cast: four launches for 26 tables instead of 78) and handed back
+        as views of it; anything else goes tensor by tensor through `_u32`."""
+        t = self.torch
+        xs = xs if isinstance(xs, list) else list(xs)
+        if xs and all(isinstance(x, t.Tensor) and x.dtype == t.int64 and x.is_cuda and x.dim() == 1 for x in xs) \
+                and len({x.device for x in xs}) == 1:
+            flat = t.cat(xs)
+            narrow = flat.clamp_(-1, 0xffffffff).to(t.int32)       # (the cast keeps the low 32 bits: -1 and 0xffffffff both become 0xffffffff)
+            return list(narrow.split([int(x.numel()) for x in xs]))
+        return xs
 
     def prepare(self, indices: Sequence, offsets: Sequence | None = None, fixed_pooling: int = 0, outs: Sequence | None = None):
         """Descriptor array of one batch (reusable while the tensors stay where they are): (array, n_bags, outs, keep).
@@ -293,6 +306,9 @@ class ShardedEmbeddingBags:
         t = self.torch
         if len(indices) != self.T or (offsets is not None and len(offsets) != self.T):
             raise ValueError("one index (and offset) tensor per table")
+        # int64 ids (what DLRM passes) are narrowed on the GPU first -- ALL tables in one pass, not three small kernels per table
+        indices = self._u32_list(indices)
+        offsets = self._u32_list(offsets) if offsets is not None else None
         fast = self._prepare_fast(indices, offsets, fixed_pooling, outs)
         if fast is not None:
             return fast

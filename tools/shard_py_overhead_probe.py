@@ -38,7 +38,11 @@ for check in (False, True):
         S.forward(None, d_i, fixed_pooling=1)
     def prepared(i):
         S._check(S._L.emb_shard_lookup(S._h, slots[i % 4][2][0], B, S._stream(None)))
-    for name, fn in (("forward(lists, outs given)", fwd), ("forward(lists, outs allocated)", fwd_alloc), ("emb_shard_lookup on a prepared array", prepared)):
+    i64 = [[x.to(torch.int64) for x in sl[0]] for sl in slots]
+    def fwd_i64(i):          # what DLRM passes: int64 ids, narrowed on the GPU first
+        S.forward(None, i64[i % 4], fixed_pooling=1, outs=slots[i % 4][1])
+    for name, fn in (("forward(lists, outs given)", fwd), ("forward(lists, outs allocated)", fwd_alloc), ("forward(int64 lists, outs given)", fwd_i64),
+                     ("emb_shard_lookup on a prepared array", prepared)):
         h, w = timed(fn)
         print("check=%-5s %-38s host %.1f us per call, wall %.1f us per call" % (check, name, h, w), flush=True)
     S.close(); eng.close()
