@@ -139,14 +139,41 @@ class ShardedEmbeddingBagCollection:
             raise ValueError("need one (offsets, indices) pair per table")
         peer = self.sharded.peer
         if peer is not None:
-            t = self.torch
-
-            def to_arena(x):
-                y = peer.empty(x.shape, t.int32)
-                y.copy_(self.sharded._u32(x))
-                return y
-            lS_o, lS_i = [to_arena(o) for o in lS_o], [to_arena(i) for i in lS_i]
+            return self._apply_emb_peer(peer, list(lS_o), list(lS_i))
         return self.sharded.forward(list(lS_o), list(lS_i))
+
+    def _apply_emb_peer(self, peer, lS_o, lS_i):
+        """Peer stores: the owners gather this rank's indices IN PLACE and store pooled rows straight into its buffers, so all
+        three must live in the group's ARENA -- a bump allocator that frees nothing before the group closes.  A training /
+        serving loop therefore must not carve fresh blocks per call (round 4's harness did: the arena ran dry after a few
+        hundred batches): three rotating slots per table, grown geometrically when a batch outgrows them, reused for ever.
+        The rows a call returns stay valid for the next two calls."""
+        t = self.torch
+        T = len(self.ln_emb)
+        if not hasattr(self, "_arena"):
+            self._arena = {"slot": 0, "idx": [[None] * T for _ in range(3)], "off": [[None] * T for _ in range(3)], "out": [None] * 3}
+        a = self._arena
+        slot = a["slot"] = (a["slot"] + 1) % 3
+        sh = self.sharded
+        lS_i, lS_o = sh._u32_list(lS_i), sh._u32_list(lS_o)
+
+        def staged(cache, k, x):
+            x = sh._u32(x)
+            n = int(x.numel())
+            buf = cache[slot][k]
+            if buf is None or buf.numel() < n:
+                buf = cache[slot][k] = peer.empty((max(2 * n, 64),), t.int32)
+            y = buf[:n]
+            y.copy_(x)
+            return y
+        idx = [staged(a["idx"], k, lS_i[k]) for k in range(T)]
+        off = [staged(a["off"], k, lS_o[k]) for k in range(T)]
+        B = int(off[0].numel())
+        one = a["out"][slot]
+        if one is None or one.shape[1] < B:
+            one = a["out"][slot] = peer.empty((T, max(2 * B, 16), self.m), t.float32)
+        outs = [one[k][:B] for k in range(T)]
+        return self.sharded.forward(off, idx, outs=outs)
 
     forward = __call__ = apply_emb
 

@@ -210,8 +210,8 @@ def main():
                                                    replicate_bytes=cfg["rep"])
             assert set(ebc.plan.kinds) >= {"replicated"} and len(set(ebc.plan.kinds)) >= 2, ebc.plan.kinds
             rng = np.random.default_rng(4000 + rank)
-            for j in range(3):
-                b = make_batch(rng, rows, cfg["bags"] + rank + j, cfg["max_len"], False)
+            for j in range(cfg.get("harness_batches", 3)):
+                b = make_batch(rng, rows, cfg["bags"] + rank + j % 7, cfg["max_len"], False)
                 ly = ebc.apply_emb([torch.from_numpy(o).to(dev) for o in b[1]], [torch.from_numpy(i).to(dev) for i in b[0]])   # int64, as DLRM passes them
                 torch.cuda.synchronize()
                 for t in range(len(rows)):

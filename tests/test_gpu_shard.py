@@ -141,6 +141,19 @@ def test_shard_peer_stores_missing_rank_times_out_nonzero(tmp_path):
     assert "did not" in p.stdout + p.stderr or "within" in p.stdout + p.stderr
 
 
+def test_sharded_apply_emb_harness_peer_stores_does_not_eat_the_arena(tmp_path):
+    """A training / serving loop over peer stores: 1 500 `apply_emb` calls through an arena of 4 MiB.  The arena is a bump
+    allocator (nothing is freed before the group closes); round 4's harness carved fresh index / offset / output blocks out
+    of it on every call and would have run dry after ~250 of these batches -- it rotates three slots per table now.  Every
+    batch against the oracle on both ranks."""
+    import uuid
+    cfg = dict(rows=[7, 300, 5000, 64, 2000, 1500], dim=16, rep=64 * 16 * 4, split=3000 * 16 * 4, bags=19, max_len=5, depths=[0], batches=1,
+               harness=True, harness_batches=1500, peer=True, peer_tag="t" + uuid.uuid4().hex[:12], arena_bytes=4 << 20)
+    res = _run(cfg, 2, tmp_path)
+    assert all("replicated" in st["harness"] for st in res)
+    assert all(st["peer"]["arena_bytes"] == 4 << 20 for st in res)
+
+
 @pytest.mark.parametrize("transport", ["rccl", "peer"])
 def test_sharded_apply_emb_harness_two_ranks(transport, tmp_path):
     """dlrm_harness.ShardedEmbeddingBagCollection: the `apply_emb(lS_o, lS_i)` contract over the sharded call (int64 tensors as
