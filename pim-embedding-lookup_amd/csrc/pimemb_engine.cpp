@@ -117,7 +117,14 @@ struct XmapCacheEntry {
     bool direct = false;
     uint64_t last_use = 0;
 };
-constexpr size_t kXmapCacheEntries = 8;
+// 32 shapes in HBM; a shape earns its place on its SECOND sighting (the first one carries its map in the launch image), and an
+// evicted map is freed later, never between two launches.  Round 5 found the old policy -- 8 entries, allocate + blocking copy on
+// every miss, hipDeviceSynchronize + hipFree on every eviction -- to be a cliff for launches whose shapes do NOT recur: the routed
+// sharded step of two ranks went from 76 to 129 us per step as soon as its pieces stopped cycling through 8 sizes, i.e. with any
+// real index stream (profiles/r05/README.md "launch shapes that do not recur").
+constexpr size_t kXmapCacheEntries = 32;
+constexpr size_t kXmapSeenEntries = 256;       // hashes of shapes seen once (a ring: the oldest is forgotten)
+constexpr size_t kXmapGraveyard = 64;          // evicted maps kept until this many have piled up (then ONE device-wide wait frees them)
 
 }  // namespace
 
@@ -136,6 +143,9 @@ struct emb_engine {
     std::mutex ring_mu[kRingPool];
     std::vector<XmapCacheEntry> xmap_cache;
     uint64_t xmap_clock = 0;
+    std::vector<uint64_t> xmap_seen;       // hashes of launch shapes sighted once
+    size_t xmap_seen_at = 0;
+    std::vector<uint32_t *> xmap_graveyard;
     // staging for EMB_MEM_HOST calls
     char *h_stage = nullptr;
     size_t h_stage_cap = 0;
@@ -271,15 +281,37 @@ int cached_xcd_map(emb_engine *e, PlanGroup &g, uint32_t bpt, const std::vector<
         key.push_back(tiles_of[i]);
         key.push_back(bytes_of[i]);
     }
+    static const bool cache_off = getenv("PIMEMB_XMAP_CACHE") && atoi(getenv("PIMEMB_XMAP_CACHE")) == 0;   // A/B: every map in the launch image
+    if (cache_off) return EMB_ERR_UNSUPPORTED;
     std::lock_guard<std::mutex> lk(e->mu);
+    ++e->xmap_clock;                                   // (every transient launch with a map ages the entries)
     for (XmapCacheEntry &c : e->xmap_cache)
         if (c.key == key) {
-            c.last_use = ++e->xmap_clock;
+            c.last_use = e->xmap_clock;
             g.cached_xmap = c.d_map;
             g.xgrid = c.xgrid;
             g.xdirect = c.direct;
             return EMB_OK;
         }
+    // not cached.  First sighting of the shape: remember its hash and let the caller carry the map in the launch image (no
+    // allocation, no copy engine, nothing to wait for) -- shapes that never come back cost their host-side build and nothing else.
+    uint64_t h = 1469598103934665603ull;
+    for (uint64_t v : key) h = (h ^ v) * 1099511628211ull;
+    bool seen = false;
+    for (uint64_t v : e->xmap_seen) seen = seen || v == h;
+    if (!seen) {
+        if (e->xmap_seen.size() < kXmapSeenEntries) e->xmap_seen.push_back(h);
+        else e->xmap_seen[e->xmap_seen_at++ % kXmapSeenEntries] = h;
+        return EMB_ERR_UNSUPPORTED;                // (any non-OK: resolve() builds the map inline)
+    }
+    // a full cache gives a place up only if its least recently used shape has been idle for a while: more shapes in rotation than
+    // entries would otherwise evict each other in turn (48 shapes cycling through 32 entries: every launch a miss)
+    size_t victim = 0;
+    if (e->xmap_cache.size() >= kXmapCacheEntries) {
+        for (size_t i = 1; i < e->xmap_cache.size(); i++)
+            if (e->xmap_cache[i].last_use < e->xmap_cache[victim].last_use) victim = i;
+        if (e->xmap_clock - e->xmap_cache[victim].last_use < 4 * kXmapCacheEntries) return EMB_ERR_UNSUPPORTED;
+    }
     XmapCacheEntry n;
     std::vector<uint32_t> words;
     n.xgrid = pimemb::build_xcd_map(tiles_of, bytes_of, &words, 1);
@@ -294,16 +326,17 @@ int cached_xcd_map(emb_engine *e, PlanGroup &g, uint32_t bpt, const std::vector<
         (void)hipFree(n.d_map);
         return EMB_ERR_DEVICE;
     }
-    if (e->xmap_cache.size() >= kXmapCacheEntries) {   // evict the least recently used shape (rare)
-        size_t victim = 0;
-        for (size_t i = 1; i < e->xmap_cache.size(); i++)
-            if (e->xmap_cache[i].last_use < e->xmap_cache[victim].last_use) victim = i;
-        (void)hipDeviceSynchronize();                  // a launch in flight may still read it
-        (void)hipFree(e->xmap_cache[victim].d_map);
+    if (e->xmap_cache.size() >= kXmapCacheEntries) {   // evict it: a launch in flight may still read its map, so it is only set aside here, freed later
+        e->xmap_graveyard.push_back(e->xmap_cache[victim].d_map);
         e->xmap_cache.erase(e->xmap_cache.begin() + (long)victim);
+        if (e->xmap_graveyard.size() >= kXmapGraveyard) {
+            (void)hipDeviceSynchronize();
+            for (uint32_t *m : e->xmap_graveyard) (void)hipFree(m);
+            e->xmap_graveyard.clear();
+        }
     }
     n.key.swap(key);
-    n.last_use = ++e->xmap_clock;
+    n.last_use = e->xmap_clock;
     g.cached_xmap = n.d_map;
     g.xgrid = n.xgrid;
     g.xdirect = n.direct;
@@ -861,6 +894,7 @@ int emb_destroy(emb_engine *e) {
     }
     for (ImageRing &rg : e->ring) rg.release();
     for (XmapCacheEntry &c : e->xmap_cache) (void)hipFree(c.d_map);
+    for (uint32_t *m : e->xmap_graveyard) (void)hipFree(m);
     for (hipEvent_t ev : e->pipe_ev)
         if (ev) (void)hipEventDestroy(ev);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
