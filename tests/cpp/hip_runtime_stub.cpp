@@ -340,7 +340,9 @@ hipError_t hipSetDevice(int d) {
     t_device = d;
     return hipSuccess;
 }
-hipError_t hipDeviceSynchronize(void) { track("hipDeviceSynchronize"); return hipSuccess; }
+std::atomic<long> g_device_syncs{0};
+long pimemb_stub_device_syncs(void) { return g_device_syncs.load(); }
+hipError_t hipDeviceSynchronize(void) { track("hipDeviceSynchronize"); g_device_syncs.fetch_add(1); return hipSuccess; }
 
 hipError_t hipMalloc(void **p, size_t n) {
     track("hipMalloc");
