@@ -291,9 +291,9 @@ class ShardedEmbeddingBags:
         as views of it; anything else goes tensor by tensor through `_u32`."""
         t = self.torch
         xs = xs if isinstance(xs, list) else list(xs)
-        if xs and all(isinstance(x, t.Tensor) and x.dtype == t.int64 and x.is_cuda and x.dim() == 1 for x in xs) \
+        if len(xs) > 1 and all(isinstance(x, t.Tensor) and x.dtype == t.int64 and x.is_cuda and x.dim() == 1 for x in xs) \
                 and len({x.device for x in xs}) == 1:
-            flat = t.cat(xs)
+            flat = t.cat(xs)                                      # (a fresh tensor: clamping it in place touches nothing of the caller's)
             narrow = flat.clamp_(-1, 0xffffffff).to(t.int32)       # (the cast keeps the low 32 bits: -1 and 0xffffffff both become 0xffffffff)
             return list(narrow.split([int(x.numel()) for x in xs]))
         return xs
