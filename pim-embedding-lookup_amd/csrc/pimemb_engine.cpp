@@ -442,6 +442,18 @@ int resolve(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs, emb_i
         // keep the plain 2-D grid.
         if (g.n > 1 && g.max_tiles > 0 &&
             (g.kind == pimemb::KERNEL_WAVEBATCH || g.kind == pimemb::KERNEL_WAVEBATCH2)) {
+            // Plan-less launches: the map is built for tile counts rounded UP to 1/16 of their power of two (< 6.25 % more
+            // workgroups; a workgroup whose tile lies beyond its descriptor's n_tiles leaves at once), so that launches whose sizes
+            // wander by a few bags -- the pieces of a routed sharded step, a server's batches -- share a shape and with it a cached
+            // map, instead of each paying ~8 us of host time for a map of its own (profiles/r05/xmap_cache_shapes.log).
+            if (cache_maps)
+                for (uint32_t &v : tiles_of)
+                    if (v > 16) {
+                        uint32_t q = 1;
+                        while ((q << 1) <= v) q <<= 1;
+                        q >>= 4;
+                        v = (v + q - 1) / q * q;
+                    }
             uint64_t total_tiles = 0;
             for (uint32_t t : tiles_of) total_tiles += t;
             if (total_tiles + 8 * (uint64_t)g.n > 0x7fffffffull)
