@@ -206,6 +206,18 @@ int emb_lookup_ranged_counted(emb_engine *e, const emb_lookup_desc *descs, const
                               uint32_t n_descs, void *stream);
 int emb_plan_create_ranged_counted(emb_engine *e, const emb_lookup_desc *descs, const uint64_t *row_lo,
                                    uint32_t *const *served, uint32_t n_descs, emb_plan **out);
+/* The same for either index width (the entry points above take uint32, the reference's width; DLRM's tensors are int64: SURVEY
+ * App. B.4): itype is the width of every descriptor's index array.  An int64 id is compared as it is -- negative ids and ids of
+ * 2^32 and more fall into no range.  row_lo[i] may carry EMB_RANGE_OPEN_END: descriptor i then also answers for every id at or
+ * beyond the END of its range (the last shard of a row-split table, the one holder of a whole table -- ids no rank holds, negative
+ * int64 ids included): such a bag is not served and not counted, but its pooled row is written as ZEROS instead of being left
+ * untouched, so that a caller who logs the error a checked shard reports and still consumes the outputs reads zero rows, never
+ * stale bytes. */
+#define EMB_RANGE_OPEN_END (1ull << 63)
+int emb_lookup_ranged_typed(emb_engine *e, const emb_lookup_desc *descs, const uint64_t *row_lo, uint32_t *const *served,
+                            uint32_t n_descs, emb_index_type itype, void *stream);
+int emb_plan_create_ranged_typed(emb_engine *e, const emb_lookup_desc *descs, const uint64_t *row_lo, uint32_t *const *served,
+                                 uint32_t n_descs, emb_index_type itype, emb_plan **out);
 
 /* Prepared lookup over DEVICE buffers: descriptors are resolved and uploaded once, every launch is
  * then a single kernel enqueue (graph-capturable: no allocation, copy or sync inside).  The plan
@@ -220,6 +232,12 @@ int emb_plan_destroy(emb_plan *p);
  * sum_t n_idx*(dim*elem + idx) + n_bags*off + n_bags*dim*4. */
 int emb_plan_bytes(const emb_plan *p, uint64_t *algorithmic_bytes, uint64_t *n_bags,
                    uint64_t *n_indices);
+/* A hash of what the plan's launches ARE -- kernel kind and row geometry, grid, the XCD-aware workgroup map word for word, index
+ * width, per descriptor its tile / bag / index / row counts -- and of nothing that names a buffer.  Two plans with the same
+ * signature enqueue the same grid of the same kernel over the same shapes, whatever host code built them: bench.py ties a
+ * committed counter profile (profiles/traffic.json) to the launch it measured with this and with the kernel's own code bytes,
+ * so that host-only edits of the library do not orphan a profile and a changed launch always does. */
+int emb_plan_signature(const emb_plan *p, uint64_t *signature);
 /* Time `iters` back-to-back launches with HIP events on `stream` after `warmup` untimed ones;
  * *avg_us = mean device time per launch. */
 int emb_plan_time(emb_plan *p, void *stream, uint32_t warmup, uint32_t iters, float *avg_us);
@@ -354,8 +372,8 @@ int emb_queue_destroy(emb_queue *q);
  * padding).  emb_unroute_bags then reads `recv` = the returned rows of shard 0, shard 1, ... back to back
  * and writes pooled[k][b][:].  dim must be a multiple of 4; indices are uint32; at most 64 tables per call. */
 typedef struct emb_route_table {
-    const uint32_t *indices;  /* DEVICE uint32[n_indices]: global row ids */
-    const uint32_t *offsets;  /* DEVICE uint32[n_bags] bag starts (last bag runs to n_indices), or NULL */
+    const void *indices;      /* DEVICE uint32[n_indices] (int64 through emb_route_bags_typed): global row ids */
+    const void *offsets;      /* DEVICE bag starts, same width (last bag runs to n_indices), or NULL */
     uint64_t n_indices;
     uint32_t fixed_pooling;   /* offsets == NULL: offsets[b] = b * fixed_pooling */
     uint32_t rows_per_shard;  /* shard d owns rows [d*rows_per_shard, (d+1)*rows_per_shard) */
@@ -365,6 +383,12 @@ int emb_route_bags_sizes(uint32_t n_tables, uint64_t n_bags, uint64_t total_indi
 int emb_route_bags(emb_engine *e, const emb_route_table *tables /* host array */, uint32_t n_tables,
                    uint64_t n_bags, uint32_t n_shards, void *send, uint32_t *meta, uint32_t *slots,
                    void *work, void *stream);
+/* emb_route_bags over int64 (or uint32) index / offset arrays: the request pieces are uint32 LOCAL row ids whatever the width
+ * handed in (a shard holds fewer than 2^32 rows); an id no shard can hold (negative, or beyond the last shard's 32-bit reach)
+ * travels as local id 0xffffffff, which no shard's table contains -- a validating server refuses it, it never wraps into range. */
+int emb_route_bags_typed(emb_engine *e, const emb_route_table *tables /* host array */, uint32_t n_tables,
+                         emb_index_type itype, uint64_t n_bags, uint32_t n_shards, void *send, uint32_t *meta,
+                         uint32_t *slots, void *work, void *stream);
 int emb_unroute_bags(emb_engine *e, const float *recv, const uint32_t *meta, const uint32_t *slots,
                      uint32_t n_tables, uint64_t n_bags, uint32_t n_shards, uint32_t dim,
                      float *pooled /* [n_tables][n_bags][dim] */, void *stream);
@@ -494,8 +518,9 @@ int emb_peer_destroy(emb_peer *p);   /* call emb_peer_barrier first: a peer may 
  *
  * Threading: one caller thread per shard object (the reference assumes a single caller too, emb_host.h:32-33); several shard
  * objects may share an engine.
- * Indices and offsets are uint32 (the reference's width, emb_host.h:234); every table has `dim` columns; a batch has the
- * same number of bags for every table (the reference's MAX_NR_BATCHES).  At most 64 row-split tables per shard object. */
+ * Indices and offsets are uint32 (the reference's width, emb_host.h:234) or int64 (torch's; emb_shard_input.index_type, one
+ * width per batch, every rank of a job the same); every table has `dim` columns; a batch has the same number of bags for
+ * every table (the reference's MAX_NR_BATCHES).  At most 64 row-split tables per shard object. */
 typedef struct emb_shard emb_shard;
 #define EMB_PLACE_REPLICATED 0u
 #define EMB_PLACE_WHOLE 1u
@@ -509,11 +534,15 @@ typedef struct emb_shard_table {
     uint32_t rows_per_shard; /* EMB_PLACE_ROWS */
 } emb_shard_table;
 typedef struct emb_shard_input {      /* one per table, in table order */
-    const uint32_t *indices;  /* DEVICE uint32[n_indices] */
-    const uint32_t *offsets;  /* DEVICE uint32[n_bags] bag starts (last bag runs to n_indices), or NULL */
+    const void *indices;      /* DEVICE uint32[n_indices] or int64[n_indices] (index_type) */
+    const void *offsets;      /* DEVICE bag starts of the same width (last bag runs to n_indices), or NULL */
     uint64_t n_indices;
     uint32_t fixed_pooling;   /* offsets == NULL: offsets[b] = b * fixed_pooling */
-    uint32_t reserved;
+    uint32_t index_type;      /* EMB_IDX_U32 (0: the reference's width, emb_host.h:234) or EMB_IDX_I64 (torch's: DLRM hands
+                                 int64 tensors over) -- the same for every table of one batch.  int64 arrays
+                                 are used IN PLACE: the router reads them, replicated / whole tables and the direct path gather
+                                 through them, whole tables' arrays travel as they are (8 bytes per id); nothing is narrowed,
+                                 and an id outside its table stays what it is for the checks below to refuse */
     float *pooled;            /* DEVICE float[n_bags][dim] */
 } emb_shard_input;
 #define EMB_SHARD_SELF_VIA_COMM 1u /* pieces a rank addresses to ITSELF go through RCCL like any other (rehearsal / A-B);
@@ -527,9 +556,12 @@ typedef struct emb_shard_input {      /* one per table, in table order */
                                       lookups are all one index per bag) -- nothing is validated up front: every launch counts the bags
                                       it serves, the counts travel back with the "served" handshake, and the REQUESTING rank compares:
                                       each replicated / whole table must have served all its bags, the shards of a row-split table
-                                      must add up to the bag count.  A shortfall = an index no rank holds, whose bag was left
-                                      untouched: EMB_ERR_RANGE on the requesting rank when the batch completes (emb_last_error names
-                                      the table and the count); the other bags of the batch are correct, the next batch is unaffected */
+                                      must add up to the bag count.  A shortfall = an index no rank holds: EMB_ERR_RANGE on the requesting
+                                      rank when the batch completes (emb_last_error names the table and the count), ONCE per batch;
+                                      the other bags of the batch are correct, the next batch is unaffected.  Both mechanisms leave
+                                      the same thing in the outputs: an offending bag's pooled row is ZEROS (routed: the offending
+                                      pieces pool to zero rows; counted: the last shard / the holder of a whole table writes zero rows
+                                      for ids beyond every range, EMB_RANGE_OPEN_END) -- never stale bytes of an earlier batch */
 #define EMB_SHARD_PEER_STORES 4u   /* the collective-free exchange (needs emb_shard_config.peer): nothing travels through RCCL.  A
                                       rank posts what it asks each peer for -- counts and buffer addresses -- into the peer's
                                       mailbox; the owner's ONE fused lookup gathers the requester's indices IN PLACE (its mapped
@@ -538,6 +570,16 @@ typedef struct emb_shard_input {      /* one per table, in table order */
                                       host's waits are polls of mailbox words.  The caller's index / offset / output buffers of
                                       tables held by OTHER ranks, whole or split, must come from emb_peer_alloc. */
 #define EMB_SHARD_NO_DIRECT 8u      /* never take the direct path for one-index-per-bag row-split tables (below): always route */
+#define EMB_SHARD_DEFER_REPORT 16u  /* with EMB_SHARD_CHECK_SERVED: what the REQUESTING rank learns from the served counts of batch b is
+                                      compared -- and a shortfall reported -- by a LATER call instead of inside the call that completes
+                                      batch b: by the first emb_shard_submit / _lookup that finds b's counts arrived (it only looks,
+                                      never waits; at the latest the submit that recycles b's slot, six batches on), by emb_shard_wait
+                                      for b, by an emb_shard_flush the caller makes, or by emb_shard_report.  The call that completes a
+                                      batch then never waits for the GPU: without the flag the synchronous emb_shard_lookup polls the
+                                      counts its own launch is still producing (59 -> 73 us per call on the C4 share,
+                                      profiles/r05/dist_world1.md).  The error names the batch it belongs to; unserved bags hold zero
+                                      rows either way.  Like a device-side assert: a call or a few late, never lost --
+                                      emb_shard_destroy prints a finding nobody collected to stderr. */
 typedef struct emb_shard_config {
     uint32_t n_tables;
     uint32_t dim;
@@ -569,6 +611,9 @@ int emb_shard_submit(emb_shard *s, const emb_shard_input *in, uint64_t n_bags, v
 int emb_shard_flush(emb_shard *s);
 int emb_shard_wait(emb_shard *s, uint64_t seq, void *stream);
 int emb_shard_lookup(emb_shard *s, const emb_shard_input *in, uint64_t n_bags, void *stream);
+/* EMB_SHARD_DEFER_REPORT: compare the served counts of every completed batch not looked at yet, now (waits for their publish
+ * kernels): EMB_OK, or EMB_ERR_RANGE with the first finding in emb_last_error().  A no-op (EMB_OK) without the flag. */
+int emb_shard_report(emb_shard *s);
 int emb_shard_get_stats(emb_shard *s, emb_shard_stats *out, int reset);
 /* Bracket the library's kernels with timing events (off by default: an event between two kernels costs GPU time itself). */
 int emb_shard_set_kernel_timing(emb_shard *s, int on);

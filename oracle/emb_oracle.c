@@ -8,6 +8,16 @@
  * What it restates (reference = /root/reference, paths relative to it):
  *   - bag bounds, "last bag runs to indices_len", empty bag = 0, duplicates summed:
  *       upmem/src/dpu/emb_dpu_lookup.c:106-116
+ *   - the BAG-0 START RULE of the reference's own entry points: the first bag starts at index 0, NOT at
+ *     offsets[0] -- tasklet 0 sets indices_ptr = 0 (emb_dpu_lookup.c:60-63: `if(me()!=0) indices_ptr[me()]=
+ *     offsets[me()]; else indices_ptr[me()]=0;`) and the reference's validator walks every table from
+ *     ind_ptr = 0 as well (load_generator.c:46).  Restated in oracle_dpu_column_i32, oracle_lookup_fixed32
+ *     and oracle_validate_result -- the functions behind populate_mram / lookup.  Identical to offsets[0]
+ *     whenever offsets[0] == 0, which every caller in the reference passes (load_generator.c:88: i*L) and
+ *     torch requires; pinned for offsets[0] != 0 by tests/test_oracle_golden.py::test_reference_bag0_start_rule
+ *     and, through lookup() on the GPU, tests/test_gpu_parity.py::test_compat_lookup_bag0_starts_at_index_0.
+ *     The fp32 functions below (oracle_bag_sum_*: nn.EmbeddingBag's contract, the native emb_lookup API)
+ *     start bag 0 at offsets[0]: torch raises for offsets[0] != 0, so the two rules never meet on valid input.
  *   - the int32 wrap-around accumulate of one (table, column) DPU:
  *       upmem/src/dpu/emb_dpu_lookup.c:108,112-114
  *   - fixed-point -> float conversion and the [bag][col] output layout:
@@ -153,7 +163,7 @@ int oracle_dpu_column_i32(const int32_t *column, uint64_t nr_rows, const uint32_
                           int32_t *results) {
     for (uint32_t i = 0; i < nr_batches; i++) {
         uint32_t acc = 0; /* unsigned arithmetic == int32 two's-complement wrap */
-        uint32_t p = offsets[i];
+        uint32_t p = (i == 0) ? 0u : offsets[i]; /* :60-63: tasklet 0 starts its first bag at index 0 */
         uint32_t e = (i + 1 < nr_batches) ? offsets[i + 1] : indices_len;
         for (; p < e; p++) {
             uint32_t ind = indices[p];
@@ -183,7 +193,7 @@ int oracle_lookup_fixed32(const int32_t *table_row_major, uint64_t nr_rows, uint
                           const uint32_t *indices, uint32_t indices_len, const uint32_t *offsets,
                           uint32_t nr_batches, float *out) {
     for (uint32_t i = 0; i < nr_batches; i++) {
-        uint32_t p0 = offsets[i];
+        uint32_t p0 = (i == 0) ? 0u : offsets[i]; /* emb_dpu_lookup.c:60-63: bag 0 starts at index 0 */
         uint32_t e = (i + 1 < nr_batches) ? offsets[i + 1] : indices_len;
         for (uint32_t t = 0; t < nr_cols; t++) {
             uint32_t acc = 0;
@@ -209,7 +219,7 @@ uint64_t oracle_validate_result(const int32_t *table_row_major, uint32_t nr_cols
                                 const float *results) {
     uint64_t bad = 0;
     for (uint32_t j = 0; j < nr_batches; j++) {
-        uint32_t p0 = offsets[j];
+        uint32_t p0 = (j == 0) ? 0u : offsets[j]; /* load_generator.c:46: ind_ptr = 0 at the head of every table */
         uint32_t e = (j + 1 < nr_batches) ? offsets[j + 1] : indices_len;
         for (uint32_t t = 0; t < nr_cols; t++) {
             int32_t tmp = 0;

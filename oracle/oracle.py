@@ -214,6 +214,8 @@ def np_lookup_fixed32(table_i32: np.ndarray, indices: np.ndarray, offsets: np.nd
     cols = table_i32.shape[1]
     acc = np.zeros((n_bags, cols), dtype=np.uint32)
     start = offsets.astype(np.int64)
+    if n_bags:
+        start[0] = 0          # emb_dpu_lookup.c:60-63: tasklet 0 starts its first bag at index 0, not at offsets[0]
     end = bag_ends(offsets, indices.shape[0])
     lens = end - start
     idx = indices.astype(np.int64)

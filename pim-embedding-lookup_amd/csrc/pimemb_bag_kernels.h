@@ -11,7 +11,8 @@
 // Mapping to the machine (bandwidth/latency-bound indexing; no MFMA -- there is no contraction):
 //   * rows stay row-major [nr_rows][dim] in HBM; a row is read as 16-byte pieces, one per lane,
 //     so the LPR = row_bytes/16 lanes of a "lane group" fetch a whole row with one coalesced
-//     global_load_dwordx4 (64 B for dim 16 fp32, 512 B for dim 128 fp32);
+//     16-byte-per-lane load -- flat_load_dwordx4 in the shipped code object (PIMEMB_GLOBAL_AS 0, below) --
+//     (64 B for dim 16 fp32, 512 B for dim 128 fp32);
 //   * a 64-lane wavefront owns 64 consecutive bags per step ("wave batch"): lane l first loads the
 //     bounds of bag l (two coalesced 256-B loads instead of 64/LPR scattered ones), then the
 //     wavefront walks the batch in LPR rounds of 64/LPR bags, lane groups picking their bag's
@@ -85,10 +86,11 @@ template <int DT>
 struct RowOps;
 
 // Address space of row / index / pooled-row accesses.  Pointers that come out of a descriptor in memory are generic
-// ("flat"); every buffer this library touches is GPU-visible memory (HBM, or pinned host memory on the zero-copy
-// host path), never LDS or scratch, so they can be accessed as GLOBAL (address space 1): global_load / global_store
-// skip the aperture check, and -- unlike flat accesses -- count on vmcnt alone and return in order, so the compiler
-// may consume the first of several gathers while the others are still in flight.
+// ("flat"), and the SHIPPED build keeps them so (PIMEMB_GLOBAL_AS 0): its row gathers are flat_load_dwordx4, its pooled-row
+// stores flat_store_dwordx4 ... nt.  Every buffer this library touches is GPU-visible memory (HBM, or pinned host memory on
+// the zero-copy host path), never LDS or scratch, so they COULD be accessed as GLOBAL (address space 1, -DPIMEMB_GLOBAL_AS=1):
+// global_load / global_store skip the aperture check and count on vmcnt alone.  Measured A/B on MI355X: no difference on any
+// shape (profiles/r02/tune_address_space_flat_vs_global.log), so the default stays the plain one.
 #ifndef PIMEMB_GLOBAL_AS
 #define PIMEMB_GLOBAL_AS 0
 #endif
@@ -254,6 +256,7 @@ struct XcdSegDev {
     uint32_t desc, tile0, slot_begin, slot_end;
 };
 constexpr uint32_t kXmapDirect = 0x80000000u;   // flag in the `chunks` kernel argument: xmap is a per-workgroup table
+constexpr uint64_t kRangeOpenEnd = 1ull << 63;  // flag in DevDesc::pad_[0] of a ranged launch (EMB_RANGE_OPEN_END, pimemb.h)
 
 __device__ __forceinline__ bool decode_block(const uint32_t *__restrict__ xmap, uint32_t direct,
                                              uint32_t *desc_i, uint32_t *tile) {
@@ -580,9 +583,11 @@ bag_sum_wavebatch_kernel(const DevDesc *__restrict__ descs, uint32_t chunks_arg,
     const char *__restrict__ wsub = weights + sub * 16u;
     const bool lane_live = sub < chunks;
     uint64_t row_lo = 0;
+    bool open_end = false;               // RANGED: ids at or beyond the end of this range are this descriptor's to ZERO (EMB_RANGE_OPEN_END)
     uint32_t *served_ctr = nullptr;      // RANGED: where this descriptor's launch adds the number of bags it served (or null)
     if constexpr (RANGED) {
-        row_lo = dp->pad_[0];
+        row_lo = dp->pad_[0] & ~kRangeOpenEnd;
+        open_end = (dp->pad_[0] & kRangeOpenEnd) != 0;
         served_ctr = reinterpret_cast<uint32_t *>(dp->pad_[1]);
     }
 
@@ -639,8 +644,11 @@ bag_sum_wavebatch_kernel(const DevDesc *__restrict__ descs, uint32_t chunks_arg,
                     if (len[q]) my[q] = load_meta<Cfg::kNtMeta>(indices + st[q]);
                 }
                 if constexpr (RANGED) {     // row ids relative to this shard; a bag of another shard counts as empty
-                    const uint64_t r = (uint64_t)my[q] - row_lo;       // (wraps far out of range below row_lo)
-                    if (r > last_row) len[q] = 0;
+                    const uint64_t id = (uint64_t)my[q];               // (a negative int64 id: huge, beyond every range)
+                    const uint64_t r = id - row_lo;                    // (wraps far out of range below row_lo)
+                    // len: 1 = served here; 2 = an id no range holds, and this descriptor answers for the open end: the bag's
+                    // pooled row is written as zeros (not served, not counted); 0 = some other shard's bag, left alone
+                    if (r > last_row) len[q] = (len[q] && open_end && id >= row_lo) ? 2u : 0u;
                     my[q] = (IdxT)r;
                 }
             }
@@ -654,7 +662,7 @@ bag_sum_wavebatch_kernel(const DevDesc *__restrict__ descs, uint32_t chunks_arg,
                 if (served_ctr != nullptr) {     // wave-uniform (a scalar load of the descriptor)
                     uint32_t n = 0;
 #pragma unroll
-                    for (uint32_t q = 0; q < NB; q++) n += (uint32_t)__popcll(__ballot(len[q] != 0u));
+                    for (uint32_t q = 0; q < NB; q++) n += (uint32_t)__popcll(__ballot(len[q] == 1u));
                     uint32_t *slot = served_ctr + (size_t)(blockIdx.x % EMB_SERVED_LANES) * (EMB_SERVED_STRIDE / 4u);
                     if (lane == 0 && n) (void)__hip_atomic_fetch_add(slot, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -663,13 +671,16 @@ bag_sum_wavebatch_kernel(const DevDesc *__restrict__ descs, uint32_t chunks_arg,
             for (uint32_t j0 = 0; j0 < ROUNDS; j0 += RU) {
                 u32x4 v[NB][RU];
                 bool has[NB][RU];
+                bool zero_it[NB][RU];      // (RANGED only: the open end's bags)
 #pragma unroll
                 for (uint32_t q = 0; q < NB; q++)
 #pragma unroll
                     for (uint32_t jj = 0; jj < RU; jj++) {
                         const uint32_t src = (j0 + jj) * BPR + grp;
                         const uint64_t r = clamp_row<Cfg::kClamp, IdxT>(shfl_index<IdxT>(my[q], src), last_row);
-                        has[q][jj] = shfl_u32(len[q], src) != 0u;
+                        const uint32_t l = shfl_u32(len[q], src);
+                        has[q][jj] = RANGED ? l == 1u : l != 0u;
+                        zero_it[q][jj] = RANGED && l == 2u;
                         v[q][jj] = u32x4{0u, 0u, 0u, 0u};
                         if (has[q][jj] && lane_live) v[q][jj] = load_row<Cfg::kNtRow>(wsub + r * row_bytes);
                     }
@@ -679,7 +690,7 @@ bag_sum_wavebatch_kernel(const DevDesc *__restrict__ descs, uint32_t chunks_arg,
                     for (uint32_t jj = 0; jj < RU; jj++) {
                         const uint64_t bag = step_base + 64u * q + (j0 + jj) * BPR + grp;
                         // (RANGED: only the bags this shard holds the row of are written)
-                        const bool wr = RANGED ? has[q][jj] : bag < n_bags;
+                        const bool wr = RANGED ? (has[q][jj] || zero_it[q][jj]) : bag < n_bags;
                         if constexpr (!Ops::kGroupStore) {
                             if (wr && lane_live) {
                                 typename Ops::Acc acc = Ops::zero();

@@ -18,6 +18,11 @@
 //     (emb_host.h:305-318,386-393);
 //   * errors do not exit() the process: populate_mram returns NULL, lookup leaves final_results
 //     untouched, and emb_last_error() holds the text.
+// Kept as the reference has it: the BAG-0 START RULE -- the first bag of every table starts at index 0
+// whatever offsets[t][0] says (tasklet 0: `indices_ptr[me()]=0`, emb_dpu_lookup.c:60-63; the reference's own
+// validator walks from ind_ptr = 0 too, load_generator.c:46).  The native emb_lookup* API follows
+// nn.EmbeddingBag instead (bag 0 starts at offsets[0], which torch requires to be 0): lookup() hands the
+// engine a copy of a table's offsets with entry 0 zeroed when a caller passes anything else.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -157,15 +162,22 @@ int32_t *lookup(uint32_t **indices, uint32_t **offsets, float **final_results,
     // emb_host.h:30,282-283: lengths are always the configured maxima
     const uint64_t indices_len = (uint64_t)g_cfg.max_indices_per_batch * g_cfg.max_nr_batches;
     std::vector<emb_lookup_desc> descs(g_cfg.nr_tables);
+    std::vector<std::vector<uint32_t>> patched;       // offsets of tables whose caller passed offsets[t][0] != 0
     for (uint32_t t = 0; t < g_cfg.nr_tables; t++) {
         descs[t] = emb_lookup_desc{};
         descs[t].table_id = t;
         descs[t].indices = indices[t];
         descs[t].offsets = offsets[t];
+        if (offsets[t] && g_cfg.max_nr_batches && offsets[t][0] != 0) {     // emb_dpu_lookup.c:60-63: bag 0 starts at index 0
+            patched.emplace_back(offsets[t], offsets[t] + g_cfg.max_nr_batches);
+            patched.back()[0] = 0;
+        }
         descs[t].n_indices = indices_len;
         descs[t].n_bags = g_cfg.max_nr_batches;
         descs[t].pooled = final_results[t];
     }
+    for (uint32_t t = 0, k = 0; t < g_cfg.nr_tables && k < patched.size(); t++)       // (the vectors no longer move)
+        if (offsets[t] && g_cfg.max_nr_batches && offsets[t][0] != 0) descs[t].offsets = patched[k++].data();
     emb_stats before{}, after{};
     emb_get_stats(e, &before);
     if (latency_print == 1) emb_set_stage_timing(e, 1);   // the reference's per-stage TIME_NOW brackets

@@ -116,6 +116,20 @@ struct XmapCacheEntry {
     uint32_t xgrid = 0;
     bool direct = false;
     uint64_t last_use = 0;
+    size_t bytes = 0;
+    // the streams whose launches have read this map (a handful at most: a caller's stream, a queue's): an evicted map may be
+    // freed once an event recorded on each of them AT EVICTION has fired -- no device-wide wait
+    hipStream_t streams[4] = {};
+    uint32_t n_streams = 0;
+    bool many_streams = false;   // more than four: only a device-wide wait can vouch for it
+};
+// an evicted map on its way out
+struct XmapGrave {
+    uint32_t *d_map = nullptr;
+    size_t bytes = 0;
+    hipEvent_t ev[4] = {};
+    uint32_t n_ev = 0;
+    bool needs_device_wait = false;
 };
 // 32 shapes in HBM; a shape earns its place on its SECOND sighting (the first one carries its map in the launch image), and an
 // evicted map is freed later, never between two launches.  Round 5 found the old policy -- 8 entries, allocate + blocking copy on
@@ -124,7 +138,7 @@ struct XmapCacheEntry {
 // real index stream (profiles/r05/README.md "launch shapes that do not recur").
 constexpr size_t kXmapCacheEntries = 32;
 constexpr size_t kXmapSeenEntries = 256;       // hashes of shapes seen once (a ring: the oldest is forgotten)
-constexpr size_t kXmapGraveyard = 64;          // evicted maps kept until this many have piled up (then ONE device-wide wait frees them)
+constexpr size_t kXmapGraveBytes = 64u << 20;  // evicted maps not yet known to be unread: beyond this many bytes the oldest ones are waited for
 
 }  // namespace
 
@@ -145,7 +159,8 @@ struct emb_engine {
     uint64_t xmap_clock = 0;
     std::vector<uint64_t> xmap_seen;       // hashes of launch shapes sighted once
     size_t xmap_seen_at = 0;
-    std::vector<uint32_t *> xmap_graveyard;
+    std::vector<XmapGrave> xmap_graveyard;
+    size_t xmap_grave_bytes = 0;
     // staging for EMB_MEM_HOST calls
     char *h_stage = nullptr;
     size_t h_stage_cap = 0;
@@ -205,6 +220,7 @@ struct emb_plan {
     std::vector<PlanGroup> groups;
     char *d_image = nullptr;  // descriptors + XCD maps in HBM
     uint64_t bytes = 0, n_bags = 0, n_indices = 0;
+    uint64_t signature = 0;   // hash of what the launches ARE (kernel kind, grid, XCD map, per-descriptor counts) -- never of addresses
     std::vector<std::pair<uint32_t, uint64_t>> table_gens;  // (table id, generation) the plan was built on
 };
 
@@ -240,6 +256,7 @@ struct Resolved {
     std::vector<PlanGroup> groups;    // kernel kind, tile counts, XCD map; device pointers set by bind()
     uint64_t bytes = 0, n_bags = 0, n_indices = 0;
     std::vector<char> image;          // descriptors of every group, then each group's XCD map
+    hipStream_t stream = nullptr;     // transient launches: the stream the launch goes to (the map cache notes who reads a map)
 
     // Lay descriptors and maps out in one host image; offsets go into the groups.
     void build_image() {
@@ -271,8 +288,37 @@ struct Resolved {
 
 // Transient launches: find (or build, upload and remember) the XCD map of this launch shape.  On
 // success the group points at the cached device copy and carries no map words of its own.
+// Free the evicted maps whose launches are known to be over: every event recorded at their eviction has fired (a query, never a
+// wait).  Round 5 kept up to 64 of them (up to 8 MB each, outside every HBM budget) and then called hipDeviceSynchronize under
+// e->mu -- a stall for every launching thread, and illegal while another thread captures a stream.  wait_oldest: the graveyard
+// is over its byte cap -- wait for the oldest entries' OWN events (or, for a map more than four streams have read, the device).
+void reap_xmap_graveyard(emb_engine *e, bool wait_oldest) {
+    size_t kept = 0;
+    for (size_t i = 0; i < e->xmap_graveyard.size(); i++) {
+        XmapGrave &gv = e->xmap_graveyard[i];
+        const bool over = wait_oldest && e->xmap_grave_bytes > kXmapGraveBytes;
+        bool done = !gv.needs_device_wait;
+        if (gv.needs_device_wait && over) done = hipDeviceSynchronize() == hipSuccess;
+        for (uint32_t k = 0; k < gv.n_ev && done; k++) {
+            hipError_t q = over ? hipEventSynchronize(gv.ev[k]) : hipEventQuery(gv.ev[k]);
+            if (q != hipSuccess) {
+                (void)hipGetLastError();
+                done = false;
+            }
+        }
+        if (done) {
+            for (uint32_t k = 0; k < gv.n_ev; k++) (void)hipEventDestroy(gv.ev[k]);
+            (void)hipFree(gv.d_map);
+            e->xmap_grave_bytes -= gv.bytes;
+        } else {
+            e->xmap_graveyard[kept++] = gv;
+        }
+    }
+    e->xmap_graveyard.resize(kept);
+}
+
 int cached_xcd_map(emb_engine *e, PlanGroup &g, uint32_t bpt, const std::vector<uint32_t> &tiles_of,
-                   const std::vector<uint64_t> &bytes_of) {
+                   const std::vector<uint64_t> &bytes_of, hipStream_t stream) {
     std::vector<uint64_t> key;
     key.reserve(2 + 2 * tiles_of.size());
     key.push_back((uint64_t)g.kind);
@@ -285,9 +331,16 @@ int cached_xcd_map(emb_engine *e, PlanGroup &g, uint32_t bpt, const std::vector<
     if (cache_off) return EMB_ERR_UNSUPPORTED;
     std::lock_guard<std::mutex> lk(e->mu);
     ++e->xmap_clock;                                   // (every transient launch with a map ages the entries)
+    auto note_stream = [stream](XmapCacheEntry &c) {
+        for (uint32_t k = 0; k < c.n_streams; k++)
+            if (c.streams[k] == stream) return;
+        if (c.n_streams < 4) c.streams[c.n_streams++] = stream;
+        else c.many_streams = true;
+    };
     for (XmapCacheEntry &c : e->xmap_cache)
         if (c.key == key) {
             c.last_use = e->xmap_clock;
+            note_stream(c);
             g.cached_xmap = c.d_map;
             g.xgrid = c.xgrid;
             g.xdirect = c.direct;
@@ -327,15 +380,29 @@ int cached_xcd_map(emb_engine *e, PlanGroup &g, uint32_t bpt, const std::vector<
         return EMB_ERR_DEVICE;
     }
     if (e->xmap_cache.size() >= kXmapCacheEntries) {   // evict it: a launch in flight may still read its map, so it is only set aside here, freed later
-        e->xmap_graveyard.push_back(e->xmap_cache[victim].d_map);
-        e->xmap_cache.erase(e->xmap_cache.begin() + (long)victim);
-        if (e->xmap_graveyard.size() >= kXmapGraveyard) {
-            (void)hipDeviceSynchronize();
-            for (uint32_t *m : e->xmap_graveyard) (void)hipFree(m);
-            e->xmap_graveyard.clear();
+        const XmapCacheEntry &v = e->xmap_cache[victim];
+        XmapGrave gv;
+        gv.d_map = v.d_map;
+        gv.bytes = v.bytes;
+        gv.needs_device_wait = v.many_streams;
+        for (uint32_t k = 0; k < v.n_streams && !gv.needs_device_wait; k++) {     // behind the last launch that read it, on every stream that did
+            hipEvent_t ev = nullptr;
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess && hipEventRecord(ev, v.streams[k]) == hipSuccess) {
+                gv.ev[gv.n_ev++] = ev;
+            } else {          // (the caller destroyed that stream: its launches are over or lost -- only the device can say)
+                if (ev) (void)hipEventDestroy(ev);
+                (void)hipGetLastError();
+                gv.needs_device_wait = true;
+            }
         }
+        e->xmap_grave_bytes += gv.bytes;
+        e->xmap_graveyard.push_back(gv);
+        e->xmap_cache.erase(e->xmap_cache.begin() + (long)victim);
+        reap_xmap_graveyard(e, /*wait_oldest=*/true);
     }
     n.key.swap(key);
+    n.bytes = words.size() * 4;
+    note_stream(n);
     n.last_use = e->xmap_clock;
     g.cached_xmap = n.d_map;
     g.xgrid = n.xgrid;
@@ -347,7 +414,8 @@ int cached_xcd_map(emb_engine *e, PlanGroup &g, uint32_t bpt, const std::vector<
 // st_indices / st_offsets / st_out: if non-null, per-descriptor device pointers that replace the
 // caller's (the staged copies of a host-pointer call).
 // row_lo: if non-null, a RANGED launch -- descriptor i serves only the bags whose row falls into
-// [row_lo[i], row_lo[i] + the table's rows); one index per bag, uint32 indices, the wave-batch kernels.
+// [row_lo[i], row_lo[i] + the table's rows); one index per bag, the wave-batch kernels (EMB_RANGE_OPEN_END in row_lo[i]
+// travels to the kernel as it is: ids beyond the end of the range pool to zero rows).
 // served (ranged launches only): if non-null, served[i] (may be null) is a uint32 counter in HBM that descriptor i's
 // launch adds the number of bags it served to.
 int resolve(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs, emb_index_type itype,
@@ -355,7 +423,6 @@ int resolve(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs, emb_i
             const std::vector<float *> *st_out, Resolved *r, bool cache_maps = false, const uint64_t *row_lo = nullptr,
             uint32_t *const *served = nullptr) {
     if (itype != EMB_IDX_U32 && itype != EMB_IDX_I64) return fail(EMB_ERR_INVALID, "bad index type");
-    if (row_lo && itype != EMB_IDX_U32) return fail(EMB_ERR_INVALID, "ranged lookups take uint32 indices");
     std::map<std::pair<int, uint32_t>, std::vector<uint32_t>> by_shape;
     for (uint32_t i = 0; i < n_descs; i++) {
         const emb_lookup_desc &u = descs[i];
@@ -458,7 +525,7 @@ int resolve(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs, emb_i
             for (uint32_t t : tiles_of) total_tiles += t;
             if (total_tiles + 8 * (uint64_t)g.n > 0x7fffffffull)
                 return fail(EMB_ERR_UNSUPPORTED, "launch too large for one grid");
-            if (!cache_maps || cached_xcd_map(e, g, bpt, tiles_of, bytes_of) != EMB_OK) {
+            if (!cache_maps || cached_xcd_map(e, g, bpt, tiles_of, bytes_of, r->stream) != EMB_OK) {
                 g.xgrid = pimemb::build_xcd_map(tiles_of, bytes_of, &g.xmap_words, 1);
                 if (g.xgrid <= (1u << 20)) {   // <= 8 MB of map: one scalar load per workgroup instead of a search
                     std::vector<uint32_t> direct;
@@ -714,6 +781,7 @@ int lookup_host_pipelined(emb_engine *e, const emb_lookup_desc *descs, uint32_t 
         std::vector<const void *> dof(hs.d_offsets.begin() + lo, hs.d_offsets.begin() + lo + cnt);
         std::vector<float *> dout(hs.d_out.begin() + lo, hs.d_out.begin() + lo + cnt);
         Resolved r;
+        r.stream = s;
         int rc = resolve(e, descs + lo, cnt, itype, &di, &dof, &dout, &r, /*cache_maps=*/true);
         if (rc == EMB_OK) rc = launch_resolved(e, r, itype, s, true);
         if (rc) {
@@ -761,6 +829,7 @@ int lookup_host(emb_engine *e, const emb_lookup_desc *descs, uint32_t n, emb_ind
     if (hs.zero_copy && !timed && hs.out_bytes >= kPipelineBytes && n >= 2)
         return lookup_host_pipelined(e, descs, n, itype, s, hs, t0);
     Resolved r;
+    r.stream = s;
     int rc = resolve(e, descs, n, itype, &hs.d_indices, &hs.d_offsets, &hs.d_out, &r, /*cache_maps=*/true);
     if (rc) return rc;
     // descriptor upload ("query copying" in the reference's stage list) + the fused launch
@@ -906,7 +975,10 @@ int emb_destroy(emb_engine *e) {
     }
     for (ImageRing &rg : e->ring) rg.release();
     for (XmapCacheEntry &c : e->xmap_cache) (void)hipFree(c.d_map);
-    for (uint32_t *m : e->xmap_graveyard) (void)hipFree(m);
+    for (XmapGrave &gv : e->xmap_graveyard) {          // (emb_destroy has waited for the device)
+        for (uint32_t k = 0; k < gv.n_ev; k++) (void)hipEventDestroy(gv.ev[k]);
+        (void)hipFree(gv.d_map);
+    }
     for (hipEvent_t ev : e->pipe_ev)
         if (ev) (void)hipEventDestroy(ev);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
@@ -1071,6 +1143,7 @@ static int lookup_batched_impl(emb_engine *e, const emb_lookup_desc *descs, uint
         return lookup_host(e, descs, n_descs, itype, s);
     }
     Resolved r;
+    r.stream = s;
     const double p0 = g_prof.on ? now_us() : 0;
     int rc = resolve(e, descs, n_descs, itype, nullptr, nullptr, nullptr, &r, /*cache_maps=*/true);
     if (rc) return rc;
@@ -1118,14 +1191,20 @@ int emb_lookup_ranged(emb_engine *e, const emb_lookup_desc *descs, const uint64_
 
 int emb_lookup_ranged_counted(emb_engine *e, const emb_lookup_desc *descs, const uint64_t *row_lo, uint32_t *const *served,
                               uint32_t n_descs, void *stream) {
+    return emb_lookup_ranged_typed(e, descs, row_lo, served, n_descs, EMB_IDX_U32, stream);
+}
+
+int emb_lookup_ranged_typed(emb_engine *e, const emb_lookup_desc *descs, const uint64_t *row_lo, uint32_t *const *served,
+                            uint32_t n_descs, emb_index_type itype, void *stream) {
     if (!e) return fail(EMB_ERR_INVALID, "engine is NULL");
     if (n_descs == 0) return EMB_OK;
     if (!descs || !row_lo) return fail(EMB_ERR_INVALID, "emb_lookup_ranged: NULL argument");
     DeviceGuard g(e->device);
     Resolved r;
-    int rc = resolve(e, descs, n_descs, EMB_IDX_U32, nullptr, nullptr, nullptr, &r, /*cache_maps=*/true, row_lo, served);
+    r.stream = static_cast<hipStream_t>(stream);
+    int rc = resolve(e, descs, n_descs, itype, nullptr, nullptr, nullptr, &r, /*cache_maps=*/true, row_lo, served);
     if (rc) return rc;
-    rc = launch_resolved(e, r, EMB_IDX_U32, static_cast<hipStream_t>(stream));
+    rc = launch_resolved(e, r, itype, static_cast<hipStream_t>(stream));
     if (rc) return rc;
     e->n_lookup_calls.fetch_add(1, std::memory_order_relaxed);
     e->n_bags.fetch_add(r.n_bags, std::memory_order_relaxed);
@@ -1148,6 +1227,12 @@ int emb_plan_create_ranged_counted(emb_engine *e, const emb_lookup_desc *descs, 
     return plan_create(e, descs, row_lo, served, n_descs, EMB_IDX_U32, out);
 }
 
+int emb_plan_create_ranged_typed(emb_engine *e, const emb_lookup_desc *descs, const uint64_t *row_lo, uint32_t *const *served,
+                                 uint32_t n_descs, emb_index_type itype, emb_plan **out) {
+    if (!row_lo) return fail(EMB_ERR_INVALID, "emb_plan_create_ranged_typed: row_lo is NULL");
+    return plan_create(e, descs, row_lo, served, n_descs, itype, out);
+}
+
 int emb_plan_create(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs,
                     emb_index_type itype, emb_plan **out) {
     return plan_create(e, descs, nullptr, nullptr, n_descs, itype, out);
@@ -1166,6 +1251,23 @@ static int plan_create(emb_engine *e, const emb_lookup_desc *descs, const uint64
     if (!p) return fail(EMB_ERR_NOMEM, "out of host memory");
     p->e = e;
     p->itype = itype;
+    {   // launch signature (emb_plan_signature): FNV-1a over everything that shapes the launches, nothing that names a buffer
+        uint64_t h = 1469598103934665603ull;
+        auto mix = [&h](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
+        mix((uint64_t)itype);
+        size_t di = 0;
+        for (const PlanGroup &g : r.groups) {
+            mix(g.kind); mix((uint64_t)g.dtype); mix(g.geom.lanes_per_row); mix(g.geom.chunks); mix(g.geom.scalar_lanes); mix(g.n); mix(g.max_tiles);
+            mix(g.xgrid); mix(g.xdirect); mix(g.ranged); mix(g.hot_wgs); mix(g.hot_lds); mix(pimemb::bags_per_tile(g.kind, g.geom));
+            for (uint32_t w : g.xmap_words) mix(w);
+            for (uint32_t i = 0; i < g.n; i++, di++) {
+                const DevDesc &d = r.descs[di];
+                mix(d.n_tiles); mix(d.n_bags); mix(d.n_idx); mix(d.nr_rows); mix(d.fixed_pooling); mix(d.offsets != nullptr); mix(d.n_hot);
+                mix(d.pad_[0]); mix(d.pad_[1] != 0);
+            }
+        }
+        p->signature = h;
+    }
     p->bytes = r.bytes;
     p->n_bags = r.n_bags;
     p->n_indices = r.n_indices;
@@ -1218,6 +1320,12 @@ int emb_plan_bytes(const emb_plan *p, uint64_t *algorithmic_bytes, uint64_t *n_b
     if (algorithmic_bytes) *algorithmic_bytes = p->bytes;
     if (n_bags) *n_bags = p->n_bags;
     if (n_indices) *n_indices = p->n_indices;
+    return EMB_OK;
+}
+
+int emb_plan_signature(const emb_plan *p, uint64_t *signature) {
+    if (!p || !signature) return fail(EMB_ERR_INVALID, "emb_plan_signature: NULL argument");
+    *signature = p->signature;
     return EMB_OK;
 }
 
@@ -1347,6 +1455,7 @@ static int validate_on(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_d
                        emb_memspace space, hipStream_t s, uint64_t *n_bad) {
     HostStage hs;
     Resolved r;
+    r.stream = s;
     int rc;
     std::unique_lock<std::mutex> host_lk(e->host_mu, std::defer_lock);
     if (space == EMB_MEM_HOST) host_lk.lock();
@@ -1875,7 +1984,13 @@ int emb_route_bags_sizes(uint32_t n_tables, uint64_t n_bags, uint64_t total_indi
 
 int emb_route_bags(emb_engine *e, const emb_route_table *tables, uint32_t n_tables, uint64_t n_bags,
                    uint32_t n_shards, void *send, uint32_t *meta, uint32_t *slots, void *work, void *stream) {
+    return emb_route_bags_typed(e, tables, n_tables, EMB_IDX_U32, n_bags, n_shards, send, meta, slots, work, stream);
+}
+
+int emb_route_bags_typed(emb_engine *e, const emb_route_table *tables, uint32_t n_tables, emb_index_type itype, uint64_t n_bags,
+                         uint32_t n_shards, void *send, uint32_t *meta, uint32_t *slots, void *work, void *stream) {
     if (!e || !tables || !send || !meta || !slots || !work) return fail(EMB_ERR_INVALID, "emb_route_bags: NULL argument");
+    if (itype != EMB_IDX_U32 && itype != EMB_IDX_I64) return fail(EMB_ERR_INVALID, "emb_route_bags: bad index type");
     if (n_tables == 0 || n_tables > pimemb::kRouteBagMaxTables)
         return fail(EMB_ERR_UNSUPPORTED, "emb_route_bags: 1..%u tables per call", pimemb::kRouteBagMaxTables);
     if (n_shards == 0 || n_shards > 255 || n_bags == 0 || n_bags * n_shards > 0x7fffffffull * 256)
@@ -1897,7 +2012,7 @@ int emb_route_bags(emb_engine *e, const emb_route_table *tables, uint32_t n_tabl
                     (unsigned long long)words);
     DeviceGuard g(e->device);
     HIP_TRY(pimemb::launch_route_bags(d, n_tables, n_bags, n_shards, static_cast<uint32_t *>(send), meta, slots,
-                                      static_cast<uint32_t *>(work), static_cast<hipStream_t>(stream)));
+                                      static_cast<uint32_t *>(work), static_cast<hipStream_t>(stream), itype == EMB_IDX_I64));
     return EMB_OK;
 }
 

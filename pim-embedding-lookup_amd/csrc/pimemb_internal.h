@@ -51,8 +51,9 @@ hipError_t launch_bag_sum(const DevDesc *d_descs, uint32_t n_descs, uint32_t max
 hipError_t launch_bag_sum_hot(const DevDesc *d_descs, uint32_t n_descs, uint32_t wgs, uint32_t lds_bytes,
                               emb_dtype dtype, emb_index_type itype, const LaunchGeom &g, hipStream_t stream);
 
-// ranged (wave-batch kinds, uint32 indices, one index per bag): a descriptor serves only the bags whose row falls into
-// [row_lo, row_lo + nr_rows) -- row_lo in DevDesc::pad_[0] -- as out[b] = W[idx[b] - row_lo]; other bags are left untouched.
+// ranged (wave-batch kinds, one index per bag): a descriptor serves only the bags whose row falls into
+// [row_lo, row_lo + nr_rows) -- row_lo in DevDesc::pad_[0] -- as out[b] = W[idx[b] - row_lo]; other bags are left untouched
+// (kRangeOpenEnd in pad_[0]: bags whose id lies at or beyond the end of the range are written as zero rows).
 
 // Scatter an int32 column (device buffer, nr_rows entries) into column `col` of a row-major
 // [nr_rows][dim] int32 table: the inverse of alloc_buffers' split (emb_host.h:116-118).
@@ -78,14 +79,15 @@ hipError_t launch_validate(DevDesc *d_descs, uint32_t n_descs, emb_index_type it
 // are enqueued on `stream`.
 constexpr uint32_t kRouteBagMaxTables = 64;
 struct RouteBagDesc {
-    const uint32_t *indices;
-    const uint32_t *offsets;
+    const void *indices;      // uint32, or int64 with idx64 (launch_route_bags)
+    const void *offsets;
     uint64_t n_indices;
     uint32_t fixed_pooling;
     uint32_t rows_per_shard;
 };
 hipError_t launch_route_bags(const RouteBagDesc *tables, uint32_t n_tables, uint64_t n_bags, uint32_t n_shards,
-                             uint32_t *send, uint32_t *meta, uint32_t *slots, uint32_t *work, hipStream_t stream);
+                             uint32_t *send, uint32_t *meta, uint32_t *slots, uint32_t *work, hipStream_t stream,
+                             bool idx64 = false);
 uint32_t route_bags_meta_words(uint32_t n_tables, uint32_t n_shards);   // uint32 words of `meta`
 hipError_t launch_unroute_bags(const float *recv, const uint32_t *meta, const uint32_t *slots, uint32_t n_tables,
                                uint64_t n_bags, uint32_t n_shards, uint32_t dim, float *pooled, hipStream_t stream);

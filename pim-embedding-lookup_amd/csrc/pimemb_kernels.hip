@@ -54,13 +54,11 @@ void launch_one(const DevDesc *d, uint32_t n, uint32_t max_tiles, const LaunchGe
     struct { uint32_t chunks; } g{g_in.chunks | ((xmap && xdirect) ? kXmapDirect : 0u)};
     using One = typename WaveCfgOf<DT>::One;
     using Two = typename WaveCfgOf<DT>::Two;
-    if (ranged) {      // launch_bag_sum lets uint32 indices and the two wave-batch kinds through only
-        if constexpr (sizeof(IdxT) == 4) {
-            if (kind == KERNEL_WAVEBATCH)
-                hipLaunchKernelGGL((bag_sum_wavebatch_kernel<IdxT, DT, L, One, true>), grid, dim3(One::kBlock), 0, s, d, g.chunks, xmap);
-            else if constexpr (L <= 4)
-                hipLaunchKernelGGL((bag_sum_wavebatch_kernel<IdxT, DT, L, Two, true>), grid, dim3(Two::kBlock), 0, s, d, g.chunks, xmap);
-        }
+    if (ranged) {      // launch_bag_sum lets the two wave-batch kinds through only (uint32 and int64 indices alike)
+        if (kind == KERNEL_WAVEBATCH)
+            hipLaunchKernelGGL((bag_sum_wavebatch_kernel<IdxT, DT, L, One, true>), grid, dim3(One::kBlock), 0, s, d, g.chunks, xmap);
+        else if constexpr (L <= 4)
+            hipLaunchKernelGGL((bag_sum_wavebatch_kernel<IdxT, DT, L, Two, true>), grid, dim3(Two::kBlock), 0, s, d, g.chunks, xmap);
         return;
     }
     if (kind == KERNEL_WAVEBATCH) {
@@ -289,20 +287,26 @@ __host__ __device__ __forceinline__ uint32_t counts_at(uint32_t d, uint32_t k, u
 constexpr uint32_t kModeBags = 0, kModeOneHot = 1;   // meta[mode]: how `slots` is encoded (see unroute_bags_kernel)
 
 struct RouteBagTable {
-    const uint32_t *indices;
-    const uint32_t *offsets;
+    const void *indices;      // uint32 or int64 (RouteBagParams::idx64), like the offsets
+    const void *offsets;
     uint64_t n_indices;
     uint32_t fixed_pooling;
     uint32_t rows_per_shard;
 };
 struct RouteBagParams {
     RouteBagTable t[kRouteBagMaxTables];
+    uint32_t idx64;           // the arrays of every table are int64 (torch's width) instead of uint32 (the reference's)
 };
 
-__device__ __forceinline__ void bag_bounds(const RouteBagTable &t, uint64_t b, uint64_t n_bags, uint64_t *p, uint64_t *e) {
+// one entry of an index / offset array as an unsigned 64-bit id (a negative int64 id: huge, beyond every range)
+__device__ __forceinline__ uint64_t route_word(const void *a, uint32_t idx64, uint64_t i) {
+    return idx64 ? (uint64_t)static_cast<const int64_t *>(a)[i] : (uint64_t)static_cast<const uint32_t *>(a)[i];
+}
+
+__device__ __forceinline__ void bag_bounds(const RouteBagTable &t, uint32_t idx64, uint64_t b, uint64_t n_bags, uint64_t *p, uint64_t *e) {
     if (t.offsets != nullptr) {
-        *p = t.offsets[b];
-        *e = (b + 1 < n_bags) ? (uint64_t)t.offsets[b + 1] : t.n_indices;
+        *p = route_word(t.offsets, idx64, b);
+        *e = (b + 1 < n_bags) ? route_word(t.offsets, idx64, b + 1) : t.n_indices;
     } else {
         *p = b * t.fixed_pooling;
         *e = *p + t.fixed_pooling;
@@ -311,11 +315,44 @@ __device__ __forceinline__ void bag_bounds(const RouteBagTable &t, uint64_t b, u
     if (*p > *e) *p = *e;
 }
 
-// shard d owns rows [lo, hi); the last shard also takes anything beyond (an out-of-range index stays in bounds
-// of the routing structures; the lookup kernel sees it as a local row id like any other)
-__device__ __forceinline__ void shard_range(uint32_t rps, uint32_t d, uint32_t n_shards, uint64_t *lo, uint64_t *hi) {
-    *lo = (uint64_t)d * rps;
-    *hi = (d + 1 == n_shards) ? ~0ull : *lo + rps;
+// shard d owns rows [lo, hi); the LAST shard also takes anything beyond (an out-of-range index stays in bounds of the
+// routing structures; the lookup kernel sees it as a local row id like any other -- one no table of < 2^32 rows holds
+// when it does not fit 32 bits: route_local)
+struct ShardRange {
+    uint64_t lo, hi;
+    bool last;
+    __device__ __forceinline__ bool holds(uint64_t r) const { return r >= lo && (last || r < hi); }
+};
+__device__ __forceinline__ ShardRange shard_range(uint32_t rps, uint32_t d, uint32_t n_shards) {
+    ShardRange s;
+    s.lo = (uint64_t)d * rps;
+    s.hi = s.lo + rps;
+    s.last = d + 1 == n_shards;
+    return s;
+}
+__device__ __forceinline__ uint32_t route_local(uint64_t r, uint64_t lo) {
+    const uint64_t v = r - lo;
+    return v > 0xffffffffull ? 0xffffffffu : (uint32_t)v;      // (never wraps into range)
+}
+
+// f(id) for the indices [p, e) of one table, in order.  uint32 arrays: up to the next 16-byte boundary one by one, then four
+// per load; int64 arrays: one by one (8 bytes each, consecutive: the same lines).
+template <class F>
+__device__ __forceinline__ void route_for_each(const RouteBagTable &t, uint32_t idx64, uint64_t p, uint64_t e, F &&f) {
+    if (idx64) {
+        const int64_t *ix = static_cast<const int64_t *>(t.indices);
+#pragma unroll 4
+        for (; p < e; p++) f((uint64_t)ix[p]);
+        return;
+    }
+    const uint32_t *ix = static_cast<const uint32_t *>(t.indices);
+    for (; p < e && (p & 3u); p++) f((uint64_t)ix[p]);
+    for (; p + 4 <= e; p += 4) {
+        const u32x4_a4 r4 = *reinterpret_cast<const u32x4_a4 *>(ix + p);   // (4-byte aligned type: the caller's array may start anywhere)
+#pragma unroll
+        for (int q = 0; q < 4; q++) f((uint64_t)r4[q]);
+    }
+    for (; p < e; p++) f((uint64_t)ix[p]);
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -326,23 +363,11 @@ route_bags_count_kernel(RouteBagParams rp, uint64_t n_bags, uint32_t n_shards, u
     const uint32_t d = (uint32_t)(gid % n_shards);
     if (b >= n_bags) return;
     const RouteBagTable &t = rp.t[k];
-    uint64_t p, e, lo, hi;
-    bag_bounds(t, b, n_bags, &p, &e);
-    shard_range(t.rows_per_shard, d, n_shards, &lo, &hi);
+    uint64_t p, e;
+    bag_bounds(t, rp.idx64, b, n_bags, &p, &e);
+    const ShardRange sr = shard_range(t.rows_per_shard, d, n_shards);
     uint32_t c = 0;
-    for (; p < e && (p & 3u); p++) {                       // up to the next 16-byte boundary of the index array
-        const uint64_t r = t.indices[p];
-        c += (r >= lo && r < hi) ? 1u : 0u;
-    }
-    for (; p + 4 <= e; p += 4) {                           // four indices per load
-        const u32x4_a4 r4 = *reinterpret_cast<const u32x4_a4 *>(t.indices + p);   // (4-byte aligned type: the caller's array may start anywhere)
-#pragma unroll
-        for (int q = 0; q < 4; q++) c += ((uint64_t)r4[q] >= lo && (uint64_t)r4[q] < hi) ? 1u : 0u;
-    }
-    for (; p < e; p++) {
-        const uint64_t r = t.indices[p];
-        c += (r >= lo && r < hi) ? 1u : 0u;
-    }
+    route_for_each(t, rp.idx64, p, e, [&](uint64_t r) { c += sr.holds(r) ? 1u : 0u; });
     work[((uint64_t)k * n_shards + d) * n_bags + b] = c;
 }
 
@@ -516,23 +541,12 @@ route_bags_place_kernel(RouteBagParams rp, uint64_t n_bags, uint32_t n_shards, u
     uint32_t pos = work[at];
     send[base[0] + slot] = pos;                       // the sub-bag's start in the shard's index list (bag-start offsets)
     uint32_t *list = send + base[1];
-    uint64_t p, e, lo, hi;
-    bag_bounds(t, b, n_bags, &p, &e);
-    shard_range(t.rows_per_shard, d, n_shards, &lo, &hi);
-    for (; p < e && (p & 3u); p++) {
-        const uint64_t r = t.indices[p];
-        if (r >= lo && r < hi) list[pos++] = (uint32_t)(r - lo);
-    }
-    for (; p + 4 <= e; p += 4) {                           // four indices per load, kept in bag order
-        const u32x4_a4 r4 = *reinterpret_cast<const u32x4_a4 *>(t.indices + p);   // (4-byte aligned type: the caller's array may start anywhere)
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-            if ((uint64_t)r4[q] >= lo && (uint64_t)r4[q] < hi) list[pos++] = (uint32_t)((uint64_t)r4[q] - lo);
-    }
-    for (; p < e; p++) {
-        const uint64_t r = t.indices[p];
-        if (r >= lo && r < hi) list[pos++] = (uint32_t)(r - lo);
-    }
+    uint64_t p, e;
+    bag_bounds(t, rp.idx64, b, n_bags, &p, &e);
+    const ShardRange sr = shard_range(t.rows_per_shard, d, n_shards);
+    route_for_each(t, rp.idx64, p, e, [&](uint64_t r) {          // kept in bag order
+        if (sr.holds(r)) list[pos++] = route_local(r, sr.lo);
+    });
 }
 
 // ---- one index per bag (the Criteo shape): every bag lives in exactly ONE shard --------------------------------
@@ -550,6 +564,13 @@ route_bags_place_kernel(RouteBagParams rp, uint64_t n_bags, uint32_t n_shards, u
 constexpr int kOneHotBlock = 1024;
 constexpr uint32_t kOneHotMaxShards = 64;
 
+// the shard of a one-index bag: id / rows_per_shard; an out-of-range id (beyond the table, a negative int64) goes to the last
+// shard, as ShardRange::holds does (a 32-bit division unless the id needs more)
+__device__ __forceinline__ uint32_t onehot_dest(uint64_t id, uint32_t rps, uint32_t n_shards) {
+    const uint64_t d = (id >> 32) ? id / rps : (uint64_t)((uint32_t)id / rps);
+    return d >= n_shards ? n_shards - 1 : (uint32_t)d;
+}
+
 __global__ void __launch_bounds__(kOneHotBlock)
 route_onehot_count_kernel(RouteBagParams rp, uint64_t n_bags, uint32_t n_shards, uint32_t n_blocks,
                           uint32_t *__restrict__ packed, uint32_t *__restrict__ blockcnt) {
@@ -559,10 +580,7 @@ route_onehot_count_kernel(RouteBagParams rp, uint64_t n_bags, uint32_t n_shards,
     const bool live = b < n_bags;
     const RouteBagTable &t = rp.t[k];
     uint32_t dest = 0;
-    if (live) {
-        dest = t.indices[b] / t.rows_per_shard;
-        if (dest >= n_shards) dest = n_shards - 1;       // an out-of-range index goes to the last shard (as shard_range does)
-    }
+    if (live) dest = onehot_dest(route_word(t.indices, rp.idx64, b), t.rows_per_shard, n_shards);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t rank = 0;
     for (uint32_t d = 0; d < n_shards; d++) {            // wave-uniform trip count
@@ -618,7 +636,7 @@ route_onehot_place_kernel(RouteBagParams rp, uint64_t n_bags, uint32_t n_shards,
     const uint32_t slot = blockcnt[((uint64_t)k * n_blocks + blk) * n_shards + dest] + (pk & 0xffffffu);
     const uint32_t *base = meta + meta_layout(n_shards, n_tables).base + 2 * (dest * n_tables + k);
     send[base[0] + slot] = slot;                                          // sub-bag `slot` starts at index `slot`
-    send[base[1] + slot] = t.indices[b] - dest * t.rows_per_shard;       // local row id
+    send[base[1] + slot] = route_local(route_word(t.indices, rp.idx64, b), (uint64_t)dest * t.rows_per_shard);   // local row id
     packed[(uint64_t)k * n_bags + b] = (dest << 24) | slot;
 }
 
@@ -711,7 +729,7 @@ route_onehot_place_fused_kernel(RouteBagParams rp, uint64_t n_bags, uint32_t n_s
     const uint32_t slot = s_before[dest] + (pk & 0xffffffu);
     const uint32_t cnt = s_tot[e], w0 = s_w[e] - 2u * pad4(cnt);
     send[w0 + slot] = slot;                                              // sub-bag `slot` starts at index `slot`
-    send[w0 + pad4(cnt) + slot] = t.indices[b] - dest * t.rows_per_shard;   // local row id
+    send[w0 + pad4(cnt) + slot] = route_local(route_word(t.indices, rp.idx64, b), (uint64_t)dest * t.rows_per_shard);   // local row id
     packed[(uint64_t)k * n_bags + b] = (dest << 24) | slot;
 }
 
@@ -778,9 +796,10 @@ bool route_bags_is_onehot(const RouteBagDesc *tables, uint32_t n_tables, uint64_
 }
 
 hipError_t launch_route_bags(const RouteBagDesc *tables, uint32_t n_tables, uint64_t n_bags, uint32_t n_shards,
-                             uint32_t *send, uint32_t *meta, uint32_t *slots, uint32_t *work, hipStream_t stream) {
+                             uint32_t *send, uint32_t *meta, uint32_t *slots, uint32_t *work, hipStream_t stream, bool idx64) {
     if (n_tables == 0 || n_bags == 0 || n_tables > kRouteBagMaxTables) return hipErrorInvalidValue;
     RouteBagParams rp{};
+    rp.idx64 = idx64 ? 1u : 0u;
     for (uint32_t k = 0; k < n_tables; k++)
         rp.t[k] = RouteBagTable{tables[k].indices, tables[k].offsets, tables[k].n_indices, tables[k].fixed_pooling,
                                 tables[k].rows_per_shard};
@@ -1050,8 +1069,7 @@ hipError_t launch_bag_sum(const DevDesc *d_descs, uint32_t n_descs, uint32_t max
                           hipStream_t stream, bool ranged) {
     if (n_descs == 0 || max_tiles == 0) return hipSuccess;
     if (d_xmap == nullptr && n_descs > 65535u) return hipErrorInvalidValue;
-    if (ranged && (itype != EMB_IDX_U32 || (kind != KERNEL_WAVEBATCH && kind != KERNEL_WAVEBATCH2) ||
-                   (kind == KERNEL_WAVEBATCH2 && g.lanes_per_row > 4)))
+    if (ranged && ((kind != KERNEL_WAVEBATCH && kind != KERNEL_WAVEBATCH2) || (kind == KERNEL_WAVEBATCH2 && g.lanes_per_row > 4)))
         return hipErrorInvalidValue;
     if (kind == KERNEL_ANYDIM) {
         if (g.scalar_lanes == 0 || d_xmap != nullptr) return hipErrorInvalidValue;
@@ -1060,7 +1078,7 @@ hipError_t launch_bag_sum(const DevDesc *d_descs, uint32_t n_descs, uint32_t max
     }
     if (itype == EMB_IDX_U32)
         return launch_dtype<uint32_t>(d_descs, n_descs, max_tiles, dtype, g, kind, d_xmap, xgrid, xdirect, ranged, stream);
-    return launch_dtype<int64_t>(d_descs, n_descs, max_tiles, dtype, g, kind, d_xmap, xgrid, xdirect, false, stream);
+    return launch_dtype<int64_t>(d_descs, n_descs, max_tiles, dtype, g, kind, d_xmap, xgrid, xdirect, ranged, stream);
 }
 
 hipError_t launch_bag_sum_hot(const DevDesc *d_descs, uint32_t n_descs, uint32_t wgs, uint32_t lds_bytes,

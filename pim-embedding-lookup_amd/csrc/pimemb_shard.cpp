@@ -75,6 +75,10 @@ constexpr uint32_t kWholeWords = 12;
 constexpr uint32_t kPeerConstHead = 8;   // host-written words in front of a destination's whole entries: req_send offset (2), ret_recv offset (2), bags, whole entries, 2 spare
 
 inline uint64_t pad4(uint64_t v) { return (v + 3u) & ~(uint64_t)3u; }
+// index / offset arrays are uint32 (the reference's width) or int64 (torch's): bytes per entry, and the 16-byte aligned uint32
+// words an array of n entries takes in a staging buffer
+inline uint32_t isz_of(uint32_t itype) { return itype == EMB_IDX_I64 ? 8u : 4u; }
+inline uint64_t idx_words(uint64_t n, uint32_t itype) { return pad4(n * (isz_of(itype) / 4u)); }
 
 struct DevBuf {
     void *p = nullptr;
@@ -88,6 +92,7 @@ struct PeerFrom {
     uint32_t piece_word = 0, ret_row0 = 0;
     // the source handed its one-index-per-bag row-split tables over DIRECTLY: raw index array + output buffer per table
     bool direct = false;
+    uint32_t itype = EMB_IDX_U32;                  // width of the source's raw index arrays (direct path)
     uint64_t n_bags = 0;
     std::vector<uint64_t> idx_off, out_off;        // per row-split table (peers: arena offsets; this rank itself: unused)
 };
@@ -111,6 +116,7 @@ struct Batch {
     uint64_t seq = ~0ull;
     Stage stage = FREE;
     uint64_t n_bags = 0;
+    uint32_t itype = EMB_IDX_U32;       // width of this batch's index / offset arrays (emb_shard_input.index_type, every table alike)
     std::vector<emb_shard_input> in;
     // HBM, grow-only, owned by the slot
     DevBuf req_send, meta, slotmap, counts_in, wc_send, req_recv, ret_send, ret_recv;
@@ -125,6 +131,8 @@ struct Batch {
     // per-peer sizes of this batch (row-split path), from the counts
     std::vector<uint64_t> out_words, in_words, rows_back, rows_served;
     int deferred_rc = EMB_OK;
+    bool reported = false;              // deferred_rc has been handed to the caller (a batch's finding is returned ONCE)
+    bool check_pending = false;         // EMB_SHARD_DEFER_REPORT: the served counts of this (completed) batch have not been compared yet
     bool direct = false;                // this batch's row-split tables skip router and un-router (see stage_route)
     // checked shards: what the counted ranged launches served (see stage_serve / stage_unroute)
     DevBuf chk_ctr;                     // HBM counters [N][Kr + M] (source p: its row-split tables, then the whole tables owned here) + [R] replicated
@@ -153,6 +161,7 @@ struct emb_shard {
     std::vector<uint32_t> elem_bytes;                // per table: element size of what this rank holds (0: nothing held)
     uint32_t Kr = 0, M = 0, Wtot = 0;                // row-split tables, whole tables owned here, whole tables in all
     bool self_via_comm = false, check_served = false;
+    bool defer_report = false;                       // EMB_SHARD_DEFER_REPORT: requester-side findings surface at the next call
     hipStream_t s_comm = nullptr;                    // every transfer (RCCL group) of every batch, in one order on all ranks
     hipStream_t cs = nullptr;                        // the caller's stream: every kernel runs there
     bool cs_known = false;
@@ -162,6 +171,7 @@ struct emb_shard {
         std::vector<emb_lookup_desc> key;
         std::vector<uint64_t> key_lo;                // row ranges of a ranged launch (empty: an ordinary one)
         std::vector<uint32_t *> key_ctr;             // ... and its served counters (a checked shard's counted launch)
+        uint32_t itype = EMB_IDX_U32;                // width of the index arrays its descriptors point at
         emb_plan *plan = nullptr;
         uint64_t last_use = 0, seen = 0;
     };
@@ -189,6 +199,10 @@ struct emb_shard {
     std::vector<emb_lookup_desc> rdescs;             // scratch: the direct path's descriptors (one per source and row-split table)
     // checked shards count what their ranged launches serve: one counter per descriptor, parallel to descs / local / rdescs
     std::vector<uint32_t *> desc_ctr, local_ctr, rdesc_ctr;
+    // ... and the width of each descriptor's index array (routed pieces are uint32 local row ids whatever the caller's width)
+    std::vector<uint32_t> desc_it, local_it, rdesc_it;
+    uint32_t refused = 0;                            // bit w: a validating launch over descriptors of index width w found something and
+                                                     // gathered NOTHING (fused_lookup_one; its outputs were zeroed) -- the caller says whose batch that was
     uint32_t max_whole = 0;                          // most whole tables on one owner: the served counts' tail of a mailbox is Kr + max_whole words
     char range_msg[200] = {0};                       // what a requester-side count mismatch said (emb_last_error of the deferred EMB_ERR_RANGE)
 };
@@ -298,23 +312,25 @@ inline bool all_one_hot(const std::vector<emb_lookup_desc> &v) {
     return true;
 }
 
-// One fused lookup over s->descs on the caller's stream.  A call that recurs byte for byte (same tables, same buffers, same
-// lengths: static batch slots, fixed-size whole-table pieces) is served by a prepared plan from its second sighting on --
-// one kernel enqueue, no descriptor resolution.  A plan holds addresses, never values.  Checked lookups never use plans.
+// One fused lookup over s->descs (all of index width `it`) on the caller's stream.  A call that recurs byte for byte (same
+// tables, same buffers, same lengths: static batch slots, fixed-size whole-table pieces) is served by a prepared plan from its
+// second sighting on -- one kernel enqueue, no descriptor resolution.  A plan holds addresses, never values.  Checked lookups
+// never use plans.
 // ranged: s->row_lo holds a row range start per descriptor (emb_lookup_ranged: one index per bag; a whole table is row_lo 0).
-int fused_lookup(emb_shard *s, Batch &b, bool cacheable, bool ranged = false) {
+int fused_lookup_one(emb_shard *s, Batch &b, bool cacheable, bool ranged, uint32_t it) {
     const uint32_t n = (uint32_t)s->descs.size();
     if (n == 0) return EMB_OK;
+    const emb_index_type itype = (emb_index_type)it;
     if (ranged && s->row_lo.size() != n) return fail(EMB_ERR_INVALID, "emb_shard: internal: %u descriptors, %zu row ranges", n, s->row_lo.size());
     const bool counted = ranged && s->check_served;      // a checked shard's ranged launch counts the bags it serves
     if (counted && s->desc_ctr.size() != n) return fail(EMB_ERR_INVALID, "emb_shard: internal: %u descriptors, %zu counters", n, s->desc_ctr.size());
     if (s->check_served && !ranged) {
         uint64_t bad = 0;
-        int rc = emb_lookup_batched_checked(s->e, s->descs.data(), n, EMB_IDX_U32, EMB_MEM_DEVICE, s->cs, &bad);
+        int rc = emb_lookup_batched_checked(s->e, s->descs.data(), n, itype, EMB_MEM_DEVICE, s->cs, &bad);
         if (rc == EMB_ERR_RANGE) {          // nothing was gathered: the pieces pool to zero rows, the batch still completes
             for (const emb_lookup_desc &d : s->descs)
                 HIP_TRY(hipMemsetAsync(d.pooled, 0, d.n_bags * (size_t)s->dim * 4, s->cs));
-            b.deferred_rc = EMB_ERR_RANGE;
+            s->refused |= 1u << it;
             return EMB_OK;
         }
         return rc;
@@ -323,7 +339,7 @@ int fused_lookup(emb_shard *s, Batch &b, bool cacheable, bool ranged = false) {
         s->plan_clock++;
         emb_shard::CachedPlan *hit = nullptr, *victim = nullptr;
         for (emb_shard::CachedPlan &c : s->plans) {
-            if (c.key.size() == n && c.key_lo.size() == (ranged ? n : 0u) && c.key_ctr.size() == (counted ? n : 0u) &&
+            if (c.key.size() == n && c.itype == it && c.key_lo.size() == (ranged ? n : 0u) && c.key_ctr.size() == (counted ? n : 0u) &&
                 memcmp(c.key.data(), s->descs.data(), n * sizeof(emb_lookup_desc)) == 0 &&
                 (!ranged || memcmp(c.key_lo.data(), s->row_lo.data(), n * 8) == 0) &&
                 (!counted || memcmp(c.key_ctr.data(), s->desc_ctr.data(), n * sizeof(uint32_t *)) == 0))
@@ -337,8 +353,8 @@ int fused_lookup(emb_shard *s, Batch &b, bool cacheable, bool ranged = false) {
                 (void)emb_plan_destroy(hit->plan);
                 hit->plan = nullptr;
             }
-            if (++hit->seen >= 2 && (ranged ? emb_plan_create_ranged_counted(s->e, s->descs.data(), s->row_lo.data(), counted ? s->desc_ctr.data() : nullptr, n, &hit->plan)
-                                            : emb_plan_create(s->e, s->descs.data(), n, EMB_IDX_U32, &hit->plan)) == EMB_OK)
+            if (++hit->seen >= 2 && (ranged ? emb_plan_create_ranged_typed(s->e, s->descs.data(), s->row_lo.data(), counted ? s->desc_ctr.data() : nullptr, n, itype, &hit->plan)
+                                            : emb_plan_create(s->e, s->descs.data(), n, itype, &hit->plan)) == EMB_OK)
                 return emb_plan_launch(hit->plan, s->cs);
         } else {
             if (s->plans.size() < emb_shard::kPlanCache) {
@@ -357,12 +373,52 @@ int fused_lookup(emb_shard *s, Batch &b, bool cacheable, bool ranged = false) {
             if (ranged) victim->key_lo.assign(s->row_lo.begin(), s->row_lo.end());
             victim->key_ctr.clear();
             if (counted) victim->key_ctr.assign(s->desc_ctr.begin(), s->desc_ctr.end());
+            victim->itype = it;
             victim->seen = 1;
             victim->last_use = s->plan_clock;
         }
     }
-    if (ranged) return emb_lookup_ranged_counted(s->e, s->descs.data(), s->row_lo.data(), counted ? s->desc_ctr.data() : nullptr, n, s->cs);
-    return emb_lookup_batched(s->e, s->descs.data(), n, EMB_IDX_U32, EMB_MEM_DEVICE, s->cs);
+    if (ranged) return emb_lookup_ranged_typed(s->e, s->descs.data(), s->row_lo.data(), counted ? s->desc_ctr.data() : nullptr, n, itype, s->cs);
+    return emb_lookup_batched(s->e, s->descs.data(), n, itype, EMB_MEM_DEVICE, s->cs);
+}
+
+// One fused lookup over s->descs, whose index arrays are of the widths s->desc_it names.  One width (every call of a uint32 job,
+// every one-index call of an int64 job): ONE launch.  Two widths -- an int64 job's ROUTED step, whose request pieces are uint32
+// local row ids next to the callers' own int64 arrays of replicated / whole tables: one launch per width (pieces change size with
+// every batch, so nothing of such a call recurs: never cached).
+int fused_lookup(emb_shard *s, Batch &b, bool cacheable, bool ranged = false) {
+    const size_t n = s->descs.size();
+    if (n == 0) return EMB_OK;
+    if (s->desc_it.size() != n) return fail(EMB_ERR_INVALID, "emb_shard: internal: %zu descriptors, %zu index widths", n, s->desc_it.size());
+    bool mixed = false;
+    for (size_t i = 1; i < n; i++) mixed = mixed || s->desc_it[i] != s->desc_it[0];
+    if (!mixed) return fused_lookup_one(s, b, cacheable, ranged, s->desc_it[0]);
+    std::vector<emb_lookup_desc> all_d;
+    std::vector<uint64_t> all_lo;
+    std::vector<uint32_t *> all_ctr;
+    std::vector<uint32_t> all_it;
+    all_d.swap(s->descs);
+    all_lo.swap(s->row_lo);
+    all_ctr.swap(s->desc_ctr);
+    all_it.swap(s->desc_it);
+    int rc = EMB_OK;
+    for (uint32_t it = EMB_IDX_U32; it <= EMB_IDX_I64 && rc == EMB_OK; it++) {
+        s->descs.clear();
+        s->row_lo.clear();
+        s->desc_ctr.clear();
+        for (size_t i = 0; i < n; i++) {
+            if (all_it[i] != it) continue;
+            s->descs.push_back(all_d[i]);
+            if (all_lo.size() == n) s->row_lo.push_back(all_lo[i]);
+            if (all_ctr.size() == n) s->desc_ctr.push_back(all_ctr[i]);
+        }
+        rc = fused_lookup_one(s, b, false, ranged, it);
+    }
+    s->descs.swap(all_d);
+    s->row_lo.swap(all_lo);
+    s->desc_ctr.swap(all_ctr);
+    s->desc_it.swap(all_it);
+    return rc;
 }
 
 // ---- R(b) + counts out + L(b) -------------------------------------------------------------------------------------
@@ -371,7 +427,9 @@ int stage_route(emb_shard *s, Batch &b) {
     g_hp.start();
     b.req_recorded = b.ret_recorded = b.out_recorded = false;
     b.deferred_rc = EMB_OK;
+    b.reported = b.check_pending = false;
     b.rep_counted = b.self_published = false;
+    const uint32_t isz = isz_of(b.itype);
 
     // One index per bag and no peer behind RCCL (every peer is this rank itself or reachable by loads / stores): the
     // row-split tables need NO routing at all -- every shard scans the requester's raw index array and serves the bags whose
@@ -385,7 +443,7 @@ int stage_route(emb_shard *s, Batch &b) {
             const emb_shard_input &u = b.in[s->rows[k]];
             ok = u.offsets == nullptr && u.fixed_pooling == 1;
             if (ok && s->peer_mode && N > 1 && b.n_bags)       // peers gather from / store into these in place
-                ok = pimemb::peer_owns(s->peer, u.indices, b.n_bags * 4) && pimemb::peer_owns(s->peer, u.pooled, b.n_bags * (uint64_t)s->dim * 4);
+                ok = pimemb::peer_owns(s->peer, u.indices, b.n_bags * isz) && pimemb::peer_owns(s->peer, u.pooled, b.n_bags * (uint64_t)s->dim * 4);
         }
         b.direct = ok;
     }
@@ -393,8 +451,8 @@ int stage_route(emb_shard *s, Batch &b) {
     for (uint32_t k = 0; k < Kr; k++) total_idx += b.in[s->rows[k]].n_indices;
     if (b.direct) {          // accounted on the requester's side: every bag is served exactly once, by one of the shards
         for (uint32_t k = 0; k < Kr; k++)
-            s->st.served_algorithmic_bytes += b.n_bags * ((uint64_t)s->dim * s->elem_bytes[s->rows[k]] + 4 + (uint64_t)s->dim * 4) +
-                                              (uint64_t)(N - 1) * b.n_bags * 4;
+            s->st.served_algorithmic_bytes += b.n_bags * ((uint64_t)s->dim * s->elem_bytes[s->rows[k]] + isz + (uint64_t)s->dim * 4) +
+                                              (uint64_t)(N - 1) * b.n_bags * isz;
         s->st.served_sub_bags += b.n_bags * Kr;
         s->st.served_indices += b.n_bags * Kr;
     }
@@ -415,8 +473,8 @@ int stage_route(emb_shard *s, Batch &b) {
                 const emb_shard_input &u = b.in[s->rows[k]];
                 rt[k] = emb_route_table{u.indices, u.offsets, u.n_indices, u.fixed_pooling, s->tabs[s->rows[k]].rows_per_shard};
             }
-            EMB_TRY(emb_route_bags(s->e, rt, Kr, b.n_bags, N, b.req_send.p, static_cast<uint32_t *>(b.meta.p),
-                                   static_cast<uint32_t *>(b.slotmap.p), s->work.p, s->cs));
+            EMB_TRY(emb_route_bags_typed(s->e, rt, Kr, (emb_index_type)b.itype, b.n_bags, N, b.req_send.p, static_cast<uint32_t *>(b.meta.p),
+                                         static_cast<uint32_t *>(b.slotmap.p), s->work.p, s->cs));
             EMB_TRY(tick(s, b, 0, true));
         } else {         // nothing to ask for: all counts (and peaks) zero; this rank still serves
             HIP_TRY(pimemb::launch_zero_words(static_cast<uint32_t *>(b.meta.p), pimemb::route_meta_counts_words(Kr, N), s->cs));
@@ -433,9 +491,9 @@ int stage_route(emb_shard *s, Batch &b) {
                 c[0] = (uint32_t)b.n_bags;
                 c[1] = (uint32_t)u.n_indices;
                 c[2] = u.offsets ? 0u : u.fixed_pooling;
-                c[3] = 0;
+                c[3] = b.itype;                                // width of the arrays that travel (or are gathered in place)
                 if (via(s, (int)p) == PEER && b.n_bags) {     // the owner gathers / stores in place: the arrays must be where it can
-                    if (!pimemb::peer_owns(s->peer, u.indices, u.n_indices * 4) || (u.offsets && !pimemb::peer_owns(s->peer, u.offsets, b.n_bags * 4)) ||
+                    if (!pimemb::peer_owns(s->peer, u.indices, u.n_indices * isz) || (u.offsets && !pimemb::peer_owns(s->peer, u.offsets, b.n_bags * isz)) ||
                         !pimemb::peer_owns(s->peer, u.pooled, b.n_bags * (uint64_t)s->dim * 4))
                         return fail(EMB_ERR_INVALID, "emb_shard_submit: table %u is held by rank %u: with EMB_SHARD_PEER_STORES its indices / offsets / "
                                     "pooled buffers must come from emb_peer_alloc", t, p);
@@ -496,7 +554,7 @@ int stage_route(emb_shard *s, Batch &b) {
             const uint32_t nw = (uint32_t)s->whole_of[p].size();
             c[0] = (uint32_t)rs; c[1] = (uint32_t)(rs >> 32);
             c[2] = (uint32_t)rr; c[3] = (uint32_t)(rr >> 32);
-            c[4] = (uint32_t)b.n_bags; c[5] = nw; c[6] = (b.direct ? 1u : 0u) | (s->check_served ? 2u : 0u); c[7] = 0;
+            c[4] = (uint32_t)b.n_bags; c[5] = nw; c[6] = (b.direct ? 1u : 0u) | (s->check_served ? 2u : 0u) | (b.itype == EMB_IDX_I64 ? 4u : 0u); c[7] = 0;
             memcpy(c + kPeerConstHead, b.wc_host + (size_t)s->wc_off[p] * kWholeWords, (size_t)nw * kWholeWords * 4);
             uint32_t extra = 0;
             if (b.direct) {          // where this rank's raw index arrays and output buffers of the row-split tables sit
@@ -524,6 +582,7 @@ int stage_route(emb_shard *s, Batch &b) {
     // batch's S (stage_serve)
     s->local.clear();
     s->local_ctr.clear();
+    s->local_it.clear();
     s->local_of = nullptr;
     if (!s->rep.empty() && b.n_bags) {
         for (uint32_t t : s->rep) {
@@ -537,9 +596,10 @@ int stage_route(emb_shard *s, Batch &b) {
             d.n_bags = b.n_bags;
             d.pooled = u.pooled;
             s->local.push_back(d);
+            s->local_it.push_back(b.itype);
             if (s->check_served) s->local_ctr.push_back(ctr_rep(s, b, (uint32_t)s->local_ctr.size()));
-            s->st.local_algorithmic_bytes += u.n_indices * ((uint64_t)s->dim * s->elem_bytes[t] + 4) +
-                                             (u.offsets ? b.n_bags * 4 : 0) + b.n_bags * (uint64_t)s->dim * 4;
+            s->st.local_algorithmic_bytes += u.n_indices * ((uint64_t)s->dim * s->elem_bytes[t] + isz) +
+                                             (u.offsets ? b.n_bags * isz : 0) + b.n_bags * (uint64_t)s->dim * 4;
         }
         s->local_of = &b;
     }
@@ -554,15 +614,22 @@ int launch_local(emb_shard *s) {
     Batch &b = *s->local_of;
     s->descs.swap(s->local);
     s->desc_ctr.swap(s->local_ctr);
+    s->desc_it.swap(s->local_it);
     s->local.clear();
     s->local_ctr.clear();
+    s->local_it.clear();
     s->local_of = nullptr;
     // a checked shard whose replicated tables all take one index per bag: the counted ranged launch (a whole table is the
     // range from row 0) instead of validation kernel + host round trip; the requester -- this rank -- compares at U(b)
     const bool counted = s->check_served && s->allow_direct && all_one_hot(s->descs);
-    if (counted) s->row_lo.assign(s->descs.size(), 0ull);
+    if (counted) s->row_lo.assign(s->descs.size(), EMB_RANGE_OPEN_END);     // (a whole table: the range from row 0, ids beyond it pool to zero rows)
     EMB_TRY(tick(s, b, 1, false));
+    s->refused = 0;
     EMB_TRY(fused_lookup(s, b, true, /*ranged=*/counted));
+    if (s->refused) {
+        b.deferred_rc = EMB_ERR_RANGE;
+        b.reported = false;
+    }
     EMB_TRY(tick(s, b, 1, true));
     if (counted) {
         pimemb::ServedArgs sa{};
@@ -623,6 +690,7 @@ int stage_request(emb_shard *s, Batch &b) {
             if (M) memcpy(rwhole + (size_t)p * M * kWholeWords, w + at + kPeerConstHead, (size_t)M * kWholeWords * 4);
             b.from[p].n_bags = w[at + 4];
             b.from[p].direct = (w[at + 6] & 1u) != 0;
+            b.from[p].itype = (w[at + 6] & 4u) ? EMB_IDX_I64 : EMB_IDX_U32;
             if (((w[at + 6] & 2u) != 0) != s->check_served)
                 return fail(EMB_ERR_INVALID, "emb_shard: rank %u created its shard %s EMB_SHARD_CHECK_SERVED, this rank %s it (the flags must agree)", p,
                             (w[at + 6] & 2u) ? "with" : "without", s->check_served ? "with" : "without");
@@ -640,6 +708,7 @@ int stage_request(emb_shard *s, Batch &b) {
     }
     if (via(s, s->rank) == SELF) {
         b.from[(size_t)s->rank].direct = b.direct;
+        b.from[(size_t)s->rank].itype = b.itype;
         b.from[(size_t)s->rank].n_bags = b.n_bags;
     }
     b.out_words.assign(N, 0);
@@ -661,7 +730,7 @@ int stage_request(emb_shard *s, Batch &b) {
         if (via_comm(s, (int)p))
             for (uint32_t j = 0; j < M; j++) {
                 const uint32_t *c = rwhole + ((size_t)p * M + j) * kWholeWords;
-                whole_in_w += (c[2] ? 0 : pad4(c[0])) + pad4(c[1]);
+                whole_in_w += (c[2] ? 0 : idx_words(c[0], c[3])) + idx_words(c[1], c[3]);
                 whole_rows += c[0];
             }
     }
@@ -678,17 +747,18 @@ int stage_request(emb_shard *s, Batch &b) {
             add_op(s, (int)p, true, static_cast<uint32_t *>(b.req_recv.p) + in_at, b.in_words[p] * 4);
             for (uint32_t t : s->whole_of[p]) {          // straight out of the caller's buffers
                 const emb_shard_input &u = b.in[t];
-                if (u.offsets) add_op(s, (int)p, false, u.offsets, b.n_bags * 4);
-                add_op(s, (int)p, false, u.indices, u.n_indices * 4);
+                if (u.offsets) add_op(s, (int)p, false, u.offsets, b.n_bags * isz_of(b.itype));
+                add_op(s, (int)p, false, u.indices, u.n_indices * isz_of(b.itype));
             }
             for (uint32_t j = 0; j < M; j++) {
                 const uint32_t *c = rwhole + ((size_t)p * M + j) * kWholeWords;
+                if (c[3] > EMB_IDX_I64) return fail(EMB_ERR_INVALID, "emb_shard: rank %u sent an unknown index width (%u)", p, c[3]);
                 if (!c[2]) {
-                    add_op(s, (int)p, true, static_cast<uint32_t *>(b.req_recv.p) + win_at, (uint64_t)c[0] * 4);
-                    win_at += pad4(c[0]);
+                    add_op(s, (int)p, true, static_cast<uint32_t *>(b.req_recv.p) + win_at, (uint64_t)c[0] * isz_of(c[3]));
+                    win_at += idx_words(c[0], c[3]);
                 }
-                add_op(s, (int)p, true, static_cast<uint32_t *>(b.req_recv.p) + win_at, (uint64_t)c[1] * 4);
-                win_at += pad4(c[1]);
+                add_op(s, (int)p, true, static_cast<uint32_t *>(b.req_recv.p) + win_at, (uint64_t)c[1] * isz_of(c[3]));
+                win_at += idx_words(c[1], c[3]);
             }
         }
         out_at += b.out_words[p];
@@ -720,16 +790,21 @@ int stage_serve(emb_shard *s, Batch &b) {
     Batch *fused_with = (s->local_of && s->local_of != &b) ? s->local_of : nullptr;
     s->descs.clear();
     s->desc_ctr.clear();
+    s->desc_it.clear();
     Batch *local_batch = s->local_of;       // whose replicated tables ride in this call's launch (this batch, a younger one, or none)
     if (s->local_of) {
         s->descs.swap(s->local);
         s->desc_ctr.swap(s->local_ctr);
+        s->desc_it.swap(s->local_it);
         s->local.clear();
         s->local_ctr.clear();
+        s->local_it.clear();
         s->local_of = nullptr;
     }
     const size_t n_local_descs = s->descs.size();
     const bool counting = s->check_served;
+    bool own_width[2] = {false, false};      // index widths among THIS batch's descriptors (a refused launch of that width zeroed them)
+    if (local_batch == &b && n_local_descs) own_width[b.itype] = true;
     uint64_t alg = 0, n_sub = 0, n_idx = 0;
     uint32_t n_piece_descs = 0;
     // row pieces: source s asked for sub-bags of my shard of table k -- an ordinary lookup each
@@ -760,6 +835,8 @@ int stage_serve(emb_shard *s, Batch &b) {
                 d.n_bags = ns;
                 d.pooled = rows_dst + row * dim;
                 s->descs.push_back(d);
+                s->desc_it.push_back(EMB_IDX_U32);                 // (a routed piece: uint32 local row ids + sub-bag starts, whatever the source handed in)
+                own_width[EMB_IDX_U32] = true;
                 if (counting) s->desc_ctr.push_back(nullptr);      // (a routed piece has offsets: never part of a counted launch)
                 n_piece_descs++;
                 alg += ni * ((uint64_t)dim * s->elem_bytes[s->rows[k]] + 4) + ns * (4 + (uint64_t)dim * 4);
@@ -787,27 +864,30 @@ int stage_serve(emb_shard *s, Batch &b) {
             d.table_id = s->tabs[t].engine_table;
             d.n_indices = ni;
             d.n_bags = nb;
+            uint32_t it = c[3];              // the requester's width (its arrays arrive / are gathered as they are)
+            if (it > EMB_IDX_I64) return fail(EMB_ERR_INVALID, "emb_shard: rank %u posted an unknown index width (%u)", p, it);
             if (remote) {
                 d.fixed_pooling = c[2];
                 if (!c[2]) {
                     d.offsets = static_cast<uint32_t *>(b.req_recv.p) + win_at;
-                    win_at += pad4(nb);
+                    win_at += idx_words(nb, it);
                 }
                 d.indices = static_cast<uint32_t *>(b.req_recv.p) + win_at;
-                win_at += pad4(ni);
+                win_at += idx_words(ni, it);
                 d.pooled = static_cast<float *>(b.ret_send.p) + wrow_at * dim;
                 wrow_at += nb;
             } else if (how == PEER) {      // the requester's arrays in place, its output buffer in place
                 const uint64_t io = (uint64_t)c[4] | ((uint64_t)c[5] << 32), oo = (uint64_t)c[6] | ((uint64_t)c[7] << 32), ro = (uint64_t)c[8] | ((uint64_t)c[9] << 32);
                 d.fixed_pooling = c[2];
-                d.offsets = c[2] ? nullptr : pimemb::peer_ptr(s->peer, (int)p, oo, nb * 4);
-                d.indices = pimemb::peer_ptr(s->peer, (int)p, io, ni * 4);
+                d.offsets = c[2] ? nullptr : pimemb::peer_ptr(s->peer, (int)p, oo, nb * isz_of(it));
+                d.indices = pimemb::peer_ptr(s->peer, (int)p, io, ni * isz_of(it));
                 d.pooled = reinterpret_cast<float *>(pimemb::peer_ptr(s->peer, (int)p, ro, nb * (uint64_t)dim * 4));
                 if (nb && ((ni && !d.indices) || !d.pooled || (!c[2] && !d.offsets)))
                     return fail(EMB_ERR_INVALID, "emb_shard: rank %u posted buffer offsets outside its arena", p);
-                s->st.bytes_to_peers += ni * 4 + (c[2] ? 0 : nb * 4) + nb * (uint64_t)dim * 4;
+                s->st.bytes_to_peers += ni * isz_of(it) + (c[2] ? 0 : nb * isz_of(it)) + nb * (uint64_t)dim * 4;
             } else {           // my own bags of my own table: in place, straight into the caller's buffer
                 const emb_shard_input &u = b.in[t];
+                it = b.itype;
                 d.fixed_pooling = u.offsets ? 0u : u.fixed_pooling;
                 d.offsets = u.offsets;
                 d.indices = u.indices;
@@ -815,8 +895,10 @@ int stage_serve(emb_shard *s, Batch &b) {
             }
             if (nb) {
                 s->descs.push_back(d);
+                s->desc_it.push_back(it);
+                own_width[it] = true;
                 if (counting) s->desc_ctr.push_back(ctr_of(s, b, p, Kr + j));
-                alg += ni * ((uint64_t)dim * s->elem_bytes[t] + 4) + (d.offsets ? nb * 4 : 0) + nb * (uint64_t)dim * 4;
+                alg += ni * ((uint64_t)dim * s->elem_bytes[t] + isz_of(it)) + (d.offsets ? nb * isz_of(it) : 0) + nb * (uint64_t)dim * 4;
                 n_sub += nb;
                 n_idx += ni;
             }
@@ -830,7 +912,10 @@ int stage_serve(emb_shard *s, Batch &b) {
     // whose row this shard holds, straight into their outputs
     s->rdescs.clear();
     s->rdesc_ctr.clear();
+    s->rdesc_it.clear();
     s->row_lo.clear();
+    // (a checked shard: the LAST shard of a table also answers for ids beyond every range -- their bags pool to zero rows)
+    const uint64_t open_end = (counting && s->rank + 1 == s->N) ? EMB_RANGE_OPEN_END : 0ull;
     for (uint32_t p = 0; p < N; p++) {
         const PeerFrom &f = b.from[p];
         if (!f.direct || f.n_bags == 0) continue;
@@ -845,14 +930,15 @@ int stage_serve(emb_shard *s, Batch &b) {
                 d.indices = b.in[t].indices;
                 d.pooled = b.in[t].pooled;
             } else {
-                d.indices = pimemb::peer_ptr(s->peer, (int)p, f.idx_off[k], f.n_bags * 4);
+                d.indices = pimemb::peer_ptr(s->peer, (int)p, f.idx_off[k], f.n_bags * isz_of(f.itype));
                 d.pooled = reinterpret_cast<float *>(pimemb::peer_ptr(s->peer, (int)p, f.out_off[k], f.n_bags * (uint64_t)dim * 4));
                 if (!d.indices || !d.pooled) return fail(EMB_ERR_INVALID, "emb_shard: rank %u posted buffer offsets outside its arena", p);
-                s->st.bytes_to_peers += f.n_bags * 4;       // (+ the rows this shard stores: their number is not known on the host)
+                s->st.bytes_to_peers += f.n_bags * isz_of(f.itype);       // (+ the rows this shard stores: their number is not known on the host)
             }
             s->rdescs.push_back(d);
+            s->rdesc_it.push_back(f.itype);
             if (counting) s->rdesc_ctr.push_back(ctr_of(s, b, p, k));
-            s->row_lo.push_back((uint64_t)s->rank * s->tabs[t].rows_per_shard);
+            s->row_lo.push_back(((uint64_t)s->rank * s->tabs[t].rows_per_shard) | open_end);
         }
     }
     // ... in the SAME launch as everything else this call looks up when that is one index per bag as well (a whole table is
@@ -866,9 +952,10 @@ int stage_serve(emb_shard *s, Batch &b) {
                             (!s->rdescs.empty() || (counting && s->allow_direct && no_comm));
     const bool ranged_launch = one_launch || !s->rdescs.empty();
     if (one_launch) {
-        s->row_lo.insert(s->row_lo.begin(), s->descs.size(), 0ull);
+        s->row_lo.insert(s->row_lo.begin(), s->descs.size(), counting ? EMB_RANGE_OPEN_END : 0ull);      // (whole tables: the range from row 0)
         s->descs.insert(s->descs.end(), s->rdescs.begin(), s->rdescs.end());
         s->desc_ctr.insert(s->desc_ctr.end(), s->rdesc_ctr.begin(), s->rdesc_ctr.end());
+        s->desc_it.insert(s->desc_it.end(), s->rdesc_it.begin(), s->rdesc_it.end());
         s->rdescs.clear();
         EMB_TRY(tick(s, b, 4, false));
         EMB_TRY(fused_lookup(s, b, /*cacheable=*/n_piece_descs == 0, /*ranged=*/true));
@@ -876,13 +963,26 @@ int stage_serve(emb_shard *s, Batch &b) {
     } else {
         if (!s->descs.empty()) {
             EMB_TRY(tick(s, b, 2, false));
+            s->refused = 0;
             EMB_TRY(fused_lookup(s, b, /*cacheable=*/n_piece_descs == 0));      // (row pieces change size with every batch: nothing recurs)
             EMB_TRY(tick(s, b, 2, true));
-            if (fused_with && b.deferred_rc != EMB_OK) fused_with->deferred_rc = b.deferred_rc;
+            // a validating launch that found something gathered nothing: whoever had descriptors in it holds zero rows and says so
+            for (uint32_t w = 0; w < 2; w++) {
+                if (!(s->refused & (1u << w))) continue;
+                if (own_width[w]) {
+                    b.deferred_rc = EMB_ERR_RANGE;
+                    b.reported = false;
+                }
+                if (fused_with && fused_with->itype == w) {       // (its replicated tables rode in the refused launch)
+                    fused_with->deferred_rc = EMB_ERR_RANGE;
+                    fused_with->reported = false;
+                }
+            }
         }
         if (!s->rdescs.empty()) {
             s->descs.swap(s->rdescs);
             s->desc_ctr.swap(s->rdesc_ctr);
+            s->desc_it.swap(s->rdesc_it);
             EMB_TRY(tick(s, b, 4, false));
             EMB_TRY(fused_lookup(s, b, /*cacheable=*/true, /*ranged=*/true));
             EMB_TRY(tick(s, b, 4, true));
@@ -958,18 +1058,26 @@ int stage_serve(emb_shard *s, Batch &b) {
 // count per table.  A sum short of it is an index no shard holds: a bag nobody wrote (the ranged lookup leaves it untouched).
 // Called at U(b): the launches that counted were enqueued one or more calls ago (depth 0: in this call), the peers' "served"
 // words have been polled; what is left is the wait for this rank's own publish kernels.
-int check_served_counts(emb_shard *s, Batch &b) {
+// wait = false: look only -- if any entry does not carry this batch's tag yet (its publish kernel has not run), return
+// kNotReady and change nothing; the caller asks again later.
+constexpr int kNotReady = 1;
+int check_served_counts(emb_shard *s, Batch &b, bool wait = true) {
     const uint32_t N = (uint32_t)s->N, Kr = s->Kr;
     const uint32_t R = (uint32_t)s->rep.size();
     const uint32_t tag = served_tag(s, b.seq);
     const double t0 = now_us();
     int rc = EMB_OK;
+    bool probing = !wait, not_ready = false;
     // one entry: poll the self-describing word until it carries this batch's tag (the kernel that stores it was enqueued a
     // call or more ago; a peer's: its "served" word has been seen, the entries are on their way), hand back the count
     auto entry = [&](volatile unsigned long long *w, const char *what, uint32_t who) -> uint32_t {
         for (uint64_t spin = 0;; spin++) {
             const unsigned long long v = *w;
             if ((uint32_t)(v >> 32) == tag) return (uint32_t)v;
+            if (probing) {
+                not_ready = true;
+                return 0u;
+            }
             if ((spin & 0xfff) == 0xfff && now_us() - t0 > s->timeout_s * 1e6) {
                 if (rc == EMB_OK)
                     rc = fail(EMB_ERR_DEVICE, "emb_shard: the served counts of batch %llu (%s, rank %u) did not arrive within %.0f s", (unsigned long long)b.seq, what, who, s->timeout_s);
@@ -978,10 +1086,12 @@ int check_served_counts(emb_shard *s, Batch &b) {
         }
     };
     auto bad = [&](uint32_t t, uint64_t got) {
-        if (b.deferred_rc == EMB_OK)
+        if (probing) return;
+        if (b.deferred_rc == EMB_OK && !s->range_msg[0])
             snprintf(s->range_msg, sizeof s->range_msg, "emb_shard: batch %llu, table %u: %llu of %llu bags were served -- the others name rows no rank holds "
-                     "(their pooled rows were left untouched)", (unsigned long long)b.seq, t, (unsigned long long)got, (unsigned long long)b.n_bags);
+                     "(their pooled rows are zeros)", (unsigned long long)b.seq, t, (unsigned long long)got, (unsigned long long)b.n_bags);
         b.deferred_rc = EMB_ERR_RANGE;
+        b.reported = false;
     };
     // what shard / owner q published for this rank's i-th piece (0xffffffff: not counted -- q validated it itself)
     auto word_from = [&](uint32_t q, uint32_t i) -> uint32_t {
@@ -993,47 +1103,62 @@ int check_served_counts(emb_shard *s, Batch &b) {
         }
         return 0xffffffffu;
     };
-    if (b.rep_counted)
-        for (uint32_t r = 0; r < R; r++) {
-            const uint32_t w = entry(b.chk_host + r, "replicated tables", (uint32_t)s->rank);
-            if (rc == EMB_OK && w != b.n_bags) bad(s->rep[r], w);
-        }
-    for (uint32_t q = 0; q < N && rc == EMB_OK; q++)
-        for (uint32_t j = 0; j < s->whole_of[q].size(); j++) {
-            const uint32_t w = word_from(q, Kr + j);
-            if (rc == EMB_OK && w != 0xffffffffu && w != b.n_bags) bad(s->whole_of[q][j], w);
-        }
-    if (b.direct)
-        for (uint32_t k = 0; k < Kr && rc == EMB_OK; k++) {
-            uint64_t sum = 0;
-            for (uint32_t q = 0; q < N && rc == EMB_OK; q++) {
-                const uint32_t w = word_from(q, k);
-                if (rc == EMB_OK && w == 0xffffffffu)
-                    rc = fail(EMB_ERR_INVALID, "emb_shard: rank %u did not count what it served of batch %llu (different EMB_SHARD_* flags?)", q, (unsigned long long)b.seq);
-                sum += w;
+    auto pass = [&]() {
+        if (b.rep_counted)
+            for (uint32_t r = 0; r < R; r++) {
+                const uint32_t w = entry(b.chk_host + r, "replicated tables", (uint32_t)s->rank);
+                if (rc == EMB_OK && w != b.n_bags) bad(s->rep[r], w);
             }
-            if (rc == EMB_OK && sum != b.n_bags) bad(s->rows[k], sum);
-        }
+        for (uint32_t q = 0; q < N && rc == EMB_OK; q++)
+            for (uint32_t j = 0; j < s->whole_of[q].size(); j++) {
+                const uint32_t w = word_from(q, Kr + j);
+                if (rc == EMB_OK && w != 0xffffffffu && w != b.n_bags) bad(s->whole_of[q][j], w);
+            }
+        if (b.direct)
+            for (uint32_t k = 0; k < Kr && rc == EMB_OK; k++) {
+                uint64_t sum = 0;
+                for (uint32_t q = 0; q < N && rc == EMB_OK; q++) {
+                    const uint32_t w = word_from(q, k);
+                    if (!probing && rc == EMB_OK && w == 0xffffffffu)
+                        rc = fail(EMB_ERR_INVALID, "emb_shard: rank %u did not count what it served of batch %llu (different EMB_SHARD_* flags?)", q, (unsigned long long)b.seq);
+                    sum += w;
+                }
+                if (rc == EMB_OK && sum != b.n_bags) bad(s->rows[k], sum);
+            }
+    };
+    if (probing) {
+        pass();
+        if (not_ready) return kNotReady;
+        probing = false;
+    }
+    pass();
     std::atomic_thread_fence(std::memory_order_acquire);
     s->st.us_host_wait_served += now_us() - t0;
     return rc;
 }
 
 // ---- U(b): partial rows added in shard order, into the caller's buffers ------------------------------------------------------
+// A wait that times out here (a peer that never served, served counts that never arrived) is REPORTED, not left behind: the
+// stage still runs to its end and the batch is marked done, so that later calls do not poll for the same words again -- one
+// lost 8-byte store would otherwise make every later submit / flush block for the full timeout, and emb_shard_wait never return.
 int stage_unroute(emb_shard *s, Batch &b) {
     g_hp.start();
+    int late = EMB_OK;
     if (s->peer_mode) {        // every peer has stored what it owes this rank for the batch (host poll: nothing to enqueue)
         const double t0 = now_us();
-        for (uint32_t p = 0; p < (uint32_t)s->N; p++)
+        for (uint32_t p = 0; p < (uint32_t)s->N && late == EMB_OK; p++)
             if (via(s, (int)p) == PEER) {
                 pimemb::PeerMsg *box = pimemb::peer_box(s->peer, s->rank, (int)p, (uint32_t)(b.seq % pimemb::kPeerSlots));
-                EMB_TRY(poll_word(s, &box->served, s->peer_tag + b.seq + 1, "did not serve", (int)p, b.seq));
+                late = poll_word(s, &box->served, s->peer_tag + b.seq + 1, "did not serve", (int)p, b.seq);
             }
         std::atomic_thread_fence(std::memory_order_acquire);
         s->st.us_host_wait_served += now_us() - t0;
     }
     if (b.ret_recorded) HIP_TRY(hipStreamWaitEvent(s->cs, b.ev_ret, 0));       // the rows are back (whole tables: already in place)
-    if (s->check_served && b.n_bags) EMB_TRY(check_served_counts(s, b));
+    if (s->check_served && b.n_bags && late == EMB_OK) {
+        if (s->defer_report) b.check_pending = true;       // compared at the start of the next call (collect_pending): nothing to wait for here
+        else late = check_served_counts(s, b);
+    }
     if (s->Kr && b.n_bags && !b.direct) {
         float *outs[pimemb::kRouteBagMaxTables];
         for (uint32_t k = 0; k < s->Kr; k++) outs[k] = b.in[s->rows[k]].pooled;
@@ -1045,7 +1170,33 @@ int stage_unroute(emb_shard *s, Batch &b) {
     g_hp.lap(13);
     b.stage = DONE;
     s->st.n_batches++;
-    return EMB_OK;
+    return late;
+}
+
+// A batch's finding (EMB_ERR_RANGE: the serving side's validation, or the requester's served counts) is handed to the caller
+// ONCE, by the call in which the batch completes -- or, for a deferred comparison, by the call that makes it.
+inline int take_report(Batch &b) {
+    if (b.deferred_rc == EMB_OK || b.reported) return EMB_OK;
+    b.reported = true;
+    return b.deferred_rc;
+}
+
+// EMB_SHARD_DEFER_REPORT: compare the served counts of the completed batches not looked at yet -- all of them, or batch `only`.
+// wait = false (what a submit does): only those whose counts have ARRIVED; a batch whose publish kernel has not run yet stays
+// pending -- polling for it would make the host wait for the GPU step it has just enqueued, which is the very round trip the
+// flag exists to remove (first version: "at the start of the next call" = 73 us per synchronous call against 63 unchecked) --
+// except `must`, the batch whose ring slot the caller is about to recycle.
+int collect_pending(emb_shard *s, bool wait = true, uint64_t only = ~0ull, uint64_t must = ~0ull) {
+    int deferred = EMB_OK;
+    for (Batch &b : s->ring) {
+        if (!b.check_pending || b.stage != DONE || (only != ~0ull && b.seq != only)) continue;
+        const int rc = check_served_counts(s, b, wait || b.seq == must);
+        if (rc == kNotReady) continue;
+        b.check_pending = false;
+        if (rc != EMB_OK) return rc;
+        if (take_report(b) != EMB_OK) deferred = EMB_ERR_RANGE;
+    }
+    return deferred;
 }
 
 // (requests, lookups + returns, un-routing) of a batch happen (d_req, d_serve, d_un) submits after its own
@@ -1056,6 +1207,7 @@ constexpr Lag kLag[4] = {{0, 0, 0}, {0, 1, 1}, {1, 2, 2}, {1, 2, 3}};
 // transfer stream gets: counts of the newest batch, THEN the requests of the one before it, THEN the returned rows of the
 // one before that -- so a lookup never queues behind a return transfer -- and the un-router of a batch runs at the END of a
 // call, behind the lookup of a younger one: its rows have had that whole call to come back.
+// Returns EMB_ERR_RANGE when a batch that COMPLETED in this call carries a finding (each batch's once: take_report).
 int advance(emb_shard *s, const Lag &lag, bool everything) {
     int deferred = EMB_OK;
     const uint64_t newest = s->next_seq;        // one past the last submitted
@@ -1067,20 +1219,19 @@ int advance(emb_shard *s, const Lag &lag, bool everything) {
     }
     for (uint64_t q = first; q < newest; q++) {
         Batch &b = s->ring[q % kRing];
-        if (b.seq == q && b.stage == REQUESTED && old_enough(q, lag.serve)) {
-            EMB_TRY(stage_serve(s, b));
-            if (b.deferred_rc != EMB_OK) deferred = b.deferred_rc;
-        }
+        if (b.seq == q && b.stage == REQUESTED && old_enough(q, lag.serve)) EMB_TRY(stage_serve(s, b));
     }
     EMB_TRY(launch_local(s));          // nothing was served in this call: L(n) alone
+    int late = EMB_OK;
     for (uint64_t q = first; q < newest; q++) {
         Batch &b = s->ring[q % kRing];
         if (b.seq == q && b.stage == SERVED && old_enough(q, lag.un)) {
-            EMB_TRY(stage_unroute(s, b));
-            if (b.deferred_rc != EMB_OK) deferred = b.deferred_rc;
+            const int rc = stage_unroute(s, b);
+            if (rc != EMB_OK && late == EMB_OK) late = rc;       // (a timeout: the other batches still go through their stage)
+            if (take_report(b) != EMB_OK) deferred = EMB_ERR_RANGE;
         }
     }
-    return deferred;
+    return late != EMB_OK ? late : deferred;
 }
 
 int range_error(emb_shard *s) {
@@ -1135,6 +1286,7 @@ int emb_shard_create(emb_engine *e, emb_comm *comm, const emb_shard_config *cfg,
     s->flags = cfg->flags;
     s->self_via_comm = (cfg->flags & EMB_SHARD_SELF_VIA_COMM) != 0;
     s->check_served = (cfg->flags & EMB_SHARD_CHECK_SERVED) != 0;
+    s->defer_report = s->check_served && (cfg->flags & EMB_SHARD_DEFER_REPORT) != 0;
     if (s->self_via_comm && !comm) {
         delete s;
         return fail(EMB_ERR_INVALID, "emb_shard_create: EMB_SHARD_SELF_VIA_COMM needs a communicator");
@@ -1259,9 +1411,16 @@ int emb_shard_submit(emb_shard *s, const emb_shard_input *in, uint64_t n_bags, v
     s->cs = st;
     s->cs_known = true;
     harvest(s, b);
+    // a deferred report: what the served counts of the batches completed so far say -- before this one's slot is recycled
+    const int rc_prev = s->defer_report ? collect_pending(s, /*wait=*/false, ~0ull, /*must=*/b.seq) : EMB_OK;
+    if (rc_prev != EMB_OK && rc_prev != EMB_ERR_RANGE) return rc_prev;
     b.in.assign(s->T, emb_shard_input{});
+    uint32_t itype = (in && s->T) ? in[0].index_type : (uint32_t)EMB_IDX_U32;
+    if (itype != EMB_IDX_U32 && itype != EMB_IDX_I64) return fail(EMB_ERR_INVALID, "emb_shard_submit: table 0: index_type %u (EMB_IDX_U32 or EMB_IDX_I64)", itype);
     for (uint32_t t = 0; t < s->T && in; t++) {
         const emb_shard_input &u = in[t];
+        if (u.index_type != itype)
+            return fail(EMB_ERR_INVALID, "emb_shard_submit: table %u: index_type %u, table 0 has %u (one width per batch)", t, u.index_type, itype);
         if (n_bags) {
             if (!u.pooled) return fail(EMB_ERR_INVALID, "emb_shard_submit: table %u: pooled is NULL", t);
             if (u.n_indices && !u.indices) return fail(EMB_ERR_INVALID, "emb_shard_submit: table %u: indices is NULL", t);
@@ -1274,6 +1433,7 @@ int emb_shard_submit(emb_shard *s, const emb_shard_input *in, uint64_t n_bags, v
     }
     b.seq = s->next_seq;
     b.n_bags = n_bags;
+    b.itype = itype;
     b.stage = FREE;
     int rc = stage_route(s, b);
     if (rc) return rc;
@@ -1281,21 +1441,29 @@ int emb_shard_submit(emb_shard *s, const emb_shard_input *in, uint64_t n_bags, v
     if (seq) *seq = b.seq;
     rc = advance(s, kLag[s->depth], false);
     s->st.us_host_submit += now_us() - t0;
+    if (rc == EMB_OK) rc = rc_prev;
     return rc == EMB_ERR_RANGE ? range_error(s) : rc;
 }
 
-int emb_shard_flush(emb_shard *s) {
-    if (!s) return fail(EMB_ERR_INVALID, "emb_shard_flush: shard is NULL");
+}  // extern "C"
+
+namespace {
+// collect: also compare the served counts whose report was deferred (the caller's own flush does; the one inside
+// emb_shard_lookup does not -- that is the round trip EMB_SHARD_DEFER_REPORT exists to take out of the synchronous call)
+int flush_impl(emb_shard *s, bool collect) {
     if (!s->cs_known) return EMB_OK;
     const double t0 = now_us();
     DeviceGuard g(s->device);
     int rc = advance(s, kLag[0], true);     // requests of all, then lookups + returns of all, then un-routing: same order on every rank
+    if (collect && s->defer_report && (rc == EMB_OK || rc == EMB_ERR_RANGE)) {
+        const int rc2 = collect_pending(s);
+        if (rc2 != EMB_OK) rc = (rc2 == EMB_ERR_RANGE && rc != EMB_OK) ? rc : rc2;
+    }
     s->st.us_host_submit += now_us() - t0;
     return rc == EMB_ERR_RANGE ? range_error(s) : rc;
 }
 
-int emb_shard_wait(emb_shard *s, uint64_t seq, void *stream) {
-    if (!s) return fail(EMB_ERR_INVALID, "emb_shard_wait: shard is NULL");
+int wait_impl(emb_shard *s, uint64_t seq, void *stream, bool collect) {
     if (seq >= s->next_seq) return fail(EMB_ERR_INVALID, "emb_shard_wait: batch %llu was never submitted", (unsigned long long)seq);
     Batch &b = s->ring[seq % kRing];
     if (b.seq != seq) return fail(EMB_ERR_INVALID, "emb_shard_wait: batch %llu is no longer tracked (wait within %d submits)", (unsigned long long)seq, kRing);
@@ -1303,22 +1471,48 @@ int emb_shard_wait(emb_shard *s, uint64_t seq, void *stream) {
         return fail(EMB_ERR_INVALID, "emb_shard_wait: batch %llu has not been through all its stages yet (submit %u more batch(es) or call emb_shard_flush)",
                     (unsigned long long)seq, s->depth);
     hipStream_t other = static_cast<hipStream_t>(stream);
-    if (other == s->cs) return EMB_OK;          // the submit stream itself: the batch's last kernel is already queued there
     DeviceGuard g(s->device);
-    if (!b.out_recorded) {                      // (recorded now: behind the batch's last kernel, and possibly a little more)
-        HIP_TRY(hipEventRecord(b.ev_out, s->cs));
-        b.out_recorded = true;
+    if (other != s->cs) {                       // (the submit stream itself: the batch's last kernel is already queued there)
+        if (!b.out_recorded) {                  // (recorded now: behind the batch's last kernel, and possibly a little more)
+            HIP_TRY(hipEventRecord(b.ev_out, s->cs));
+            b.out_recorded = true;
+        }
+        HIP_TRY(hipStreamWaitEvent(other, b.ev_out, 0));
     }
-    HIP_TRY(hipStreamWaitEvent(other, b.ev_out, 0));
+    if (collect && b.check_pending) {           // a deferred report: the caller is about to consume this batch -- say now what its counts said
+        const int rc = collect_pending(s, /*wait=*/true, seq);
+        return rc == EMB_ERR_RANGE ? range_error(s) : rc;
+    }
     return EMB_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int emb_shard_flush(emb_shard *s) {
+    if (!s) return fail(EMB_ERR_INVALID, "emb_shard_flush: shard is NULL");
+    return flush_impl(s, /*collect=*/true);
+}
+
+int emb_shard_report(emb_shard *s) {
+    if (!s) return fail(EMB_ERR_INVALID, "emb_shard_report: shard is NULL");
+    if (!s->defer_report) return EMB_OK;
+    DeviceGuard g(s->device);
+    const int rc = collect_pending(s);
+    return rc == EMB_ERR_RANGE ? range_error(s) : rc;
+}
+
+int emb_shard_wait(emb_shard *s, uint64_t seq, void *stream) {
+    if (!s) return fail(EMB_ERR_INVALID, "emb_shard_wait: shard is NULL");
+    return wait_impl(s, seq, stream, /*collect=*/true);
 }
 
 int emb_shard_lookup(emb_shard *s, const emb_shard_input *in, uint64_t n_bags, void *stream) {
     uint64_t seq = 0;
     int rc = emb_shard_submit(s, in, n_bags, stream, &seq);
-    const int rc2 = (rc == EMB_OK || rc == EMB_ERR_RANGE) ? emb_shard_flush(s) : rc;
+    const int rc2 = (rc == EMB_OK || rc == EMB_ERR_RANGE) ? flush_impl(s, /*collect=*/false) : rc;
     if (rc2 != EMB_OK && rc2 != EMB_ERR_RANGE) return rc2;
-    const int rc3 = emb_shard_wait(s, seq, stream);
+    const int rc3 = wait_impl(s, seq, stream, /*collect=*/false);
     if (rc3) return rc3;
     return rc != EMB_OK ? rc : rc2;
 }
@@ -1366,6 +1560,8 @@ int emb_shard_destroy(emb_shard *s) {
     if (s->cs_known) (void)hipStreamSynchronize(s->cs);
     if (s->s_comm) (void)hipStreamSynchronize(s->s_comm);
     (void)hipGetLastError();
+    if (s->defer_report && collect_pending(s) == EMB_ERR_RANGE)      // a finding nobody collected: never lost silently
+        fprintf(stderr, "[pimemb] emb_shard_destroy: an uncollected report: %s\n", s->range_msg[0] ? s->range_msg : "a batch named rows no rank holds");
     for (emb_shard::CachedPlan &c : s->plans)
         if (c.plan) (void)emb_plan_destroy(c.plan);
     for (emb_plan *p : s->retired) (void)emb_plan_destroy(p);

@@ -14,11 +14,12 @@
 //       cache; stream: torch's current stream on that device (hipStream_t as an int).
 //   fill_pooled(desc_addr, n, base_ptr, dim) -> key
 //       pooled pointers of n records laid out back to back from base_ptr (one allocation, one view per table).
-//   pack_shard(input_addr, indices, offsets | None, outs, fixed_pooling, dim) -> None | (n_bags, device, stream)
-//       the same for the SHARDED call: len(indices) emb_shard_input records (40 bytes each) at input_addr.  int32 (uint32 bits)
-//       1-D contiguous CUDA tensors only -- int64 ids must be narrowed first, which the Python path does; offsets None =
-//       fixed_pooling indices per bag; every table the same number of bags; outs float32 contiguous of n_bags x dim.
-//       ShardedEmbeddingBags.prepare spends ~1.2 us per table in Python without it (32 us for 26 tables against a 60-us step).
+//   pack_shard(input_addr, indices, offsets | None, outs, fixed_pooling, dim) -> None | (n_bags, device, stream, itype)
+//       the same for the SHARDED call: len(indices) emb_shard_input records (40 bytes each) at input_addr.  1-D contiguous CUDA
+//       tensors, int32 (uint32 bits) or int64 throughout (DLRM's dtype: handed over IN PLACE, emb_shard_input.index_type);
+//       offsets None = fixed_pooling indices per bag; every table the same number of bags; outs float32 contiguous of
+//       n_bags x dim.  ShardedEmbeddingBags.prepare spends ~1.2 us per table in Python without it (32 us for 26 tables against a
+//       60-us step).
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
 
@@ -119,7 +120,7 @@ PyObject *fill_pooled(PyObject *, PyObject *args) {
 
 struct ShardInput {        // emb_shard_input (include/pimemb.h), 40 bytes
     uint64_t indices, offsets, n_indices;
-    uint32_t fixed_pooling, reserved;
+    uint32_t fixed_pooling, index_type;
     uint64_t pooled;
 };
 static_assert(sizeof(ShardInput) == 40, "emb_shard_input layout");
@@ -136,18 +137,24 @@ PyObject *pack_shard(PyObject *, PyObject *args) {
     if (!have_off && fixed_pooling <= 0) Py_RETURN_NONE;
     ShardInput *d = reinterpret_cast<ShardInput *>(static_cast<uintptr_t>(addr));
     c10::DeviceIndex dev = -1;
+    c10::ScalarType st = c10::ScalarType::Undefined;
     uint64_t n_bags = 0;
     for (Py_ssize_t k = 0; k < n; k++) {
         const at::Tensor *ia = as_tensor(PyList_GET_ITEM(indices, k));
         const at::Tensor *oa = have_off ? as_tensor(PyList_GET_ITEM(offsets, k)) : nullptr;
         const at::Tensor *ua = as_tensor(PySequence_Fast_GET_ITEM(outs, k));
         if (!ia || !ua || (have_off && !oa)) Py_RETURN_NONE;
-        if (ia->scalar_type() != c10::ScalarType::Int || !ia->is_cuda() || ia->dim() != 1 || !ia->is_contiguous()) Py_RETURN_NONE;
-        if (k == 0) dev = ia->device().index();
+        if (k == 0) {
+            st = ia->scalar_type();
+            if (st != c10::ScalarType::Int && st != c10::ScalarType::Long) Py_RETURN_NONE;
+            if (!ia->is_cuda()) Py_RETURN_NONE;
+            dev = ia->device().index();
+        }
+        if (ia->scalar_type() != st || !ia->is_cuda() || ia->dim() != 1 || !ia->is_contiguous()) Py_RETURN_NONE;
         if (ia->device().index() != dev) Py_RETURN_NONE;
         uint64_t nb;
         if (have_off) {
-            if (oa->scalar_type() != c10::ScalarType::Int || !oa->is_cuda() || oa->device().index() != dev || oa->dim() != 1 || !oa->is_contiguous())
+            if (oa->scalar_type() != st || !oa->is_cuda() || oa->device().index() != dev || oa->dim() != 1 || !oa->is_contiguous())
                 Py_RETURN_NONE;
             nb = (uint64_t)oa->numel();
         } else {
@@ -163,11 +170,11 @@ PyObject *pack_shard(PyObject *, PyObject *args) {
         d[k].offsets = have_off ? (uint64_t)(uintptr_t)oa->const_data_ptr() : 0;
         d[k].n_indices = (uint64_t)ia->numel();
         d[k].fixed_pooling = have_off ? 0u : (uint32_t)fixed_pooling;
-        d[k].reserved = 0;
+        d[k].index_type = st == c10::ScalarType::Long ? 1u : 0u;      // EMB_IDX_I64 : EMB_IDX_U32
         d[k].pooled = (uint64_t)(uintptr_t)ua->const_data_ptr();
     }
     const unsigned long long stream = (unsigned long long)(uintptr_t)c10::hip::getCurrentHIPStream(dev).stream();
-    return Py_BuildValue("(KiK)", (unsigned long long)n_bags, (int)dev, stream);
+    return Py_BuildValue("(KiKi)", (unsigned long long)n_bags, (int)dev, stream, st == c10::ScalarType::Long ? 1 : 0);
 }
 
 PyMethodDef methods[] = {

@@ -155,14 +155,14 @@ class ShardedEmbeddingBagCollection:
         a = self._arena
         slot = a["slot"] = (a["slot"] + 1) % 3
         sh = self.sharded
-        lS_i, lS_o = sh._u32_list(lS_i), sh._u32_list(lS_o)
+        want = lS_i[0].dtype         # int64 (DLRM's) or int32: staged as they are -- the library takes both in place
 
         def staged(cache, k, x):
-            x = sh._u32(x)
+            x = sh._ids(x, want)
             n = int(x.numel())
             buf = cache[slot][k]
-            if buf is None or buf.numel() < n:
-                buf = cache[slot][k] = peer.empty((max(2 * n, 64),), t.int32)
+            if buf is None or buf.numel() < n or buf.dtype != want:
+                buf = cache[slot][k] = peer.empty((max(2 * n, 64),), want)
             y = buf[:n]
             y.copy_(x)
             return y

@@ -45,7 +45,8 @@ class EmbCommOp(C.Structure):
 
 
 EMB_PLACE_REPLICATED, EMB_PLACE_WHOLE, EMB_PLACE_ROWS = 0, 1, 2
-EMB_SHARD_SELF_VIA_COMM, EMB_SHARD_CHECK_SERVED, EMB_SHARD_PEER_STORES, EMB_SHARD_NO_DIRECT = 1, 2, 4, 8
+EMB_SHARD_SELF_VIA_COMM, EMB_SHARD_CHECK_SERVED, EMB_SHARD_PEER_STORES, EMB_SHARD_NO_DIRECT, EMB_SHARD_DEFER_REPORT = 1, 2, 4, 8, 16
+EMB_RANGE_OPEN_END = 1 << 63
 
 
 class EmbShardTable(C.Structure):
@@ -54,7 +55,7 @@ class EmbShardTable(C.Structure):
 
 class EmbShardInput(C.Structure):
     _fields_ = [("indices", C.c_void_p), ("offsets", C.c_void_p), ("n_indices", C.c_uint64), ("fixed_pooling", C.c_uint32),
-                ("reserved", C.c_uint32), ("pooled", C.c_void_p)]
+                ("index_type", C.c_uint32), ("pooled", C.c_void_p)]
 
 
 class EmbShardConfig(C.Structure):
@@ -112,6 +113,7 @@ SIGNATURES = {
     "emb_shard_flush": (C.c_int, [_vp]),
     "emb_shard_wait": (C.c_int, [_vp, _u64, _vp]),
     "emb_shard_lookup": (C.c_int, [_vp, C.POINTER(EmbShardInput), _u64, _vp]),
+    "emb_shard_report": (C.c_int, [_vp]),
     "emb_shard_get_stats": (C.c_int, [_vp, C.POINTER(EmbShardStats), C.c_int]),
     "emb_shard_set_kernel_timing": (C.c_int, [_vp, C.c_int]),
     "emb_shard_sent_counts": (C.c_int, [_vp, _u64, C.POINTER(_u32), _u32]),
@@ -129,10 +131,13 @@ SIGNATURES = {
     "emb_plan_create_ranged": (C.c_int, [_vp, C.POINTER(EmbLookupDesc), C.POINTER(_u64), _u32, C.POINTER(_vp)]),
     "emb_lookup_ranged_counted": (C.c_int, [_vp, C.POINTER(EmbLookupDesc), C.POINTER(_u64), C.POINTER(_vp), _u32, _vp]),
     "emb_plan_create_ranged_counted": (C.c_int, [_vp, C.POINTER(EmbLookupDesc), C.POINTER(_u64), C.POINTER(_vp), _u32, C.POINTER(_vp)]),
+    "emb_lookup_ranged_typed": (C.c_int, [_vp, C.POINTER(EmbLookupDesc), C.POINTER(_u64), C.POINTER(_vp), _u32, C.c_int, _vp]),
+    "emb_plan_create_ranged_typed": (C.c_int, [_vp, C.POINTER(EmbLookupDesc), C.POINTER(_u64), C.POINTER(_vp), _u32, C.c_int, C.POINTER(_vp)]),
     "emb_plan_create": (C.c_int, [_vp, C.POINTER(EmbLookupDesc), _u32, C.c_int, _pp]),
     "emb_plan_launch": (C.c_int, [_vp, _vp]),
     "emb_plan_destroy": (C.c_int, [_vp]),
     "emb_plan_bytes": (C.c_int, [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),
+    "emb_plan_signature": (C.c_int, [_vp, C.POINTER(_u64)]),
     "emb_plan_time": (C.c_int, [_vp, _vp, _u32, _u32, C.POINTER(C.c_float)]),
     "emb_validate_inputs": (C.c_int, [_vp, C.POINTER(EmbLookupDesc), _u32, C.c_int, C.c_int,
                                       C.POINTER(_u64)]),
@@ -157,6 +162,7 @@ SIGNATURES = {
     "emb_route_bags_sizes": (C.c_int, [_u32, _u64, _u64, _u32, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64),
                                        C.POINTER(_u64)]),
     "emb_route_bags": (C.c_int, [_vp, C.POINTER(EmbRouteTable), _u32, _u64, _u32, _vp, _vp, _vp, _vp, _vp]),
+    "emb_route_bags_typed": (C.c_int, [_vp, C.POINTER(EmbRouteTable), _u32, C.c_int, _u64, _u32, _vp, _vp, _vp, _vp, _vp]),
     "emb_unroute_bags": (C.c_int, [_vp, _vp, _vp, _vp, _u32, _u64, _u32, _u32, _vp, _vp]),
     "emb_route_exchange_sizes": (C.c_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, C.POINTER(_u64),
                                            C.POINTER(_u64)]),

@@ -131,13 +131,14 @@ def plan_shards(rows: Sequence[int], dim: int, elem_bytes: int, world: int,
 
 
 def hbm_budget(plan: ShardPlan, rank: int, bags: int, pooling: int, n_slots: int = 8, depth: int = 3, transport: str = "rccl",
-               checked: bool = False, balance: float = 1.0) -> dict:
+               checked: bool = False, balance: float = 1.0, index_bytes: int = 4) -> dict:
     """HBM one rank needs for a sharded job, by category, in bytes -- host arithmetic only (emb_route_bags_sizes through the C
     ABI), so that a layout can be checked against 288 GB BEFORE an 8-GPU node is booked (and by bench.py before it allocates):
 
       tables     what the rank holds: its shards, its whole tables, every replicated table;
-      batches    the caller's `n_slots` rotating batch slots: indices (uint32) + pooled rows of ALL tables for its own bags
-                 (peer stores: carved from the arena instead -- counted there);
+      batches    the caller's `n_slots` rotating batch slots: indices (`index_bytes` each: 4 for uint32, 8 for torch's int64,
+                 which the library uses in place) + pooled rows of ALL tables for its own bags (peer stores: carved from the
+                 arena instead -- counted there);
       staging    the library's ring of 6 batch slots (pimemb_shard.cpp kRing), grow-only with 25 % headroom: routed requests,
                  slot maps, what arrives from the peers (request pieces, whole tables' index arrays) and what goes back (partial
                  rows, pooled rows of whole tables owned here) -- the last two only over RCCL: with peer stores the owner gathers
@@ -162,7 +163,8 @@ def hbm_budget(plan: ShardPlan, rank: int, bags: int, pooling: int, n_slots: int
     grow = lambda b: int(b + b // 4 + 256)          # pimemb_shard.cpp ensure()
     live = 6                                         # (batch seq uses slot seq % 6: every slot ends up with buffers of its own)
     out = {"tables": plan.bytes_on(rank)}
-    per_slot = T * B * L * 4 + T * B * dim * 4
+    ib = int(index_bytes)
+    per_slot = T * B * L * ib + T * B * dim * 4
     out["batches"] = 0 if transport == "peer" else n_slots * per_slot
     stg = 0
     one_hot_direct = L == 1 and (transport == "peer" or N == 1)           # the direct path: nothing is routed, nothing staged
@@ -177,7 +179,7 @@ def hbm_budget(plan: ShardPlan, rank: int, bags: int, pooling: int, n_slots: int
             recv_sub = int(min(balance * Kr * B * sub, recv_idx))
             stg += live * (grow((recv_idx + recv_sub) * 4 + 64 * N * Kr) + grow(recv_sub * dim * 4))     # req_recv, ret_send
     if M and transport != "peer" and N > 1:            # whole tables owned here: the other ranks' index arrays in, their pooled rows out
-        stg += live * (grow((N - 1) * M * B * (L + 1) * 4) + grow((N - 1) * M * B * dim * 4))
+        stg += live * (grow((N - 1) * M * B * (L + 1) * ib) + grow((N - 1) * M * B * dim * 4))       # (whole tables' arrays travel as they are)
     out["staging"] = stg
     n_desc = N * (Kr + M) + len(rep)
     tiles = -(-B // 64)
@@ -185,7 +187,7 @@ def hbm_budget(plan: ShardPlan, rank: int, bags: int, pooling: int, n_slots: int
     out["counters"] = live * n_desc * 16384 if checked else 0
     out["arena"] = 0
     if transport == "peer":
-        out["arena"] = int(1.25 * n_slots * T * B * (L * 4 + dim * 4)) + 8 * 2 * Kr * B * (L * 8 + min(L, N) * dim * 4 * 2) + (256 << 20)
+        out["arena"] = int(1.25 * n_slots * T * B * (L * ib + dim * 4)) + 8 * 2 * Kr * B * (L * 8 + min(L, N) * dim * 4 * 2) + (256 << 20)
     out["runtime"] = 3 * 10**9
     out["total"] = sum(out.values())
     return out
@@ -227,12 +229,23 @@ class ShardedEmbeddingBags:
     `depth` submits old (or after `sh.flush()`); a batch's tensors belong to the library until then.  submit / flush are
     COLLECTIVE: every rank makes the same calls in the same order (a rank with nothing to look up passes empty tensors).
 
-    Indices / offsets: torch CUDA int32 (used in place) or int64 (narrowed on the GPU; ids outside [0, 2^32) become
-    0xffffffff, which no table holds).  check=True (default, like nn.EmbeddingBag): every fused lookup validates what it
-    serves first and the SERVING rank raises IndexError after the batch has gone through all its stages -- nobody is left
-    in a transfer; the offending pieces pool to zero rows."""
+    Indices / offsets: torch CUDA int32 (uint32 bits, the reference's width) or int64 (DLRM's dtype) -- BOTH are handed to the
+    library in place (emb_shard_input.index_type): no narrowing pass, no copy; an id outside its table stays what it is for the
+    checks to refuse.  One dtype per batch.
 
-    def __init__(self, plan: ShardPlan, engine, rank: int, comm=None, depth: int = 0, check: bool = True,
+    check=True (default, like nn.EmbeddingBag): indices are not trusted.  Routed batches: every fused lookup validates what it
+    serves first and the SERVING rank raises IndexError after the batch has gone through all its stages -- nobody is left in a
+    transfer.  One-index batches on the direct path: every launch counts the bags it serves and the REQUESTING rank compares.
+    Either way an offending bag pools to a ZERO row.  When the requester's comparison is made:
+      check=True / "deferred"  by a LATER forward / submit -- the first one that finds the batch's counts arrived (it only
+                               looks, never waits) -- or by wait(seq), flush(), report(), close(): the call that completes a
+                               batch never waits for the GPU (the default: an IndexError arrives a call or a few late, like a
+                               device-side assert of torch's own CUDA EmbeddingBag, and names its batch);
+      check="sync"             inside the call that completes the batch (forward() then waits for its own launch: +13 us on a
+                               59-us step, profiles/r05/dist_world1.md);
+      check=False              nothing is checked (the reference's behaviour, emb_dpu_lookup.c:113)."""
+
+    def __init__(self, plan: ShardPlan, engine, rank: int, comm=None, depth: int = 0, check: "bool | str" = True,
                  self_via_comm: bool = False, peer: "PeerGroup | None" = None):
         import ctypes as C
         import torch
@@ -254,8 +267,11 @@ class ShardedEmbeddingBags:
             else:
                 tabs[t] = _l.EmbShardTable(_l.EMB_PLACE_ROWS, -1, us[self.rank].uid, -(-plan.rows[t] // plan.world))
         self._tabs = tabs
+        if check not in (True, False, "deferred", "sync"):
+            raise ValueError("check is True / 'deferred', 'sync' or False")
+        self.check = "sync" if check == "sync" else ("deferred" if check else False)
         self._flags = (_l.EMB_SHARD_CHECK_SERVED if check else 0) | (_l.EMB_SHARD_SELF_VIA_COMM if self_via_comm else 0) | \
-                      (_l.EMB_SHARD_PEER_STORES if peer is not None else 0)
+                      (_l.EMB_SHARD_PEER_STORES if peer is not None else 0) | (_l.EMB_SHARD_DEFER_REPORT if self.check == "deferred" else 0)
         self._h = None
         self._live = {}            # seq -> tensors kept alive until the batch is waited for
 
@@ -277,26 +293,14 @@ class ShardedEmbeddingBags:
         self._h = h
 
     # ---- one batch ----------------------------------------------------------------------------
-    def _u32(self, x):
+    def _ids(self, x, want=None):
+        """One index / offset tensor as the library takes it: contiguous int32 (uint32 bits) or int64, in place."""
         t = self.torch
-        if x.dtype == t.int32:
-            return x if x.is_contiguous() else x.contiguous()
-        if x.dtype == t.int64:          # out-of-range ids must not wrap into range: they become 0xffffffff
-            return x.clamp(-1, 0xffffffff).to(t.int32)          # (the cast keeps the low 32 bits)
-        raise TypeError(f"indices/offsets must be int32 (uint32 bits) or int64 CUDA tensors, got {x.dtype}")
-
-    def _u32_list(self, xs):
-        """The per-table tensors as uint32 bits.  int32 tensors pass through; a list of int64 CUDA tensors is narrowed in ONE
-        pass over their concatenation (cat + clamp + and + cast: four launches for 26 tables instead of 78) and handed back
-        as views of it; anything else goes tensor by tensor through `_u32`."""
-        t = self.torch
-        xs = xs if isinstance(xs, list) else list(xs)
-        if len(xs) > 1 and all(isinstance(x, t.Tensor) and x.dtype == t.int64 and x.is_cuda and x.dim() == 1 for x in xs) \
-                and len({x.device for x in xs}) == 1:
-            flat = t.cat(xs)                                      # (a fresh tensor: clamping it in place touches nothing of the caller's)
-            narrow = flat.clamp_(-1, 0xffffffff).to(t.int32)       # (the cast keeps the low 32 bits: -1 and 0xffffffff both become 0xffffffff)
-            return list(narrow.split([int(x.numel()) for x in xs]))
-        return xs
+        if x.dtype not in (t.int32, t.int64):
+            raise TypeError(f"indices/offsets must be int32 (uint32 bits) or int64 CUDA tensors, got {x.dtype}")
+        if want is not None and x.dtype != want:
+            raise TypeError(f"one index dtype per batch: got {x.dtype} next to {want}")
+        return x if x.is_contiguous() else x.contiguous()
 
     def prepare(self, indices: Sequence, offsets: Sequence | None = None, fixed_pooling: int = 0, outs: Sequence | None = None):
         """Descriptor array of one batch (reusable while the tensors stay where they are): (array, n_bags, outs, keep).
@@ -306,14 +310,13 @@ class ShardedEmbeddingBags:
         t = self.torch
         if len(indices) != self.T or (offsets is not None and len(offsets) != self.T):
             raise ValueError("one index (and offset) tensor per table")
-        # int64 ids (what DLRM passes) are narrowed on the GPU first -- ALL tables in one pass, not three small kernels per table
-        indices = self._u32_list(indices)
-        offsets = self._u32_list(offsets) if offsets is not None else None
         fast = self._prepare_fast(indices, offsets, fixed_pooling, outs)
         if fast is not None:
             return fast
-        idx = [self._u32(i) for i in indices]
-        off = [self._u32(o) for o in offsets] if offsets is not None else [None] * self.T
+        want = indices[0].dtype
+        idx = [self._ids(i, want) for i in indices]
+        off = [self._ids(o, want) for o in offsets] if offsets is not None else [None] * self.T
+        itype = self._l.EMB_IDX_I64 if want == t.int64 else self._l.EMB_IDX_U32
         if offsets is not None:
             n_bags = int(off[0].numel())
             if any(int(o.numel()) != n_bags for o in off):
@@ -323,6 +326,7 @@ class ShardedEmbeddingBags:
                 raise ValueError("offsets=None needs fixed_pooling > 0")
             n_bags = int(idx[0].numel()) // int(fixed_pooling)
         dev = idx[0].device
+        self._same_device(dev)
         if outs is None:
             one = (self.peer.empty if self.peer is not None else lambda sh_, dtype: t.empty(sh_, dtype=dtype, device=dev))(
                 (self.T, n_bags, self.dim), t.float32)
@@ -332,15 +336,24 @@ class ShardedEmbeddingBags:
             o = outs[k]
             if o.dtype != t.float32 or not o.is_contiguous() or o.numel() != n_bags * self.dim:
                 raise ValueError("outs[%d] must be a contiguous float32 [n_bags, dim] tensor" % k)
+            if idx[k].device != dev or o.device != dev or (off[k] is not None and off[k].device != dev):
+                raise ValueError("table %d: every tensor of a batch must live on one device" % k)
             arr[k] = self._l.EmbShardInput(idx[k].data_ptr(), off[k].data_ptr() if off[k] is not None else None, idx[k].numel(),
-                                           0 if off[k] is not None else int(fixed_pooling), 0, o.data_ptr())
+                                           0 if off[k] is not None else int(fixed_pooling), itype, o.data_ptr())
         return arr, n_bags, list(outs), (idx, off, outs)
 
+    def _same_device(self, dev) -> None:
+        """The tensors of a batch are raw pointers to the library, which works on the ENGINE's device: tensors of another GPU
+        would be a wild access there, not a Python error -- refuse them here."""
+        index = dev if isinstance(dev, int) else (dev.index if dev.index is not None else self.torch.cuda.current_device())
+        if getattr(dev, "type", "cuda") != "cuda" or int(index) != int(self.engine.device):
+            raise ValueError(f"the batch's tensors live on {dev}, the engine on cuda:{self.engine.device}")
+
     def _prepare_fast(self, indices, offsets, fixed_pooling, outs):
-        """The descriptor array through the C helper (`_pimemb_marshal.pack_shard`: int32 CUDA tensors as they are, one call
-        instead of ~1.2 us of Python per table -- 32 us for 26 tables against a 60-us step, tools/shard_py_overhead_probe.py).
-        None when the helper is not built or the tensors are not what it takes (int64 ids, odd layouts): the general path
-        below then does the work, or words the error."""
+        """The descriptor array through the C helper (`_pimemb_marshal.pack_shard`: int32 or int64 CUDA tensors as they are, one
+        call instead of ~1.2 us of Python per table -- 32 us for 26 tables against a 60-us step, tools/shard_py_overhead_probe.py).
+        None when the helper is not built or the tensors are not what it takes (mixed dtypes, odd layouts): the general path
+        then does the work, or words the error."""
         from .engine import _marshal
         tb = _marshal()
         if tb is None or not hasattr(tb, "pack_shard") or self.peer is not None and outs is None:
@@ -350,7 +363,7 @@ class ShardedEmbeddingBags:
         offsets = None if offsets is None else (offsets if isinstance(offsets, list) else list(offsets))
         if outs is None:
             first = indices[0]
-            if not (isinstance(first, t.Tensor) and first.is_cuda and first.dtype == t.int32):
+            if not (isinstance(first, t.Tensor) and first.is_cuda and first.dtype in (t.int32, t.int64)):
                 return None
             if offsets is not None:
                 n_bags = int(offsets[0].numel())
@@ -363,6 +376,8 @@ class ShardedEmbeddingBags:
         res = tb.pack_shard(self._C.addressof(arr), indices, offsets, outs, int(fixed_pooling), self.dim)
         if res is None:
             return None
+        if int(res[1]) != int(self.engine.device):       # (raw pointers of another GPU would be a wild access on the engine's)
+            raise ValueError(f"the batch's tensors live on cuda:{int(res[1])}, the engine on cuda:{self.engine.device}")
         return arr, int(res[0]), list(outs), (indices, offsets, outs)
 
     def _stream(self, stream):
@@ -396,6 +411,12 @@ class ShardedEmbeddingBags:
     def flush(self) -> None:
         self._check(self._L.emb_shard_flush(self._h))
 
+    def report(self) -> None:
+        """check="deferred": compare the served counts of every completed batch not looked at yet, NOW (waits for their
+        kernels); raises IndexError naming the batch.  A no-op otherwise."""
+        if self._h is not None:
+            self._check(self._L.emb_shard_report(self._h))
+
     def forward(self, lS_o: Sequence | None, lS_i: Sequence, fixed_pooling: int = 0, outs=None):
         """The `apply_emb` contract: offsets per table, indices per table -> [B, dim] fp32 per table (this rank's bags)."""
         self._create()
@@ -423,9 +444,15 @@ class ShardedEmbeddingBags:
         return np.ctypeslib.as_array(buf)[:self.world * kr * 2].reshape(self.world, kr, 2).astype(np.int64)
 
     def close(self) -> None:
+        """Destroys the shard object.  A deferred finding nobody collected is raised here (after the object is gone)."""
         if self._h is not None:
+            rc = self._L.emb_shard_report(self._h) if self.check == "deferred" else self._l.EMB_OK
+            msg = self._L.emb_last_error().decode(errors="replace") if rc == self._l.EMB_ERR_RANGE else ""
             self._L.emb_shard_destroy(self._h)
             self._h = None
+            self._live.clear()
+            if rc == self._l.EMB_ERR_RANGE:
+                raise IndexError("ShardedEmbeddingBags: " + msg)
         self._live.clear()
 
 

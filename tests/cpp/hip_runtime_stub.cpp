@@ -118,23 +118,26 @@ void emulate_validate(void **args, dim3 grid) {
 // computed here): how many sub-bags and indices of every row-split table this rank asks every shard for, and the two peaks.
 // They size every transfer of the sharded step, so with them the host's offset arithmetic runs with real, ragged numbers
 // on every rank (tests/cpp/host_logic_check.cpp: ranks as threads; a receive insists on the byte count its peer sent).
-struct RouteBagTableMirror { const uint32_t *indices, *offsets; uint64_t n_indices; uint32_t fixed_pooling, rows_per_shard; };   // pimemb_kernels.hip
-struct RouteBagParamsMirror { RouteBagTableMirror t[pimemb::kRouteBagMaxTables]; };
+struct RouteBagTableMirror { const void *indices, *offsets; uint64_t n_indices; uint32_t fixed_pooling, rows_per_shard; };   // pimemb_kernels.hip
+struct RouteBagParamsMirror { RouteBagTableMirror t[pimemb::kRouteBagMaxTables]; uint32_t idx64; };
 
 void emulate_route_counts(const RouteBagParamsMirror &rp, uint64_t n_bags, uint32_t N, uint32_t K, uint32_t *meta) {
     auto pad4 = [](uint32_t v) { return (v + 3u) & ~3u; };
     std::vector<uint32_t> words(N, 0), rows(N, 0);
     for (uint32_t k = 0; k < K; k++) {
         const RouteBagTableMirror &t = rp.t[k];
+        auto word = [&](const void *a, uint64_t i) -> uint64_t {        // (route_word: uint32 or int64 arrays, a negative id = huge)
+            return rp.idx64 ? (uint64_t)static_cast<const int64_t *>(a)[i] : (uint64_t)static_cast<const uint32_t *>(a)[i];
+        };
         std::vector<uint32_t> n_sub(N, 0), n_idx(N, 0);
         for (uint64_t b = 0; b < n_bags; b++) {
-            uint64_t p = t.offsets ? t.offsets[b] : b * t.fixed_pooling;
-            uint64_t e = t.offsets ? (b + 1 < n_bags ? (uint64_t)t.offsets[b + 1] : t.n_indices) : p + t.fixed_pooling;
+            uint64_t p = t.offsets ? word(t.offsets, b) : b * t.fixed_pooling;
+            uint64_t e = t.offsets ? (b + 1 < n_bags ? word(t.offsets, b + 1) : t.n_indices) : p + t.fixed_pooling;
             if (e > t.n_indices) e = t.n_indices;
             if (p > e) p = e;
             std::vector<uint32_t> here(N, 0);
             for (; p < e; p++) {
-                uint64_t d = t.indices[p] / t.rows_per_shard;
+                uint64_t d = word(t.indices, p) / t.rows_per_shard;
                 if (d >= N) d = N - 1;                         // the last shard takes anything beyond
                 here[d]++;
             }
@@ -179,7 +182,7 @@ void emulate_route_counts(const RouteBagParamsMirror &rp, uint64_t n_bags, uint3
 // The COUNTED ranged lookup of a checked shard's direct path: no row is gathered here, but the per-descriptor counters of
 // served bags steer host control flow (the requester compares their sum with its bag count), so they are produced: the
 // number of indices inside [row_lo, row_lo + nr_rows), added to the counter the descriptor names in pad_[1].
-void emulate_ranged_counts(void **args, dim3 grid) {
+void emulate_ranged_counts(void **args, dim3 grid, bool idx64) {
     using pimemb::DevDesc;
     const DevDesc *descs = arg<const DevDesc *>(args, 0);
     const uint32_t chunks_arg = arg<uint32_t>(args, 1);
@@ -201,17 +204,19 @@ void emulate_ranged_counts(void **args, dim3 grid) {
         const DevDesc &dd = descs[d];
         uint32_t *ctr = reinterpret_cast<uint32_t *>(dd.pad_[1]);
         if (!ctr || dd.n_tiles == 0) continue;
-        const uint32_t *idx = static_cast<const uint32_t *>(dd.indices);
+        const uint64_t row_lo = dd.pad_[0] & ~pimemb::kRangeOpenEnd;      // (the open end's bags are zeroed, never counted)
         uint32_t n = 0;
-        for (uint64_t b = 0; b < dd.n_bags; b++)
-            if ((uint64_t)idx[b] - dd.pad_[0] < dd.nr_rows) n++;
+        for (uint64_t b = 0; b < dd.n_bags; b++) {
+            const uint64_t id = idx64 ? (uint64_t)static_cast<const int64_t *>(dd.indices)[b] : (uint64_t)static_cast<const uint32_t *>(dd.indices)[b];
+            if (id - row_lo < dd.nr_rows) n++;
+        }
         __atomic_fetch_add(ctr + (size_t)(d % EMB_SERVED_LANES) * (EMB_SERVED_STRIDE / 4), n, __ATOMIC_RELAXED);      // (any lane of the counter)
     }
 }
 
 void emulate(const std::string &name, void **args, dim3 grid) {
     if (name.find("bag_sum_wavebatch_kernel") != std::string::npos && name.find("EELb1EEEvPK") != std::string::npos) {
-        emulate_ranged_counts(args, grid);
+        emulate_ranged_counts(args, grid, name.find("bag_sum_wavebatch_kernelIl") != std::string::npos);
     } else if (name.find("served_counts_kernel") != std::string::npos) {
         const pimemb::ServedArgs a = arg<pimemb::ServedArgs>(args, 0);
         for (uint32_t j = 0; j < a.n_flag; j++) __atomic_store_n(reinterpret_cast<unsigned long long *>(a.flag[j]), a.value[j], __ATOMIC_RELEASE);

@@ -161,14 +161,14 @@ void xmap_cache_shapes() {
     for (uint32_t i = 0; i < 97; i++) launch(i);                                            // 97 shapes, none seen before: maps in the launch image
     for (uint32_t i = 0; i < 1400; i++) launch(100 + (i * 31) % 97 + 97 * (i / 97));        // (shape i + 97 = shape i) the same 97 in scrambled order:
                                                                                             // second sightings fill the 32 places, the rest stay inline
-    EXPECT(pimemb_stub_device_syncs() - syncs0 <= 3);
+    EXPECT(pimemb_stub_device_syncs() - syncs0 == 0);
     for (int round = 0; round < 4; round++)
         for (uint32_t i = 0; i < 48; i++) launch(i);                                        // 48 shapes in rotation, 32 entries: no thrash
     EXPECT(pimemb_stub_device_syncs() - syncs0 <= 3);
     for (uint32_t burst = 0; burst < 6; burst++)                                            // bursts of new recurring shapes push idle ones out
         for (int twice = 0; twice < 6; twice++)
             for (uint32_t i = 0; i < 40; i++) launch(48 + (burst * 40 + i) % 49);
-    EXPECT(pimemb_stub_device_syncs() - syncs0 <= 8);                                       // (the graveyard: one wait per 64 evictions)
+    EXPECT(pimemb_stub_device_syncs() - syncs0 == 0);                                       // (evicted maps are freed behind events recorded at their eviction: never a device-wide wait)
     CHECK(emb_synchronize(e, nullptr));
     CHECK(emb_device_free(e, d_idx));
     CHECK(emb_device_free(e, d_out));
@@ -288,6 +288,20 @@ void fill_tables(Mix m, int world, emb_shard_table *tabs) {
 // batches after it are clean.
 struct Drive {
     emb_engine *e; int rank, world; Mix mix; emb_comm *comm; emb_peer *peer; bool checked; std::vector<uint32_t> depths; int steps;
+    bool idx64 = false;      // int64 index / offset arrays (torch's width), used in place
+    bool defer = false;      // EMB_SHARD_DEFER_REPORT: a requester-side finding surfaces at the next call / flush, never inside the call
+};
+// index / offset arrays of either width from the same numbers (a negative `bad` id only exists as int64)
+struct IdxBuf {
+    std::vector<uint32_t> u;
+    std::vector<int64_t> l;
+    bool wide;
+    explicit IdxBuf(bool w) : wide(w) {}
+    void push(uint64_t v) { if (wide) l.push_back((int64_t)v); else u.push_back((uint32_t)v); }
+    size_t size() const { return wide ? l.size() : u.size(); }
+    void set(size_t i, int64_t v) { if (wide) l[i] = v; else u[i] = (uint32_t)v; }
+    const void *data() const { return wide ? (const void *)l.data() : (const void *)u.data(); }
+    size_t bytes() const { return size() * (wide ? 8 : 4); }
 };
 void drive_shard(const Drive &D) {
     emb_engine *e = D.e;
@@ -306,8 +320,8 @@ void drive_shard(const Drive &D) {
     std::vector<std::vector<void *>> idx(kSlots), off(kSlots), out(kSlots);
     for (int k = 0; k < kSlots; k++)
         for (uint32_t t = 0; t < T; t++) {
-            idx[k].push_back(dev_alloc(Bmax * 4 * 4));
-            off[k].push_back(dev_alloc(Bmax * 4));
+            idx[k].push_back(dev_alloc(Bmax * 4 * 8));
+            off[k].push_back(dev_alloc(Bmax * 8));
             out[k].push_back(dev_alloc((size_t)Bmax * kDim * 4));
         }
     for (uint32_t depth : D.depths) {
@@ -315,7 +329,7 @@ void drive_shard(const Drive &D) {
         cfg.n_tables = T;
         cfg.dim = kDim;
         cfg.depth = depth;
-        cfg.flags = (D.peer ? EMB_SHARD_PEER_STORES : 0u) | (D.checked ? EMB_SHARD_CHECK_SERVED : 0u);
+        cfg.flags = (D.peer ? EMB_SHARD_PEER_STORES : 0u) | (D.checked ? EMB_SHARD_CHECK_SERVED : 0u) | (D.defer ? EMB_SHARD_DEFER_REPORT : 0u);
         cfg.tables = tabs;
         cfg.peer = D.peer;
         emb_shard *s = nullptr;
@@ -335,18 +349,20 @@ void drive_shard(const Drive &D) {
             const bool one_hot = j % 2 == 1;
             emb_shard_input in[kMaxTables];
             for (uint32_t t = 0; t < T; t++) {
-                std::vector<uint32_t> o(B), ix;
+                IdxBuf o(D.idx64), ix(D.idx64);
                 const uint32_t range = tabs[t].placement == EMB_PLACE_ROWS ? kRows * (uint32_t)D.world : kRows;
                 for (uint32_t b = 0; b < B; b++) {
-                    o[b] = (uint32_t)ix.size();
+                    o.push(ix.size());
                     const uint32_t len = one_hot ? 1u : rng.next() % 4;
-                    for (uint32_t k = 0; k < len; k++) ix.push_back(rng.next() % range);
+                    for (uint32_t k = 0; k < len; k++) ix.push(rng.next() % range);
                 }
-                if (j == bad_step && D.rank == 0 && t == T - 1 && B) ix[B / 2] = range + 5;      // a row nobody holds (last table: row-split / whole)
-                if (!ix.empty()) CHECK(emb_copy_to_device(e, idx[sl][t], ix.data(), ix.size() * 4));
-                if (B) CHECK(emb_copy_to_device(e, off[sl][t], o.data(), B * 4));
-                in[t] = emb_shard_input{static_cast<const uint32_t *>(idx[sl][t]), one_hot ? nullptr : static_cast<const uint32_t *>(off[sl][t]),
-                                        ix.size(), one_hot ? 1u : 0u, 0u, static_cast<float *>(out[sl][t])};
+                // a row nobody holds (last table: row-split / whole); int64: a NEGATIVE id, or one beyond 2^32, by depth
+                if (j == bad_step && D.rank == 0 && t == T - 1 && B)
+                    ix.set(B / 2, !D.idx64 ? (int64_t)range + 5 : (depth % 2 ? -3 : (int64_t)(1ull << 32) + 7));
+                if (ix.size()) CHECK(emb_copy_to_device(e, idx[sl][t], ix.data(), ix.bytes()));
+                if (B) CHECK(emb_copy_to_device(e, off[sl][t], o.data(), o.bytes()));
+                in[t] = emb_shard_input{idx[sl][t], one_hot ? nullptr : off[sl][t], ix.size(), one_hot ? 1u : 0u,
+                                        D.idx64 ? (uint32_t)EMB_IDX_I64 : (uint32_t)EMB_IDX_U32, static_cast<float *>(out[sl][t])};
             }
             if (depth == 0 || j % 7 == 6) {
                 note(emb_shard_lookup(s, in, B, nullptr));
@@ -360,6 +376,7 @@ void drive_shard(const Drive &D) {
                     seqs.erase(seqs.begin());
                 }
             }
+            if (j == bad_step && D.defer) EXPECT(range_seen == 0);       // (deferred: the call that completed the batch said nothing)
             if (j == bad_step) {            // every rank alike: flush is collective
                 note(emb_shard_flush(s));
                 for (uint64_t q : seqs) CHECK(emb_shard_wait(s, q, nullptr));
@@ -395,7 +412,7 @@ void drive_shard(const Drive &D) {
 }
 
 // ---- one rank: every placement, every depth, ragged and one-index batches, peer-store mode, checked ---------------------------
-void shard_one_rank(bool peer_mode, bool checked, emb_engine *shared = nullptr, int device = 0) {
+void shard_one_rank(bool peer_mode, bool checked, emb_engine *shared = nullptr, int device = 0, bool idx64 = false, bool defer = false) {
     emb_engine *e = shared ? shared : make_engine(0, device);
     emb_peer *peer = nullptr;
     if (peer_mode) {
@@ -403,15 +420,84 @@ void shard_one_rank(bool peer_mode, bool checked, emb_engine *shared = nullptr, 
         snprintf(tag, sizeof tag, "hostcheck-%d-%d", (int)getpid(), (int)checked);
         CHECK(emb_peer_create(e, tag, 0, 1, 64ull << 20, &peer));
     }
-    drive_shard(Drive{e, 0, 1, MIX_SMALL, nullptr, peer, checked, {0, 1, 2, 3}, 20});
+    Drive D{e, 0, 1, MIX_SMALL, nullptr, peer, checked, {0, 1, 2, 3}, 20};
+    D.idx64 = idx64;
+    D.defer = defer;
+    drive_shard(D);
     if (peer) {
         CHECK(emb_peer_barrier(peer));
         CHECK(emb_peer_destroy(peer));
     }
     if (!shared) {
         CHECK(emb_destroy(e));
-        printf("shard one rank%s%s ok\n", peer_mode ? " (peer stores)" : "", checked ? " (checked)" : "");
+        printf("shard one rank%s%s%s%s ok\n", peer_mode ? " (peer stores)" : "", checked ? " (checked)" : "", idx64 ? " (int64 ids)" : "", defer ? " (deferred report)" : "");
     }
+}
+
+// A batch's finding is returned ONCE (round 5 returned the serving side's twice: by the call that ran S(b) and again by the one
+// that ran U(b) -- two IndexErrors in Python for one bad batch, the second on a clean submit).  One rank, checked, every depth:
+// a RAGGED batch (validated up front, not counted) hands in one index beyond a replicated table at step 8.  The launch that
+// finds it gathers nothing: the batch whose replicated tables rode in it (8) and the batch whose pieces it served (8 at depth 0;
+// 7 at depth 1; 6 at depth 2 / 3) hold zero rows -- one EMB_ERR_RANGE each, none for any other submit, and the batches after it
+// are clean.
+void report_once(bool idx64) {
+    emb_engine *e = make_engine(0);
+    emb_shard_table tabs[kMaxTables];
+    fill_tables(MIX_SMALL, 1, tabs);
+    const uint32_t T = kTables, B = 32;
+    std::vector<void *> idx(T), off(T), out(T);
+    for (uint32_t t = 0; t < T; t++) {
+        CHECK(emb_device_alloc(e, B * 2 * 8, &idx[t]));
+        CHECK(emb_device_alloc(e, B * 8, &off[t]));
+        CHECK(emb_device_alloc(e, (size_t)B * kDim * 4, &out[t]));
+    }
+    for (uint32_t depth = 0; depth < 4; depth++) {
+        emb_shard_config cfg{};
+        cfg.n_tables = T;
+        cfg.dim = kDim;
+        cfg.depth = depth;
+        cfg.flags = EMB_SHARD_CHECK_SERVED;
+        cfg.tables = tabs;
+        emb_shard *s = nullptr;
+        CHECK(emb_shard_create(e, nullptr, &cfg, &s));
+        int range_seen = 0, first = -1, last = -1;
+        for (int j = 0; j < 16; j++) {
+            emb_shard_input in[kMaxTables];
+            for (uint32_t t = 0; t < T; t++) {
+                IdxBuf o(idx64), ix(idx64);
+                for (uint32_t b = 0; b < B; b++) {
+                    o.push(ix.size());
+                    ix.push((b * 7 + j) % kRows);
+                    ix.push((b * 13 + t) % kRows);
+                }
+                if (j == 8 && t == 0) ix.set(5, (int64_t)kRows + 1);
+                CHECK(emb_copy_to_device(e, idx[t], ix.data(), ix.bytes()));
+                CHECK(emb_copy_to_device(e, off[t], o.data(), o.bytes()));
+                in[t] = emb_shard_input{idx[t], off[t], ix.size(), 0u, idx64 ? (uint32_t)EMB_IDX_I64 : (uint32_t)EMB_IDX_U32, static_cast<float *>(out[t])};
+            }
+            uint64_t seq = 0;
+            const int rc = emb_shard_submit(s, in, B, nullptr, &seq);
+            if (rc == EMB_ERR_RANGE) {
+                range_seen++;
+                if (first < 0) first = j;
+                last = j;
+            } else CHECK(rc);
+            CHECK(emb_synchronize(e, nullptr));        // (one set of buffers: the batch must be through before they are rewritten)
+        }
+        const int rc = emb_shard_flush(s);
+        if (rc == EMB_ERR_RANGE) range_seen++;
+        else CHECK(rc);
+        EXPECT(range_seen == (depth == 0 ? 1 : 2));
+        EXPECT(first >= 8 && last <= 8 + 3);            // nothing before the bad batch, nothing once it and its companion are through
+        CHECK(emb_shard_destroy(s));
+    }
+    for (uint32_t t = 0; t < T; t++) {
+        CHECK(emb_device_free(e, idx[t]));
+        CHECK(emb_device_free(e, off[t]));
+        CHECK(emb_device_free(e, out[t]));
+    }
+    CHECK(emb_destroy(e));
+    printf("one report per bad batch%s ok\n", idx64 ? " (int64 ids)" : "");
 }
 
 // several shard objects, each with its own caller thread, on ONE engine (pimemb.h: "several shard objects may share an engine")
@@ -472,13 +558,15 @@ extern "C" int emb_comm_exchange(emb_comm *c, const emb_comm_op *ops, uint32_t n
 }
 namespace {
 
-void shard_ranks_as_threads(int world, Mix mix, bool checked, std::vector<uint32_t> depths) {
+void shard_ranks_as_threads(int world, Mix mix, bool checked, std::vector<uint32_t> depths, bool idx64 = false) {
     Hub hub(world);
     std::atomic<int> finished{0};
     auto rank_main = [&](int rank) {
         emb_engine *e = make_engine(0, 0, tables_of(mix));
         emb_comm comm{rank, &hub};
-        drive_shard(Drive{e, rank, world, mix, &comm, nullptr, checked, depths, 16});
+        Drive D{e, rank, world, mix, &comm, nullptr, checked, depths, 16};
+        D.idx64 = idx64;
+        drive_shard(D);
         CHECK(emb_destroy(e));
         finished++;
     };
@@ -487,7 +575,7 @@ void shard_ranks_as_threads(int world, Mix mix, bool checked, std::vector<uint32
     for (auto &t : th) t.join();
     EXPECT(finished.load() == world);
     for (auto &q : hub.q) EXPECT(q.empty());           // every piece sent was received
-    printf("shard %d ranks as threads, mix %d%s ok\n", world, (int)mix, checked ? ", checked" : "");
+    printf("shard %d ranks as threads, mix %d%s%s ok\n", world, (int)mix, checked ? ", checked" : "", idx64 ? ", int64 ids" : "");
 }
 
 // ---- the collective-free exchange with several ranks as threads: one peer group, an IPC handle is the pointer itself --------
@@ -498,19 +586,22 @@ void shard_ranks_as_threads(int world, Mix mix, bool checked, std::vector<uint32
 #define HOST_CHECK_TSAN 1
 #endif
 #endif
-void peer_ranks_as_threads(int world, Mix mix, bool checked, std::vector<uint32_t> depths) {
+void peer_ranks_as_threads(int world, Mix mix, bool checked, std::vector<uint32_t> depths, bool idx64 = false, bool defer = false) {
 #ifdef HOST_CHECK_TSAN
-    (void)mix; (void)checked; (void)depths;
+    (void)mix; (void)checked; (void)depths; (void)idx64; (void)defer;
     printf("peer stores, %d ranks as threads: skipped under ThreadSanitizer\n", world);
 #else
     char tag[64];
-    snprintf(tag, sizeof tag, "hostcheck-peers-%d-%d-%d-%d", (int)getpid(), world, (int)mix, (int)checked);
+    snprintf(tag, sizeof tag, "hostcheck-peers-%d-%d-%d-%d-%d%d", (int)getpid(), world, (int)mix, (int)checked, (int)idx64, (int)defer);
     std::atomic<int> finished{0};
     auto rank_main = [&](int rank) {
         emb_engine *e = make_engine(0, 0, tables_of(mix));
         emb_peer *peer = nullptr;
         CHECK(emb_peer_create(e, tag, rank, world, 96ull << 20, &peer));
-        drive_shard(Drive{e, rank, world, mix, nullptr, peer, checked, depths, 24});
+        Drive D{e, rank, world, mix, nullptr, peer, checked, depths, 24};
+        D.idx64 = idx64;
+        D.defer = defer;
+        drive_shard(D);
         CHECK(emb_peer_barrier(peer));
         CHECK(emb_peer_destroy(peer));
         CHECK(emb_destroy(e));
@@ -520,7 +611,7 @@ void peer_ranks_as_threads(int world, Mix mix, bool checked, std::vector<uint32_
     for (int r = 0; r < world; r++) th.emplace_back(rank_main, r);
     for (auto &t : th) t.join();
     EXPECT(finished.load() == world);
-    printf("peer stores, %d ranks as threads, mix %d%s ok\n", world, (int)mix, checked ? ", checked" : "");
+    printf("peer stores, %d ranks as threads, mix %d%s%s%s ok\n", world, (int)mix, checked ? ", checked" : "", idx64 ? ", int64 ids" : "", defer ? ", deferred report" : "");
 #endif
 }
 
@@ -691,6 +782,15 @@ int main(int argc, char **argv) {
         shard_one_rank(true, false);
         shard_one_rank(true, true);
         shards_sharing_an_engine();
+        // int64 ids in place (the router, the ranged launches, whole tables' arrays at 8 bytes per id), the deferred report
+        shard_one_rank(false, true, nullptr, 0, /*idx64=*/true);
+        shard_one_rank(false, true, nullptr, 0, /*idx64=*/false, /*defer=*/true);
+        shard_one_rank(true, true, nullptr, 0, /*idx64=*/true, /*defer=*/true);
+        report_once(false);
+        report_once(true);
+        shard_ranks_as_threads(2, MIX_SMALL, true, {0, 3}, /*idx64=*/true);
+        shard_ranks_as_threads(3, MIX_SMALL, false, {1, 2}, /*idx64=*/true);
+        peer_ranks_as_threads(3, MIX_SMALL, true, {0, 2, 3}, /*idx64=*/true, /*defer=*/true);
         shard_ranks_as_threads(2, MIX_SMALL, false, {0, 1, 2, 3});
         shard_ranks_as_threads(3, MIX_SMALL, true, {0, 1, 2, 3});
         peer_ranks_as_threads(2, MIX_SMALL, true, {0, 1, 2, 3});
@@ -709,6 +809,8 @@ int main(int argc, char **argv) {
     peer_ranks_as_threads(8, MIX_C4, true, {0, 3});
     peer_ranks_as_threads(8, MIX_C5, true, {0, 2});
     peer_ranks_as_threads(8, MIX_SMALL, true, {1, 3});
+    shard_ranks_as_threads(8, MIX_C4, true, {3}, /*idx64=*/true);
+    peer_ranks_as_threads(8, MIX_C4, true, {0, 3}, /*idx64=*/true, /*defer=*/true);
     printf("host logic ok\n");
     return 0;
 }

@@ -120,8 +120,8 @@ def main():
                 x = torch.from_numpy(a).to(dev).to(dt)
                 if peer is None:
                     return x
-                y = peer.empty(x.shape, torch.int32)          # peers gather from it in place: it must live in the arena
-                y.copy_(x.to(torch.int32))
+                y = peer.empty(x.shape, dt)                   # peers gather from it in place: it must live in the arena
+                y.copy_(x)
                 return y
 
             def dev_batch(b):
@@ -180,19 +180,30 @@ def main():
             if cfg.get("bad_index"):           # a row id outside the table: the SERVING rank raises, nobody hangs
                 b = make_batch(rng, rows, cfg["bags"], max(1, cfg["max_len"]), True)
                 t_bad = cfg["bad_index"]["table"]
+                bad_value = {"beyond": rows[t_bad] + 5, "negative": -3, "huge": (1 << 32) + 2}[cfg["bad_index"].get("value", "beyond")]
                 if rank == cfg["bad_index"]["rank"]:
-                    b[0][t_bad][3] = rows[t_bad] + 5
+                    b[0][t_bad][3] = bad_value
                 di = [to_dev(i) for i in b[0]]
-                raised = False
-                try:
-                    if depth == 0:
-                        S.forward(None, di, fixed_pooling=max(1, cfg["max_len"]))
+                n_raised, outs = 0, None
+                try:                       # check="sync": the call that completes the batch raises; "deferred" (the default): the
+                    if depth == 0:         # NEXT call does -- report() here, so that both forms are counted in one place
+                        outs = S.forward(None, di, fixed_pooling=max(1, cfg["max_len"]))
                     else:
-                        S.submit(di, None, fixed_pooling=max(1, cfg["max_len"]))
+                        q, outs = S.submit(di, None, fixed_pooling=max(1, cfg["max_len"]))
                         S.flush()
                 except IndexError:
-                    raised = True
-                status["raised_depth%d" % depth] = raised
+                    n_raised += 1
+                try:
+                    S.report()
+                except IndexError:
+                    n_raised += 1
+                status["raised_depth%d" % depth] = n_raised > 0
+                status["n_raised_depth%d" % depth] = n_raised
+                torch.cuda.synchronize()
+                if outs is not None and rank == cfg["bad_index"]["rank"] and cfg.get("check", True):
+                    # whichever mechanism refused it: the offending bag pooled to a ZERO row, never to stale bytes
+                    row = outs[t_bad][3 // max(1, cfg["max_len"])].cpu().numpy()
+                    assert not row.any(), ("the bag of the refused index holds", row[:4])
                 if cfg.get("good_after_bad"):      # the shard object is still usable: a clean batch after the refused one, against the oracle
                     torch.cuda.synchronize()
                     g = make_batch(rng, rows, cfg["bags"] + 1, max(1, cfg["max_len"]), True)
@@ -202,6 +213,29 @@ def main():
                         S.flush()
                         S.wait(q)
                     check(outs, g, "clean batch after a refused one")
+            if cfg.get("bad_pipeline"):        # ONE bad batch in the middle of a pipelined stream of clean ones: how many calls raise?
+                t_bad = cfg["bad_pipeline"]["table"]
+                n_raised = 0
+                keep = []
+                for j in range(8):
+                    b = make_batch(rng, rows, cfg["bags"], max(1, cfg["max_len"]), cfg.get("fixed", False))
+                    if j == 2 and rank == cfg["bad_pipeline"]["rank"]:
+                        b[0][t_bad][min(3, len(b[0][t_bad]) - 1)] = rows[t_bad] + 5
+                    di, do = dev_batch(b)
+                    keep.append((di, do))
+                    try:
+                        if cfg.get("fixed", False):
+                            S.submit(di, None, fixed_pooling=cfg["max_len"])
+                        else:
+                            S.submit(di, do)
+                    except IndexError:
+                        n_raised += 1
+                for final in (S.flush, S.report):
+                    try:
+                        final()
+                    except IndexError:
+                        n_raised += 1
+                status["pipeline_raised_depth%d" % depth] = n_raised
             torch.cuda.synchronize()
             S.close()
         if cfg.get("harness"):        # the apply_emb-shaped module over the sharded call: its own engine, the same communicator

@@ -113,6 +113,61 @@ def test_reference_lookup_semantics_random(pel, oracle):
     compat.reset()
 
 
+def test_compat_lookup_bag0_starts_at_index_0(pel, oracle):
+    """The reference's bag-0 start rule through its own entry point: lookup() serves bag 0 from index 0 whatever
+    offsets[t][0] says (emb_dpu_lookup.c:60-63: tasklet 0's indices_ptr = 0; load_generator.c:46) -- bit for bit the
+    oracle's fixed-point restatement, which follows the same rule; a table whose offsets[0] IS 0 rides in the same call."""
+    from importlib import import_module
+    compat = import_module("pim-embedding-lookup_amd.compat")
+    rng = np.random.default_rng(61)
+    T, Cc, Bmax, Lmax, rows = 3, 16, 33, 6, 700
+    tabs = [rng.integers(-2**31, 2**31 - 1, size=(rows, Cc), dtype=np.int64).astype(np.int32) for _ in range(T)]
+    compat.reset()
+    compat.configure(T, Cc, Bmax, Lmax)
+    h = compat.populate(tabs)
+    idx = [rng.integers(0, rows, size=Bmax * Lmax).astype(np.uint32) for _ in range(T)]
+    off = [np.sort(rng.integers(5, Bmax * Lmax, size=Bmax)).astype(np.uint32) for _ in range(T)]     # offsets[t][0] >= 5
+    off[1][0] = 0
+    res = compat.lookup(h, idx, off, nr_cols=Cc)
+    for t in range(T):
+        want = oracle.c_lookup_fixed32(tabs[t], idx[t], off[t])
+        assert np.array_equal(res[t], want)
+        head = off[t].copy()
+        head[0] = 0
+        assert np.array_equal(res[t], oracle.c_lookup_fixed32(tabs[t], idx[t], head))
+        assert oracle.c_validate_result(tabs[t], idx[t], off[t], res[t]) == 0
+    assert off[0][0] != 0 and off[2][0] != 0            # the caller's arrays are not written to
+    compat.reset()
+
+
+def test_plan_less_launch_with_a_searched_map_just_above_a_rounding_boundary(pel, eng, oracle):
+    """A plan-less multi-table one-hot launch whose XCD map is too large to be expanded (more than 2^20 workgroups: the
+    binary-searched form) and whose tile counts sit just ABOVE a quantisation boundary of the map cache (rounded up to 1/16
+    of their power of two: up to 6 % more workgroups than tiles, every surplus one must leave at `tile < n_tiles`): twice
+    (second sighting = the cached map), every bag against the table row."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(77)
+    tabs = [rng.standard_normal((r, 4)).astype(np.float32) for r in (9000, 333)]
+    eng.load_table(60, tabs[0])
+    eng.load_table(61, tabs[1])
+    # dim 4 fp32 = one lane per row, two-batch geometry: 256 bags per tile; 2^20 + 2^15 + 1 tiles -> rounded to 2^20 + 2^16
+    bags = [((1 << 20) + (1 << 15)) * 256 + 1, 70_001]
+    idx = [torch.from_numpy(rng.integers(0, t.shape[0], size=b).astype(np.int32)).to(dev) for t, b in zip(tabs, bags)]
+    outs = [torch.empty((b, 4), dtype=torch.float32, device=dev) for b in bags]
+    for _ in range(2):
+        for o in outs:
+            o.fill_(7.0)
+        eng.lookup_batched([60, 61], idx, [None, None], outs=outs, fixed_pooling=1)
+        torch.cuda.synchronize()
+        for t in range(2):
+            w = torch.from_numpy(tabs[t]).to(dev)
+            for lo in range(0, bags[t], 1 << 24):          # (in pieces: torch's own gather over 2.8e8 indices at once returned zero rows at the tail)
+                hi = min(lo + (1 << 24), bags[t])
+                assert torch.equal(outs[t][lo:hi], w.index_select(0, idx[t][lo:hi].long())), (t, lo)
+    del outs, idx
+
+
 def test_kaggle26_fixture_one_fused_launch(pel, eng, golden_dir):
     """C1-shaped plumbing: 26 tables, D=16, all tables in ONE batched call."""
     z = np.load(os.path.join(golden_dir, "kaggle26_capped_b4.npz"))

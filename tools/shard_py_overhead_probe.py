@@ -12,7 +12,7 @@ sh = import_module("pim-embedding-lookup_amd.sharding")
 dev = torch.device("cuda", 0)
 rows, dim, B, _ = pel.workloads.table_set("c4", rows_scale=0.125)
 plan = sh.plan_shards(rows, dim, 4, 1, replicate_bytes=64 << 20, split_bytes=64 << 20, pooling=1.0, split_single_rank=True)
-for check in (False, True):
+for check in (False, "deferred", "sync"):       # "deferred" is what check=True means (the default)
     eng = pel.EmbeddingEngine(device=0, max_tables=len(plan.units) + 1)
     S = sh.ShardedEmbeddingBags(plan, eng, 0, None, depth=0, check=check)
     S.load_tables(lambda t, lo, hi: torch.zeros((hi - lo, dim), device=dev))
@@ -39,10 +39,13 @@ for check in (False, True):
     def prepared(i):
         S._check(S._L.emb_shard_lookup(S._h, slots[i % 4][2][0], B, S._stream(None)))
     i64 = [[x.to(torch.int64) for x in sl[0]] for sl in slots]
-    def fwd_i64(i):          # what DLRM passes: int64 ids, narrowed on the GPU first
+    def fwd_i64(i):          # what DLRM passes: int64 ids, handed to the library IN PLACE (round 5 narrowed them on the GPU first: 76 / 114 us)
         S.forward(None, i64[i % 4], fixed_pooling=1, outs=slots[i % 4][1])
+    def fwd_i64_alloc(i):
+        S.forward(None, i64[i % 4], fixed_pooling=1)
     for name, fn in (("forward(lists, outs given)", fwd), ("forward(lists, outs allocated)", fwd_alloc), ("forward(int64 lists, outs given)", fwd_i64),
-                     ("emb_shard_lookup on a prepared array", prepared)):
+                     ("forward(int64 lists, outs allocated)", fwd_i64_alloc), ("emb_shard_lookup on a prepared array", prepared)):
         h, w = timed(fn)
-        print("check=%-5s %-38s host %.1f us per call, wall %.1f us per call" % (check, name, h, w), flush=True)
+        print("check=%-8s %-38s host %.1f us per call, wall %.1f us per call" % (check, name, h, w), flush=True)
+    S.report()
     S.close(); eng.close()
