@@ -156,24 +156,33 @@ def profile_key(args, spec):
 
 
 KERNEL_OF_KIND = ["bag_sum_wavebatch_kernel", "bag_sum_group_kernel", "bag_sum_wavebatch_kernel", "bag_sum_anydim", "bag_sum_hot_kernel"]
+# rounds 4-5: an entry was tied to these sources (and to the library's bytes).  Host-only edits of the last two orphaned every
+# entry -- four re-collections in round 5.  Entries collected from round 6 on are tied to the DEVICE CODE and the LAUNCH instead
+# (launch_identity below); the source hash is still recorded, and still honoured for the old entries.
 KERNEL_SOURCES = ["pimemb_bag_kernels.h", "pimemb_kernels.hip", "pimemb_xcd_map.h", "pimemb_internal.h", "pimemb_engine.cpp", "pimemb_shard.cpp"]
+SHARD_SOURCES = ["pimemb_shard.cpp"]          # what a dist-* entry is tied to besides its kernels' code (the sharded step's launch logic)
+SHARD_KERNEL_FAMILIES = ("bag_sum_wavebatch_kernel", "bag_sum_group_kernel", "route_bags", "route_onehot", "unroute_bags", "served_counts_kernel",
+                         "publish_words_kernel", "peer_post_kernel", "peer_done_kernel")
+
+
+def _pkg_path(*parts):
+    return os.path.join(ROOT, "pim-embedding-lookup_amd", *parts)
 
 
 def library_identity():
-    """What a profiles/traffic.json entry is tied to: the sha256 of the loaded libpimemb.so and of the sources its kernels
-    and launch logic are built from (a rebuild of unchanged sources may differ in bytes; changed sources never match)."""
+    """sha256 of the loaded libpimemb.so and of the sources its kernels and launch logic are built from -- what entries of
+    rounds 4-5 were tied to (a rebuild of unchanged sources may differ in bytes; changed sources never match)."""
     import hashlib
-    pkg = os.path.join(ROOT, "pim-embedding-lookup_amd")
     out = {"lib_sha256": None, "src_sha256": None}
     try:
-        with open(os.path.join(pkg, "lib", "libpimemb.so"), "rb") as f:
+        with open(_pkg_path("lib", "libpimemb.so"), "rb") as f:
             out["lib_sha256"] = hashlib.sha256(f.read()).hexdigest()
     except OSError:
         pass
     try:
         h = hashlib.sha256()
         for name in KERNEL_SOURCES:
-            with open(os.path.join(pkg, "csrc", name), "rb") as f:
+            with open(_pkg_path("csrc", name), "rb") as f:
                 h.update(name.encode() + b"\0" + f.read())
         out["src_sha256"] = h.hexdigest()
     except OSError:
@@ -181,13 +190,61 @@ def library_identity():
     return out
 
 
-def traffic_entry_status(entry, kernel_name=None, ident=None):
-    """None when the committed PMC entry may be used for this run, else the reason it must not be: it was collected with
-    another build of the library (neither the library's nor the kernel sources' hash matches), or the launch's dominant
-    kernel is not the one the counters were summed over (an entry keyed by workload name only mis-prices
-    frac_measured silently after a kernel change)."""
+def launch_identity(plan=None, lib_path=None):
+    """What a profile of a single-GPU launch is tied to, by construction: the machine code of the kernel instantiation the launch
+    runs (sha256 of its text + kernel descriptor out of the library's gfx950 code object: pim-embedding-lookup_amd/codeobj.py)
+    and the launch itself (emb_plan_signature: kernel kind, grid, XCD map word for word, per-descriptor counts -- no address).
+    A host-only edit of the engine leaves both unchanged (the profile stays valid); a changed kernel, grid or map changes one of
+    them (the profile is dropped, with the reason on the line).  plan = None: the code-object half only."""
+    from importlib import import_module
+    codeobj = import_module("pim-embedding-lookup_amd.codeobj")
+    lib_path = lib_path or _pkg_path("lib", "libpimemb.so")
+    out = {"device_code_sha256": codeobj.device_code_sha256(lib_path)}
+    if plan is not None:
+        launches = plan.describe()
+        top = max(launches, key=lambda g: g["grid"])          # the dominant launch of the plan (one launch for every BASELINE shape)
+        sym, sha = codeobj.kernel_of_launch(lib_path, top)
+        out.update(kernel_symbol=sym, kernel_sha256=sha, launch_signature="%016x" % plan.signature(), launches=len(launches))
+    return out
+
+
+def shard_identity(lib_path=None):
+    """What a dist-* entry (the sharded step at world 1: several kernels, launched by pimemb_shard.cpp) is tied to: one sha256 over
+    the code of every kernel of the families the step runs, and the sha256 of pimemb_shard.cpp."""
+    import hashlib
+    from importlib import import_module
+    codeobj = import_module("pim-embedding-lookup_amd.codeobj")
+    hashes = codeobj.kernel_hashes(lib_path or _pkg_path("lib", "libpimemb.so"))
+    h = hashlib.sha256()
+    for sym in sorted(hashes):
+        if any(f in sym for f in SHARD_KERNEL_FAMILIES):
+            h.update(sym.encode() + b"\0" + hashes[sym].encode())
+    hs = hashlib.sha256()
+    for name in SHARD_SOURCES:
+        with open(_pkg_path("csrc", name), "rb") as f:
+            hs.update(name.encode() + b"\0" + f.read())
+    return {"shard_kernels_sha256": h.hexdigest(), "shard_src_sha256": hs.hexdigest()}
+
+
+def traffic_entry_status(entry, kernel_name=None, ident=None, launch=None):
+    """None when the committed PMC entry may be used for this run, else the reason it must not be.
+    Round-6 entries (they carry kernel_sha256 / launch_signature, or shard_kernels_sha256 for the sharded legs): the kernel's CODE
+    and the LAUNCH of this run (`launch` = launch_identity(plan) / shard_identity()) must be the ones the counters were collected
+    on -- whatever the host sources or the library's bytes are now.  Older entries: the library's or the kernel sources' hash must
+    match (an entry keyed by workload name only mis-prices frac_measured silently after a kernel change).  Either way
+    the launch's dominant kernel must be the family the counters were summed over."""
     if not entry:
         return "no entry"
+    if kernel_name and entry.get("kernel") and kernel_name not in entry["kernel"]:
+        return "the counters were summed over %s, this launch runs %s" % (entry["kernel"][:60], kernel_name)
+    if entry.get("kernel_sha256") or entry.get("shard_kernels_sha256"):
+        if launch is None:
+            return "no launch identity for this run (the entry is tied to the kernel's code and the launch signature)"
+        for k, what in (("kernel_sha256", "the kernel's machine code"), ("launch_signature", "the launch (grid / XCD map / counts)"),
+                        ("shard_kernels_sha256", "the sharded step's kernels"), ("shard_src_sha256", "pimemb_shard.cpp")):
+            if entry.get(k) and entry[k] != launch.get(k):
+                return "%s differs from the profiled one (%s.. vs %s..)" % (what, str(entry[k])[:12], str(launch.get(k))[:12])
+        return None
     ident = ident or library_identity()
     have = [entry.get("lib_sha256"), entry.get("src_sha256")]
     if not any(have):
@@ -196,16 +253,14 @@ def traffic_entry_status(entry, kernel_name=None, ident=None):
             (entry.get("src_sha256") and entry["src_sha256"] == ident["src_sha256"])):
         return "collected with another build (library %s.., sources %s..; loaded: %s.., %s..)" % (
             str(entry.get("lib_sha256"))[:10], str(entry.get("src_sha256"))[:10], str(ident["lib_sha256"])[:10], str(ident["src_sha256"])[:10])
-    if kernel_name and entry.get("kernel") and kernel_name not in entry["kernel"]:
-        return "the counters were summed over %s, this launch runs %s" % (entry["kernel"][:60], kernel_name)
     return None
 
 
-def measured_traffic(key, kernel_name=None):
+def measured_traffic(key, kernel_name=None, launch=None):
     """This command's entry of profiles/traffic.json: HBM-side bytes per launch of the dominant kernel from the
     committed rocprofv3 PMC passes (collected and corrected as MI355X_MICROARCH.md "HBM" prescribes), L2 hit / miss
     requests per launch.  None when no profile exists for the command being run; {"dropped": reason} when one exists but
-    belongs to another build of the library or another kernel (traffic_entry_status)."""
+    belongs to another kernel, another launch or another build (traffic_entry_status)."""
     if key is None:
         return None
     try:
@@ -215,7 +270,7 @@ def measured_traffic(key, kernel_name=None):
         return None
     if entry is None:
         return None
-    why = traffic_entry_status(entry, kernel_name)
+    why = traffic_entry_status(entry, kernel_name, launch=launch)
     return entry if why is None else {"dropped": why, "source": entry.get("source")}
 
 
@@ -240,7 +295,44 @@ def unique_line_bytes(batch, row_bytes, line=128):
     return int(total) * line
 
 
-def roofline_object(alg_bytes, kernel_us, entry, uniq_bytes, meta_bytes=0, uniq_line_bytes=None):
+L1_TA_PEAK_GBS = 64 * 256 * 2.4      # MI355X_MICROARCH.md: a CU's vector L1 / texture-address path delivers 64 B/clk; 256 CUs, ~2.4 GHz
+LAUNCH_FLOOR_US = 2.7                # an empty kernel of the same grid, back to back on one stream (2.5-2.9 us)
+
+
+def binding_roof(r, entry, alg_read_bytes, kernel_us):
+    """Which roof binds the launch, from the committed counters -- so that every line carries a fraction <= 1 on the roof it is
+    quoted against (round 5 printed bound "hbm" with frac 2.53 for the cache-served C3 launch).  Candidates, each as a fraction
+    of its own peak: `hbm` -- the MEASURED HBM-side bytes against 8 TB/s; `l2` -- the L2's requests x 128 B against 34.5 TB/s;
+    `l1_ta` -- the texture-address / vector-L1 path: its own busy counter (TA_BUSY_avr / kernel cycles) where the profile has one,
+    else the bytes the lanes were handed against 64 B/clk/CU; `launch` -- an empty kernel of the same grid takes ~2.7 us.  The
+    largest one binds.  Without a counter profile only `launch` and the algorithmic HBM figure exist: a fraction above 1 is then
+    marked as unattributed, never printed as a utilisation."""
+    t = kernel_us * 1e-6
+    cand = {}
+    if r.get("frac_measured") is not None:
+        cand["hbm"] = (r["frac_measured"], r["achieved_measured"], HBM_PEAK_GBS, "measured HBM-side bytes (profiles/traffic.json) / launch time")
+    elif r["frac"] <= 1.0:
+        cand["hbm"] = (r["frac"], r["achieved"], HBM_PEAK_GBS, "algorithmic bytes / launch time (no counter profile of this command)")
+    if r.get("l2_frac") is not None:
+        cand["l2"] = (r["l2_frac"], r["l2_frac"] * L2_PEAK_GBS, L2_PEAK_GBS, "(TCC_HIT + TCC_MISS) x 128 B / launch time")
+    if entry and entry.get("ta_busy_frac") is not None:
+        cand["l1_ta"] = (min(entry["ta_busy_frac"], 1.0), alg_read_bytes / t / 1e9, L1_TA_PEAK_GBS, "TA_BUSY_avr / kernel cycles (GRBM_GUI_ACTIVE / 8)")
+    elif entry and alg_read_bytes:
+        cand["l1_ta"] = (alg_read_bytes / t / 1e9 / L1_TA_PEAK_GBS, alg_read_bytes / t / 1e9, L1_TA_PEAK_GBS, "bytes gathered by the lanes / launch time against 64 B/clk/CU")
+    cand["launch"] = (min(LAUNCH_FLOOR_US / max(kernel_us, 1e-9), 1.0), None, None, "an empty kernel of the same grid: ~%.1f us" % LAUNCH_FLOOR_US)
+    if "hbm" not in cand and len(cand) == 1 and cand["launch"][0] < 0.5:
+        r["binding"], r["frac_binding"] = None, None
+        r["binding_note"] = "cache-served (algorithmic frac > 1) and no counter profile of this exact command: the binding roof is not attributed"
+        return
+    name = max(cand, key=lambda k: cand[k][0])
+    frac, ach, peak, basis = cand[name]
+    r["binding"], r["frac_binding"], r["binding_basis"] = name, frac, basis
+    if peak is not None:
+        r["binding_achieved"], r["binding_peak"] = ach, peak
+    r["roofs"] = {k: v[0] for k, v in cand.items()}
+
+
+def roofline_object(alg_bytes, kernel_us, entry, uniq_bytes, meta_bytes=0, uniq_line_bytes=None, alg_read_bytes=None):
     """HBM roofline of the dominant kernel, ONE basis on every line: `achieved` / `frac` = ALGORITHMIC bytes per launch
     (cache hits still count) / the launch's duration / the 8 TB/s peak.  A launch that is
     mostly served by L2 / Infinity Cache gathers more than the HBM delivers, so its `frac` can exceed 1: `cache_served`
@@ -278,7 +370,11 @@ def roofline_object(alg_bytes, kernel_us, entry, uniq_bytes, meta_bytes=0, uniq_
     if r["frac"] > 1.0:
         r["basis"] = ("algorithmic bytes; above 1 because most rows were served by L2 / Infinity Cache -- not an HBM "
                       "utilisation" + ("; the HBM-side rate is frac_measured" if r.get("frac_measured") is not None else
-                                       "; no PMC profile of this exact command in profiles/traffic.json"))
+                                       "; no PMC profile of this exact command in profiles/traffic.json")
+                      + "; the roof that binds the launch and the fraction of IT are `binding` / `frac_binding`")
+    if entry and entry.get("ta_busy_frac") is not None:
+        r["ta_busy"] = entry["ta_busy_frac"]
+    binding_roof(r, entry, alg_read_bytes if alg_read_bytes is not None else alg_bytes, kernel_us)
     return r
 
 
@@ -336,58 +432,95 @@ def make_batches(pel, spec, nbatch, seed=1, order="drawn"):
     return batches
 
 
-def usable_cores(cap=16):
-    """Threads worth starting: the affinity mask, cut to the cgroup CPU quota when there is one and to
-    `cap` (a one-GPU box exposes all 256 host CPUs but grants a share of about 16)."""
+def cpu_conditions():
+    """What the host granted this process -- a stated baseline states its conditions (round 4 and round 5 quoted 1.05e9 and 5.2e8
+    lookups/s for the same code on "16 of 256 CPUs"; nothing on the line said why): the cgroup CPU quota, the load of the box,
+    the affinity mask."""
+    out = {"host_cpus": os.cpu_count(), "cpu_quota": None, "affinity_cpus": None, "loadavg_1m": None}
     try:
-        n = len(os.sched_getaffinity(0))
+        out["affinity_cpus"] = len(os.sched_getaffinity(0))
     except AttributeError:
-        n = os.cpu_count() or 1
+        pass
     try:
         with open("/sys/fs/cgroup/cpu.max") as f:
             quota, period = f.read().split()[:2]
-        if quota != "max":
-            n = min(n, max(1, int(quota) // int(period)))
+        out["cpu_quota"] = None if quota == "max" else round(int(quota) / int(period), 2)
+        out["cpu_quota_raw"] = "%s %s" % (quota, period)
     except (OSError, ValueError):
         pass
+    try:
+        out["loadavg_1m"] = round(os.getloadavg()[0], 2)
+    except OSError:
+        pass
+    return out
+
+
+def usable_cores(cap=16):
+    """Threads worth starting: the affinity mask, cut to the cgroup CPU quota when there is one and to
+    `cap` (a one-GPU box exposes all 256 host CPUs but grants a share of about 16)."""
+    c = cpu_conditions()
+    n = c["affinity_cpus"] or c["host_cpus"] or 1
+    if c["cpu_quota"]:
+        n = min(n, max(1, int(c["cpu_quota"])))
     return max(1, min(n, cap))
+
+
+def best_of_legs(run_once, budget, legs=3):
+    """`legs` short timed legs of whole batches within `budget` seconds in all; returns (best rate in calls/s, calls in all,
+    seconds in all, rates of every leg) -- the best leg is the baseline (a neighbour's burst on a shared host slows a leg, never
+    speeds one up), the spread says how quiet the box was."""
+    rates, n_all, el_all = [], 0, 0.0
+    for _ in range(legs):
+        n, t0 = 0, time.perf_counter()
+        while True:
+            run_once()
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= budget / legs or n >= 2000:
+                break
+        rates.append(n / el)
+        n_all += n
+        el_all += el
+    return max(rates), n_all, el_all, rates
 
 
 def cpu_baseline(pel, host_tables, batch, seconds):
     """The oracle (kind "port": C restatement of the reference loop) timed on this host on a bounded
-    sample of the same workload: whole batches until ~`seconds` have elapsed, half of the budget with
-    one thread and half with the bags split over the cores this process may use (OpenMP, at most 16).  `value` /
-    `cores` are the faster of the two; both are kept in the object."""
+    sample of the same workload: whole batches for ~`seconds` in all, half of the budget with one thread and half with the bags
+    split over the cores this process may use (OpenMP, at most 16), each as the BEST of three short legs.  `value` / `cores` are
+    the faster of the two; both are kept in the object, with what the host granted (cpu_quota, affinity, load)."""
     from oracle import oracle
     idx, off = batch
     idx, off = idx[:len(host_tables)], off[:len(host_tables)]
     per_call = sum(o.shape[0] for o in off)
 
     outs = [np.empty((o.shape[0], host_tables[0].shape[1]), dtype=np.float32) for o in off]   # reused: no page faults in the loop
+    cond = cpu_conditions()
+    ncores = usable_cores()
 
     def leg(threads, budget):
         oracle.c_lookup_tables(host_tables, idx, off, threads, outs)      # warm
-        n, t0 = 0, time.perf_counter()
-        while True:
-            oracle.c_lookup_tables(host_tables, idx, off, threads, outs)
-            n += 1
-            el = time.perf_counter() - t0
-            if el >= budget or n >= 2000:
-                return n, el
+        return best_of_legs(lambda: oracle.c_lookup_tables(host_tables, idx, off, threads, outs), budget)
 
-    ncores = usable_cores()
-    n1, el1 = leg(1, seconds / 2)
-    v1 = n1 * per_call / el1
-    nm, elm = leg(ncores, seconds / 2) if ncores > 1 else (n1, el1)
-    vm = nm * per_call / elm
+    r1, n1, el1, legs1 = leg(1, seconds / 2)
+    v1 = r1 * per_call
+    rm, nm, elm, legsm = leg(ncores, seconds / 2) if ncores > 1 else (r1, n1, el1, legs1)
+    vm = rm * per_call
     best_v, best_c = (vm, ncores) if vm > v1 else (v1, 1)
-    res = {"value": best_v, "unit": "pooled-lookups/s", "cores": best_c, "kind": "port",
-           "one_thread": v1, "all_threads": {"threads": ncores, "value": vm},
-           "sample": f"{n1} + {nm} batches of the bench workload restricted to its first {len(host_tables)} tables "
+    res = {"all_threads": {"threads": ncores, "value": vm, "legs": [x * per_call for x in legsm]},
+           "one_thread_legs": [x * per_call for x in legs1],
+           "value": best_v, "unit": "pooled-lookups/s", "cores": best_c, "kind": "port",
+           "one_thread": v1, "all_threads_value": vm, "threads_granted": ncores,
+           "cpu_quota": cond["cpu_quota"], "affinity_cpus": cond["affinity_cpus"], "host_cpus": cond["host_cpus"],
+           "loadavg_1m": cond["loadavg_1m"], "loadavg_1m_after": cpu_conditions()["loadavg_1m"],
+           "legs_spread": (max(legsm) - min(legsm)) / max(legsm) if legsm else None,
+           "omp_wait_policy": os.environ.get("OMP_WAIT_POLICY", ""),
+           "sample": f"best of 3 legs each: {n1} + {nm} batches of the bench workload restricted to its first {len(host_tables)} tables "
                      f"({off[0].shape[0]} bags/table, {idx[0].shape[0] // max(off[0].shape[0], 1)} indices/bag) "
                      f"through oracle/emb_oracle.c in {el1:.1f} s (1 thread) + {elm:.1f} s ({ncores} OpenMP "
-                     f"threads over bags), host has {os.cpu_count()} cpus"}
+                     f"threads over bags); host has {cond['host_cpus']} cpus, cgroup quota {cond['cpu_quota']}, load {cond['loadavg_1m']}"}
     res["torch"] = cpu_baseline_torch(host_tables, (idx, off), max(seconds * 0.6, 2.0), ncores)
+    res["torch_value"], res["torch_threads"] = res["torch"]["value"], res["torch"]["threads"]
     return res
 
 
@@ -411,23 +544,18 @@ def cpu_baseline_torch(host_tables, batch, seconds, ncores):
         torch.set_num_threads(threads)
         with torch.no_grad():
             one()
-            n, t0 = 0, time.perf_counter()
-            while True:
-                one()
-                n += 1
-                el = time.perf_counter() - t0
-                if el >= budget or n >= 2000:
-                    return n, el
+            r, n, el, _legs = best_of_legs(one, budget)
+            return r, n, el
 
     prev = torch.get_num_threads()
-    n1, el1 = leg(1, seconds / 2)
-    nm, elm = leg(ncores, seconds / 2) if ncores > 1 else (n1, el1)
+    r1, n1, el1 = leg(1, seconds / 2)
+    rm, nm, elm = leg(ncores, seconds / 2) if ncores > 1 else (r1, n1, el1)
     torch.set_num_threads(prev)
-    v1, vm = n1 * per_call / el1, nm * per_call / elm
+    v1, vm = r1 * per_call, rm * per_call
     return {"value": max(v1, vm), "unit": "pooled-lookups/s", "threads": ncores if vm > v1 else 1,
             "one_thread": v1, "all_threads": {"threads": ncores, "value": vm},
             "torch_version": torch.__version__, "omp_wait_policy": os.environ.get("OMP_WAIT_POLICY", ""),
-            "sample": f"{n1} + {nm} batches, F.embedding_bag(mode='sum') looped over {len(ws)} tables, "
+            "sample": f"best of 3 legs each: {n1} + {nm} batches, F.embedding_bag(mode='sum') looped over {len(ws)} tables, "
                       f"{el1:.1f} s (1 thread) + {elm:.1f} s ({ncores} threads)"}
 
 
@@ -561,6 +689,12 @@ def run_single(args):
         raise SystemExit(1)
     kinds = eng.stats()["n_launches_by_kind"]
     dominant_kernel = KERNEL_OF_KIND[max(range(len(kinds)), key=lambda k: kinds[k])]
+    try:                        # the kernel's own code bytes + the launch's signature: what a counter profile is tied to
+        launch_id = launch_identity(plans[0])
+    except Exception as ex:  # noqa: BLE001 -- an unreadable code object drops the profile (with the reason), never the run
+        launch_id = None
+        print(f"bench.py: no launch identity ({type(ex).__name__}: {ex}): counter profiles are not used", file=sys.stderr)
+    elem_b = 2 if spec.get("dtype") == "f16" else 4
     result = {
         "metric": "pooled-lookups/sec + achieved HBM GB/s, 26-table dim-16 Kaggle, 1/2/4/8 GPU",
         "value": args.steps * n_bags / wall,
@@ -592,13 +726,17 @@ def run_single(args):
                    "launch_mode": "one hipGraph holding the K launches" if args.graph else "K eager kernel enqueues",
                    "launches_by_kind": kinds, "dominant_kernel": dominant_kernel,
                    "parallelism": "single" if len(handles) == 1 else "single GPU, %d streams" % len(handles)},
-        "roofline": roofline_object(alg_bytes, kernel_us, measured_traffic(profile_key(args, spec), dominant_kernel),
-                                    unique_row_bytes(batches[0], dim * (2 if spec.get("dtype") == "f16" else 4))
+        "roofline": roofline_object(alg_bytes, kernel_us, measured_traffic(profile_key(args, spec), dominant_kernel, launch_id),
+                                    unique_row_bytes(batches[0], dim * elem_b)
                                     if spec["L"] > 1 or spec["dist"] != "uniform" else None,
                                     meta_bytes=4 * (n_idx + n_bags),
-                                    uniq_line_bytes=unique_line_bytes(batches[0], dim * (2 if spec.get("dtype") == "f16" else 4))
-                                    if spec["L"] == 1 and spec["dist"] != "uniform" else None),
+                                    uniq_line_bytes=unique_line_bytes(batches[0], dim * elem_b)
+                                    if spec["L"] == 1 and spec["dist"] != "uniform" else None,
+                                    alg_read_bytes=n_idx * (dim * elem_b + 4) + 4 * n_bags),
     }
+    if launch_id:               # (scalars: a record that keeps only scalar members of `roofline` keeps them)
+        result["roofline"].update(kernel_symbol=launch_id["kernel_symbol"], kernel_sha256=launch_id["kernel_sha256"],
+                                  launch_signature=launch_id["launch_signature"], device_code_sha256=launch_id["device_code_sha256"])
     if want_cpu:
         result["cpu_baseline"] = cpu_baseline(pel, host_tables, batches[0], args.cpu_seconds)
     print(json.dumps(result))

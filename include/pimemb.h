@@ -238,6 +238,11 @@ int emb_plan_bytes(const emb_plan *p, uint64_t *algorithmic_bytes, uint64_t *n_b
  * committed counter profile (profiles/traffic.json) to the launch it measured with this and with the kernel's own code bytes,
  * so that host-only edits of the library do not orphan a profile and a changed launch always does. */
 int emb_plan_signature(const emb_plan *p, uint64_t *signature);
+/* The plan's launches as text, one "key=value ..." record per kernel launch, ';' between them: kind (0 wave-batch, 1 lane-group,
+ * 2 two-batch wave-batch, 3 any-dim, 4 hot rows), dtype, itype, lanes_per_row, chunks, scalar_lanes, anydim_vec, ranged, descs, grid
+ * (workgroups), bags_per_tile -- enough to name the kernel INSTANTIATION each launch runs (bench.py finds its code in the library's
+ * gfx950 code object with it: pim-embedding-lookup_amd/codeobj.py). */
+int emb_plan_describe(const emb_plan *p, char *buf, size_t capacity);
 /* Time `iters` back-to-back launches with HIP events on `stream` after `warmup` untimed ones;
  * *avg_us = mean device time per launch. */
 int emb_plan_time(emb_plan *p, void *stream, uint32_t warmup, uint32_t iters, float *avg_us);

@@ -115,6 +115,31 @@ def kernel_hashes(lib_path: str, arch: str = "gfx950") -> dict[str, str]:
     return out
 
 
+def symbol_fragments(launch: dict) -> list[str]:
+    """Fragments of the mangled name of the kernel instantiation one launch of a plan runs (Plan.describe() record): enough to
+    pick it out of kernel_hashes().  The template heads are pimemb_kernels.hip's: bag_sum_<family>_kernel<IdxT, DT, LPR, Cfg
+    [, RANGED]>, the any-dim kernels <IdxT, DT, CLAMP>."""
+    idx = "j" if launch["itype"] == 0 else "l"
+    kind, dt, lpr = launch["kind"], launch["dtype"], launch["lanes_per_row"]
+    if kind == 3:
+        return ["bag_sum_anydim_vec_kernelI%sLi%dE" % (idx, dt)] if launch.get("anydim_vec") else ["bag_sum_anydim_kernelI%sLi%dE" % (idx, dt)]
+    if kind == 1:
+        return ["bag_sum_group_kernelI%sLi%dELi%dENS_6BagCfgI" % (idx, dt, lpr)]
+    if kind == 4:
+        return ["bag_sum_hot_kernelI%sLi%dELi%dENS_6BagCfgI" % (idx, dt, lpr)]
+    block = 128 if kind == 2 else 64          # the two-batch geometry runs 128-thread workgroups (pimemb_kernels.hip: Wave2Cfg)
+    return ["bag_sum_wavebatch_kernelI%sLi%dELi%dENS_6BagCfgILi%dE" % (idx, dt, lpr, block), "EELb%dEEEvPK" % (1 if launch.get("ranged") else 0)]
+
+
+def kernel_of_launch(lib_path: str, launch: dict, arch: str = "gfx950") -> tuple[str, str]:
+    """(mangled symbol, sha256 of its code) of the kernel a plan's launch runs; raises when the library holds no such kernel or
+    more than one (the fragments are then not an identification any more: fix symbol_fragments)."""
+    hits = kernel_text_sha256(lib_path, symbol_fragments(launch), arch)
+    if len(hits) != 1:
+        raise LookupError("launch %s matches %d kernels of %s: %s" % (launch, len(hits), lib_path, sorted(hits)[:4]))
+    return next(iter(hits.items()))
+
+
 def kernel_text_sha256(lib_path: str, must_contain: list[str], arch: str = "gfx950") -> dict[str, str]:
     """The kernels whose mangled name contains every fragment of `must_contain` (e.g. ["bag_sum_wavebatch_kernel", "IjLi0ELi4E"])."""
     return {k: v for k, v in kernel_hashes(lib_path, arch).items() if all(m in k for m in must_contain)}

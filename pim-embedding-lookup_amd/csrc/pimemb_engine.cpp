@@ -1323,6 +1323,21 @@ int emb_plan_bytes(const emb_plan *p, uint64_t *algorithmic_bytes, uint64_t *n_b
     return EMB_OK;
 }
 
+int emb_plan_describe(const emb_plan *p, char *buf, size_t capacity) {
+    if (!p || !buf || capacity == 0) return fail(EMB_ERR_INVALID, "emb_plan_describe: NULL argument");
+    size_t at = 0;
+    buf[0] = 0;
+    for (const PlanGroup &g : p->groups) {
+        const uint32_t block = g.kind == pimemb::KERNEL_ANYDIM ? 256u : (g.geom.lanes_per_row ? pimemb::bags_per_tile(g.kind, g.geom) : 0u);
+        const int n = snprintf(buf + at, capacity - at, "%skind=%u dtype=%d itype=%d lanes_per_row=%u chunks=%u scalar_lanes=%u anydim_vec=%d ranged=%d descs=%u "
+                               "grid=%u bags_per_tile=%u", at ? ";" : "", (unsigned)g.kind, (int)g.dtype, (int)p->itype, g.geom.lanes_per_row, g.geom.chunks,
+                               g.geom.scalar_lanes, (int)g.geom.anydim_vec, (int)g.ranged, g.n, g.d_xmap ? g.xgrid : g.max_tiles * g.n, block);
+        if (n < 0 || (size_t)n >= capacity - at) return fail(EMB_ERR_INVALID, "emb_plan_describe: %zu bytes do not hold the text", capacity);
+        at += (size_t)n;
+    }
+    return EMB_OK;
+}
+
 int emb_plan_signature(const emb_plan *p, uint64_t *signature) {
     if (!p || !signature) return fail(EMB_ERR_INVALID, "emb_plan_signature: NULL argument");
     *signature = p->signature;

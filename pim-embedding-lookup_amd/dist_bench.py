@@ -527,7 +527,7 @@ def sharded_traffic_entry(args, mode, world, direct=False):
         key += "-direct"
     try:
         import bench
-        return bench.measured_traffic(key, "bag_sum")
+        return bench.measured_traffic(key, "bag_sum", bench.shard_identity())
     except Exception:  # noqa: BLE001
         return None
 
@@ -650,6 +650,117 @@ def run_dp(args, hbm_peak_gbs: float, ctx):
     return result
 
 
+_SCALAR = (int, float, str, bool, type(None))
+# the keys of bench.py's contract: they close the line (a record that keeps only its tail still holds them)
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                 "dtype", "data", "verified")
+
+
+def headline_from_legs(replica: dict, sec: dict, mode: str) -> dict:
+    """The N > 1 line of the metric's config (26 Kaggle tables, which fit every GPU many times over): `value` / `ms_per_step`
+    are the SHARDED leg over RCCL -- tables above 64 MiB placed on owner ranks, indices in / pooled rows out through grouped
+    ncclSend / ncclRecv issued from C: the path `north_star` names, the one number of this run that can see a link.  The
+    replica leg of the same run (every table on every rank, no data-path transfer: it scales with N by construction and says
+    nothing about xGMI) rides along as `config.replica_value` / `value_replica` and the `replica` object.  Both legs time
+    EXACTLY K steps after W warm-up steps on the same clocks.  The reference serves all its devices from one lookup() call and
+    prints its per-stage figures flat on every call (upmem/include/emb_host.h:258-321, :395-402)."""
+    res = dict(sec)
+    res["config"] = dict(sec["config"])
+    res["roofline"] = dict(sec["roofline"])
+    res["headline"] = "sharded-rccl" if "RCCL" in str(sec["config"].get("exchange_transport", "")) else "sharded-peer"
+    res["config"]["workload"] = (sec["config"]["workload"] + " -- HEADLINE (value, ms_per_step): this sharded leg, shard mode '%s', "
+                                 "transport: %s; the replica leg of the same run (all tables on every rank, no transfer) is "
+                                 "config.replica_value" % (mode, sec["config"].get("exchange_transport")))
+    res["replica"] = {k: replica[k] for k in ("value", "unit", "ms_per_step", "ms_per_step_event", "ms_per_step_sync", "clock", "steps")
+                      if k in replica}
+    res["replica"]["verified"] = bool(replica.get("verified", True))
+    res["replica"]["roofline"] = replica.get("roofline")
+    res["replica"]["config"] = "%s; %s" % (replica["config"].get("workload"), replica["config"].get("parallelism"))
+    res["value_replica"], res["ms_per_step_replica"] = replica["value"], replica["ms_per_step"]
+    res["config"]["replica_value"], res["config"]["replica_ms_per_step"] = replica["value"], replica["ms_per_step"]
+    res["config"]["replica_prewarm_ms"] = replica["config"].get("prewarm_ms")
+    rr = replica.get("roofline") or {}
+    res["roofline"]["replica_frac"], res["roofline"]["replica_kernel_us"], res["roofline"]["replica_achieved"] = \
+        rr.get("frac"), rr.get("kernel_us"), rr.get("achieved")
+    res["value_exchange"], res["ms_per_step_exchange"], res["exchange_mode"] = res["value"], res["ms_per_step"], mode
+    res["exchange_transport"] = sec["config"].get("exchange_transport")
+    return res
+
+
+def driver_proof(result: dict) -> dict:
+    """Make the line survive a record that keeps only the SCALAR members of `config` / `roofline` / `cpu_baseline`, the names of
+    other keys, and the last ~2 kB of the text (what BENCH / SCALE records kept of round 5's line: config.exchange{...},
+    roofline.exchange{...} and value_exchange were dropped or reduced to their names).  Every figure of the sharded legs -- RCCL
+    and peer stores -- is mirrored as a scalar member of `config` / `roofline`; the nested objects stay for human readers.  Key
+    order: objects and lists first, scalars after them, the contract's keys last -- at the top level and inside both objects."""
+    cfg, roof = result.get("config") or {}, result.get("roofline") or {}
+    ex, rx = cfg.get("exchange") or {}, roof.get("exchange") or {}
+    if ex:
+        cfg["exchange_value"] = ex.get("value", result.get("value_exchange"))
+        cfg["exchange_ms_per_step"] = ex.get("ms_per_step", result.get("ms_per_step_exchange"))
+        cfg["exchange_mode"] = ex.get("mode", result.get("exchange_mode"))
+        cfg["exchange_transport"] = ex.get("transport", cfg.get("exchange_transport", result.get("exchange_transport")))
+        cfg["exchange_verified"] = bool(ex.get("verified", False))
+        cfg["exchange_steps"] = ex.get("steps", result.get("steps"))
+        cfg["exchange_bytes_out_per_rank_per_step"] = ex.get("bytes_out_per_rank_per_step")
+        cfg["exchange_host_us_per_step"] = ex.get("host_us_per_step")
+        cfg["exchange_sha1"] = ex.get("last_step_sharded_outputs_sha1", cfg.get("last_step_sharded_outputs_sha1"))
+        if ex.get("failed"):
+            cfg["exchange_failed"] = str(ex["failed"])
+    if "value_replica" in result:
+        cfg.setdefault("replica_value", result["value_replica"])
+        cfg.setdefault("replica_ms_per_step", result.get("ms_per_step_replica"))
+    pe = cfg.get("exchange_peer") or {}
+    if pe:
+        if "value" in pe:
+            cfg["exchange_peer_value"], cfg["exchange_peer_ms_per_step"] = pe["value"], pe.get("ms_per_step")
+            cfg["exchange_peer_transport"], cfg["exchange_peer_verified"] = pe.get("transport"), bool(pe.get("verified", False))
+            cfg["exchange_same_bits"] = bool(pe.get("same_bits_as_rccl_leg", result.get("exchange_same_bits", False)))
+            cfg["exchange_peer_direct_one_hot_path"] = pe.get("direct_one_hot_path")
+            cfg["exchange_peer_bytes_out_per_rank_per_step"] = pe.get("bytes_out_per_rank_per_step")
+        for k in ("skipped", "failed"):
+            if pe.get(k):
+                cfg["exchange_peer_" + k] = str(pe[k])
+    for name, obj in (("exchange", rx), ("exchange_peer", roof.get("exchange_peer") or {})):
+        for k in ("step_frac", "step_GBps", "xgmi_GBps", "xgmi_frac", "xgmi_peak_GBps", "host_us_per_step", "host_wait_counts_us_per_step",
+                  "host_wait_served_us_per_step", "bytes_out_per_rank_per_step"):
+            if k in obj:
+                roof["%s_%s" % (name, k)] = obj[k]
+    ks = roof.get("kernels") or {}
+    for k in ("router_us", "lookup_us", "unrouter_us", "direct_lookup_us", "lookup_GBps"):
+        if k in ks:
+            roof["kernel_" + k] = ks[k]
+
+    def ordered(d, first_scalar=None):
+        nested = {k: v for k, v in d.items() if not isinstance(v, _SCALAR)}
+        flat = {k: v for k, v in d.items() if isinstance(v, _SCALAR) and k != first_scalar}
+        head = {first_scalar: d[first_scalar]} if first_scalar in d else {}
+        return {**nested, **head, **flat}
+
+    out = dict(result)
+    # (config.workload is the longest string of the line: it leads config's scalars, so that the figures -- not the prose -- are
+    #  what sits nearest the end)
+    out["config"], out["roofline"] = ordered(cfg, "workload"), ordered(roof)
+    top_nested = {k: v for k, v in out.items() if not isinstance(v, _SCALAR) and k not in ("config", "roofline", "cpu_baseline")}
+    top_flat = {k: v for k, v in out.items() if isinstance(v, _SCALAR) and k not in CONTRACT_KEYS}
+    return {**top_nested, **top_flat, **{k: out[k] for k in ("cpu_baseline", "config", "roofline") if k in out},
+            **{k: out[k] for k in CONTRACT_KEYS if k in out}}
+
+
+def driver_record_stand_in(line: str, tail_bytes: int = 2300) -> dict:
+    """What a BENCH / SCALE record keeps of a bench line, as the round-5 records show it: the contract's top-level keys, the SCALAR
+    members of config / roofline / cpu_baseline (lists and objects dropped), the NAMES of every other key, the last ~2.3 kB of the
+    text.  tests/test_bench_contract.py runs the N > 1 line through this and asserts that every sharded-leg figure survives."""
+    d = json.loads(line)
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    parsed = {k: d.get(k) for k in keep}
+    for obj in ("config", "roofline", "cpu_baseline"):
+        if isinstance(d.get(obj), dict):
+            parsed[obj] = {k: v for k, v in d[obj].items() if isinstance(v, _SCALAR)}
+    parsed["extra_keys"] = sorted(k for k in d if k not in keep and k not in ("config", "roofline", "cpu_baseline"))
+    return {"parsed": parsed, "tail": line[-tail_bytes:]}
+
+
 def run(args, hbm_peak_gbs: float) -> None:
     """N > 1 entry.  Placement policy (--replicate-mb, default auto): tables are replicated while the
     whole set fits a quarter of one GPU's HBM -- the 26 Kaggle tables (2.16 GB) do, so the metric's
@@ -736,7 +847,8 @@ def run(args, hbm_peak_gbs: float) -> None:
             os.write(json_fd, (json.dumps(res) + "\n").encode())
 
     def finish(res):
-        """backend / rank count on every N > 1 line, so a SCALE record shows what RCCL saw."""
+        """backend / rank count on every N > 1 line, so a SCALE record shows what RCCL saw; then the scalar mirrors and the key
+        order that let the line survive the driver's record (driver_proof)."""
         if res is not None:
             res.setdefault("verified", True)     # every leg compares its outputs bit for bit before AND after timing
             res["config"]["backend"] = backend
@@ -744,6 +856,7 @@ def run(args, hbm_peak_gbs: float) -> None:
             if one_gpu and world > 1:
                 res["config"]["rccl_transport"] = "sockets over loopback, %d ranks on %d GPU(s) (PIMEMB_RCCL_ONE_GPU=1)" % (world, n_dev)
             res["config"]["world_size"] = world
+            res = driver_proof(res)
         return res
 
     def die(code, note):
@@ -751,6 +864,7 @@ def run(args, hbm_peak_gbs: float) -> None:
         wait for this rank in a collective are ended by the launcher (bench.py's self-launch / torchrun)."""
         if rank == 0 and state.get("primary") is not None:
             state["primary"]["sharded_exchange"] = {"failed": note}
+            state["primary"]["headline"] = "replica (the sharded leg failed: %s)" % note
             state["primary"]["config"]["exchange"] = {"failed": note, "verified": False}
             state["primary"]["verified"] = False
             emit(finish(state["primary"]))
@@ -759,52 +873,43 @@ def run(args, hbm_peak_gbs: float) -> None:
         os._exit(code)
 
     if auto and total_bytes <= hbm // 4:
+        # The metric's tables fit every GPU many times over.  Two legs, EXACTLY K timed steps each: the replica leg (every table on
+        # every rank: the placement policy's own choice, no data-path transfer) and the sharded leg over RCCL (tables above 64 MiB on
+        # owner ranks / split by row range: indices in, pooled rows out).  The SHARDED leg is the line's value -- the path
+        # north_star names and the only curve of the run that can see a link; the replica figure rides in config.replica_value.
         result = run_dp(args, hbm_peak_gbs, ctx)
         state["primary"] = result
         if not getattr(args, "no_exchange_leg", False):
-            # secondary leg: the sharded exchange (the xGMI all-to-all curve), fewer steps.  A parity failure, an
-            # exception or a hang in it FAILS the run: the primary line is still printed, the exit status is not 0.
-            import copy
-            a2 = copy.copy(args)
-            a2.steps, a2.warmup = min(args.steps, 400), min(args.warmup, 40)
+            # A parity failure, an exception or a hang in the sharded leg FAILS the run: what there is (the replica line, with
+            # the failure noted) is still printed, the exit status is not 0.
             limit = float(os.environ.get("PIMEMB_EXCHANGE_TIMEOUT", "180"))
             state["dog"] = threading.Timer(limit, die, (3, "timed out after %.0f s" % limit))
             state["dog"].daemon = True
             state["dog"].start()
             try:
-                sec = shard_leg(a2, hbm_peak_gbs, ctx, 64 << 20)
+                sec = shard_leg(args, hbm_peak_gbs, ctx, 64 << 20)
             except BaseException as ex:  # noqa: BLE001 -- SystemExit from a leg included
                 import traceback
                 traceback.print_exc()
                 die(4, f"{type(ex).__name__}: {ex}")
             state["dog"].cancel()
             if rank == 0:
-                result["sharded_exchange"] = {k: sec[k] for k in ("value", "unit", "ms_per_step", "ms_per_step_event",
-                                                                  "ms_per_step_sync", "clock", "steps", "roofline")}
-                result["sharded_exchange"]["verified"] = True
-                result["sharded_exchange"]["config"] = sec["config"]["workload"] + "; " + sec["config"]["parallelism"]
-                # the same numbers inside the two objects a SCALE record keeps (config / roofline) ...
-                result["config"]["exchange"] = dict(sec["config"]["exchange"], steps=sec["steps"],
-                                                    what="secondary leg of the same run: " + sec["config"]["workload"],
-                                                    transport=sec["config"]["exchange_transport"],
-                                                    last_step_sharded_outputs_sha1=sec["config"].get("last_step_sharded_outputs_sha1"))
-                result["exchange_transport"] = sec["config"]["exchange_transport"]
-                result["roofline"]["exchange"] = sec["roofline"]["exchange"]
-                # ... and at the TOP LEVEL: `value` is the replica curve (every table on every rank, no data-path transfer:
-                # it scales with N by construction), `value_exchange` the all-to-all curve north_star asks for -- the five
-                # tables above 64 MiB sharded, indices in / pooled rows out over the links
-                result["value_exchange"] = sec["value"]
-                result["ms_per_step_exchange"] = sec["ms_per_step"]
-                result["exchange_mode"] = mode
+                sec["config"]["exchange"] = dict(sec["config"]["exchange"], steps=sec["steps"], transport=sec["config"]["exchange_transport"],
+                                                 last_step_sharded_outputs_sha1=sec["config"].get("last_step_sharded_outputs_sha1"))
+                result = headline_from_legs(result, sec, mode)
+        elif rank == 0 and result is not None:
+            result["headline"] = "replica"
+            result["config"]["workload"] += " -- --no-exchange-leg: value is the REPLICA leg (no data-path transfer; scales with N by construction)"
     else:
         rep_mb = 64 if auto else int(args.replicate_mb)
         result = shard_leg(args, hbm_peak_gbs, ctx, rep_mb << 20)
         if rank == 0 and result is not None:       # the primary leg IS the exchange: one number, two names
             result["value_exchange"], result["ms_per_step_exchange"], result["exchange_mode"] = result["value"], result["ms_per_step"], mode
             result["exchange_transport"] = result["config"]["exchange_transport"]
-    secondary = auto and total_bytes <= hbm // 4          # the sharded leg was the run's secondary leg (fewer steps)
-    if exchange == "both" and not (secondary and getattr(args, "no_exchange_leg", False)):
-        peer_leg(args, (64 if auto else int(args.replicate_mb)) << 20, result, emit, finish, ctx, shard_leg, hbm_peak_gbs, secondary)
+            result["headline"] = "sharded-rccl" if "RCCL" in result["exchange_transport"] else "sharded-peer"
+    two_legs = auto and total_bytes <= hbm // 4           # (replica + sharded: --no-exchange-leg leaves nothing for a peer leg to be compared with)
+    if exchange == "both" and not (two_legs and getattr(args, "no_exchange_leg", False)):
+        peer_leg(args, (64 if auto else int(args.replicate_mb)) << 20, result, emit, finish, ctx, shard_leg, hbm_peak_gbs, False)
     emit(finish(result))
     # teardown under a deadline: a peer leg that lost a rank must not keep the survivors in a barrier nobody will complete
     bye = threading.Timer(float(os.environ.get("PIMEMB_TEARDOWN_TIMEOUT", "60")), lambda: os._exit(0))

@@ -150,6 +150,19 @@ class Plan:
         _l.check(self.engine._L.emb_plan_time(self._p, stream, warmup, iters, C.byref(us)))
         return us.value
 
+    def signature(self) -> int:
+        """Hash of what the plan's launches ARE (kernel kind, grid, XCD map, per-descriptor counts; no addresses)."""
+        v = C.c_uint64()
+        _l.check(self.engine._L.emb_plan_signature(self._p, C.byref(v)))
+        return v.value
+
+    def describe(self) -> list[dict]:
+        """One dict per kernel launch of the plan: kind, dtype, itype, lanes_per_row, chunks, scalar_lanes, anydim_vec, ranged,
+        descs, grid, bags_per_tile (emb_plan_describe)."""
+        buf = C.create_string_buffer(4096)
+        _l.check(self.engine._L.emb_plan_describe(self._p, buf, len(buf)))
+        return [{k: int(v) for k, v in (kv.split("=") for kv in rec.split())} for rec in buf.value.decode().split(";") if rec]
+
     def destroy(self) -> None:
         if self._p:
             self.engine._L.emb_plan_destroy(self._p)

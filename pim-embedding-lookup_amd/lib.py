@@ -138,6 +138,7 @@ SIGNATURES = {
     "emb_plan_destroy": (C.c_int, [_vp]),
     "emb_plan_bytes": (C.c_int, [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),
     "emb_plan_signature": (C.c_int, [_vp, C.POINTER(_u64)]),
+    "emb_plan_describe": (C.c_int, [_vp, C.c_char_p, _sz]),
     "emb_plan_time": (C.c_int, [_vp, _vp, _u32, _u32, C.POINTER(C.c_float)]),
     "emb_validate_inputs": (C.c_int, [_vp, C.POINTER(EmbLookupDesc), _u32, C.c_int, C.c_int,
                                       C.POINTER(_u64)]),

@@ -35,6 +35,11 @@ for key in keys:
     ident_file = os.path.join(here, rnd, f"{key}_identity.json")     # written on the GPU box next to the counters (collect.sh)
     ident = json.load(open(ident_file)) if os.path.exists(ident_file) else bench.library_identity()
     e["lib_sha256"], e["src_sha256"] = ident.get("lib_sha256"), ident.get("src_sha256")
+    for k in ("kernel_symbol", "kernel_sha256", "launch_signature", "device_code_sha256"):     # round 6: the entry is tied to THESE
+        if ident.get(k):
+            e[k] = ident[k]
+    if "TA_BUSY_avr" in c and c.get("GRBM_GUI_ACTIVE"):     # GRBM_GUI_ACTIVE is summed over the 8 XCDs: / 8 = kernel cycles
+        e["ta_busy_frac"] = c["TA_BUSY_avr"] / (c["GRBM_GUI_ACTIVE"] / 8.0)
     if "FETCH_SIZE" in c:
         e["fetch_size_x2_bytes"] = int(c["FETCH_SIZE"] * 1024 * 2)     # cross-check of read_bytes
     if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:

@@ -317,17 +317,29 @@ def test_distributed_bench_two_ranks_on_one_gpu(mode):
         assert "5 whole" in w and "21 replicated" in w
         assert d["config"]["pooling"] == (5 if mode == "whole-pooled" else 1)
     else:
-        assert "replicated on every rank" in d["config"]["parallelism"]
-        sec = d["sharded_exchange"]
-        assert isinstance(sec, dict) and sec["value"] > 0 and "5 whole" in sec["config"]
-        assert sec["verified"] is True and sec["roofline"]["bound"] == "hbm" and sec["roofline"]["achieved"] > 0
-        # the same leg inside the objects a SCALE record keeps
+        # the default policy on the metric's tables: TWO legs, exactly K steps each.  The line's value is the SHARDED leg over RCCL
+        # (the one curve that can see a link); the replica leg rides along as scalars and as an object
+        assert d["headline"] == "sharded-rccl" and "HEADLINE" in w and "5 whole" in w and "21 replicated" in w
+        assert "ONE library call per batch" in d["config"]["parallelism"] and d["steps"] == 6
+        rp = d["replica"]
+        assert rp["value"] > 0 and rp["verified"] is True and "replicated on every rank" in rp["config"] and rp["steps"] == 6
         cx, rx = d["config"]["exchange"], d["roofline"]["exchange"]
-        assert cx["mode"] == "whole" and cx["verified"] is True and cx["value"] == sec["value"]
-        # ... and at the top level: the replica curve in `value`, the all-to-all curve in `value_exchange`
-        assert d["value_exchange"] == sec["value"] and d["ms_per_step_exchange"] == sec["ms_per_step"] and d["exchange_mode"] == "whole"
-        assert d["value"] != d["value_exchange"]
+        assert cx["mode"] == "whole" and cx["verified"] is True and cx["value"] == d["value"] == d["value_exchange"]
+        assert d["ms_per_step_exchange"] == d["ms_per_step"] and d["exchange_mode"] == "whole"
+        assert d["value_replica"] == rp["value"] != d["value"]
         assert cx["bytes_out_per_rank_per_step"] > 0 and 0 < rx["step_frac"] < 1 and rx["xgmi_GBps"] > 0
+        # ... every figure again as SCALAR members of config / roofline -- what a BENCH / SCALE record keeps
+        c, r = d["config"], d["roofline"]
+        assert c["exchange_value"] == d["value"] and c["exchange_ms_per_step"] == d["ms_per_step"] and c["exchange_mode"] == "whole"
+        assert c["exchange_verified"] is True and "RCCL" in c["exchange_transport"] and c["replica_value"] == rp["value"]
+        assert r["exchange_step_frac"] == rx["step_frac"] and r["exchange_xgmi_GBps"] == rx["xgmi_GBps"] and r["replica_frac"] == rp["roofline"]["frac"]
+        if "value" in (c.get("exchange_peer") or {}):
+            assert c["exchange_peer_value"] == c["exchange_peer"]["value"] and c["exchange_same_bits"] is True
+            assert r["exchange_peer_xgmi_GBps"] == r["exchange_peer"]["xgmi_GBps"]
+        from importlib import import_module
+        rec = import_module("pim-embedding-lookup_amd.dist_bench").driver_record_stand_in(res.stdout.strip().splitlines()[-1])
+        assert rec["parsed"]["config"]["exchange_value"] == d["value"] and rec["parsed"]["roofline"]["exchange_xgmi_GBps"] == rx["xgmi_GBps"]
+        assert '"ms_per_step"' in rec["tail"] and '"exchange_xgmi_GBps"' in rec["tail"]
 
 
 def _check_row_split_dump_with_oracle(oracle, prefix, world, pooling):
@@ -399,6 +411,7 @@ def test_exchange_leg_failure_is_a_failed_run():
     assert res.returncode != 0
     assert d is not None and d["value"] > 0 and d["verified"] is False
     assert "timed out" in d["sharded_exchange"]["failed"] and d["config"]["exchange"]["verified"] is False
+    assert d["config"]["exchange_verified"] is False and "timed out" in d["config"]["exchange_failed"] and d["headline"].startswith("replica")
 
 
 def test_route_bags_limits_many_shards_and_tables(pel, eng):
@@ -549,14 +562,15 @@ def test_rccl_several_ranks_on_one_gpu(mode):
     assert "sockets over loopback" in c["rccl_transport"]
     assert c["exchange"]["verified"] is True and c["exchange"]["bytes_out_per_rank_per_step"] > 0
     assert d["ms_per_step_sync"] >= d["ms_per_step_event"] > 0
-    assert "RCCL groups issued from C" in (c["parallelism"] if mode != "auto-torchrun" else d["sharded_exchange"]["config"])
-    assert d["value_exchange"] > 0 and d["ms_per_step_exchange"] > 0
+    assert "RCCL groups issued from C" in c["parallelism"]
+    assert d["value_exchange"] > 0 and d["ms_per_step_exchange"] > 0 and c["exchange_value"] == d["value_exchange"]
     if mode == "rows-self-via-comm":
         assert "through RCCL too" in c["parallelism"]
     if mode == "plan-pooled":
         assert c["shard_mode"] == "plan" and c["placement"]["whole"] + c["placement"]["row_split"] == 5
-    if mode == "auto-torchrun":
-        assert c["bags_per_table_per_rank"] == 39292 and "replicated on every rank" in c["parallelism"]
+    if mode == "auto-torchrun":          # the driver's line: value = the sharded RCCL leg, the replica leg beside it
+        assert c["bags_per_table_per_rank"] == 39292 and d["headline"] == "sharded-rccl" and d["value"] == d["value_exchange"]
+        assert "replicated on every rank" in d["replica"]["config"] and c["replica_value"] == d["value_replica"] > d["value"]
 
 
 def test_terabyte_shaped_row_shards_two_rccl_ranks_same_bits_as_gloo(oracle, tmp_path):
@@ -648,6 +662,16 @@ def _assert_both_transports(d):
     assert "fine-grained" in xp["transport"] or "ordinary" in xp["transport"]          # which kind of arena the peers stored into
     assert d["roofline"]["exchange_peer"]["step_frac"] > 0 and d["exchange_peer"] == xp
     assert d["verified"] is True
+    # value IS the sharded RCCL leg, and every figure of both legs is a SCALAR member of config / roofline
+    c, r = d["config"], d["roofline"]
+    assert d["value"] == d["value_exchange"] == c["exchange_value"] and c["exchange_ms_per_step"] == d["ms_per_step"]
+    assert c["exchange_peer_value"] == d["value_exchange_peer"] and c["exchange_peer_ms_per_step"] == d["ms_per_step_exchange_peer"]
+    assert c["exchange_same_bits"] is True and c["exchange_verified"] is True and c["exchange_peer_verified"] is True
+    assert "RCCL" in c["exchange_transport"] and "peer stores" in c["exchange_peer_transport"] and c["exchange_mode"] == d["exchange_mode"]
+    for k in ("step_frac", "xgmi_GBps", "xgmi_frac", "host_us_per_step"):
+        assert r["exchange_" + k] == r["exchange"][k] and r["exchange_peer_" + k] == r["exchange_peer"][k], k
+    if "replica" in d:
+        assert c["replica_value"] == d["replica"]["value"] == d["value_replica"] and r["replica_frac"] == d["replica"]["roofline"]["frac"]
 
 
 def test_driver_command_shape_four_ranks_on_one_gpu():
@@ -721,4 +745,5 @@ def test_peer_leg_that_cannot_come_up_is_skipped_not_failed(how):
     d = json.loads(lines[0])
     assert d["verified"] is True and d["value_exchange"] > 0 and d["config"]["exchange"]["verified"] is True
     assert "skipped" in d["exchange_peer"] and "value_exchange_peer" not in d
+    assert d["config"]["exchange_peer_skipped"] == d["exchange_peer"]["skipped"] and "exchange_peer_value" not in d["config"]
     assert ("no result within" in d["exchange_peer"]["skipped"]) == (how == "deadline"), d["exchange_peer"]

@@ -16,14 +16,15 @@ run c4-l32 --workload c4 --pooling 32 --steps 100 --warmup 10
 run c5 --workload c5 --steps 100 --warmup 10
 python3 - "$out" <<'PY'
 import glob, json, os, sys
-print("| key | ms / step (sync clock) | event clock | pooled lookups / s | algorithmic GB/s | frac (algorithmic) | measured HBM-side GB/s | frac_measured | l2_frac | L2 hit | read / unique rows | cold us/step | verified |")
-print("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+print("| key | ms / step (sync clock) | event clock | pooled lookups / s | algorithmic GB/s | frac (algorithmic) | measured HBM-side GB/s | frac_measured | l2_frac | L2 hit | TA busy | binding roof | frac_binding | read / unique rows | cold us/step | verified |")
+print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
 for f in sorted(glob.glob(os.path.join(sys.argv[1], "bench_*.json"))):
     d = json.load(open(f)); r = d["roofline"]
     g = lambda k, fmt="%.3f": (fmt % r[k]) if r.get(k) is not None else "—"
     cold = d["config"].get("timed_without_prewarm_us")
-    print("| %s | %.4f | %.4f | %.3e | %.0f | %.3f | %s | %s | %s | %s | %s | %s | %s |" % (
+    print("| %s | %.4f | %.4f | %.3e | %.0f | %.3f | %s | %s | %s | %s | %s | %s | %s | %s | %s | %s |" % (
         os.path.basename(f)[6:-5], d["ms_per_step"], d.get("ms_per_step_event", float("nan")), d["value"], r["achieved"], r["frac"],
-        g("achieved_measured", "%.0f"), g("frac_measured"), g("l2_frac"), g("l2_hit_rate"), g("read_over_unique_rows", "%.2f"),
+        g("achieved_measured", "%.0f"), g("frac_measured"), g("l2_frac"), g("l2_hit_rate"), g("ta_busy"), r.get("binding") or "—", g("frac_binding"),
+        g("read_over_unique_rows", "%.2f"),
         "—" if cold is None else "%.1f" % cold, d["verified"]))
 PY
