@@ -83,6 +83,9 @@ def parse_args():
     ap.add_argument("--checked", action="store_true",
                     help="sharded legs: create the shard with EMB_SHARD_CHECK_SERVED (one-index batches keep the direct path and count "
                          "what every shard serves; routed batches validate what they serve)")
+    ap.add_argument("--ids", choices=["uint32", "int64"], default="uint32",
+                    help="sharded legs: index dtype handed to the library -- uint32 (the reference's width, emb_host.h:234) or int64 "
+                         "(DLRM's tensors, used in place: emb_shard_input.index_type)")
     ap.add_argument("--exchange", choices=["rccl", "peer", "both"], default=None,
                     help="N>1 sharded legs: how pieces travel between ranks -- grouped ncclSend/ncclRecv issued from C (rccl), "
                          "the collective-free exchange (peer: HIP IPC mappings, the owner gathers a requester's indices in place "
@@ -739,6 +742,10 @@ def run_single(args):
                                   launch_signature=launch_id["launch_signature"], device_code_sha256=launch_id["device_code_sha256"])
     if want_cpu:
         result["cpu_baseline"] = cpu_baseline(pel, host_tables, batches[0], args.cpu_seconds)
+    # key order as on the N > 1 lines: objects first, scalars after them, the contract's keys last (a record that keeps only the
+    # tail of the text still holds them)
+    from importlib import import_module
+    result = import_module("pim-embedding-lookup_amd.dist_bench").driver_proof(result)
     print(json.dumps(result))
     for p in plans:
         p.destroy()

@@ -49,9 +49,9 @@ def step_fractions(alg_bytes_per_rank: int, bytes_out_per_rank: int, ms_per_step
     return out
 
 
-def lookup_bytes(T: int, B: int, L: int, dim: int, elem: int) -> int:
-    """Algorithmic bytes of one rank's step: T tables x B bags x (L rows + L u32 indices + one u32 offset + one fp32 row)."""
-    return T * B * (L * (dim * elem + 4) + 4 + dim * 4)
+def lookup_bytes(T: int, B: int, L: int, dim: int, elem: int, isz: int = 4) -> int:
+    """Algorithmic bytes of one rank's step: T tables x B bags x (L rows + L indices + one offset + one fp32 row)."""
+    return T * B * (L * (dim * elem + isz) + isz + dim * 4)
 
 
 def job_times(torch, dist, t0: float, t_event: float, stage_cpu: bool, dev):
@@ -230,7 +230,8 @@ def run_sharded(args, hbm_peak_gbs: float, ctx, rep_bytes: int, mode: str):
     fit_for = ("rccl", "peer") if getattr(args, "exchange_both", False) else (transport,)
     fit_scale, rows_list, plan, hbm_need = sh.fit_to_hbm(
         rows_list, hbm_total, make_plan,
-        lambda p_, r_: max((sh.hbm_budget(p_, r_, B, L, NBATCH, depth, tr_, checked) for tr_ in fit_for), key=lambda d_: d_["total"]))
+        lambda p_, r_: max((sh.hbm_budget(p_, r_, B, L, NBATCH, depth, tr_, checked, index_bytes=8 if getattr(args, "ids", "uint32") == "int64" else 4)
+                            for tr_ in fit_for), key=lambda d_: d_["total"]))
     if fit_scale < 1.0:
         label += " (rows x %.3f more: tables + batch slots + staging must fit %.0f GB of HBM)" % (fit_scale, hbm_total / 1e9)
         if rank == 0:
@@ -256,19 +257,26 @@ def run_sharded(args, hbm_peak_gbs: float, ctx, rep_bytes: int, mode: str):
         comm = sh.native_comm(eng, rank, world, always=via)
     # --checked: EMB_SHARD_CHECK_SERVED -- what ShardedEmbeddingBags does by default for tensors it does not trust.  One-index
     # batches keep the direct path and COUNT what every shard serves (the requester compares); routed batches validate first.
-    S = sh.ShardedEmbeddingBags(plan, eng, rank, comm, depth=depth, check=checked, self_via_comm=via and not use_peer, peer=peer)
+    # (--checked: the deferred report, what check=True means; PIMEMB_BENCH_CHECK=sync compares inside the completing call, as round 5 did)
+    S = sh.ShardedEmbeddingBags(plan, eng, rank, comm, depth=depth, check=(os.environ.get("PIMEMB_BENCH_CHECK", "deferred") if checked else False),
+                                self_via_comm=via and not use_peer, peer=peer)
     S.load_tables(lambda t, lo, hi: table_values(torch, t, lo, hi, dim, dev))
     torch.cuda.empty_cache()
 
     rng = np.random.default_rng(1 + rank)
+    # --ids int64: DLRM's dtype, handed to the library in place (emb_shard_input.index_type); default: the reference's uint32
+    ids64 = getattr(args, "ids", "uint32") == "int64"
+    isz, idt = (8, torch.int64) if ids64 else (4, torch.int32)
     idx_host = [[gen(rng, n, B * L, t).view(np.int32) for t, n in enumerate(rows_list)] for _ in range(NBATCH)]
+    if ids64:
+        idx_host = [[x.view(np.uint32).astype(np.int64) for x in b_] for b_ in idx_host]
     stream = torch.cuda.current_stream(dev)
     h = stream.cuda_stream
     slots = []
     for j in range(NBATCH):
         d_idx = [torch.from_numpy(idx_host[j][t]).to(dev) for t in range(T)]
         if peer is not None:      # peers gather from / store into these in place: they live in this rank's arena (one
-            a_idx = [peer.empty(x.shape, torch.int32) for x in d_idx]       # allocation per table: a chunk of it holds 1 GiB)
+            a_idx = [peer.empty(x.shape, idt) for x in d_idx]       # allocation per table: a chunk of it holds 1 GiB)
             for a, x in zip(a_idx, d_idx):
                 a.copy_(x)
             d_idx = a_idx
@@ -424,7 +432,7 @@ def run_sharded(args, hbm_peak_gbs: float, ctx, rep_bytes: int, mode: str):
         clk = clock_fields(wall_ev, wall_sync, args.steps, world * args.steps * T * B)
         n_st = max(int(st["n_batches"]), 1)
         bytes_out = int(st["bytes_to_peers"] / n_st)
-        fr = step_fractions(lookup_bytes(T, B, L, dim, elem), bytes_out, clk["ms_per_step"], hbm_peak_gbs)
+        fr = step_fractions(lookup_bytes(T, B, L, dim, elem, isz), bytes_out, clk["ms_per_step"], hbm_peak_gbs)
         fr["host_us_per_step"] = st["us_host_submit"] / n_st
         fr["host_wait_counts_us_per_step"] = st["us_host_wait_counts"] / n_st
         fr["host_wait_served_us_per_step"] = st["us_host_wait_served"] / n_st
@@ -457,6 +465,7 @@ def run_sharded(args, hbm_peak_gbs: float, ctx, rep_bytes: int, mode: str):
                                    % (label, dim, "fp16" if TABLE_F16[0] else "fp32", B, L, dist_name, NBATCH, plan.describe()),
                        "tables": T, "dim": dim, "bags_per_table_per_rank": B, "global_bags_per_table": world * B,
                        "pooling": L, "index_dist": dist_name, "shard_mode": mode, "pipeline_depth": depth,
+                       "index_type": "int64" if ids64 else "uint32",
                        # one index per bag and no peer behind RCCL: row-split tables are not routed -- every shard scans the
                        # requesters' raw index arrays and serves the bags whose row it holds (PIMEMB_SHARD_DIRECT=0: always route)
                        "direct_one_hot_path": bool(direct),

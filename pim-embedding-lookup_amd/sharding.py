@@ -144,6 +144,9 @@ def hbm_budget(plan: ShardPlan, rank: int, bags: int, pooling: int, n_slots: int
                  rows, pooled rows of whole tables owned here) -- the last two only over RCCL: with peer stores the owner gathers
                  and stores in place; batches rotate through ALL six slots whatever the depth, and a slot keeps what it grew to;
       plans      64 cached plans (emb_shard's kPlanCache): descriptors (128 B) + the XCD map (8 B per workgroup);
+      maps       the engine's cache of XCD maps of plan-less launches (the routed step's): 32 live entries of up to 8 MB each
+                 (8 B per workgroup, <= 2^20 workgroups expanded) + evicted ones awaiting their events, capped at 64 MB
+                 (pimemb_engine.cpp kXmapCacheEntries / kXmapGraveBytes) -- round 5 left these inside the flat runtime term;
       counters   a checked shard's served-bag counters (16 KiB per descriptor and ring slot);
       arena      peer stores: what emb_peer_create allocates (bench.py's formula);
       runtime    3 GB flat: the HIP context, code objects, torch's allocator slack, RCCL's buffers -- the world-1 runs of
@@ -184,6 +187,7 @@ def hbm_budget(plan: ShardPlan, rank: int, bags: int, pooling: int, n_slots: int
     n_desc = N * (Kr + M) + len(rep)
     tiles = -(-B // 64)
     out["plans"] = 64 * (n_desc * 128 + (n_desc * tiles + 8 * n_desc) * 8)
+    out["maps"] = 32 * min(8 << 20, (n_desc * tiles + 8 * n_desc) * 8) + (64 << 20)
     out["counters"] = live * n_desc * 16384 if checked else 0
     out["arena"] = 0
     if transport == "peer":

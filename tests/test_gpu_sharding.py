@@ -283,7 +283,7 @@ def _bench_two_ranks(extra, launcher="self", timeout=600, env_extra=None):
     return res, (json.loads(lines[-1]) if lines else None)
 
 
-@pytest.mark.parametrize("mode", ["rows", "whole", "auto", "whole-pooled", "rows-pooled", "rows-zipf"])
+@pytest.mark.parametrize("mode", ["rows", "whole", "auto", "whole-pooled", "rows-pooled", "rows-zipf", "rows-pooled-int64", "whole-int64"])
 def test_distributed_bench_two_ranks_on_one_gpu(mode):
     """The N > 1 path end to end on the real HIP engine, started WITHOUT a launcher.  dist_bench verifies all 26
     tables bit for bit on every rank (two pipelined steps before timing, the last step after it) before it
@@ -296,6 +296,9 @@ def test_distributed_bench_two_ranks_on_one_gpu(mode):
              "auto": [],
              "whole-pooled": ["--shard-mode", "whole", "--replicate-mb", "64", "--pooling", "5"],
              "rows-pooled": ["--shard-mode", "rows", "--replicate-mb", "64", "--pooling", "7"],
+             # DLRM's int64 ids handed to the library in place: the router reads them, whole tables' arrays travel at 8 B per id
+             "rows-pooled-int64": ["--shard-mode", "rows", "--replicate-mb", "64", "--pooling", "7", "--ids", "int64"],
+             "whole-int64": ["--shard-mode", "whole", "--replicate-mb", "64", "--ids", "int64"],
              "rows-zipf": ["--shard-mode", "rows", "--replicate-mb", "64", "--index-dist", "zipf"]}[mode]
     res, d = _bench_two_ranks(base + extra)
     assert res.returncode == 0 and d is not None, res.stdout[-2000:] + res.stderr[-4000:]
@@ -308,7 +311,8 @@ def test_distributed_bench_two_ranks_on_one_gpu(mode):
         assert "5 row-split" in w and "21 replicated" in w and "counts first" in d["config"]["parallelism"]
         assert d["config"]["placement"] == {"replicated": 21, "whole": 0, "row_split": 5, "rules": d["config"]["placement"]["rules"]}
         assert "ONE library call per batch" in d["config"]["parallelism"] and d["value_exchange"] == d["value"]
-        assert d["config"]["pooling"] == (7 if mode == "rows-pooled" else 1)
+        assert d["config"]["pooling"] == (7 if mode.startswith("rows-pooled") else 1)
+        assert d["config"]["index_type"] == ("int64" if mode.endswith("int64") else "uint32")
         rows_out = d["config"]["last_step_request_rows_per_peer"]
         assert len(rows_out) == 2 and sum(rows_out) >= 5 * 4099
         if mode == "rows-zipf":
@@ -316,6 +320,8 @@ def test_distributed_bench_two_ranks_on_one_gpu(mode):
     elif mode.startswith("whole"):
         assert "5 whole" in w and "21 replicated" in w
         assert d["config"]["pooling"] == (5 if mode == "whole-pooled" else 1)
+        if mode == "whole-int64":        # the same bags as the uint32 run, 8 bytes per id on the wire: more bytes out, the same rows back
+            assert d["config"]["index_type"] == "int64" and d["config"]["exchange"]["bytes_out_per_rank_per_step"] > 0
     else:
         # the default policy on the metric's tables: TWO legs, exactly K steps each.  The line's value is the SHARDED leg over RCCL
         # (the one curve that can see a link); the replica leg rides along as scalars and as an object
