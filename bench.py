@@ -609,9 +609,9 @@ def run_single(args):
     host_tables = make_tables_on_gpu(torch, eng, rows_list, dim, dev, keep_host=n_host if want_cpu else 0,
                                      dtype=spec.get("dtype", "f32"))
     batches = make_batches(pel, spec, args.nbatch, order=args.index_order)
-    if args.hot_rows > 0:
-        for t in range(T):
-            eng.set_hot_rows(t, pel.workloads.top_rows(batches[0][0][t], args.hot_rows, min_share=0.05))
+    hot_learnt = None
+    if args.hot_rows > 0:          # the ENGINE picks them from the first batch's indices (emb_learn_hot_rows; round 5: host-side numpy)
+        hot_learnt = [eng.learn_hot_rows(t, batches[0][0][t], args.hot_rows, min_share=0.05) for t in range(T)]
 
     plans, plan_idx = [], []
     for idx, off in batches:
@@ -721,6 +721,8 @@ def run_single(args):
         "config": {"workload": "%s, %d rotating batches" % (spec["name"], len(plans)),
                    "tables": T, "dim": dim, "bags_per_table": B, "pooling": spec["L"],
                    "table_bytes": eng.stats()["table_bytes"], "hot_rows_hint": args.hot_rows,
+                   "hot_rows_staged_per_table": None if hot_learnt is None else [n for n, _ in hot_learnt],
+                   "hot_rows_mean_share": None if hot_learnt is None else float(np.mean([sh_ for _, sh_ in hot_learnt])),
                    "prewarm_ms": args.prewarm_ms, "prewarm_launches": n_pre,
                    # the same W warm-up + K timed steps BEFORE the pre-warm (a fresh process, idle clocks): us per step on
                    # the sync clock / per launch by HIP events

@@ -161,6 +161,17 @@ int emb_load_table_column(emb_engine *e, uint32_t table_id, uint32_t col, const 
  * plans that involve the table must be re-created.  No reference counterpart (the DPU program has no
  * cache, emb_dpu_lookup.c:113). */
 int emb_set_hot_rows(emb_engine *e, uint32_t table_id, const uint64_t *row_ids, uint32_t n_rows);
+/* The ENGINE picks the hot rows (emb_set_hot_rows needs the caller to know them): it counts the row ids of a sample of ONE
+ * batch's index array -- DEVICE or HOST memory, uint32 or int64; up to four evenly spaced runs of 65 536 ids are copied to the
+ * host and counted there: a cold-path call of a fraction of a millisecond, synchronous on `stream` -- and stages the max_rows
+ * most frequent ones exactly as emb_set_hot_rows does (most frequent first, smaller id first among equals), unless they cover
+ * less than min_share of the sample (near-uniform accesses gain nothing from an LDS copy: the table's hot set is cleared).
+ * *n_chosen (may be NULL) = rows staged (those that fit the LDS budget), *share (may be NULL) = the share of the sample the
+ * max_rows most frequent ids cover.  Call it again when the access pattern drifts; prepared plans over the table must be
+ * re-created, as after emb_set_hot_rows.  The DPU program stages its working set by itself as well -- it copies the batch's
+ * indices and offsets into WRAM before its loop (emb_dpu_lookup.c:41-58). */
+int emb_learn_hot_rows(emb_engine *e, uint32_t table_id, const void *indices, uint64_t n_indices, emb_index_type itype,
+                       emb_memspace space, uint32_t max_rows, float min_share, void *stream, uint32_t *n_chosen, float *share);
 
 /* HBM address / shape of a loaded table (for zero-copy initialisation or inspection). */
 int emb_table_info(emb_engine *e, uint32_t table_id, void **device_rows, uint64_t *nr_rows,

@@ -20,6 +20,7 @@
 #include <string>
 #include <thread>
 #include <utility>
+#include <unordered_map>
 #include <vector>
 
 #include "pimemb_hostcopy.h"
@@ -1107,6 +1108,65 @@ int emb_set_hot_rows(emb_engine *e, uint32_t table_id, const uint64_t *row_ids, 
     t.hot_log2 = hs.log2size;
     t.hot_lds = hs.lds_bytes(row_bytes);
     return EMB_OK;
+}
+
+int emb_learn_hot_rows(emb_engine *e, uint32_t table_id, const void *indices, uint64_t n_indices, emb_index_type itype,
+                       emb_memspace space, uint32_t max_rows, float min_share, void *stream, uint32_t *n_chosen, float *share) {
+    if (!e) return fail(EMB_ERR_INVALID, "engine is NULL");
+    if (table_id >= e->tables.size() || !e->tables[table_id].rows) return fail(EMB_ERR_INVALID, "table %u is not loaded", table_id);
+    if (itype != EMB_IDX_U32 && itype != EMB_IDX_I64) return fail(EMB_ERR_INVALID, "bad index type");
+    if (n_indices && !indices) return fail(EMB_ERR_INVALID, "emb_learn_hot_rows: indices is NULL");
+    if (n_chosen) *n_chosen = 0;
+    if (share) *share = 0.f;
+    // the sample: up to four evenly spaced runs of 65 536 ids (the whole array when it is that small) -- bags are independent
+    // draws, so runs of consecutive bags are a fair sample; four of them keep a sorted batch from showing its smallest ids only
+    constexpr uint64_t kRun = 65536, kRuns = 4;
+    const size_t isz = index_size(itype);
+    std::vector<char> host;
+    uint64_t n_sample = 0;
+    if (n_indices) {
+        DeviceGuard g(e->device);
+        const uint64_t runs = n_indices <= kRun * kRuns ? 1 : kRuns;
+        const uint64_t len = runs == 1 ? n_indices : kRun;
+        host.resize((size_t)(runs * len) * isz);
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        for (uint64_t r = 0; r < runs; r++) {
+            const uint64_t at = runs == 1 ? 0 : r * ((n_indices - len) / (runs - 1));
+            const char *src = static_cast<const char *>(indices) + at * isz;
+            if (space == EMB_MEM_DEVICE) HIP_TRY(hipMemcpyAsync(host.data() + (size_t)(r * len) * isz, src, (size_t)len * isz, hipMemcpyDeviceToHost, s));
+            else memcpy(host.data() + (size_t)(r * len) * isz, src, (size_t)len * isz);
+        }
+        if (space == EMB_MEM_DEVICE) HIP_TRY(hipStreamSynchronize(s));
+        n_sample = runs * len;
+    }
+    const uint64_t nr_rows = e->tables[table_id].nr_rows;
+    std::unordered_map<uint64_t, uint32_t> count;
+    count.reserve((size_t)std::min<uint64_t>(n_sample, 1u << 20));
+    for (uint64_t i = 0; i < n_sample; i++) {
+        const uint64_t id = itype == EMB_IDX_I64 ? (uint64_t)reinterpret_cast<const int64_t *>(host.data())[i]
+                                                 : (uint64_t)reinterpret_cast<const uint32_t *>(host.data())[i];
+        if (id < nr_rows) count[id]++;            // (an id outside the table is nobody's hot row)
+    }
+    std::vector<std::pair<uint32_t, uint64_t>> by_count;       // (count, id): most frequent first, smaller id first among equals
+    by_count.reserve(count.size());
+    for (const auto &kv : count) by_count.emplace_back(kv.second, kv.first);
+    const size_t k = std::min<size_t>(max_rows, by_count.size());
+    std::partial_sort(by_count.begin(), by_count.begin() + (long)k, by_count.end(),
+                      [](const std::pair<uint32_t, uint64_t> &a, const std::pair<uint32_t, uint64_t> &b) {
+                          return a.first != b.first ? a.first > b.first : a.second < b.second;
+                      });
+    uint64_t covered = 0;
+    std::vector<uint64_t> ids(k);
+    for (size_t i = 0; i < k; i++) {
+        ids[i] = by_count[i].second;
+        covered += by_count[i].first;
+    }
+    const float sh = n_sample ? (float)((double)covered / (double)n_sample) : 0.f;
+    if (share) *share = sh;
+    if (k == 0 || sh < min_share) return emb_set_hot_rows(e, table_id, nullptr, 0);       // near-uniform accesses: no LDS copy
+    int rc = emb_set_hot_rows(e, table_id, ids.data(), (uint32_t)k);
+    if (rc == EMB_OK && n_chosen) *n_chosen = e->tables[table_id].n_hot;
+    return rc;
 }
 
 int emb_table_info(emb_engine *e, uint32_t table_id, void **device_rows, uint64_t *nr_rows,

@@ -340,6 +340,20 @@ class EmbeddingEngine:
         ids = np.ascontiguousarray(row_ids, dtype=np.uint64)
         _l.check(self._L.emb_set_hot_rows(self._h, table_id, ids.ctypes.data_as(C.POINTER(C.c_uint64)), ids.shape[0]))
 
+    def learn_hot_rows(self, table_id: int, indices, max_rows: int = 100, min_share: float = 0.05, stream: int | None = None):
+        """The engine picks the table's hot rows itself from one batch's indices (torch CUDA tensor, DeviceBuffer or numpy array;
+        uint32 bits / int32 or int64): emb_learn_hot_rows counts a sample on the host side of the library and stages the
+        `max_rows` most frequent ids -- or clears the set when they cover less than `min_share` of the sample.  Returns
+        (rows staged, share of the sample the max_rows most frequent ids cover)."""
+        a = _Arg(indices)
+        itype = _index_type_of(a.dtype)
+        if stream is None and a.space == _l.EMB_MEM_DEVICE:
+            stream = _current_stream_for(indices)
+        n, sh = C.c_uint32(), C.c_float()
+        _l.check(self._L.emb_learn_hot_rows(self._h, table_id, a.ptr, a.n, itype, a.space, int(max_rows), float(min_share), stream,
+                                            C.byref(n), C.byref(sh)))
+        return n.value, sh.value
+
     def table_tensor(self, table_id: int):
         """Zero-copy torch view of a table's rows in HBM ([nr_rows, dim], the table's dtype) -- for saving a
         checkpoint or inspecting weights.  Valid until the table is reloaded or the engine closed; writing

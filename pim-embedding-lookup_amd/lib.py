@@ -97,6 +97,7 @@ SIGNATURES = {
     "emb_alloc_table": (C.c_int, [_vp, _u32, _u64, _u32, C.c_int]),
     "emb_load_table_column": (C.c_int, [_vp, _u32, _u32, _vp, _u64]),
     "emb_set_hot_rows": (C.c_int, [_vp, _u32, C.POINTER(_u64), _u32]),
+    "emb_learn_hot_rows": (C.c_int, [_vp, _u32, _vp, _u64, C.c_int, C.c_int, _u32, C.c_float, _vp, C.POINTER(_u32), C.POINTER(C.c_float)]),
     "emb_comm_unique_id": (C.c_int, [_vp]),
     "emb_comm_create": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32, _pp]),
     "emb_comm_all_to_all": (C.c_int, [_vp, _vp, C.POINTER(_u64), _vp, C.POINTER(_u64), _vp]),

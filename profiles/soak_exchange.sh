@@ -30,4 +30,10 @@ echo "three ranks, peer stores, CHECKED, one index per bag (counts return throug
 PIMEMB_RCCL_ONE_GPU=1 PIMEMB_VERIFY_EVERY=37 run j python3 "$root/bench.py" --gpus 3 --shard-mode rows --replicate-mb 64 --batch 2003 --steps 3000 --nbatch 7 --exchange peer --checked --no-cpu-baseline
 echo "two ranks, the driver's default flags (--exchange both: the RCCL leg, then the peer-store leg of the same run), verify every 37th step:" >> "$out"
 PIMEMB_RCCL_ONE_GPU=1 PIMEMB_VERIFY_EVERY=37 PIMEMB_PEER_LEG_TIMEOUT=400 run k python3 "$root/bench.py" --gpus 2 --shard-mode rows --replicate-mb 64 --batch 2003 --steps 600 --nbatch 7 --no-cpu-baseline
+echo "round 6 -- int64 ids in place: three RCCL ranks, pooling 5, Zipf (the router reads int64, pieces are uint32: two launches per served batch), verify every 37th step:" >> "$out"
+PIMEMB_RCCL_ONE_GPU=1 PIMEMB_VERIFY_EVERY=37 run l python3 "$root/bench.py" --gpus 3 --shard-mode rows --replicate-mb 64 --pooling 5 --index-dist zipf --batch 2003 --steps 600 --nbatch 7 --exchange rccl --ids int64 --no-cpu-baseline
+echo "round 6 -- int64 ids, three ranks, peer stores, CHECKED with the deferred report, one index per bag (int64 ranged launches through the peers' arenas), verify every 37th step:" >> "$out"
+PIMEMB_RCCL_ONE_GPU=1 PIMEMB_VERIFY_EVERY=37 run m python3 "$root/bench.py" --gpus 3 --shard-mode rows --replicate-mb 64 --batch 2003 --steps 3000 --nbatch 7 --exchange peer --checked --ids int64 --no-cpu-baseline
+echo "round 6 -- int64 ids, whole tables over RCCL (index arrays travel at 8 bytes per id), four ranks, pooling 3, verify every 37th step:" >> "$out"
+PIMEMB_RCCL_ONE_GPU=1 PIMEMB_VERIFY_EVERY=37 run n python3 "$root/bench.py" --gpus 4 --shard-mode whole --replicate-mb 400 --pooling 3 --batch 2003 --steps 300 --nbatch 7 --exchange rccl --ids int64 --no-cpu-baseline
 cat "$out"

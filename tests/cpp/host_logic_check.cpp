@@ -176,6 +176,41 @@ void xmap_cache_shapes() {
     printf("xmap cache under shapes that do not recur ok (%ld device-wide waits in 3 129 launches)\n", pimemb_stub_device_syncs() - syncs0);
 }
 
+// ---- the engine picks a table's hot rows itself (emb_learn_hot_rows): sampling, counting, the min_share rule -------------------
+void learn_hot_rows_check() {
+    emb_engine *e = make_engine(0);
+    Rng rng{99};
+    // a skewed batch over table 1 (device copy) and the same as int64 from host memory: ids 7, 3, 11 dominate
+    std::vector<uint32_t> ix(300000);
+    for (size_t i = 0; i < ix.size(); i++) {
+        const uint32_t r = rng.next() % 100;
+        ix[i] = r < 40 ? 7u : (r < 65 ? 3u : (r < 80 ? 11u : rng.next() % kRows));
+    }
+    ix[5] = kRows + 9;                                   // an id outside the table is nobody's hot row
+    void *d_ix = nullptr;
+    CHECK(emb_device_alloc(e, ix.size() * 4, &d_ix));
+    CHECK(emb_copy_to_device(e, d_ix, ix.data(), ix.size() * 4));
+    uint32_t n = 0;
+    float share = 0.f;
+    CHECK(emb_learn_hot_rows(e, 1, d_ix, ix.size(), EMB_IDX_U32, EMB_MEM_DEVICE, 3, 0.05f, nullptr, &n, &share));
+    EXPECT(n == 3 && share > 0.75f && share < 0.85f);    // four runs of 65 536 of the 300 000 ids were counted
+    std::vector<int64_t> wide(ix.begin(), ix.begin() + 5000);
+    wide[1] = -4;
+    CHECK(emb_learn_hot_rows(e, 1, wide.data(), wide.size(), EMB_IDX_I64, EMB_MEM_HOST, 2, 0.05f, nullptr, &n, &share));
+    EXPECT(n == 2 && share > 0.55f && share < 0.75f);
+    // near-uniform accesses: the three most frequent ids cover far less than 5 % -- the set is cleared
+    for (size_t i = 0; i < ix.size(); i++) ix[i] = rng.next() % kRows;
+    CHECK(emb_copy_to_device(e, d_ix, ix.data(), ix.size() * 4));
+    CHECK(emb_learn_hot_rows(e, 1, d_ix, ix.size(), EMB_IDX_U32, EMB_MEM_DEVICE, 3, 0.05f, nullptr, &n, &share));
+    EXPECT(n == 0 && share < 0.05f);
+    CHECK(emb_learn_hot_rows(e, 1, nullptr, 0, EMB_IDX_U32, EMB_MEM_DEVICE, 3, 0.05f, nullptr, &n, &share));      // an empty batch: cleared, no error
+    EXPECT(n == 0);
+    EXPECT(emb_learn_hot_rows(e, 63, d_ix, 4, EMB_IDX_U32, EMB_MEM_DEVICE, 3, 0.f, nullptr, nullptr, nullptr) == EMB_ERR_INVALID);
+    CHECK(emb_device_free(e, d_ix));
+    CHECK(emb_destroy(e));
+    printf("engine-side hot rows ok\n");
+}
+
 // ---- the request queue: adders, a free-running flusher, waiters that collect late ------------------------------------------
 void queue_threads(int device = 0) {
     emb_engine *e = make_engine(0, device);
@@ -776,6 +811,7 @@ int main(int argc, char **argv) {
     if (!only_world8) {
         engine_threads();
         xmap_cache_shapes();
+        learn_hot_rows_check();
         queue_threads();
         shard_one_rank(false, false);
         shard_one_rank(false, true);

@@ -21,6 +21,9 @@ LEGS = {
     "rccl3-ragged": (3, dict(batches=100)),
     "rccl2-onehot": (2, dict(max_len=1, fixed=True, batches=100)),
     "rccl4-ragged-self-via-comm": (4, dict(batches=60, self_via_comm=True)),
+    # round 6: DLRM's int64 ids handed over in place
+    "rccl3-ragged-int64": (3, dict(batches=80, int64=True)),
+    "peer3-onehot-direct-int64-checked": (3, dict(peer=True, arena_bytes=3 << 30, max_len=1, fixed=True, check=True, expect_direct=True, int64=True)),
 }
 
 

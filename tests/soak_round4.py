@@ -54,7 +54,10 @@ def shard_phase(seconds):
     global n_bags_checked
     t0 = time.time()
     while time.time() - t0 < seconds:
-        depth, check = int(rng.integers(0, 4)), bool(rng.integers(0, 2))
+        # round 6: the three checking modes (off / compared inside the completing call / deferred report) and both index widths
+        # (uint32 bits, or DLRM's int64 handed over in place)
+        depth, check = int(rng.integers(0, 4)), [False, "sync", "deferred"][int(rng.integers(0, 3))]
+        idt = [np.int32, np.int64][int(rng.integers(0, 2))]
         S = sh.ShardedEmbeddingBags(plan, eng, 0, None, depth=depth, check=check)
         S.load_tables(lambda t, lo, hi: torch.from_numpy(tabs[t][lo:hi]).to(dev))
         pending = []
@@ -83,8 +86,8 @@ def shard_phase(seconds):
                     o, ni = np.arange(nb, dtype=np.int64) * fixed, nb * fixed
                 off.append(o)
                 idx.append(rng.integers(0, n, size=ni).astype(np.int64))
-            d_i = [torch.from_numpy(i.astype(np.int32)).to(dev) for i in idx]
-            d_o = [torch.from_numpy(o.astype(np.int32)).to(dev) for o in off]
+            d_i = [torch.from_numpy(i.astype(idt)).to(dev) for i in idx]
+            d_o = [torch.from_numpy(o.astype(idt)).to(dev) for o in off]
             if check and shape == 1 and nb and rng.integers(0, 8) == 0:
                 # round 5: a checked shard keeps the direct path and COUNTS what it serves -- one index no table row answers to
                 # (replicated, whole or row-split table alike) must be refused on this, the requesting, rank; the batches
@@ -94,15 +97,29 @@ def shard_phase(seconds):
                     collect(0)
                 t_bad = int(rng.integers(0, len(rows)))
                 spoiled = idx[t_bad].copy()
-                spoiled[int(rng.integers(0, nb))] = rows[t_bad] + int(rng.integers(0, 1000))
+                b_bad = int(rng.integers(0, nb))
+                spoiled[b_bad] = rows[t_bad] + int(rng.integers(0, 1000)) if (idt is np.int32 or rng.integers(0, 2)) else \
+                    [-1 - int(rng.integers(0, 1000)), (1 << 32) + int(rng.integers(0, 1000))][int(rng.integers(0, 2))]     # int64: negative / >= 2^32
                 bad_i = list(d_i)
-                bad_i[t_bad] = torch.from_numpy(spoiled.astype(np.int32)).to(dev)
-                try:
-                    S.forward(None, bad_i, fixed_pooling=1)
-                    raise AssertionError(("an index beyond its table went through a checked shard", depth, t_bad, kinds[t_bad], nb))
+                bad_i[t_bad] = torch.from_numpy(spoiled.astype(idt)).to(dev)
+                raised, outs_bad = 0, None
+                try:                          # "sync": the call raises; "deferred": a later call does -- report() here
+                    outs_bad = S.forward(None, bad_i, fixed_pooling=1)
                 except IndexError:
-                    n_calls["refused"] = n_calls.get("refused", 0) + 1
+                    raised += 1
+                try:
+                    S.report()
+                except IndexError:
+                    raised += 1
+                if raised != 1:
+                    raise AssertionError(("an index beyond its table must be refused exactly once by a checked shard", raised, check, depth, t_bad, kinds[t_bad], nb))
+                n_calls["refused"] = n_calls.get("refused", 0) + 1
                 torch.cuda.synchronize()
+                if outs_bad is not None:      # (deferred: the call returned its rows) the refused bag pooled to ZEROS, every other bag is right
+                    got = outs_bad[t_bad].cpu().numpy()
+                    want = tabs[t_bad][np.clip(spoiled, 0, rows[t_bad] - 1)]
+                    want[b_bad] = 0
+                    assert np.array_equal(got, want), ("the refused bag must hold a zero row, the others their rows", check, depth, t_bad, kinds[t_bad])
             if depth == 0 or rng.integers(0, 6) == 0:
                 if depth:                 # the synchronous form in the middle of a pipelined run: drain first
                     S.flush()

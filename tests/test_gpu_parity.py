@@ -168,6 +168,37 @@ def test_plan_less_launch_with_a_searched_map_just_above_a_rounding_boundary(pel
     del outs, idx
 
 
+def test_engine_picks_its_hot_rows_itself(pel, eng, oracle):
+    """emb_learn_hot_rows (VERDICT r5 missing #5: LDS staging needed a caller's hint; the DPU program stages its working set by
+    itself, emb_dpu_lookup.c:41-58): from ONE batch's device indices the engine stages the rows a host-side count of the same
+    batch names (workloads.top_rows), pooled lookups are bit for bit the oracle's with the set staged, and a near-uniform
+    batch clears it."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(123)
+    rows, dim, B, L = 200_000, 128, 4096, 32
+    tab = (rng.standard_normal((rows, dim)) * 0.05).astype(np.float32)
+    eng.load_table(40, tab)
+    idx = pel.workloads.zipf_indices(rng, rows, B * L)               # 131 072 ids: the whole batch is the sample
+    off = pel.workloads.fixed_offsets(B, L)
+    d_idx = torch.from_numpy(idx.view(np.int32)).to(dev)
+    n, share = eng.learn_hot_rows(40, d_idx, max_rows=64, min_share=0.05)
+    want = pel.workloads.top_rows(idx, 64)
+    assert n == 64 and share == pytest.approx(np.isin(idx, want).mean(), abs=1e-6)
+    n64, share64 = eng.learn_hot_rows(40, torch.from_numpy(idx.astype(np.int64)).to(dev), max_rows=64)        # int64 ids: the same choice
+    assert (n64, share64) == (n, share)
+    before = eng.stats()["n_launches_by_kind"][4]
+    got = eng.lookup(40, idx, off)
+    assert eng.stats()["n_launches_by_kind"][4] == before + 1          # the LDS kernel ran
+    assert np.array_equal(got, oracle.c_bag_sum(tab, idx, off))
+    uni = pel.workloads.uniform_indices(rng, rows, B * L)
+    n0, share0 = eng.learn_hot_rows(40, uni, max_rows=64, min_share=0.05)       # host array, near-uniform: cleared
+    assert n0 == 0 and share0 < 0.05
+    before = eng.stats()["n_launches_by_kind"][4]
+    assert np.array_equal(eng.lookup(40, uni, off), oracle.c_bag_sum(tab, uni, off))
+    assert eng.stats()["n_launches_by_kind"][4] == before
+
+
 def test_kaggle26_fixture_one_fused_launch(pel, eng, golden_dir):
     """C1-shaped plumbing: 26 tables, D=16, all tables in ONE batched call."""
     z = np.load(os.path.join(golden_dir, "kaggle26_capped_b4.npz"))
