@@ -138,6 +138,7 @@ struct Batch {
     DevBuf chk_ctr;                     // HBM counters [N][Kr + M] (source p: its row-split tables, then the whole tables owned here) + [R] replicated
     unsigned long long *chk_host = nullptr;    // pinned, one self-describing word (tag << 32 | count) per entry: [R] replicated | [Kr + M] what this rank served ITSELF
     bool rep_counted = false, self_published = false;
+    bool lazy_unpublished = false;      // deferred report: some of this batch's counters wait in emb_shard::lazy_segs for the next shared publish kernel
     // optional kernel timing (emb_shard_set_kernel_timing): start / stop around R, L, S, U
     hipEvent_t tev[10] = {};
     bool timed[5] = {false, false, false, false, false}, harvest = false;
@@ -201,6 +202,11 @@ struct emb_shard {
     std::vector<uint32_t *> desc_ctr, local_ctr, rdesc_ctr;
     // ... and the width of each descriptor's index array (routed pieces are uint32 local row ids whatever the caller's width)
     std::vector<uint32_t> desc_it, local_it, rdesc_it;
+    // EMB_SHARD_DEFER_REPORT with no peer-store peer: the counters of a counted launch go to this rank's own pinned words only, and
+    // nobody waits for them inside the call -- so they are not published by a kernel of their own behind every lookup (+4.7 us on a
+    // 62-us step) but collected here and carried by ONE kernel every second submit (and before anything that waits for them)
+    std::vector<pimemb::ServedSeg> lazy_segs;
+    uint32_t lazy_age = 0;
     uint32_t refused = 0;                            // bit w: a validating launch over descriptors of index width w found something and
                                                      // gathered NOTHING (fused_lookup_one; its outputs were zeroed) -- the caller says whose batch that was
     uint32_t max_whole = 0;                          // most whole tables on one owner: the served counts' tail of a mailbox is Kr + max_whole words
@@ -421,11 +427,14 @@ int fused_lookup(emb_shard *s, Batch &b, bool cacheable, bool ranged = false) {
     return rc;
 }
 
+int publish_lazy(emb_shard *s);
+
 // ---- R(b) + counts out + L(b) -------------------------------------------------------------------------------------
 int stage_route(emb_shard *s, Batch &b) {
     const uint32_t N = (uint32_t)s->N, Kr = s->Kr, M = s->M;
     g_hp.start();
     b.req_recorded = b.ret_recorded = b.out_recorded = false;
+    if (b.lazy_unpublished) EMB_TRY(publish_lazy(s));       // (never reached: submit has collected this slot's previous occupant; the counters must be zero before new adds)
     b.deferred_rc = EMB_OK;
     b.reported = b.check_pending = false;
     b.rep_counted = b.self_published = false;
@@ -608,6 +617,32 @@ int stage_route(emb_shard *s, Batch &b) {
     return EMB_OK;
 }
 
+// Carry every collected counter segment to its words with ONE kernel on the caller's stream (see emb_shard::lazy_segs).
+int publish_lazy(emb_shard *s) {
+    s->lazy_age = 0;
+    if (s->lazy_segs.empty()) return EMB_OK;
+    for (size_t at = 0; at < s->lazy_segs.size(); at += pimemb::kServedSegs) {
+        pimemb::ServedArgs sa{};
+        for (size_t i = at; i < s->lazy_segs.size() && sa.n_seg < pimemb::kServedSegs; i++) sa.seg[sa.n_seg++] = s->lazy_segs[i];
+        HIP_TRY(pimemb::launch_served_counts(sa, s->cs));
+    }
+    s->lazy_segs.clear();
+    for (Batch &b : s->ring) b.lazy_unpublished = false;
+    return EMB_OK;
+}
+
+// The served counters of a counted launch -> whoever asked.  Segments that raise no peer's "served" word and are read by this rank
+// alone may wait for the shared publish kernel (deferred report); everything else is published behind the launch, as before.
+int publish_served(emb_shard *s, const pimemb::ServedArgs &sa, Batch *owners[2]) {
+    bool lazy = s->defer_report && sa.n_flag == 0;
+    for (uint32_t p = 0; p < (uint32_t)s->N && lazy; p++) lazy = via(s, (int)p) != PEER;
+    if (!lazy) return pimemb::launch_served_counts(sa, s->cs) == hipSuccess ? EMB_OK : fail(EMB_ERR_DEVICE, "emb_shard: the served-counts kernel could not be enqueued");
+    for (uint32_t i = 0; i < sa.n_seg; i++) s->lazy_segs.push_back(sa.seg[i]);
+    for (int k = 0; k < 2; k++)
+        if (owners[k]) owners[k]->lazy_unpublished = true;
+    return EMB_OK;
+}
+
 // L(b) on its own (no older batch is served in this call: the pipeline is filling, or depth 0 / flush order).
 int launch_local(emb_shard *s) {
     if (s->local.empty()) return EMB_OK;
@@ -634,7 +669,8 @@ int launch_local(emb_shard *s) {
     if (counted) {
         pimemb::ServedArgs sa{};
         sa.seg[sa.n_seg++] = pimemb::ServedSeg{ctr_rep(s, b, 0), b.chk_host, (uint32_t)s->descs.size(), 0u, served_tag(s, b.seq), 0u};
-        HIP_TRY(pimemb::launch_served_counts(sa, s->cs));
+        Batch *owners[2] = {&b, nullptr};
+        EMB_TRY(publish_served(s, sa, owners));
         b.rep_counted = true;
     }
     return EMB_OK;
@@ -1013,7 +1049,8 @@ int stage_serve(emb_shard *s, Batch &b) {
             }
             sa.seg[sa.n_seg++] = pimemb::ServedSeg{ctr_of(s, b, p, 0), dst, n_counted, Kr + M - n_counted, served_tag(s, b.seq), 0u};
         }
-        HIP_TRY(pimemb::launch_served_counts(sa, s->cs));
+        Batch *owners[2] = {&b, (one_launch && n_local_descs) ? local_batch : nullptr};
+        EMB_TRY(publish_served(s, sa, owners));
     } else if (s->peer_mode) {        // behind the lookup (its kernel boundary completes the stores into the peers' HBM): "served"
         pimemb::PeerDoneArgs da{};
         for (uint32_t p = 0; p < N; p++)
@@ -1190,6 +1227,7 @@ int collect_pending(emb_shard *s, bool wait = true, uint64_t only = ~0ull, uint6
     int deferred = EMB_OK;
     for (Batch &b : s->ring) {
         if (!b.check_pending || b.stage != DONE || (only != ~0ull && b.seq != only)) continue;
+        if ((wait || b.seq == must) && b.lazy_unpublished) EMB_TRY(publish_lazy(s));       // (about to be waited for: its counters must be on their way)
         const int rc = check_served_counts(s, b, wait || b.seq == must);
         if (rc == kNotReady) continue;
         b.check_pending = false;
@@ -1440,6 +1478,10 @@ int emb_shard_submit(emb_shard *s, const emb_shard_input *in, uint64_t n_bags, v
     s->next_seq++;
     if (seq) *seq = b.seq;
     rc = advance(s, kLag[s->depth], false);
+    if (!s->lazy_segs.empty() && ++s->lazy_age >= 2 && (rc == EMB_OK || rc == EMB_ERR_RANGE)) {     // one publish kernel per two batches
+        const int rc2 = publish_lazy(s);
+        if (rc2 != EMB_OK) rc = rc2;
+    }
     s->st.us_host_submit += now_us() - t0;
     if (rc == EMB_OK) rc = rc_prev;
     return rc == EMB_ERR_RANGE ? range_error(s) : rc;
@@ -1560,6 +1602,10 @@ int emb_shard_destroy(emb_shard *s) {
     if (s->cs_known) (void)hipStreamSynchronize(s->cs);
     if (s->s_comm) (void)hipStreamSynchronize(s->s_comm);
     (void)hipGetLastError();
+    if (s->defer_report && s->cs_known) {
+        (void)publish_lazy(s);
+        (void)hipStreamSynchronize(s->cs);
+    }
     if (s->defer_report && collect_pending(s) == EMB_ERR_RANGE)      // a finding nobody collected: never lost silently
         fprintf(stderr, "[pimemb] emb_shard_destroy: an uncollected report: %s\n", s->range_msg[0] ? s->range_msg : "a batch named rows no rank holds");
     for (emb_shard::CachedPlan &c : s->plans)
