@@ -546,6 +546,10 @@ bag_sum_anydim_vec_kernel(const DevDesc *__restrict__ descs, uint32_t dim, uint3
     }
 }
 
+#ifndef PIMEMB_LPR64_ONEHOT_INFLIGHT
+#define PIMEMB_LPR64_ONEHOT_INFLIGHT 8
+#endif
+
 // ---- v2: wave batches of 64 bags, coalesced bounds, shuffle-distributed, one-hot fast path -------
 // RANGED (the sharded lookup's direct path, pimemb_shard.cpp): one index per bag, and a descriptor serves only the bags
 // whose row falls into [row_lo, row_lo + nr_rows) (row_lo in DevDesc::pad_[0]): out[b] = W[idx[b] - row_lo]; the other bags
@@ -563,7 +567,10 @@ bag_sum_wavebatch_kernel(const DevDesc *__restrict__ descs, uint32_t chunks_arg,
     constexpr uint32_t ROUNDS = LPR;        // rounds per 64-bag wave batch
     constexpr uint32_t NB = Cfg::kBatches;  // wave batches per step
     constexpr int U = Cfg::kUnroll;
-    constexpr uint32_t RU = (ROUNDS < (uint32_t)Cfg::kOneHot) ? ROUNDS : (uint32_t)Cfg::kOneHot;
+    // (1-KiB rows, LPR = 64: eight rounds in flight = 8 KiB per wavefront and two registers more than the 64-VGPR cap of the
+    // fp32 configurations holds -- 12 bytes of scratch per lane; PIMEMB_LPR64_ONEHOT_INFLIGHT picks the depth for that row width)
+    constexpr uint32_t kInFlight = (LPR == 64) ? (uint32_t)PIMEMB_LPR64_ONEHOT_INFLIGHT : (uint32_t)Cfg::kOneHot;
+    constexpr uint32_t RU = (ROUNDS < kInFlight) ? ROUNDS : kInFlight;
 
     uint32_t desc_i, tile;
     if (!decode_block(xmap, chunks_arg & kXmapDirect, &desc_i, &tile)) return;
