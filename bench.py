@@ -299,6 +299,8 @@ def unique_line_bytes(batch, row_bytes, line=128):
 
 
 L1_TA_PEAK_GBS = 64 * 256 * 2.4      # MI355X_MICROARCH.md: a CU's vector L1 / texture-address path delivers 64 B/clk; 256 CUs, ~2.4 GHz
+HBM_SUSTAINED_FRAC = 0.70            # MI355X_MICROARCH.md "HBM" / "Indexed rows": ~6.3 TB/s streaming, 5.5-5.8 TB/s for random rows fetched
+                                     # once, of the 8 TB/s spec: a launch whose MEASURED HBM-side rate is there is HBM-bound, whatever else is busy
 LAUNCH_FLOOR_US = 2.7                # an empty kernel of the same grid, back to back on one stream (2.5-2.9 us)
 
 
@@ -307,8 +309,11 @@ def binding_roof(r, entry, alg_read_bytes, kernel_us):
     quoted against (round 5 printed bound "hbm" with frac 2.53 for the cache-served C3 launch).  Candidates, each as a fraction
     of its own peak: `hbm` -- the MEASURED HBM-side bytes against 8 TB/s; `l2` -- the L2's requests x 128 B against 34.5 TB/s;
     `l1_ta` -- the texture-address / vector-L1 path: its own busy counter (TA_BUSY_avr / kernel cycles) where the profile has one,
-    else the bytes the lanes were handed against 64 B/clk/CU; `launch` -- an empty kernel of the same grid takes ~2.7 us.  The
-    largest one binds.  Without a counter profile only `launch` and the algorithmic HBM figure exist: a fraction above 1 is then
+    else the bytes the lanes were handed against 64 B/clk/CU; `launch` -- an empty kernel of the same grid takes ~2.7 us.  A
+    launch whose measured HBM-side rate has reached what this chip sustains for gathered rows (>= 0.70 of the 8 TB/s spec: 5.6 TB/s)
+    is HBM-bound whatever else is busy -- the TA's busy counter says that requests are in flight, not that it is the limit: the
+    uniform C3 launch shows TA busy 0.85 at 5.86 TB/s of HBM traffic, and its pace is the HBM's -- otherwise the
+    largest fraction binds.  Without a counter profile only `launch` and the algorithmic HBM figure exist: a fraction above 1 is then
     marked as unattributed, never printed as a utilisation."""
     t = kernel_us * 1e-6
     cand = {}
@@ -327,7 +332,7 @@ def binding_roof(r, entry, alg_read_bytes, kernel_us):
         r["binding"], r["frac_binding"] = None, None
         r["binding_note"] = "cache-served (algorithmic frac > 1) and no counter profile of this exact command: the binding roof is not attributed"
         return
-    name = max(cand, key=lambda k: cand[k][0])
+    name = "hbm" if r.get("frac_measured") is not None and r["frac_measured"] >= HBM_SUSTAINED_FRAC else max(cand, key=lambda k: cand[k][0])
     frac, ach, peak, basis = cand[name]
     r["binding"], r["frac_binding"], r["binding_basis"] = name, frac, basis
     if peak is not None:

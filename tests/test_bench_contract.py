@@ -194,6 +194,11 @@ def test_roofline_object_names_the_roof_that_binds():
     assert r3["binding"] == "l1_ta" and abs(r3["frac_binding"] - 0.86) < 1e-9 and r3["ta_busy"] == 0.86
     assert abs(r3["binding_peak"] - 64 * 256 * 2.4) < 1e-6 and "TA_BUSY" in r3["binding_basis"] and "binding" in r3["basis"]
     assert set(r3["roofs"]) == {"hbm", "l2", "l1_ta", "launch"} and all(0 <= v <= 1 for v in r3["roofs"].values())
+    # c3 with uniform indices: TA busy 0.85 as well -- but 13.4 GB of HBM-side traffic in 2.29 ms = 5.86 TB/s = 0.73 of the spec, which is
+    # what this chip sustains for gathered rows: the HBM binds (the busy counter says requests are in flight, not that the TA is the limit)
+    r3u = bench.roofline_object(13_390_000_000, 2288.0, dict(traffic_bytes_per_launch=13_402_323_942, read_bytes=12_999_670_758, source="x", tcc_hit=3_000_000,
+                                                            tcc_miss=101_000_000, ta_busy_frac=0.85), None, alg_read_bytes=12_987_000_000)
+    assert r3u["binding"] == "hbm" and 0.72 < r3u["frac_binding"] < 0.75 and r3u["roofs"]["l1_ta"] == 0.85
     # the same entry without a TA counter: the bytes the lanes were handed against 64 B/clk/CU (0.49) -- HBM (0.59) then binds
     r3b = bench.roofline_object(13_390_000_000, 668.0, dict(traffic_bytes_per_launch=3_170_800_000, read_bytes=2_768_000_000, source="x", tcc_hit=40_428_845,
                                                            tcc_miss=24_771_780), None, alg_read_bytes=12_987_000_000)
