@@ -211,22 +211,46 @@ def launch_identity(plan=None, lib_path=None):
     return out
 
 
-def shard_identity(lib_path=None):
+def _demangled_symbols(hashes):
+    """{demangled name: mangled symbol} of the library's kernels (c++filt: binutils, on this image and on the GPU boxes), or None."""
+    import subprocess
+    syms = sorted(hashes)
+    try:
+        out = subprocess.run(["c++filt"], input="\n".join(syms), capture_output=True, text=True, timeout=30)
+        names = out.stdout.splitlines()
+        return dict(zip(names, syms)) if out.returncode == 0 and len(names) == len(syms) else None
+    except (OSError, subprocess.SubprocessError):
+        return None
+
+
+def shard_identity(kernel_names=None, lib_path=None):
     """What a dist-* entry (the sharded step at world 1: several kernels, launched by pimemb_shard.cpp) is tied to: one sha256 over
-    the code of every kernel of the families the step runs, and the sha256 of pimemb_shard.cpp."""
+    the code of the kernels the profiled step RAN -- `kernel_names`: their demangled names as rocprofv3's kernel trace lists them
+    (the entry keeps the list) -- and the sha256 of pimemb_shard.cpp.  Without names (or without c++filt): over every kernel of the
+    families a sharded step can run, which also moves when an instantiation the step never launches changes."""
     import hashlib
     from importlib import import_module
     codeobj = import_module("pim-embedding-lookup_amd.codeobj")
     hashes = codeobj.kernel_hashes(lib_path or _pkg_path("lib", "libpimemb.so"))
+    picked, basis = None, "families"
+    if kernel_names:
+        by_name = _demangled_symbols(hashes)
+        if by_name is not None:
+            norm = lambda n: n.replace(" ", "")
+            table = {norm(k): v for k, v in by_name.items()}
+            found = [table.get(norm(n)) for n in kernel_names]
+            if all(found):
+                picked, basis = sorted(found), "kernels of the profiled step"
+    if picked is None:
+        picked = sorted(sym for sym in hashes if any(f in sym for f in SHARD_KERNEL_FAMILIES))
     h = hashlib.sha256()
-    for sym in sorted(hashes):
-        if any(f in sym for f in SHARD_KERNEL_FAMILIES):
-            h.update(sym.encode() + b"\0" + hashes[sym].encode())
+    for sym in picked:
+        h.update(sym.encode() + b"\0" + hashes[sym].encode())
     hs = hashlib.sha256()
     for name in SHARD_SOURCES:
         with open(_pkg_path("csrc", name), "rb") as f:
             hs.update(name.encode() + b"\0" + f.read())
-    return {"shard_kernels_sha256": h.hexdigest(), "shard_src_sha256": hs.hexdigest()}
+    return {"shard_kernels_sha256": h.hexdigest(), "shard_src_sha256": hs.hexdigest(), "shard_kernels_basis": basis, "shard_kernels_hashed": len(picked)}
 
 
 def traffic_entry_status(entry, kernel_name=None, ident=None, launch=None):
@@ -273,6 +297,8 @@ def measured_traffic(key, kernel_name=None, launch=None):
         return None
     if entry is None:
         return None
+    if callable(launch):          # (a sharded entry names the kernels its step ran: the identity is computed over those)
+        launch = launch(entry)
     why = traffic_entry_status(entry, kernel_name, launch=launch)
     return entry if why is None else {"dropped": why, "source": entry.get("source")}
 

@@ -546,8 +546,12 @@ bag_sum_anydim_vec_kernel(const DevDesc *__restrict__ descs, uint32_t dim, uint3
     }
 }
 
+// Rounds of the one-hot fast path a wavefront keeps in flight for 1-KiB rows (LPR = 64: one bag per round).  Eight -- what every
+// narrower row width uses -- needs two registers more than the 64-VGPR cap holds there (12 bytes of scratch per lane); four leaves one.
+// 26 Kaggle-sized tables, dim 256 fp32, B = 39 292, us per launch (tools/wide_row_onehot_probe.py, profiles/r06/wide_rows_*.log):
+// 8 in flight 270.4, 4 in flight 257.0-259.6 (-4 %), 2 in flight 267.4; dim 128 (LPR = 32, untouched) 122.6-125.2 in the same runs.
 #ifndef PIMEMB_LPR64_ONEHOT_INFLIGHT
-#define PIMEMB_LPR64_ONEHOT_INFLIGHT 8
+#define PIMEMB_LPR64_ONEHOT_INFLIGHT 4
 #endif
 
 // ---- v2: wave batches of 64 bags, coalesced bounds, shuffle-distributed, one-hot fast path -------

@@ -536,7 +536,7 @@ def sharded_traffic_entry(args, mode, world, direct=False):
         key += "-direct"
     try:
         import bench
-        return bench.measured_traffic(key, "bag_sum", bench.shard_identity())
+        return bench.measured_traffic(key, "bag_sum", lambda e: bench.shard_identity(e.get("shard_kernel_names")))
     except Exception:  # noqa: BLE001
         return None
 

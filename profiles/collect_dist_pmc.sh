@@ -27,6 +27,10 @@ for counters in "FETCH_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RD
 done
 cp "$scratch/pmc1.json" "$out/${key}_bench_under_pmc.json"
 python3 "$root/profiles/pmc_by_kernel.py" "$scratch" lookup=bag_sum "router=route_bags_,route_onehot_,!unroute" unrouter=unroute_bags > "$out/${key}_pmc_summary.txt"
-(cd "$root" && python3 -c "import json, bench; print(json.dumps(dict(bench.library_identity(), **bench.shard_identity(), **bench.launch_identity())))") > "$out/${key}_identity.json"
+# what the entry is tied to: the code of the library's kernels the kernel trace of THIS step lists + pimemb_shard.cpp
+(cd "$root" && python3 -c "
+import csv, json, sys, bench
+names = sorted({r['Name'] for r in csv.DictReader(open(sys.argv[1])) if 'pimemb::' in r['Name']})
+print(json.dumps(dict(bench.library_identity(), **bench.shard_identity(names), **bench.launch_identity(), shard_kernel_names=names)))" "$out/${key}_kernel_stats.csv") > "$out/${key}_identity.json"
 rm -rf "$scratch"
 echo "== $key"; grep -E "bag_sum|route" "$out/${key}_kernel_stats.csv" | cut -c1-160 | head -8; true || head -8 "$out/${key}_kernel_stats.csv" | cut -c1-200; cat "$out/${key}_pmc_summary.txt"

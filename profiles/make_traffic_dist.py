@@ -60,7 +60,7 @@ for key in keys:
     if e is None:
         print(f"{key}: no lookup counters in {src}", file=sys.stderr)
         continue
-    for k in ("shard_kernels_sha256", "shard_src_sha256", "device_code_sha256"):       # round 6: what a dist-* entry is tied to
+    for k in ("shard_kernels_sha256", "shard_src_sha256", "device_code_sha256", "shard_kernel_names", "shard_kernels_basis"):       # round 6: what a dist-* entry is tied to
         if ident.get(k):
             e[k] = ident[k]
     e.update({"round": rnd, "source": f"profiles/{src}", "lib_sha256": ident.get("lib_sha256"), "src_sha256": ident.get("src_sha256"),
