@@ -588,9 +588,9 @@ typedef struct emb_shard_input {      /* one per table, in table order */
 #define EMB_SHARD_NO_DIRECT 8u      /* never take the direct path for one-index-per-bag row-split tables (below): always route */
 #define EMB_SHARD_DEFER_REPORT 16u  /* with EMB_SHARD_CHECK_SERVED: what the REQUESTING rank learns from the served counts of batch b is
                                       compared -- and a shortfall reported -- by a LATER call instead of inside the call that completes
-                                      batch b: by the first emb_shard_submit / _lookup that finds b's counts arrived (it only looks,
-                                      never waits; at the latest the submit that recycles b's slot, six batches on), by emb_shard_wait
-                                      for b, by an emb_shard_flush the caller makes, or by emb_shard_report.  The call that completes a
+                                      batch b: by the first emb_shard_submit / _lookup / emb_shard_wait(b) that finds b's counts arrived (they
+                                      only look, never wait; at the latest the submit that recycles b's slot, six batches on), by an
+                                      emb_shard_flush the caller makes, or by emb_shard_report (these two wait for the counts).  The call that completes a
                                       batch then never waits for the GPU: without the flag the synchronous emb_shard_lookup polls the
                                       counts its own launch is still producing (59 -> 73 us per call on the C4 share,
                                       profiles/r05/dist_world1.md).  The error names the batch it belongs to; unserved bags hold zero

@@ -339,9 +339,15 @@ __device__ __forceinline__ uint32_t route_local(uint64_t r, uint64_t lo) {
 // per load; int64 arrays: one by one (8 bytes each, consecutive: the same lines).
 template <class F>
 __device__ __forceinline__ void route_for_each(const RouteBagTable &t, uint32_t idx64, uint64_t p, uint64_t e, F &&f) {
-    if (idx64) {
+    if (idx64) {           // two ids per 16-byte load (torch's arrays are 8-byte aligned: up to the next 16-byte boundary one by one)
         const int64_t *ix = static_cast<const int64_t *>(t.indices);
-#pragma unroll 4
+        typedef int64_t i64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+        for (; p < e && (p & 1u); p++) f((uint64_t)ix[p]);
+        for (; p + 2 <= e; p += 2) {
+            const i64x2_a8 r2 = *reinterpret_cast<const i64x2_a8 *>(ix + p);
+            f((uint64_t)r2[0]);
+            f((uint64_t)r2[1]);
+        }
         for (; p < e; p++) f((uint64_t)ix[p]);
         return;
     }

@@ -1521,8 +1521,12 @@ int wait_impl(emb_shard *s, uint64_t seq, void *stream, bool collect) {
         }
         HIP_TRY(hipStreamWaitEvent(other, b.ev_out, 0));
     }
-    if (collect && b.check_pending) {           // a deferred report: the caller is about to consume this batch -- say now what its counts said
-        const int rc = collect_pending(s, /*wait=*/true, seq);
+    if (collect && b.check_pending) {           // a deferred report: the caller is about to consume this batch -- say what its counts said IF they
+        // have arrived.  Only a look: emb_shard_wait orders a stream, it must not make the HOST wait for the GPU (the first version
+        // did, and a pipelined loop that calls wait(b) every step ran behind its own publish kernels: 63.9 us per step against 61.0
+        // with the comparison inside the call, profiles/r06/dist_world1_wait_blocks.md) -- a finding not yet visible surfaces at a
+        // later submit, the caller's flush, or emb_shard_report
+        const int rc = collect_pending(s, /*wait=*/false, seq);
         return rc == EMB_ERR_RANGE ? range_error(s) : rc;
     }
     return EMB_OK;

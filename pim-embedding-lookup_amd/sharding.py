@@ -241,8 +241,8 @@ class ShardedEmbeddingBags:
     serves first and the SERVING rank raises IndexError after the batch has gone through all its stages -- nobody is left in a
     transfer.  One-index batches on the direct path: every launch counts the bags it serves and the REQUESTING rank compares.
     Either way an offending bag pools to a ZERO row.  When the requester's comparison is made:
-      check=True / "deferred"  by a LATER forward / submit -- the first one that finds the batch's counts arrived (it only
-                               looks, never waits) -- or by wait(seq), flush(), report(), close(): the call that completes a
+      check=True / "deferred"  by a LATER forward / submit / wait(seq) -- the first one that finds the batch's counts arrived
+                               (they only look, never wait) -- or by flush(), report(), close(): the call that completes a
                                batch never waits for the GPU (the default: an IndexError arrives a call or a few late, like a
                                device-side assert of torch's own CUDA EmbeddingBag, and names its batch);
       check="sync"             inside the call that completes the batch (forward() then waits for its own launch: +13 us on a

@@ -32,9 +32,17 @@ run c4_rows_L1_direct_checked --workload c4 --rows-scale 0.125 --pooling 1 --rep
 PIMEMB_SHARD_DEPTH=0 run c4_rows_L1_direct_checked_depth0 --workload c4 --rows-scale 0.125 --pooling 1 --replicate-mb 64 --steps 400 --warmup 40 --checked
 PIMEMB_SHARD_DIRECT=0 run c4_rows_L1_routed_checked --workload c4 --rows-scale 0.125 --pooling 1 --replicate-mb 64 --steps 400 --warmup 40 --checked
 run c4_rows_L1_peer_checked --workload c4 --rows-scale 0.125 --pooling 1 --replicate-mb 64 --steps 400 --warmup 40 --exchange peer --checked
+# round 6: (a) the comparison INSIDE the completing call, as round 5 had it (PIMEMB_BENCH_CHECK=sync), next to the deferred report the
+# --checked legs above now run; (b) DLRM's int64 ids handed over in place (--ids int64): direct, routed, checked
+PIMEMB_BENCH_CHECK=sync run c4_rows_L1_direct_checked_sync --workload c4 --rows-scale 0.125 --pooling 1 --replicate-mb 64 --steps 400 --warmup 40 --checked
+PIMEMB_BENCH_CHECK=sync PIMEMB_SHARD_DEPTH=0 run c4_rows_L1_direct_checked_sync_depth0 --workload c4 --rows-scale 0.125 --pooling 1 --replicate-mb 64 --steps 400 --warmup 40 --checked
+run c4_rows_L1_direct_int64 --workload c4 --rows-scale 0.125 --pooling 1 --replicate-mb 64 --steps 400 --warmup 40 --ids int64
+run c4_rows_L1_direct_int64_checked --workload c4 --rows-scale 0.125 --pooling 1 --replicate-mb 64 --steps 400 --warmup 40 --ids int64 --checked
+PIMEMB_SHARD_DIRECT=0 run c4_rows_L1_routed_int64 --workload c4 --rows-scale 0.125 --pooling 1 --replicate-mb 64 --steps 400 --warmup 40 --ids int64
+PIMEMB_SHARD_DIRECT=0 run c4_rows_L32_int64 --workload c4 --rows-scale 0.125 --pooling 32 --replicate-mb 64 --steps 200 --warmup 20 --ids int64
 # the same two direct legs with the loop's consumer on a SECOND stream (emb_shard_wait then records an event between two
 # kernels of the caller's stream every step: the cost of that hand-over, whatever the sharding does)
 PIMEMB_BENCH_CONSUMER=other run c2_rows_direct_other_stream --shard-mode rows --replicate-mb 64 --steps 400 --warmup 40
 PIMEMB_BENCH_CONSUMER=other run c4_rows_L1_direct_other_stream --workload c4 --rows-scale 0.125 --pooling 1 --replicate-mb 64 --steps 400 --warmup 40
-python3 "$root/profiles/summarize_dist_world1.py" "$out" "$root/profiles/r04/dist_world1" > "$root/gpurun_out/profiles_${round}/dist_world1.md"
+python3 "$root/profiles/summarize_dist_world1.py" "$out" "$root/profiles/r05/dist_world1" > "$root/gpurun_out/profiles_${round}/dist_world1.md"
 cat "$root/gpurun_out/profiles_${round}/dist_world1.md"

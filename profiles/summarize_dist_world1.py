@@ -28,7 +28,7 @@ for f in sorted(glob.glob(os.path.join(cur, "*.json"))):
     prev = same = ""
     base = key        # the previous round's line of the SAME command if it has one, else of the command it is a variant of
     if not (old and os.path.exists(os.path.join(old, base + ".json"))):
-        base = key.replace("_other_stream", "").replace("_depth0", "").replace("_checked", "").replace("_routed", "").replace("_direct", "").replace("_self_via_rccl", "").replace("_peer", "")
+        base = key.replace("_sync", "").replace("_int64", "").replace("_other_stream", "").replace("_depth0", "").replace("_checked", "").replace("_routed", "").replace("_direct", "").replace("_self_via_rccl", "").replace("_peer", "")
     if old and os.path.exists(os.path.join(old, base + ".json")):
         o = json.load(open(os.path.join(old, base + ".json")))
         prev = "%.4f" % o["ms_per_step"]
@@ -42,6 +42,6 @@ for f in sorted(glob.glob(os.path.join(cur, "*.json"))):
         continue
     pl = d["config"]["placement"]
     print("| %s | %d repl / %d whole / %d split%s | %.4f | %s | %s | %.1f (%.1f) | %.1f / %.1f (%.1f) / %.1f | %.3f |" % (
-        key, pl["replicated"], pl["whole"], pl["row_split"], (", direct one-hot path" if d["config"].get("direct_one_hot_path") else "") + (", consumer on a second stream" if d["config"].get("consumer_stream") == "other" else "") + (", depth 0" if d["config"].get("pipeline_depth") == 0 else "") + (", CHECKED" if d["config"].get("checked") else ""),
+        key, pl["replicated"], pl["whole"], pl["row_split"], (", direct one-hot path" if d["config"].get("direct_one_hot_path") else "") + (", consumer on a second stream" if d["config"].get("consumer_stream") == "other" else "") + (", depth 0" if d["config"].get("pipeline_depth") == 0 else "") + (", CHECKED" if d["config"].get("checked") else "") + (", int64 ids" if d["config"].get("index_type") == "int64" else "") + (" (headline of the auto run; replica leg %.4f ms)" % d["ms_per_step_replica"] if "ms_per_step_replica" in d else ""),
         d["ms_per_step"], prev, same, x.get("host_us_per_step", 0), x.get("host_wait_counts_us_per_step", 0),
         k["router_us"], k["lookup_us"], k.get("direct_lookup_us", 0), k["unrouter_us"], x.get("step_frac", 0)))

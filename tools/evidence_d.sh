@@ -6,7 +6,7 @@ mkdir -p gpurun_out/profiles_$round
 bash profiles/collect_round.sh $round d 2>&1 | tail -13
 bash profiles/collect_dist_world1.sh $round 2>&1 | tail -26
 bash profiles/collect_peer_vs_rccl.sh $round 2>&1 | tail -13
-bash tools/r05_checked_trace.sh 2>&1 | tail -3
+bash tools/r05_checked_trace.sh $round 2>&1 | tail -3
 python3 bench.py > gpurun_out/profiles_$round/bench_default.json 2> gpurun_out/profiles_$round/bench_default.err; echo "default bench rc=$?"
 python3 bench.py --steps 20 --warmup 5 > gpurun_out/profiles_$round/bench_short_w5_k20.json 2>/dev/null; echo "k20 bench rc=$?"
 for m in 8 1; do echo "PIMEMB_RING_POOL=$m"; PIMEMB_RING_POOL=$m pim-embedding-lookup_amd/lib/emb_threads_bench 26 16 100000 2048 4000; PIMEMB_RING_POOL=$m pim-embedding-lookup_amd/lib/emb_threads_bench 26 16 100000 64 8000; done > gpurun_out/profiles_$round/threads_scaling.log 2>&1; tail -5 gpurun_out/profiles_$round/threads_scaling.log

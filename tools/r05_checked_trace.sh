@@ -1,7 +1,8 @@
 #!/bin/bash
 # Kernel trace of the CHECKED direct path (world 1): what the publish kernel behind the counted launch costs by itself.
 root=${GRAFT_REPO_ROOT:-$(pwd)}
-out=$root/gpurun_out/profiles_r05; mkdir -p "$out"
+round=${1:-r05}
+out=$root/gpurun_out/profiles_$round; mkdir -p "$out"
 export PIMEMB_FORCE_DIST=1 MASTER_ADDR=127.0.0.1
 cd /tmp && export TMPDIR=/tmp
 for key in c4 c2; do
