@@ -144,7 +144,7 @@ PROFILED_NBATCH = 8      # the --nbatch every entry of profiles/traffic.json was
 def profile_key(args, spec):
     """Key of this run in profiles/traffic.json, or None when the run is not one of the profiled commands
     (another batch size / table count / hint changes the traffic)."""
-    if args.batch is not None or args.tables is not None or args.hot_rows or args.streams != 1 \
+    if args.batch is not None or args.tables is not None or args.streams != 1 \
             or getattr(args, "nbatch", PROFILED_NBATCH) != PROFILED_NBATCH:     # (another rotation length = another index reuse)
         return None
     key = args.workload
@@ -155,6 +155,8 @@ def profile_key(args, spec):
         key += "-" + spec["dist"]
     if getattr(args, "index_order", "drawn") != "drawn":
         key += "-" + args.index_order
+    if args.hot_rows:                  # rows served from LDS: another kernel, other traffic (profiled for c3 --hot-rows 32)
+        key += "-hot%d" % args.hot_rows
     return key
 
 

@@ -20,5 +20,6 @@ f) bash profiles/collect_dist_pmc.sh $round dist-c4-rows-l1 --workload c4 --rows
    DIST_PMC_DIRECT=1 bash profiles/collect_dist_pmc.sh $round dist-c2-whole-l1 --shard-mode whole --replicate-mb 64 ;;
 b) STEPS_STATS=60 bash profiles/collect.sh $round c3 --workload c3 && STEPS_STATS=30 bash profiles/collect.sh $round c3-uniform --workload c3 --index-dist uniform ;;
 c) STEPS_STATS=60 bash profiles/collect.sh $round c5 --workload c5 ;;
+h) STEPS_STATS=60 bash profiles/collect.sh $round c3-hot32 --workload c3 --hot-rows 32 ;;
 d) bash tools/run_all_benches.sh gpurun_out/profiles_$round/benches ;;
 esac

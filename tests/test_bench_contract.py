@@ -26,9 +26,9 @@ def test_profile_key_of_a_command():
     assert bench.profile_key(_args(workload="c4", pooling=32), dict(L=32, dist="uniform")) == "c4-l32"
     assert bench.profile_key(_args(workload="c5"), dict(L=32, dist="mixed")) == "c5"
     # anything that changes the traffic has no profile: another batch, table count, hint, stream count or rotation length
-    for kw in (dict(batch=2048), dict(tables=16, workload="c3"), dict(hot_rows=32, workload="c3"), dict(streams=2),
-               dict(nbatch=2)):
+    for kw in (dict(batch=2048), dict(tables=16, workload="c3"), dict(streams=2), dict(nbatch=2)):
         assert bench.profile_key(_args(**kw), dict(L=1, dist="uniform")) is None
+    assert bench.profile_key(_args(workload="c3", hot_rows=32), dict(L=32, dist="zipf")) == "c3-hot32"      # the LDS kernel: a profile of its own
 
 
 def test_traffic_json_entries_are_backed_by_files():
