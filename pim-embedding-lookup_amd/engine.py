@@ -760,12 +760,13 @@ class EmbeddingEngine:
         return dict(zip(("send", "meta", "slots", "work"), (x.value for x in v)))
 
     def route_bags(self, tables, n_bags: int, n_shards: int, send_ptr: int, meta_ptr: int, slots_ptr: int,
-                   work_ptr: int, stream: int | None = None) -> None:
+                   work_ptr: int, stream: int | None = None, itype: int = _l.EMB_IDX_U32) -> None:
         """tables: sequence of (indices_ptr, offsets_ptr or None, n_indices, fixed_pooling, rows_per_shard) or a
-        prepared array from route_tables().  Enqueue only (emb_route_bags in pimemb.h)."""
+        prepared array from route_tables().  itype: width of the index / offset arrays (EMB_IDX_I64: torch's int64, read in
+        place; the request pieces are uint32 local row ids either way).  Enqueue only (emb_route_bags_typed in pimemb.h)."""
         arr = tables if isinstance(tables, C.Array) else self.route_tables(tables)
-        _l.check(self._L.emb_route_bags(self._h, arr, len(arr), n_bags, n_shards, send_ptr, meta_ptr, slots_ptr,
-                                        work_ptr, stream))
+        _l.check(self._L.emb_route_bags_typed(self._h, arr, len(arr), itype, n_bags, n_shards, send_ptr, meta_ptr, slots_ptr,
+                                              work_ptr, stream))
 
     @staticmethod
     def route_tables(tables):

@@ -1897,6 +1897,69 @@ def test_lookup_ranged_serves_only_its_row_range(pel, oracle, dim, dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dim,dtype,B", [(16, np.float32, 600_001), (16, np.float32, 4099), (128, np.float32, 33_000), (64, np.float16, 20_000)])
+def test_lookup_ranged_typed_int64_ids_and_the_open_end(pel, dim, dtype, B):
+    """Round 6: emb_lookup_ranged_typed / emb_plan_create_ranged_typed over int64 index arrays (torch's width, compared as they
+    are: a negative id is beyond every range) and EMB_RANGE_OPEN_END -- the descriptor that carries it (the last shard) writes a
+    ZERO row for every id at or beyond the end of its range, counts none of them, and the other shards still leave foreign bags
+    alone: after all shards have run every bag holds its table row, or zeros where no shard holds the id; the served counters add up
+    to the bags that were really served.  Small and very large launches (64-bag tiles / two batches per wavefront + XCD map),
+    transient and prepared, uint32 next to int64: the same bits."""
+    import ctypes as C
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(B % 1000 + dim)
+    rows, N = 50_003, 3
+    tab = (rng.standard_normal((rows, dim)) * 0.1).astype(dtype)
+    per = -(-rows // N)
+    eng = pel.EmbeddingEngine(device=0, max_tables=8)
+    for d in range(N):
+        eng.load_table(d, tab[d * per:min((d + 1) * per, rows)])
+    idx = rng.integers(0, rows, size=B).astype(np.int64)
+    nobody = {3: rows + 100, 11: -1, 500: -(1 << 45), 1000: (1 << 32) + 5, B - 1: (1 << 62)}
+    for p, v in nobody.items():
+        idx[p] = v
+    held = (idx >= 0) & (idx < rows)
+    want = np.where(held[:, None], tab.astype(np.float32)[np.clip(idx, 0, rows - 1)], np.float32(0))
+    L = pel.lib.load()
+    OPEN = pel.lib.EMB_RANGE_OPEN_END
+    ctr = torch.zeros((N, 64 * 256 // 4), dtype=torch.int32, device=dev)        # EMB_SERVED_LANES x EMB_SERVED_STRIDE bytes per counter
+    outs = {}
+    for itype, d_idx in ((pel.lib.EMB_IDX_I64, torch.from_numpy(idx).to(dev)),
+                         (pel.lib.EMB_IDX_U32, torch.from_numpy(np.where(held, idx, rows + 7).astype(np.uint32).view(np.int32)).to(dev))):
+        for prepared in (False, True):
+            out = torch.full((B, dim), float("nan"), device=dev)
+            ctr.zero_()
+            descs = (pel.lib.EmbLookupDesc * N)(*[pel.lib.EmbLookupDesc(d, 1, d_idx.data_ptr(), None, B, B, out.data_ptr()) for d in range(N)])
+            lo = (C.c_uint64 * N)(*[(d * per) | (OPEN if d == N - 1 else 0) for d in range(N)])
+            served = (C.c_void_p * N)(*[ctr[d].data_ptr() for d in range(N)])
+            if prepared:
+                plan = C.c_void_p()
+                pel.lib.check(L.emb_plan_create_ranged_typed(eng._h, descs, lo, served, N, itype, C.byref(plan)))
+                pel.lib.check(L.emb_plan_launch(plan, None))
+                torch.cuda.synchronize()
+                pel.lib.check(L.emb_plan_destroy(plan))
+            else:
+                pel.lib.check(L.emb_lookup_ranged_typed(eng._h, descs, lo, served, N, itype, None))
+                torch.cuda.synchronize()
+            got = out.cpu().numpy()
+            assert np.array_equal(got, want), (itype, prepared)                     # rows where held, ZEROS where nobody holds the id, no NaN left
+            counts = ctr.cpu().numpy().astype(np.int64).sum(axis=1)
+            mine = [int(((idx >= d * per) & (idx < min((d + 1) * per, rows))).sum()) for d in range(N)]
+            assert counts.tolist() == mine and sum(mine) == B - len(nobody)          # the open end's bags are zeroed, never counted
+            outs[(itype, prepared)] = got
+    # without the flag the last shard leaves them alone too (the round-5 behaviour, what an unchecked shard keeps)
+    out = torch.full((B, dim), float("nan"), device=dev)
+    d_idx = torch.from_numpy(idx).to(dev)
+    descs = (pel.lib.EmbLookupDesc * N)(*[pel.lib.EmbLookupDesc(d, 1, d_idx.data_ptr(), None, B, B, out.data_ptr()) for d in range(N)])
+    pel.lib.check(L.emb_lookup_ranged_typed(eng._h, descs, (C.c_uint64 * N)(*[d * per for d in range(N)]), None, N, pel.lib.EMB_IDX_I64, None))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert np.isnan(got[~held]).all() and np.array_equal(got[held], want[held])
+    eng.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dim,dtype,B", [(16, np.float32, 150_001), (16, np.float32, 9001), (128, np.float32, 33_000),
                                          (64, np.float16, 40_000), (32, "fixed32", 20_011)])
 def test_ranged_launch_mixes_whole_tables_and_shards(pel, oracle, dim, dtype, B):

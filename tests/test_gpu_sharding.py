@@ -61,7 +61,7 @@ def _route_bags_reference(idx, off, n_idx, rps, N):
     return out
 
 
-def _router_case(pel, eng, oracle, rng, rows, N, B, dim, ragged, max_len=40, zipf_first=True, onehot=False):
+def _router_case(pel, eng, oracle, rng, rows, N, B, dim, ragged, max_len=40, zipf_first=True, onehot=False, ids64=False):
     """One router / un-router round trip in ONE process: emb_route_bags cuts every bag into per-shard sub-bags, every
     'shard' serves its piece with the ordinary fused lookup, emb_unroute_bags adds the partial rows in shard order.
     Checks counts / offsets / lists / slots against the host restatement of the routing rule, the result bit for bit
@@ -91,14 +91,19 @@ def _router_case(pel, eng, oracle, rng, rows, N, B, dim, ragged, max_len=40, zip
     sz = eng.route_bags_sizes(K, B, total, N)
     u8 = lambda n: torch.zeros(max(n, 16), dtype=torch.uint8, device=dev)
     send, meta, slots, work = u8(sz["send"]), u8(sz["meta"]), u8(sz["slots"]), u8(sz["work"])
-    d_idx = [torch.from_numpy(np.ascontiguousarray(i).view(np.int32)).to(dev) if i.shape[0] else
-             torch.zeros(1, dtype=torch.int32, device=dev) for i in idxs]
-    d_off = [torch.from_numpy(o.view(np.int32)).to(dev) for o in offs]
+    if ids64:           # torch's width, read by the router in place; everything the router WRITES is uint32 either way
+        d_idx = [torch.from_numpy(i.astype(np.int64)).to(dev) if i.shape[0] else torch.zeros(1, dtype=torch.int64, device=dev) for i in idxs]
+        d_off = [torch.from_numpy(o.astype(np.int64)).to(dev) for o in offs]
+    else:
+        d_idx = [torch.from_numpy(np.ascontiguousarray(i).view(np.int32)).to(dev) if i.shape[0] else
+                 torch.zeros(1, dtype=torch.int32, device=dev) for i in idxs]
+        d_off = [torch.from_numpy(o.view(np.int32)).to(dev) for o in offs]
     spec = [(d_idx[k].data_ptr(), d_off[k].data_ptr() if ragged else None, idxs[k].shape[0], 0 if ragged else L_fixed, rps[k])
             for k in range(K)]
 
     def run_once():
-        eng.route_bags(spec, B, N, send.data_ptr(), meta.data_ptr(), slots.data_ptr(), work.data_ptr())
+        eng.route_bags(spec, B, N, send.data_ptr(), meta.data_ptr(), slots.data_ptr(), work.data_ptr(),
+                       itype=pel.lib.EMB_IDX_I64 if ids64 else pel.lib.EMB_IDX_U32)
         torch.cuda.synchronize()
         m = meta.view(torch.int32).cpu().numpy().view(np.uint32)
         counts, peaks, base, piece, row0, mode = _meta_views(m, N, K)
@@ -193,6 +198,62 @@ def test_route_bags_one_index_per_bag_fast_path(pel, eng, oracle, dim, N, B):
         rows = [100_003, 7_000, 50_000, 999]     # re-derives per workgroup -> the three-kernel form of the same path
     pooled, run_once = _router_case(pel, eng, oracle, rng, rows, N, B, dim, False, onehot=True)
     assert np.array_equal(run_once()[-1], pooled)
+
+
+@pytest.mark.parametrize("shape", ["ragged", "fixed32", "one-hot", "one-hot-three-kernels"])
+def test_route_bags_int64_ids_in_place(pel, eng, oracle, shape):
+    """Round 6: the router reads DLRM's int64 index / offset arrays in place (emb_route_bags_typed) -- general path (ragged bags
+    with empty ones, 32 indices per bag) and the one-index-per-bag path in both of its forms -- and writes the SAME request pieces,
+    counts, slots and peaks as for uint32 arrays: uint32 sub-bag starts and local row ids, checked against the host restatement;
+    the un-routed rows against the oracle; twice the same bits."""
+    rng = np.random.default_rng(640 + len(shape))
+    if shape == "ragged":
+        pooled, run_once = _router_case(pel, eng, oracle, rng, [100_003, 5_000, 40_001], 4, 3001, 16, True, ids64=True)
+    elif shape == "fixed32":
+        pooled, run_once = _router_case(pel, eng, oracle, rng, [100_003, 5_000], 3, 2049, 64, False, ids64=True)
+    elif shape == "one-hot":
+        pooled, run_once = _router_case(pel, eng, oracle, rng, [100_003, 64, 40_001], 8, 39_292, 16, False, onehot=True, ids64=True)
+    else:
+        pooled, run_once = _router_case(pel, eng, oracle, rng, [100_003, 7_000, 50_000, 999], 32, 140_000, 16, False, onehot=True, ids64=True)
+    assert np.array_equal(run_once()[-1], pooled)
+
+
+@pytest.mark.parametrize("onehot", [False, True])
+def test_route_bags_int64_ids_no_shard_can_hold_never_wrap_into_range(pel, eng, onehot):
+    """An int64 id no shard can hold -- negative, or beyond the last shard's 32-bit reach -- goes to the LAST shard's list as local
+    row id 0xffffffff, which no table of fewer than 2^32 rows contains (a validating server refuses it); it is counted by exactly
+    one shard and never truncated into range.  Round 5's rule `r < hi` with hi = ~0 for the last shard would have lost id -1."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(65)
+    rows, N, B = 10_000, 4, 513
+    L = 1 if onehot else 3
+    rps = -(-rows // N)
+    idx = rng.integers(0, rows, size=B * L).astype(np.int64)
+    bad = {5: -1, 40: -(1 << 40), 77: (1 << 32) + 17, 300: (1 << 62) + 3, 301: rows + 9}       # position -> id
+    for p, v in bad.items():
+        idx[p] = v
+    sz = eng.route_bags_sizes(1, B, B * L, N)
+    u8 = lambda n: torch.zeros(max(n, 16), dtype=torch.uint8, device=dev)
+    send, meta, slots, work = u8(sz["send"]), u8(sz["meta"]), u8(sz["slots"]), u8(sz["work"])
+    d_idx = torch.from_numpy(idx).to(dev)
+    eng.route_bags([(d_idx.data_ptr(), None, B * L, L, rps)], B, N, send.data_ptr(), meta.data_ptr(), slots.data_ptr(), work.data_ptr(),
+                   itype=pel.lib.EMB_IDX_I64)
+    torch.cuda.synchronize()
+    m = meta.view(torch.int32).cpu().numpy().view(np.uint32)
+    counts, _peaks, base, _piece, _row0, _mode = _meta_views(m, N, 1)
+    assert int(counts[:, 0, 1].sum()) == B * L                     # every index is in exactly one shard's list
+    words = send.view(torch.int32).cpu().numpy().view(np.uint32)
+    last = words[int(base[N - 1, 0, 1]):int(base[N - 1, 0, 1]) + int(counts[N - 1, 0, 1])]
+    # the four ids beyond 32 bits travel as 0xffffffff; rows + 9 is an ordinary (out-of-table) local id of the last shard
+    assert int((last == 0xffffffff).sum()) == 4 and int((last == rows + 9 - (N - 1) * rps).sum()) == 1
+    for d in range(N - 1):
+        lst = words[int(base[d, 0, 1]):int(base[d, 0, 1]) + int(counts[d, 0, 1])]
+        assert int(lst.max(initial=0)) < rps                           # nothing wrapped into another shard's range
+    good = np.ones(B * L, bool)
+    good[list(bad)] = False
+    want_last = np.sort(idx[good & (idx >= (N - 1) * rps)] - (N - 1) * rps)
+    assert np.array_equal(np.sort(last[(last != 0xffffffff) & (last != rows + 9 - (N - 1) * rps)].astype(np.int64)), want_last)
 
 
 def test_route_bags_hypothesis_shapes(pel, eng, oracle):
