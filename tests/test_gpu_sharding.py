@@ -245,15 +245,17 @@ def test_route_bags_int64_ids_no_shard_can_hold_never_wrap_into_range(pel, eng, 
     assert int(counts[:, 0, 1].sum()) == B * L                     # every index is in exactly one shard's list
     words = send.view(torch.int32).cpu().numpy().view(np.uint32)
     last = words[int(base[N - 1, 0, 1]):int(base[N - 1, 0, 1]) + int(counts[N - 1, 0, 1])]
-    # the four ids beyond 32 bits travel as 0xffffffff; rows + 9 is an ordinary (out-of-table) local id of the last shard
-    assert int((last == 0xffffffff).sum()) == 4 and int((last == rows + 9 - (N - 1) * rps).sum()) == 1
+    # ids whose LOCAL value does not fit 32 bits (-1, -2^40, 2^62 + 3) travel as 0xffffffff; 2^32 + 17 and rows + 9 are ordinary local ids
+    # of the last shard, far outside its table (2^32 + 17 - 7500 still fits): a validating server refuses all five
+    assert int((last == 0xffffffff).sum()) == 3 and int((last == (1 << 32) + 17 - (N - 1) * rps).sum()) == 1
+    assert int((last == rows + 9 - (N - 1) * rps).sum()) == 1 and int((last.astype(np.int64) >= rps).sum()) == 5
     for d in range(N - 1):
         lst = words[int(base[d, 0, 1]):int(base[d, 0, 1]) + int(counts[d, 0, 1])]
         assert int(lst.max(initial=0)) < rps                           # nothing wrapped into another shard's range
     good = np.ones(B * L, bool)
     good[list(bad)] = False
     want_last = np.sort(idx[good & (idx >= (N - 1) * rps)] - (N - 1) * rps)
-    assert np.array_equal(np.sort(last[(last != 0xffffffff) & (last != rows + 9 - (N - 1) * rps)].astype(np.int64)), want_last)
+    assert np.array_equal(np.sort(last[last.astype(np.int64) < rps].astype(np.int64)), want_last)
 
 
 def test_route_bags_hypothesis_shapes(pel, eng, oracle):
