@@ -76,6 +76,14 @@ typedef struct emb_config {
                                     is >= nr_rows or the offsets are broken.  Off by default: the reference never
                                     checks (emb_dpu_lookup.c:113) and the check costs a kernel and a host wait per
                                     call.  Prepared plans (emb_plan_launch) are never checked. */
+#define EMB_FLAG_DEFER_CHECK 4u  /* with EMB_FLAG_CHECK_INPUTS: the verdict of a checked DEVICE-pointer call is not waited for
+                                    inside the call (that wait puts the host one launch behind the GPU on every call: 21 -> 41 us
+                                    per 26-table call at 39 292 bags per table).  The validation kernel still disarms the call's
+                                    lookup on the device when it finds something (outputs untouched); the finding is returned --
+                                    EMB_ERR_RANGE, emb_last_error naming the call it belongs to -- by the first later checked call
+                                    that finds it arrived (that call's own work has been launched), or by emb_check_report.  Like a
+                                    device-side assert: late, never lost (emb_destroy prints a verdict nobody read).
+                                    emb_lookup_batched_checked stays synchronous. */
 
 /*
  * One table's share of a batched lookup -- what emb_host.h:234 passes as indices[t], offsets[t],
@@ -260,7 +268,7 @@ int emb_plan_time(emb_plan *p, void *stream, uint32_t warmup, uint32_t iters, fl
 
 /* Debug-only input check (the reference never checks: an out-of-range index is a wild MRAM read,
  * emb_dpu_lookup.c:113).  Counts indices >= nr_rows and non-monotone / out-of-range offsets over
- * DEVICE or HOST buffers; returns EMB_ERR_RANGE if *n_bad > 0. */
+ * DEVICE or HOST buffers; returns EMB_ERR_RANGE if *n_bad > 0.  (*n_bad, here and below, counts up to 16 777 215 and stays there.) */
 int emb_validate_inputs(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs,
                         emb_index_type itype, emb_memspace space, uint64_t *n_bad);
 /* The same on a stream of the caller's (emb_validate_inputs uses the default stream): the check is ordered behind
@@ -273,6 +281,13 @@ int emb_validate_inputs_on(emb_engine *e, const emb_lookup_desc *descs, uint32_t
  * values, nothing launched.  What nn.EmbeddingBag-shaped layers call for tensors they do not trust (IndexError). */
 int emb_lookup_batched_checked(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs,
                                emb_index_type itype, emb_memspace space, void *stream, uint64_t *n_bad);
+/* emb_lookup_batched_checked with the verdict DEFERRED (see EMB_FLAG_DEFER_CHECK; DEVICE pointers -- a host-pointer call is synchronous anyway):
+ * returns EMB_ERR_RANGE for an EARLIER deferred call whose verdict has arrived (this call's work is launched all the same). */
+int emb_lookup_batched_checked_deferred(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs,
+                                        emb_index_type itype, emb_memspace space, void *stream);
+/* Wait for the verdicts of every deferred checked call made so far: EMB_OK, or EMB_ERR_RANGE with *n_bad (may be NULL) offending
+ * values in all and the first offending call named in emb_last_error. */
+int emb_check_report(emb_engine *e, uint64_t *n_bad);
 
 int emb_get_stats(emb_engine *e, emb_stats *out);
 int emb_reset_stats(emb_engine *e);

@@ -48,6 +48,11 @@ using pimemb::fail;
                         "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,    \
                         __LINE__);                                                          \
     } while (0)
+#define EMB_TRY(expr)                  \
+    do {                               \
+        int _rc = (expr);              \
+        if (_rc != EMB_OK) return _rc; \
+    } while (0)
 
 double now_us() {
     using namespace std::chrono;
@@ -169,11 +174,25 @@ struct emb_engine {
     size_t d_stage_cap = 0;
     // input validation (checked_launch, under mu): 16 bytes of HBM the validation kernels count in, and what the host
     // remembers of them -- tickets drawn and offending values found by all earlier calls, and a sequence number
-    pimemb::ValidateCtl *d_val = nullptr;
-    unsigned long long val_tickets = 0, val_bad = 0, val_seq = 0;
+    // A checked call takes SLOT seq % kValSlots of these: its own counters in HBM (which its validation kernel leaves zeroed) and
+    // its own pinned verdict word.  Per-call counters (round 6; one running pair before) make a call's finding its own whatever
+    // else is in flight, so a verdict need not be waited for inside the call (EMB_FLAG_DEFER_CHECK): it is read -- in order -- by
+    // a later call, or by emb_check_report.
+    static constexpr uint32_t kValSlots = 64;
+    pimemb::ValidateCtl *d_val = nullptr;                           // [kValSlots]
+    unsigned long long val_seq = 0;
+    struct PendingVerdict {
+        unsigned long long seq;
+        hipStream_t stream;
+        uint32_t n_groups;
+        KernelKind kinds[8];
+        bool launched;
+    };
+    std::deque<PendingVerdict> val_pending;                         // deferred verdicts not read yet, oldest first (under val_mu)
+    bool defer_check = false;                                       // EMB_FLAG_DEFER_CHECK
     std::mutex val_mu;          // checked calls take turns (their findings are read as deltas of one device counter); `mu` is
                                 // held only while such a call enqueues, not while it waits for its result
-    volatile unsigned long long *val_result = nullptr;   // two pinned, device-visible words the validation kernels report into
+    volatile unsigned long long *val_result = nullptr;   // [kValSlots] pinned, device-visible words the validation kernels report into (validate_word)
     volatile unsigned long long *host_done = nullptr;    // host-pointer calls (under host_mu): "the kernel of call host_seq is done"
     unsigned long long host_seq = 0;
     // stats
@@ -942,6 +961,7 @@ int emb_create(const emb_config *cfg, emb_engine **out) {
     e->device = dev;
     e->stage_timing = cfg && (cfg->flags & EMB_FLAG_STAGE_TIMING);
     e->check_inputs = cfg && (cfg->flags & EMB_FLAG_CHECK_INPUTS);
+    e->defer_check = cfg && (cfg->flags & EMB_FLAG_DEFER_CHECK);
     {   // transient launches read their descriptors straight from the pinned segment (measured with
         // tools/transient_probe.py: 20.6 vs 22.4 us per C2-shaped call, 5.6 vs 8.7 us at 2048 bags per
         // table); PIMEMB_DESC_MODE=copy stages them into HBM with an in-stream copy instead
@@ -957,6 +977,8 @@ int emb_create(const emb_config *cfg, emb_engine **out) {
     return EMB_OK;
 }
 
+static int read_verdicts(emb_engine *e, bool wait, unsigned long long *bad_total, unsigned long long *first_seq);
+
 int emb_destroy(emb_engine *e) {
     if (!e) return EMB_OK;
     if (e->live_plans.load() != 0)
@@ -964,6 +986,12 @@ int emb_destroy(emb_engine *e) {
                     e->live_plans.load());
     DeviceGuard g(e->device);
     (void)hipDeviceSynchronize();
+    {       // a deferred verdict nobody read is never lost silently
+        std::lock_guard<std::mutex> vlk(e->val_mu);
+        unsigned long long bad = 0, first = 0;
+        if (!e->val_pending.empty() && read_verdicts(e, true, &bad, &first) == EMB_OK && bad)
+            fprintf(stderr, "[pimemb] emb_destroy: an unread verdict: %llu out-of-range indices / broken offsets in checked call number %llu\n", bad, first);
+    }
     if (g_prof.on && g_prof.calls) {
         const double n = (double)g_prof.calls;
         fprintf(stderr, "[pimemb host profile] %llu transient calls, us/call: resolve %.2f  slot %.2f  image memcpy %.2f  "
@@ -1184,10 +1212,10 @@ int emb_table_info(emb_engine *e, uint32_t table_id, void **device_rows, uint64_
 
 static int validate_on(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs, emb_index_type itype,
                        emb_memspace space, hipStream_t s, uint64_t *n_bad);
-static int checked_launch(emb_engine *e, Resolved &r, emb_index_type itype, hipStream_t s, bool launch, uint64_t *n_bad);
+static int checked_launch(emb_engine *e, Resolved &r, emb_index_type itype, hipStream_t s, bool launch, uint64_t *n_bad, bool defer = false);
 
 static int lookup_batched_impl(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs, emb_index_type itype,
-                               emb_memspace space, void *stream, bool check, uint64_t *n_bad) {
+                               emb_memspace space, void *stream, bool check, uint64_t *n_bad, bool defer = false) {
     if (n_bad) *n_bad = 0;
     if (!e) return fail(EMB_ERR_INVALID, "engine is NULL");
     if (n_descs == 0) return EMB_OK;
@@ -1211,16 +1239,21 @@ static int lookup_batched_impl(emb_engine *e, const emb_lookup_desc *descs, uint
     // checked: the descriptors are resolved ONCE; the validation kernel and the lookup kernels share one launch image and
     // are enqueued back to back -- a finding disarms the lookup on the device (validate_kernel's poison) -- and the host
     // waits for the validation result only
-    rc = check ? checked_launch(e, r, itype, s, /*launch=*/true, n_bad) : launch_resolved(e, r, itype, s);
-    if (rc) return rc;
+    rc = check ? checked_launch(e, r, itype, s, /*launch=*/true, n_bad, defer) : launch_resolved(e, r, itype, s);
+    if (rc != EMB_OK && !(defer && rc == EMB_ERR_RANGE)) return rc;      // (deferred: EMB_ERR_RANGE speaks of an EARLIER call; this one was launched)
     e->n_bags.fetch_add(r.n_bags, std::memory_order_relaxed);
     e->n_indices.fetch_add(r.n_indices, std::memory_order_relaxed);
-    return EMB_OK;
+    return rc;
 }
 
 int emb_lookup_batched(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs,
                        emb_index_type itype, emb_memspace space, void *stream) {
-    return lookup_batched_impl(e, descs, n_descs, itype, space, stream, e && e->check_inputs, nullptr);
+    return lookup_batched_impl(e, descs, n_descs, itype, space, stream, e && e->check_inputs, nullptr, e && e->defer_check);
+}
+
+int emb_lookup_batched_checked_deferred(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs,
+                                        emb_index_type itype, emb_memspace space, void *stream) {
+    return lookup_batched_impl(e, descs, n_descs, itype, space, stream, true, nullptr, /*defer=*/space == EMB_MEM_DEVICE);
 }
 
 int emb_lookup_batched_checked(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs,
@@ -1430,49 +1463,93 @@ int emb_plan_time(emb_plan *p, void *stream, uint32_t warmup, uint32_t iters, fl
     return EMB_OK;
 }
 
-// After a failed enqueue on the validation path: let the stream drain and read the device's counters back, so that the
-// next clean checked call does not see findings (or tickets) of this one as its own.
-static void resync_validation(emb_engine *e, hipStream_t s) {
-    (void)hipStreamSynchronize(s);
-    pimemb::ValidateCtl c{};
-    if (e->d_val && hipMemcpy(&c, e->d_val, sizeof c, hipMemcpyDeviceToHost) == hipSuccess) {
-        e->val_tickets = c.tickets;
-        e->val_bad = c.bad;
-    }
+// After a failed enqueue on the validation path: a validation kernel may or may not be queued, so its counters may or may
+// not come back zeroed.  Let the device drain, zero them all, and forget the verdicts that were outstanding (whatever they
+// found disarmed their lookups on the device all the same).
+static void resync_validation(emb_engine *e) {
+    (void)hipDeviceSynchronize();
+    if (e->d_val) (void)hipMemset(e->d_val, 0, sizeof(pimemb::ValidateCtl) * emb_engine::kValSlots);
+    e->val_pending.clear();
     (void)hipGetLastError();
+}
+
+// Read the verdicts of deferred checked calls, oldest first (caller holds val_mu).  wait = false: only those that have arrived;
+// wait = true: all of them (a spin, then the call's stream).  *bad_total / *first_seq: offending values found and the sequence
+// number of the first call they belong to.  A refused call's lookup kernels were disarmed on the device: they are taken out of
+// the launch statistics here.
+static int read_verdicts(emb_engine *e, bool wait, unsigned long long *bad_total, unsigned long long *first_seq) {
+    *bad_total = 0;
+    *first_seq = 0;
+    while (!e->val_pending.empty()) {
+        const emb_engine::PendingVerdict pv = e->val_pending.front();
+        const uint32_t slot = (uint32_t)(pv.seq % emb_engine::kValSlots);
+        volatile unsigned long long *result = e->val_result + slot;
+        unsigned long long word = *result;
+        if ((word >> 24) != pv.seq) {
+            if (!wait) break;
+            for (int spin = 0; spin < 200000 && ((word = *result) >> 24) != pv.seq; spin++) {
+            }
+            if ((word >> 24) != pv.seq) {
+                HIP_TRY(hipStreamSynchronize(pv.stream));
+                if (((word = *result) >> 24) != pv.seq) {
+                    resync_validation(e);
+                    return fail(EMB_ERR_DEVICE, "validation kernel of checked call %llu did not report", pv.seq);
+                }
+            }
+        }
+        e->val_pending.pop_front();
+        const unsigned long long bad = word & pimemb::kValCountMask;
+        if (bad) {
+            if (!*bad_total) *first_seq = pv.seq;
+            *bad_total += bad;
+            if (pv.launched) {
+                e->n_kernel_launches.fetch_sub(pv.n_groups, std::memory_order_relaxed);
+                for (uint32_t g = 0; g < pv.n_groups && g < 8; g++) e->n_by_kind[pv.kinds[g]].fetch_sub(1, std::memory_order_relaxed);
+            }
+        }
+    }
+    return EMB_OK;
 }
 
 // Validate the resolved descriptors of a call (device-resident buffers) on stream `s` and -- with `launch` -- enqueue its
 // lookup kernels right behind the validation kernel, over the SAME launch image: a finding zeroes the descriptors' tile
 // counts on the device, so the lookup does nothing.  The host waits for the validation result only (two pinned words the
-// kernel's last workgroup writes; polled), not for the lookup.  No allocation on this path (the 16-byte HBM counter block
-// and the pinned result words are created once), no event, no device-wide synchronize.  Checked calls take turns (val_mu);
-// the engine mutex is held while the call enqueues, not while it waits.
-static int checked_launch(emb_engine *e, Resolved &r, emb_index_type itype, hipStream_t s, bool launch, uint64_t *n_bad) {
+// kernel's last workgroup writes; polled), not for the lookup -- or, `defer`, for nothing at all: the verdict is read by a
+// later checked call (which returns EMB_ERR_RANGE for it, after having launched its own work) or by emb_check_report; the wait
+// inside the call puts the host one launch behind the GPU on every call (21 -> 41 us per 26-table call at 39 292 bags per table).
+// No allocation on this path (the counter block and the pinned result words are created once), no event, no device-wide
+// synchronize.  Checked calls take turns enqueueing (val_mu); the ring mutex is held while the call enqueues, not while it waits.
+static int checked_launch(emb_engine *e, Resolved &r, emb_index_type itype, hipStream_t s, bool launch, uint64_t *n_bad, bool defer) {
     if (n_bad) *n_bad = 0;
     if (r.descs.empty()) return EMB_OK;
     std::lock_guard<std::mutex> vlk(e->val_mu);
-    unsigned long long seq = 0;
+    unsigned long long seq = 0, earlier_bad = 0, earlier_seq = 0;
+    // verdicts of earlier deferred calls: what has arrived (all of them before a slot is reused, or when this call will wait anyway)
+    if (!e->val_pending.empty())
+        EMB_TRY(read_verdicts(e, /*wait=*/!defer || e->val_pending.size() + 1 >= emb_engine::kValSlots, &earlier_bad, &earlier_seq));
     volatile unsigned long long *result = nullptr;
+    uint32_t slot = 0;
     {
         // (d_val, val_result and the val_* bookkeeping are only touched under val_mu, held above)
         const int rk = ring_of_thread();
         std::lock_guard<std::mutex> lk(e->ring_mu[rk]);        // enqueue only; released before the wait below
         if (!e->d_val) {
-            HIP_TRY(hipMalloc((void **)&e->d_val, sizeof(pimemb::ValidateCtl)));
-            HIP_TRY(hipMemset(e->d_val, 0, sizeof(pimemb::ValidateCtl)));
+            HIP_TRY(hipMalloc((void **)&e->d_val, sizeof(pimemb::ValidateCtl) * emb_engine::kValSlots));
+            HIP_TRY(hipMemset(e->d_val, 0, sizeof(pimemb::ValidateCtl) * emb_engine::kValSlots));
         }
         if (!e->val_result) {     // its own pinned block, not the launch-image ring: a segment may be recycled while we wait
             void *p = nullptr;
-            HIP_TRY(hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocCoherent));
+            HIP_TRY(hipHostMalloc(&p, 8 * emb_engine::kValSlots, hipHostMallocMapped | hipHostMallocCoherent));
+            memset(p, 0, 8 * emb_engine::kValSlots);
             e->val_result = static_cast<volatile unsigned long long *>(p);
         }
-        result = e->val_result;
+        seq = ++e->val_seq;
+        slot = (uint32_t)(seq % emb_engine::kValSlots);
+        result = e->val_result + slot;
         char *h = nullptr, *d = nullptr;
         int rc = take_image_space(e->ring[rk], r.image.size(), s, &h, &d);
         if (rc) return rc;
         memcpy(h, r.image.data(), r.image.size());
-        result[0] = result[1] = 0;
         char *base = h;        // the kernels' scalar loads read the pinned, device-visible segment itself ...
         if (d != nullptr) {    // ... or its HBM twin (PIMEMB_DESC_MODE=copy)
             HIP_TRY(hipMemcpyAsync(d, h, r.image.size(), hipMemcpyHostToDevice, s));
@@ -1481,47 +1558,38 @@ static int checked_launch(emb_engine *e, Resolved &r, emb_index_type itype, hipS
         r.bind(base);
         uint64_t max_items = 1;
         for (const DevDesc &dd : r.descs) max_items = std::max<uint64_t>(max_items, std::max<uint64_t>(dd.n_idx, dd.n_bags));
-        const uint32_t wgs = pimemb::validate_workgroups(max_items);
-        const unsigned long long n_wgs = (unsigned long long)wgs * r.descs.size();
-        seq = ++e->val_seq;
-        const bool tickets = n_wgs <= 32;      // small grid: its last workgroup reports; else a one-thread kernel behind it
+        const uint32_t wgs = pimemb::validate_workgroups(max_items, itype);
         hipError_t err = pimemb::launch_validate(reinterpret_cast<DevDesc *>(base + r.groups[0].desc_off), (uint32_t)r.descs.size(),
-                                                 itype, e->d_val, tickets ? e->val_tickets + n_wgs : 0ull,
-                                                 const_cast<unsigned long long *>(result), seq, wgs, /*poison=*/launch, s);
-        if (err != hipSuccess) {               // the validation kernel may be queued without its reporting kernel
-            resync_validation(e, s);
+                                                 itype, e->d_val + slot, const_cast<unsigned long long *>(result), seq, wgs,
+                                                 /*poison=*/launch, s);
+        if (err != hipSuccess) {
+            resync_validation(e);
             return fail(EMB_ERR_DEVICE, "validation kernel: %s", hipGetErrorString(err));
         }
-        if (tickets) e->val_tickets += n_wgs;
         if (launch) {
             rc = launch_groups(e, r.groups, itype, s);
-            if (rc) {
-                resync_validation(e, s);           // keep the counters' bookkeeping in step with the device
+            if (rc) {                              // (the validation kernel runs and reports; its verdict has no call to belong to)
+                resync_validation(e);
                 return rc;
             }
         }
+        emb_engine::PendingVerdict pv{seq, s, (uint32_t)r.groups.size(), {}, launch};
+        for (size_t g = 0; g < r.groups.size() && g < 8; g++) pv.kinds[g] = r.groups[g].kind;
+        e->val_pending.push_back(pv);
     }
-    bool done = false;
-    for (int spin = 0; spin < 200000 && !(done = result[1] == seq); spin++) {
+    unsigned long long bad = 0, bad_seq = 0;
+    if (!defer) {              // this call's own verdict (and whatever was still outstanding in front of it)
+        unsigned long long mine = 0, mine_seq = 0;
+        EMB_TRY(read_verdicts(e, /*wait=*/true, &mine, &mine_seq));
+        bad = mine;
+        bad_seq = mine_seq;
     }
-    if (!done) {
-        HIP_TRY(hipStreamSynchronize(s));
-        if (result[1] != seq) {
-            resync_validation(e, s);
-            return fail(EMB_ERR_DEVICE, "validation kernel did not report");
-        }
-    }
-    const unsigned long long total = result[0];
-    const unsigned long long bad = total - e->val_bad;
-    e->val_bad = total;
-    if (n_bad) *n_bad = bad;
-    if (bad) {
-        if (launch) {      // the lookup kernels were disarmed on the device: they gathered and stored nothing, do not count them
-            e->n_kernel_launches.fetch_sub(r.groups.size(), std::memory_order_relaxed);
-            for (const PlanGroup &g : r.groups) e->n_by_kind[g.kind].fetch_sub(1, std::memory_order_relaxed);
-        }
-        return fail(EMB_ERR_RANGE, "%llu out-of-range indices / broken offsets", bad);
-    }
+    if (n_bad) *n_bad = bad + earlier_bad;
+    if (earlier_bad && (defer || !bad))
+        return fail(EMB_ERR_RANGE, "%llu out-of-range indices / broken offsets in an EARLIER checked call (number %llu of this engine; its "
+                    "lookup was disarmed on the device: outputs untouched) -- reported now: the verdict was deferred", earlier_bad, earlier_seq);
+    if (bad) return fail(EMB_ERR_RANGE, "%llu out-of-range indices / broken offsets", bad + earlier_bad);
+    (void)bad_seq;
     return EMB_OK;
 }
 
@@ -1561,6 +1629,20 @@ int emb_validate_inputs_on(emb_engine *e, const emb_lookup_desc *descs, uint32_t
     if (!e || !descs) return fail(EMB_ERR_INVALID, "engine or descs is NULL");
     DeviceGuard g(e->device);
     return validate_on(e, descs, n_descs, itype, space, static_cast<hipStream_t>(stream), n_bad);
+}
+
+int emb_check_report(emb_engine *e, uint64_t *n_bad) {
+    if (n_bad) *n_bad = 0;
+    if (!e) return fail(EMB_ERR_INVALID, "engine is NULL");
+    DeviceGuard g(e->device);
+    std::lock_guard<std::mutex> vlk(e->val_mu);
+    unsigned long long bad = 0, first = 0;
+    EMB_TRY(read_verdicts(e, /*wait=*/true, &bad, &first));
+    if (n_bad) *n_bad = bad;
+    if (bad)
+        return fail(EMB_ERR_RANGE, "%llu out-of-range indices / broken offsets in checked call number %llu of this engine (its lookup was "
+                    "disarmed on the device: outputs untouched)", bad, first);
+    return EMB_OK;
 }
 
 int emb_get_stats(emb_engine *e, emb_stats *out) {

@@ -61,18 +61,42 @@ hipError_t launch_scatter_column(int32_t *table, const int32_t *column, uint64_t
                                  uint32_t dim, uint32_t col, hipStream_t stream);
 
 // Input validation (see validate_kernel): counts out-of-range indices / broken offsets over the descriptors of a launch
-// image and reports through `result` (two pinned, device-visible words: [0] running total of ctl->bad, [1] = seq once the
-// kernel's last workgroup is done).  ctl: 16 bytes of HBM owned by the engine, zeroed once, never reset.  poison: a
-// finding zeroes n_tiles of every descriptor, so lookup kernels enqueued behind it do nothing.  ticket_target: tickets of
-// all earlier calls + this grid's workgroups (its last workgroup reports), or 0: a one-thread kernel behind it reports.
+// image and reports ONE pinned, device-visible word, written by the kernel's last workgroup: validate_word(seq, n) -- the
+// call's sequence number over the number of offending values (saturating).  ctl: one ValidateCtl of HBM per call in flight
+// (the engine keeps a ring of them), zeroed once at creation; the reporting workgroup leaves it zeroed for the next user.
+// poison: a finding zeroes n_tiles of every descriptor, so lookup kernels enqueued behind it do nothing.
+//
+// Who is last: returning atomics on ONE address retire at ~20 per microsecond on this chip, a thousand workgroups drawing
+// tickets from one counter would cost more than the checking.  So two levels: workgroup w signs off at sub[w % kValLanes]
+// (each counter on a line of its own, kValStride bytes apart), and the workgroup that completes a sub-counter signs off at
+// `tickets` with the sub-counter's findings; the one that completes THAT reports.  (Rounds 3-6 had a one-thread kernel behind big grids for this: 4.8 us of
+// stream time per checked call, two PCIe writes with a system fence between them.)
+#ifndef PIMEMB_VALIDATE_LANES
+#define PIMEMB_VALIDATE_LANES 32
+#endif
+constexpr uint32_t kValLanes = PIMEMB_VALIDATE_LANES;
+#ifndef PIMEMB_VALIDATE_STRIDE
+#define PIMEMB_VALIDATE_STRIDE 1024
+#endif
+constexpr uint32_t kValStride = PIMEMB_VALIDATE_STRIDE;     // bytes between two counters of a ValidateCtl
+// A counter: finished workgroups in the low kValTicketBits bits, what they found above.
+constexpr uint32_t kValTicketBits = 24;
+constexpr unsigned long long kValTicketMask = (1ull << kValTicketBits) - 1;
 struct ValidateCtl {
-    unsigned long long tickets;   // workgroups of all validation kernels so far
-    unsigned long long bad;       // offending values found so far
+    unsigned long long tickets;   // completed sub-counters (small grids: finished workgroups) | offending values << kValTicketBits
+    char pad_[kValStride - 8];
+    struct Lane {
+        unsigned long long done;  // finished workgroups of this lane | what they found << kValTicketBits
+        char pad_[kValStride - 8];
+    } sub[kValLanes];
 };
-uint32_t validate_workgroups(uint64_t max_items /* largest n_idx / n_bags of a descriptor */);
-hipError_t launch_validate(DevDesc *d_descs, uint32_t n_descs, emb_index_type itype, ValidateCtl *ctl,
-                           unsigned long long ticket_target, unsigned long long *result, unsigned long long seq,
-                           uint32_t wgs_per_desc, bool poison, hipStream_t stream);
+constexpr unsigned long long kValCountMask = 0xffffffull;     // a verdict word carries min(offending values, this)
+constexpr unsigned long long validate_word(unsigned long long seq, unsigned long long bad) {
+    return (seq << 24) | (bad < kValCountMask ? bad : kValCountMask);
+}
+uint32_t validate_workgroups(uint64_t max_items /* largest n_idx / n_bags of a descriptor */, emb_index_type itype);
+hipError_t launch_validate(DevDesc *d_descs, uint32_t n_descs, emb_index_type itype, ValidateCtl *ctl, unsigned long long *result,
+                           unsigned long long seq, uint32_t wgs_per_desc, bool poison, hipStream_t stream);
 
 // Row-range routing of variable-length bags (pooled lookups over row-split tables; see pimemb.h,
 // emb_route_bags).  All pointers are device pointers; the kernels (four; three on the one-index-per-bag fast path)

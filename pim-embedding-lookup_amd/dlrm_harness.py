@@ -25,10 +25,11 @@ class EmbeddingBagCollection:
     """emb_l of a DLRM: T tables of dim m in HBM; forward(lS_o, lS_i) -> list of [B, m]."""
 
     def __init__(self, ln_emb, m_spa: int, device: int = 0, weights=None, seed: int = 0, dtype="f32",
-                 trusted_inputs: bool = False):
+                 trusted_inputs: bool = False, deferred_check: bool = False):
         import torch
         self.torch = torch
         self.trusted_inputs = bool(trusted_inputs)     # False: every apply_emb checks its indices first (IndexError)
+        self.deferred_check = bool(deferred_check)     # ... without waiting for the verdict (a later call / close() raises it)
         self.device = torch.device("cuda", device)
         self.ln_emb, self.m = [int(n) for n in ln_emb], int(m_spa)
         self.engine = EmbeddingEngine(device=device, max_tables=len(self.ln_emb))
@@ -60,7 +61,8 @@ class EmbeddingBagCollection:
         launch on torch's current stream, no plan and no state kept (every batch brings new tensors)."""
         if len(lS_o) != len(self.ln_emb) or len(lS_i) != len(self.ln_emb):
             raise ValueError("need one (offsets, indices) pair per table")
-        check = not self.trusted_inputs      # validated and looked up in ONE engine call; nothing is launched on bad input
+        # validated and looked up in ONE engine call; nothing runs on bad input
+        check = False if self.trusted_inputs else ("deferred" if self.deferred_check else True)
         if hasattr(lS_i, "dim") and hasattr(lS_o, "dim") and lS_i.dim() == 2 and lS_o.dim() == 2 and lS_i.is_cuda:
             # DLRM stacks fixed-size batches into [T, N] / [T, B] tensors: one [T, B, m] result, unbound
             return list(self.engine.lookup_stacked(self._ids, lS_i, lS_o, check=check).unbind(0))

@@ -271,11 +271,16 @@ class EmbeddingEngine:
     """One engine per GPU: tables resident in HBM, lookups as fused HIP launches."""
 
     def __init__(self, device: int = -1, max_tables: int = 1024, lib_path: str | None = None,
-                 check_inputs: bool = False):
+                 check_inputs: bool | str = False):
         # lib_path: another build of libpimemb.so (e.g. the -DPIMEMB_CLAMP_INPUTS=1 flavour)
-        # check_inputs: EMB_FLAG_CHECK_INPUTS -- every plan-less lookup validates its indices / offsets first
+        # check_inputs: EMB_FLAG_CHECK_INPUTS -- every plan-less lookup validates its indices / offsets first;
+        #   "deferred": + EMB_FLAG_DEFER_CHECK -- a device-pointer call does not wait for its verdict (a later call, check_report()
+        #   or close() raises it; the refused call's lookup is kept from running on the GPU all the same)
         self._L = _l.load(lib_path)
-        cfg = _l.EmbConfig(device, max_tables, _l.EMB_FLAG_CHECK_INPUTS if check_inputs else 0)
+        flags = _l.EMB_FLAG_CHECK_INPUTS if check_inputs else 0
+        if check_inputs == "deferred":
+            flags |= _l.EMB_FLAG_DEFER_CHECK
+        cfg = _l.EmbConfig(device, max_tables, flags)
         h = C.c_void_p()
         _l.check(self._L.emb_create(C.byref(cfg), C.byref(h)))
         self._h = h.value
@@ -465,6 +470,33 @@ class EmbeddingEngine:
         raise IndexError(f"{bad} index / offset value(s) out of range for the embedding table(s) "
                          "(checked on the GPU before anything was launched)")
 
+    def _checked_call(self, arr, n, itype, space, stream, check) -> None:
+        """One checked plan-less call.  check = True / "sync": the verdict is waited for inside the call (IndexError before
+        anything is launched, like nn.EmbeddingBag).  check = "deferred" (device buffers): the call does not wait -- a finding
+        disarms the call's lookup on the GPU (outputs untouched) and is raised as IndexError by a LATER checked call of this
+        engine, by check_report() or by close(), naming the call it belongs to (emb_lookup_batched_checked_deferred)."""
+        if check == "deferred" and space == _l.EMB_MEM_DEVICE:
+            rc = self._L.emb_lookup_batched_checked_deferred(self._h, arr, n, itype, space, stream)
+            if rc == _l.EMB_ERR_RANGE:
+                raise IndexError(self._L.emb_last_error().decode(errors="replace"))
+            _l.check(rc)
+            return
+        bad = C.c_uint64()
+        rc = self._L.emb_lookup_batched_checked(self._h, arr, n, itype, space, stream, C.byref(bad))
+        if rc == _l.EMB_ERR_RANGE:
+            if "EARLIER" in self._L.emb_last_error().decode(errors="replace"):     # a deferred call's finding, met by this one
+                raise IndexError(self._L.emb_last_error().decode(errors="replace"))
+            self._raise_range(bad.value)
+        _l.check(rc)
+
+    def check_report(self) -> None:
+        """Wait for the verdicts of every check="deferred" call made so far; IndexError if one of them was refused."""
+        bad = C.c_uint64()
+        rc = self._L.emb_check_report(self._h, C.byref(bad))
+        if rc == _l.EMB_ERR_RANGE:
+            raise IndexError(self._L.emb_last_error().decode(errors="replace"))
+        _l.check(rc)
+
     def _lookup_batched_marshal(self, tb, table_ids, indices, offsets, outs, stream, check):
         """_lookup_batched_cuda with the tensor lists unpacked by the C helper (one call instead of ~8 attribute
         reads / method calls per table), same checks, same plan cache -- keyed on the descriptor bytes themselves, which
@@ -487,11 +519,7 @@ class EmbeddingEngine:
         if stream is None:
             stream = cur_stream
         if check:
-            bad = C.c_uint64()
-            rc = self._L.emb_lookup_batched_checked(self._h, buf_ptr, n, itype, _l.EMB_MEM_DEVICE, stream, C.byref(bad))
-            if rc == _l.EMB_ERR_RANGE:
-                self._raise_range(bad.value)
-            _l.check(rc)
+            self._checked_call(buf_ptr, n, itype, _l.EMB_MEM_DEVICE, stream, check)
             return res
         if self.plan_cache_size:
             key = (key, itype)
@@ -588,12 +616,7 @@ class EmbeddingEngine:
             pack(buf, off, t, 0, ia.data_ptr(), oa.data_ptr(), ia.numel(), b, o.data_ptr())
             off += size
         if check:
-            bad = C.c_uint64()
-            rc = self._L.emb_lookup_batched_checked(self._h, buf_ptr, n, itype, _l.EMB_MEM_DEVICE, stream, C.byref(bad))
-            if rc == _l.EMB_ERR_RANGE:
-                raise IndexError(f"{bad.value} index / offset value(s) out of range for the embedding table(s) "
-                                 "(checked on the GPU before anything was launched)")
-            _l.check(rc)
+            self._checked_call(buf_ptr, n, itype, _l.EMB_MEM_DEVICE, stream, check)
             return list(outs)
         _l.check(self._L.emb_lookup_batched(self._h, buf_ptr, n, itype, _l.EMB_MEM_DEVICE, stream))
         if key is not None:
@@ -683,12 +706,7 @@ class EmbeddingEngine:
         arr["n_indices"] = N
         arr["n_bags"] = B
         if check:
-            bad = C.c_uint64()
-            rc = self._L.emb_lookup_batched_checked(self._h, arr_ptr, T, itype, _l.EMB_MEM_DEVICE, stream, C.byref(bad))
-            if rc == _l.EMB_ERR_RANGE:
-                raise IndexError(f"{bad.value} index / offset value(s) out of range for the embedding table(s) "
-                                 "(checked on the GPU before anything was launched)")
-            _l.check(rc)
+            self._checked_call(arr_ptr, T, itype, _l.EMB_MEM_DEVICE, stream, check)
             return out
         _l.check(self._L.emb_lookup_batched(self._h, arr_ptr, T, itype, _l.EMB_MEM_DEVICE, stream))
         if pkey is not None:
@@ -705,10 +723,12 @@ class EmbeddingEngine:
                                             itype, _l.EMB_MEM_DEVICE, stream))
 
     def lookup_batched(self, table_ids: Sequence[int], indices: Sequence, offsets: Sequence,
-                       outs: Sequence | None = None, fixed_pooling=0, stream: int | None = None, check: bool = False):
+                       outs: Sequence | None = None, fixed_pooling=0, stream: int | None = None, check: bool | str = False):
         """All tables in one fused launch; returns the list of pooled [B_t, D] outputs
         (the `apply_emb` contract: one [B, D] per table).  check=True: indices / offsets are validated on the GPU
-        first (emb_lookup_batched_checked) and IndexError is raised, like nn.EmbeddingBag, before anything is launched."""
+        first (emb_lookup_batched_checked) and IndexError is raised, like nn.EmbeddingBag, before anything is launched.
+        check="deferred": validated all the same and a finding still keeps the lookup from running, but the call does not wait
+        for the verdict (see _checked_call / check_report)."""
         if not fixed_pooling and len(table_ids) and _is_torch(indices[0]):
             res = self._lookup_batched_cuda(table_ids, indices, offsets, outs, stream, check)
             if res is not None:
@@ -717,12 +737,7 @@ class EmbeddingEngine:
         if stream is None and space == _l.EMB_MEM_DEVICE:
             stream = _current_stream_for(*indices)
         if check:
-            bad = C.c_uint64()
-            rc = self._L.emb_lookup_batched_checked(self._h, arr, n, itype, space, stream, C.byref(bad))
-            if rc == _l.EMB_ERR_RANGE:
-                raise IndexError(f"{bad.value} index / offset value(s) out of range for the embedding table(s) "
-                                 "(checked on the GPU before anything was launched)")
-            _l.check(rc)
+            self._checked_call(arr, n, itype, space, stream, check)
             return results
         _l.check(self._L.emb_lookup_batched(self._h, arr, n, itype, space, stream))
         return results
@@ -837,8 +852,15 @@ class EmbeddingEngine:
     def close(self) -> None:
         if self._h:
             self._drop_plans()                       # the plan cache's own plans
+            pending = None
+            try:
+                self.check_report()                  # a deferred verdict nobody met is raised here, after the engine is gone
+            except IndexError as ex:
+                pending = ex
             _l.check(self._L.emb_destroy(self._h))   # raises while plans are alive
             self._h = None
+            if pending is not None:
+                raise pending
 
     def __enter__(self):
         return self

@@ -13,7 +13,7 @@ EMB_ERR_INVALID, EMB_ERR_NOMEM, EMB_ERR_DEVICE, EMB_ERR_UNSUPPORTED, EMB_ERR_RAN
 EMB_F32, EMB_F16, EMB_FIXED32 = 0, 1, 2
 EMB_IDX_U32, EMB_IDX_I64 = 0, 1
 EMB_MEM_HOST, EMB_MEM_DEVICE = 0, 1
-EMB_FLAG_STAGE_TIMING, EMB_FLAG_CHECK_INPUTS = 1, 2
+EMB_FLAG_STAGE_TIMING, EMB_FLAG_CHECK_INPUTS, EMB_FLAG_DEFER_CHECK = 1, 2, 4
 
 
 class EmbConfig(C.Structure):
@@ -147,6 +147,8 @@ SIGNATURES = {
                                          C.POINTER(_u64)]),
     "emb_lookup_batched_checked": (C.c_int, [_vp, C.POINTER(EmbLookupDesc), _u32, C.c_int, C.c_int, _vp,
                                              C.POINTER(_u64)]),
+    "emb_lookup_batched_checked_deferred": (C.c_int, [_vp, C.POINTER(EmbLookupDesc), _u32, C.c_int, C.c_int, _vp]),
+    "emb_check_report": (C.c_int, [_vp, C.POINTER(_u64)]),
     "emb_get_stats": (C.c_int, [_vp, C.POINTER(EmbStats)]),
     "emb_reset_stats": (C.c_int, [_vp]),
     "emb_set_stage_timing": (C.c_int, [_vp, C.c_int]),

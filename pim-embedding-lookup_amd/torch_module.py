@@ -15,7 +15,10 @@ emb_dpu_lookup.c:113); these modules are what user tensors reach first, so by de
 emb_lookup_batched_checked: indices / offsets are validated on the GPU first and IndexError is raised, like
 nn.EmbeddingBag does, before anything is launched.  That costs one small kernel and one event wait per call (no
 allocation, no device-wide synchronize); pass `trusted_inputs=True` (constructor or attribute) for the unchecked
-fast path once the producer of the indices is known to be sound.
+fast path once the producer of the indices is known to be sound, or `deferred_check=True` to keep the check (a bad call's
+lookup is still kept from running, on the GPU) without the wait: the IndexError then comes out of a LATER forward, of
+`engine.check_report()` or of `engine.close()`, naming the call -- the wait inside the call is what a checked forward costs
+(26 tables x 39 292 bags: 41 us checked, 21 us unchecked; deferred: see profiles/r06/py_overhead_deferred_check.log).
 
 Checkpoints.  `state_dict()` carries `<prefix>weight` read out of HBM and `load_state_dict` uploads it, so a
 DLRM whose `emb_l[k]` were swapped for these modules saves / loads the same keys and shapes as before."""
@@ -74,9 +77,10 @@ class EmbeddingBag(torch.nn.Module):
 
     def __init__(self, num_embeddings: int, embedding_dim: int, mode: str = "sum", sparse: bool = False,
                  _weight=None, include_last_offset: bool = False, device: int = 0, engine: EmbeddingEngine | None = None,
-                 table_id: int | None = None, dtype=torch.float32, trusted_inputs: bool = False):
+                 table_id: int | None = None, dtype=torch.float32, trusted_inputs: bool = False, deferred_check: bool = False):
         super().__init__()
         self.trusted_inputs = bool(trusted_inputs)
+        self.deferred_check = bool(deferred_check)
         self._table_dtype = dtype
         if mode != "sum":
             raise NotImplementedError("only mode='sum' (the reference pools by summation, emb_dpu_lookup.c:114)")
@@ -116,7 +120,8 @@ class EmbeddingBag(torch.nn.Module):
             raise NotImplementedError("per_sample_weights are not part of the reference path")
         idx, off = _bags_from(input, offsets, self.include_last_offset)
         idx, off = idx.contiguous(), off.contiguous()
-        return self.engine.lookup_batched(self._id_list, [idx], [off], check=not self.trusted_inputs)[0]
+        check = False if self.trusted_inputs else ("deferred" if self.deferred_check else True)
+        return self.engine.lookup_batched(self._id_list, [idx], [off], check=check)[0]
 
     # ---- checkpoints: the same key and shape as nn.EmbeddingBag ("<prefix>weight", [num_embeddings, dim]) ----
     def _save_to_state_dict(self, destination, prefix, keep_vars):
@@ -144,11 +149,12 @@ class EmbeddingBag(torch.nn.Module):
 class FusedEmbeddingBags(torch.nn.Module):
     """All tables of a model: forward(lS_o, lS_i) -> list of [B, m] with ONE fused launch (apply_emb)."""
 
-    def __init__(self, bags, trusted_inputs: bool | None = None):
+    def __init__(self, bags, trusted_inputs: bool | None = None, deferred_check: bool | None = None):
         super().__init__()
         self.bags = torch.nn.ModuleList(bags)
-        # unchecked only if every table says so (or the caller does)
+        # unchecked only if every table says so (or the caller does); the same for the deferred verdict
         self.trusted_inputs = all(b.trusted_inputs for b in bags) if trusted_inputs is None else bool(trusted_inputs)
+        self.deferred_check = all(b.deferred_check for b in bags) if deferred_check is None else bool(deferred_check)
         engines = {id(b.engine) for b in self.bags}
         if len(engines) != 1:
             raise ValueError("all tables of a FusedEmbeddingBags must live in one engine")
@@ -160,7 +166,7 @@ class FusedEmbeddingBags(torch.nn.Module):
         return cls([EmbeddingBag.from_torch(m, **kw) for m in emb_l])
 
     def forward(self, lS_o, lS_i):
-        check = not self.trusted_inputs
+        check = False if self.trusted_inputs else ("deferred" if self.deferred_check else True)
         if hasattr(lS_i, "dim") and lS_i.dim() == 2 and hasattr(lS_o, "dim") and lS_o.dim() == 2 and lS_i.is_cuda:
             return list(self.engine.lookup_stacked(self._ids, lS_i, lS_o, check=check).unbind(0))
         idx, off = [], []

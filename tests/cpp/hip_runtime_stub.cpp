@@ -7,7 +7,7 @@
 //     copies = memcpy, streams / events = small heap objects, everything synchronous;
 //   * kernel launches are NO-OPS -- no lookup is computed here, nothing a test could mistake for a result -- except the
 //     few SIGNALLING kernels whose words the host code waits for: store_word, publish_words, zero_words, validate (counts
-//     out-of-range indices: its verdict steers host control flow), validate_publish, and the routers' COUNTS (they size the
+//     out-of-range indices: its verdict steers host control flow), and the routers' COUNTS (they size the
 //     sharded step's transfers; the request pieces themselves stay zero), the two mailbox kernels of the peer-store mode, and the served-bag
 //     COUNTERS of a checked shard's counted ranged launch with the kernel that publishes them.  They run synchronously inside hipLaunchKernel,
 //     found by the name the compiler registers for them.
@@ -80,13 +80,13 @@ struct PublishSrcMirror { const uint32_t *p[3]; uint32_t n[3]; };     // pimemb_
 template <typename IdxT>
 void emulate_validate(void **args, dim3 grid) {
     using pimemb::DevDesc;
+    (void)grid;
     DevDesc *descs = arg<DevDesc *>(args, 0);
     const uint32_t n_descs = arg<uint32_t>(args, 1);
-    pimemb::ValidateCtl *ctl = arg<pimemb::ValidateCtl *>(args, 2);
-    const unsigned long long target = arg<unsigned long long>(args, 3);
-    unsigned long long *result = const_cast<unsigned long long *>(arg<volatile unsigned long long *>(args, 4));
-    const unsigned long long seq = arg<unsigned long long>(args, 5);
-    const int poison = arg<int>(args, 6);
+    // (args[2], the call's ValidateCtl: the kernel's workgroups meet there; here the whole grid is this one function)
+    unsigned long long *result = const_cast<unsigned long long *>(arg<volatile unsigned long long *>(args, 3));
+    const unsigned long long seq = arg<unsigned long long>(args, 4);
+    const int poison = arg<int>(args, 5);
     unsigned long long bad = 0;
     for (uint32_t d = 0; d < n_descs; d++) {
         const DevDesc &dd = descs[d];
@@ -102,16 +102,9 @@ void emulate_validate(void **args, dim3 grid) {
             bad++;
         }
     }
-    __atomic_fetch_add(&ctl->bad, bad, __ATOMIC_RELAXED);         // (the kernel's adds are atomics too)
     if (bad && poison)
         for (uint32_t d = 0; d < n_descs; d++) descs[d].n_tiles = 0;
-    if (target != 0) {
-        const unsigned long long t = __atomic_add_fetch(&ctl->tickets, (unsigned long long)grid.x * grid.y, __ATOMIC_ACQ_REL);
-        if (t == target) {
-            __atomic_store_n(&result[0], __atomic_load_n(&ctl->bad, __ATOMIC_RELAXED), __ATOMIC_RELAXED);
-            __atomic_store_n(&result[1], seq, __ATOMIC_RELEASE);
-        }
-    }
+    __atomic_store_n(result, pimemb::validate_word(seq, bad), __ATOMIC_RELEASE);
 }
 
 // The routers' COUNTS (nothing else of their output: request pieces, slots and the rest of `meta` stay zero -- no lookup is
@@ -279,11 +272,6 @@ void emulate(const std::string &name, void **args, dim3 grid) {
         const pimemb::PeerDoneArgs a = arg<pimemb::PeerDoneArgs>(args, 0);
         for (uint32_t i = 0; i < a.n; i++)
             __atomic_store_n(const_cast<unsigned long long *>(&reinterpret_cast<pimemb::PeerMsg *>(a.box[i])->served), arg<unsigned long long>(args, 1), __ATOMIC_RELEASE);
-    } else if (name.find("validate_publish_kernel") != std::string::npos) {
-        const pimemb::ValidateCtl *ctl = arg<const pimemb::ValidateCtl *>(args, 0);
-        unsigned long long *result = const_cast<unsigned long long *>(arg<volatile unsigned long long *>(args, 1));
-        __atomic_store_n(&result[0], __atomic_load_n(&ctl->bad, __ATOMIC_RELAXED), __ATOMIC_RELAXED);
-        __atomic_store_n(&result[1], arg<unsigned long long>(args, 2), __ATOMIC_RELEASE);
     } else if (name.find("validate_kernelIjE") != std::string::npos) {
         emulate_validate<uint32_t>(args, grid);
     } else if (name.find("validate_kernelIlE") != std::string::npos) {

@@ -176,6 +176,79 @@ void xmap_cache_shapes() {
     printf("xmap cache under shapes that do not recur ok (%ld device-wide waits in 3 129 launches)\n", pimemb_stub_device_syncs() - syncs0);
 }
 
+// ---- checked calls whose verdict is deferred (EMB_FLAG_DEFER_CHECK / emb_lookup_batched_checked_deferred / emb_check_report) -----
+// The finding of a call is returned by a LATER call or by emb_check_report, once, naming the call; more calls than verdict
+// slots between two reports; a synchronous checked call behind a deferred one reports the earlier finding.
+void deferred_check() {
+    for (int via_flag = 0; via_flag < 2; via_flag++) {
+        emb_engine *e = make_engine(via_flag ? (EMB_FLAG_CHECK_INPUTS | EMB_FLAG_DEFER_CHECK) : 0u);
+        const uint32_t B = 96;
+        std::vector<uint32_t> idx(B), off(B);
+        for (uint32_t b = 0; b < B; b++) { idx[b] = (b * 37u) % kRows; off[b] = b; }
+        void *d_idx = nullptr, *d_off = nullptr, *d_out = nullptr, *stream = nullptr;
+        CHECK(emb_stream_create(e, &stream));
+        CHECK(emb_device_alloc(e, B * 4, &d_idx));
+        CHECK(emb_device_alloc(e, B * 4, &d_off));
+        CHECK(emb_device_alloc(e, (size_t)B * kDim * 4, &d_out));
+        CHECK(emb_copy_to_device(e, d_idx, idx.data(), B * 4));
+        CHECK(emb_copy_to_device(e, d_off, off.data(), B * 4));
+        emb_lookup_desc d{1, 0, d_idx, d_off, B, B, static_cast<float *>(d_out)};
+        auto call = [&]() {
+            return via_flag ? emb_lookup_batched(e, &d, 1, EMB_IDX_U32, EMB_MEM_DEVICE, stream)
+                            : emb_lookup_batched_checked_deferred(e, &d, 1, EMB_IDX_U32, EMB_MEM_DEVICE, stream);
+        };
+        auto spoil = [&](bool on) {
+            uint32_t v = on ? kRows + 3 : idx[5];
+            CHECK(emb_copy_to_device(e, static_cast<char *>(d_idx) + 20, &v, 4));
+        };
+        uint64_t bad = 7;
+        for (int i = 0; i < 150; i++) CHECK(call());                 // more clean calls than verdict slots: every one is read in turn
+        CHECK(emb_check_report(e, &bad));
+        EXPECT(bad == 0);
+        emb_stats before{}, after{};
+        CHECK(emb_get_stats(e, &before));
+        spoil(true);
+        CHECK(call());                                               // the bad call itself: its verdict is not waited for
+        spoil(false);
+        int rc = call();                                             // the next one brings the finding (and has launched its own work)
+        EXPECT(rc == EMB_ERR_RANGE && strstr(emb_last_error(), "EARLIER") != nullptr && strstr(emb_last_error(), "number 151") != nullptr);
+        CHECK(call());                                               // ... once
+        CHECK(emb_check_report(e, &bad));
+        EXPECT(bad == 0);
+        CHECK(emb_get_stats(e, &after));
+        EXPECT(after.n_lookup_calls == before.n_lookup_calls + 3);
+        EXPECT(after.n_kernel_launches == before.n_kernel_launches + 2);       // the refused call's lookup did nothing
+        // a finding nobody met in a later call: emb_check_report has it, once, with the count
+        spoil(true);
+        CHECK(call());
+        spoil(false);
+        rc = emb_check_report(e, &bad);
+        EXPECT(rc == EMB_ERR_RANGE && bad == 1);
+        CHECK(emb_check_report(e, &bad));
+        EXPECT(bad == 0);
+        // a synchronous checked call behind a deferred bad one: the earlier finding comes out of it; its own verdict is clean
+        spoil(true);
+        CHECK(call());
+        spoil(false);
+        rc = emb_lookup_batched_checked(e, &d, 1, EMB_IDX_U32, EMB_MEM_DEVICE, stream, &bad);
+        EXPECT(rc == EMB_ERR_RANGE && bad == 1 && strstr(emb_last_error(), "EARLIER") != nullptr);
+        CHECK(emb_lookup_batched_checked(e, &d, 1, EMB_IDX_U32, EMB_MEM_DEVICE, stream, &bad));
+        EXPECT(bad == 0);
+        // emb_validate_inputs is never deferred
+        spoil(true);
+        rc = emb_validate_inputs_on(e, &d, 1, EMB_IDX_U32, EMB_MEM_DEVICE, stream, &bad);
+        EXPECT(rc == EMB_ERR_RANGE && bad == 1);
+        spoil(false);
+        CHECK(emb_synchronize(e, stream));
+        CHECK(emb_device_free(e, d_idx));
+        CHECK(emb_device_free(e, d_off));
+        CHECK(emb_device_free(e, d_out));
+        CHECK(emb_stream_destroy(e, stream));
+        CHECK(emb_destroy(e));
+    }
+    printf("deferred verdicts of checked calls ok\n");
+}
+
 // ---- the engine picks a table's hot rows itself (emb_learn_hot_rows): sampling, counting, the min_share rule -------------------
 void learn_hot_rows_check() {
     emb_engine *e = make_engine(0);
@@ -812,6 +885,7 @@ int main(int argc, char **argv) {
         engine_threads();
         xmap_cache_shapes();
         learn_hot_rows_check();
+        deferred_check();
         queue_threads();
         shard_one_rank(false, false);
         shard_one_rank(false, true);
