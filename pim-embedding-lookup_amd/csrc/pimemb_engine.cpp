@@ -977,7 +977,8 @@ int emb_create(const emb_config *cfg, emb_engine **out) {
     return EMB_OK;
 }
 
-static int read_verdicts(emb_engine *e, bool wait, unsigned long long *bad_total, unsigned long long *first_seq);
+static int read_verdicts(emb_engine *e, bool wait, unsigned long long *bad_total, unsigned long long *first_seq,
+                         unsigned long long own_seq = 0, unsigned long long *own_bad = nullptr);
 
 int emb_destroy(emb_engine *e) {
     if (!e) return EMB_OK;
@@ -1476,10 +1477,12 @@ static void resync_validation(emb_engine *e) {
 // Read the verdicts of deferred checked calls, oldest first (caller holds val_mu).  wait = false: only those that have arrived;
 // wait = true: all of them (a spin, then the call's stream).  *bad_total / *first_seq: offending values found and the sequence
 // number of the first call they belong to.  A refused call's lookup kernels were disarmed on the device: they are taken out of
-// the launch statistics here.
-static int read_verdicts(emb_engine *e, bool wait, unsigned long long *bad_total, unsigned long long *first_seq) {
+// the launch statistics here.  own_seq / own_bad: the finding of THAT call is returned apart (not in *bad_total).
+static int read_verdicts(emb_engine *e, bool wait, unsigned long long *bad_total, unsigned long long *first_seq,
+                         unsigned long long own_seq, unsigned long long *own_bad) {
     *bad_total = 0;
     *first_seq = 0;
+    if (own_bad) *own_bad = 0;
     while (!e->val_pending.empty()) {
         const emb_engine::PendingVerdict pv = e->val_pending.front();
         const uint32_t slot = (uint32_t)(pv.seq % emb_engine::kValSlots);
@@ -1500,8 +1503,12 @@ static int read_verdicts(emb_engine *e, bool wait, unsigned long long *bad_total
         e->val_pending.pop_front();
         const unsigned long long bad = word & pimemb::kValCountMask;
         if (bad) {
-            if (!*bad_total) *first_seq = pv.seq;
-            *bad_total += bad;
+            if (own_bad && pv.seq == own_seq) {
+                *own_bad = bad;
+            } else {
+                if (!*bad_total) *first_seq = pv.seq;
+                *bad_total += bad;
+            }
             if (pv.launched) {
                 e->n_kernel_launches.fetch_sub(pv.n_groups, std::memory_order_relaxed);
                 for (uint32_t g = 0; g < pv.n_groups && g < 8; g++) e->n_by_kind[pv.kinds[g]].fetch_sub(1, std::memory_order_relaxed);
@@ -1524,9 +1531,16 @@ static int checked_launch(emb_engine *e, Resolved &r, emb_index_type itype, hipS
     if (r.descs.empty()) return EMB_OK;
     std::lock_guard<std::mutex> vlk(e->val_mu);
     unsigned long long seq = 0, earlier_bad = 0, earlier_seq = 0;
-    // verdicts of earlier deferred calls: what has arrived (all of them before a slot is reused, or when this call will wait anyway)
-    if (!e->val_pending.empty())
-        EMB_TRY(read_verdicts(e, /*wait=*/!defer || e->val_pending.size() + 1 >= emb_engine::kValSlots, &earlier_bad, &earlier_seq));
+    // verdicts of earlier deferred calls: what has arrived (all of them before a slot is reused).  A call that waits for its own
+    // verdict reads them behind its launch, in one wait.
+    if (defer && !e->val_pending.empty())
+        EMB_TRY(read_verdicts(e, /*wait=*/false, &earlier_bad, &earlier_seq));
+    if (e->val_pending.size() + 1 >= emb_engine::kValSlots) {
+        unsigned long long more = 0, more_seq = 0;
+        EMB_TRY(read_verdicts(e, /*wait=*/true, &more, &more_seq));
+        if (more && !earlier_bad) earlier_seq = more_seq;
+        earlier_bad += more;
+    }
     volatile unsigned long long *result = nullptr;
     uint32_t slot = 0;
     {
@@ -1577,19 +1591,23 @@ static int checked_launch(emb_engine *e, Resolved &r, emb_index_type itype, hipS
         for (size_t g = 0; g < r.groups.size() && g < 8; g++) pv.kinds[g] = r.groups[g].kind;
         e->val_pending.push_back(pv);
     }
-    unsigned long long bad = 0, bad_seq = 0;
-    if (!defer) {              // this call's own verdict (and whatever was still outstanding in front of it)
-        unsigned long long mine = 0, mine_seq = 0;
-        EMB_TRY(read_verdicts(e, /*wait=*/true, &mine, &mine_seq));
-        bad = mine;
-        bad_seq = mine_seq;
+    unsigned long long bad = 0;
+    if (!defer) {              // this call's own verdict, and whatever was still outstanding in front of it
+        unsigned long long more = 0, more_seq = 0;
+        EMB_TRY(read_verdicts(e, /*wait=*/true, &more, &more_seq, seq, &bad));
+        if (more && !earlier_bad) earlier_seq = more_seq;
+        earlier_bad += more;
     }
     if (n_bad) *n_bad = bad + earlier_bad;
-    if (earlier_bad && (defer || !bad))
+    if (bad) {
+        if (earlier_bad)
+            return fail(EMB_ERR_RANGE, "%llu out-of-range indices / broken offsets (and %llu in EARLIER checked calls whose verdict was deferred, "
+                        "the first of them number %llu of this engine)", bad, earlier_bad, earlier_seq);
+        return fail(EMB_ERR_RANGE, "%llu out-of-range indices / broken offsets", bad);
+    }
+    if (earlier_bad)
         return fail(EMB_ERR_RANGE, "%llu out-of-range indices / broken offsets in an EARLIER checked call (number %llu of this engine; its "
                     "lookup was disarmed on the device: outputs untouched) -- reported now: the verdict was deferred", earlier_bad, earlier_seq);
-    if (bad) return fail(EMB_ERR_RANGE, "%llu out-of-range indices / broken offsets", bad + earlier_bad);
-    (void)bad_seq;
     return EMB_OK;
 }
 

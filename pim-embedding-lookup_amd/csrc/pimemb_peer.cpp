@@ -15,6 +15,7 @@
 // STATUS: exercised with 2-4 processes sharing the development box's one GPU (peer mappings of the same device); never
 // over xGMI.  Visibility of peer stores across real links rests on the arena being fine-grained memory and on kernel
 // boundaries; link rates are unmeasured.
+#include <signal.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -414,6 +415,55 @@ int emb_peer_destroy(emb_peer *p) {
     if (p->creator && !p->unlinked && !p->shm_name.empty()) (void)shm_unlink(p->shm_name.c_str());   // a set-up that failed half-way leaves no segment behind
     (void)hipGetLastError();
     delete p;
+    return EMB_OK;
+}
+
+// ---- last words (see pimemb.h) -----------------------------------------------------------------------------------------
+namespace {
+char *g_last_words = nullptr;                  // malloc'd, never freed while the handlers are in (a handler may be reading it)
+size_t g_last_words_len = 0;
+int g_last_words_fd = 1, g_last_words_status = 0;
+bool g_last_words_in = false;
+struct sigaction g_last_words_old[3];
+const int kLastWordSignals[3] = {SIGABRT, SIGSEGV, SIGBUS};
+
+void last_words_handler(int) {
+    size_t off = 0;
+    while (off < g_last_words_len) {
+        const ssize_t n = write(g_last_words_fd, g_last_words + off, g_last_words_len - off);
+        if (n <= 0) break;
+        off += (size_t)n;
+    }
+    _exit(g_last_words_status);
+}
+}  // namespace
+
+int emb_peer_last_words(const char *line, int fd, int status) {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (g_last_words_in) {                     // take the handlers out first: nothing reads the old text after this
+        for (int i = 0; i < 3; i++) (void)sigaction(kLastWordSignals[i], &g_last_words_old[i], nullptr);
+        g_last_words_in = false;
+    }
+    free(g_last_words);
+    g_last_words = nullptr;
+    g_last_words_len = 0;
+    if (!line) return EMB_OK;
+    const size_t n = strlen(line);
+    g_last_words = static_cast<char *>(malloc(n + 2));
+    if (!g_last_words) return fail(EMB_ERR_NOMEM, "emb_peer_last_words: %zu bytes", n + 2);
+    memcpy(g_last_words, line, n);
+    g_last_words_len = n;
+    g_last_words_fd = fd;
+    g_last_words_status = status;
+    if (n && line[n - 1] != '\n') g_last_words[g_last_words_len++] = '\n';
+    struct sigaction sa;
+    memset(&sa, 0, sizeof sa);
+    sa.sa_handler = last_words_handler;
+    sigemptyset(&sa.sa_mask);
+    for (int i = 0; i < 3; i++)
+        if (sigaction(kLastWordSignals[i], &sa, &g_last_words_old[i]) != 0) return fail(EMB_ERR_DEVICE, "emb_peer_last_words: sigaction failed");
+    g_last_words_in = true;
     return EMB_OK;
 }
 

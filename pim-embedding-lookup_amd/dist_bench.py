@@ -826,7 +826,7 @@ def run(args, hbm_peak_gbs: float) -> None:
     os.environ.setdefault("MASTER_PORT", "29533")
     dist.init_process_group(backend, rank=rank, world_size=world,
                             **({"device_id": dev} if backend == "nccl" else {}))
-    ctx = dict(rank=rank, world=world, dev=dev, backend=backend, stage_cpu=backend != "nccl")
+    ctx = dict(rank=rank, world=world, dev=dev, backend=backend, stage_cpu=backend != "nccl", json_fd=json_fd)
     dist.barrier()       # the first collective sets the communicator's channels up (milliseconds): not right before a clock starts
 
     rows_list, dim, _, _ = table_set_of(pel, args)
@@ -895,6 +895,19 @@ def run(args, hbm_peak_gbs: float) -> None:
             state["dog"] = threading.Timer(limit, die, (3, "timed out after %.0f s" % limit))
             state["dog"].daemon = True
             state["dog"].start()
+            # ... and so does a process that DIES in it (abort() is the runtime's answer to a GPU memory fault): rank 0 leaves the
+            # replica line with the failure noted on its way out (emb_peer_last_words), status 5
+            from . import lib as _lib
+            if rank == 0 and result is not None:
+                import copy
+                snap = copy.deepcopy(result)
+                note = "the process received a fatal signal inside the sharded leg (stderr has the runtime's message)"
+                snap["sharded_exchange"] = {"failed": note}
+                snap["headline"] = "replica (the sharded leg failed: %s)" % note
+                snap["config"]["exchange"] = {"failed": note, "verified": False}
+                snap["verified"] = False
+                sys.stdout.flush()
+                _lib.load().emb_peer_last_words(json.dumps(finish(snap)).encode(), json_fd, 5)
             try:
                 sec = shard_leg(args, hbm_peak_gbs, ctx, 64 << 20)
             except BaseException as ex:  # noqa: BLE001 -- SystemExit from a leg included
@@ -902,6 +915,8 @@ def run(args, hbm_peak_gbs: float) -> None:
                 traceback.print_exc()
                 die(4, f"{type(ex).__name__}: {ex}")
             state["dog"].cancel()
+            if rank == 0:
+                _lib.load().emb_peer_last_words(None, 1, 0)
             if rank == 0:
                 sec["config"]["exchange"] = dict(sec["config"]["exchange"], steps=sec["steps"], transport=sec["config"]["exchange_transport"],
                                                  last_step_sharded_outputs_sha1=sec["config"].get("last_step_sharded_outputs_sha1"))
@@ -961,6 +976,18 @@ def peer_leg(args, rep_bytes, result, emit, finish, ctx, shard_leg, hbm_peak_gbs
     dog = threading.Timer(limit, expire)
     dog.daemon = True
     dog.start()
+    # ... and a process that DIES in here (a GPU memory fault across links nobody has run this leg over ends in abort()) says the
+    # same thing on its way out: rank 0 leaves the line it has, every rank ends with status 0 (emb_peer_last_words)
+    from . import lib as _lib
+    last = ""
+    if rank == 0 and result is not None:
+        snap = copy.deepcopy(result)
+        snap["exchange_peer"] = snap["config"]["exchange_peer"] = {
+            "skipped": "the process received a fatal signal inside the peer-store leg (stderr has the runtime's message); "
+                       "the RCCL leg's numbers on this line were measured before it"}
+        last = json.dumps(finish(snap))
+    sys.stdout.flush()
+    _lib.load().emb_peer_last_words(last.encode(), int(ctx.get("json_fd", 1)), 0)
     a3 = copy.copy(args)
     if secondary:            # the same W / K as the RCCL leg it is compared with (the digest is over the slot the loop ends on)
         a3.steps, a3.warmup = min(args.steps, 400), min(args.warmup, 40)
@@ -982,9 +1009,18 @@ def peer_leg(args, rep_bytes, result, emit, finish, ctx, shard_leg, hbm_peak_gbs
         else:
             os.environ[k] = v
     worst = torch.tensor([status], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
-    dist.all_reduce(worst, op=dist.ReduceOp.MAX)          # every rank ends this leg the same way (under the same deadline)
-    worst = int(worst.item())
+    try:
+        dist.all_reduce(worst, op=dist.ReduceOp.MAX)      # every rank ends this leg the same way (under the same deadline)
+        worst = int(worst.item())
+    except BaseException as ex:  # noqa: BLE001 -- a rank that died in the leg takes the collective with it (gloo raises, RCCL hangs until the deadline)
+        dog.cancel()
+        record({"skipped": "a rank left the job inside the peer-store leg (%s: %s); %s" % (type(ex).__name__, str(ex)[:200], note or "its stderr says why")})
+        emit(finish(result))
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
     dog.cancel()
+    _lib.load().emb_peer_last_words(None, 1, 0)
     if worst == 2:
         record({"failed": note or "another rank's peer-store outputs differ from the expected rows", "verified": False})
         if rank == 0 and result is not None:

@@ -109,6 +109,7 @@ SIGNATURES = {
     "emb_peer_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), _pp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_i32)]),
     "emb_peer_barrier": (C.c_int, [_vp]),
     "emb_peer_destroy": (C.c_int, [_vp]),
+    "emb_peer_last_words": (C.c_int, [C.c_char_p, C.c_int, C.c_int]),
     "emb_shard_create": (C.c_int, [_vp, _vp, C.POINTER(EmbShardConfig), _pp]),
     "emb_shard_submit": (C.c_int, [_vp, C.POINTER(EmbShardInput), _u64, _vp, C.POINTER(_u64)]),
     "emb_shard_flush": (C.c_int, [_vp]),

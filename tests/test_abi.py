@@ -171,3 +171,34 @@ def test_boundary_documents_do_not_name_a_retired_transport():
     # ... and what bench.py ships agrees: --collective has the one choice
     bench = open(os.path.join(ROOT, "bench.py")).read()
     assert 'choices=["native"]' in bench and '"--collective"' in bench
+
+
+def test_last_words_survive_a_fatal_signal(tmp_path):
+    """emb_peer_last_words (what bench.py's peer-store leg leaves behind before it runs code no link has seen): a process that
+    abort()s -- the runtime's answer to a GPU memory fault -- or segfaults while a line is registered writes the line to the
+    given descriptor and ends with the given status; once the handlers are taken out again a fatal signal is fatal again."""
+    import subprocess
+    import sys
+    import textwrap
+    script = textwrap.dedent("""
+        import ctypes, os, sys
+        sys.path.insert(0, %r)
+        import pim_embedding_lookup_amd as pel
+        L = pel.lib.load()
+        how = sys.argv[1]
+        fd = os.dup(1)
+        os.dup2(2, 1)                        # (as dist_bench does: descriptor 1 belongs to the libraries)
+        assert L.emb_peer_last_words(b'{"metric": "x", "value": 1}', fd, 0) == 0
+        assert L.emb_peer_last_words(b'{"metric": "kept", "value": 2}', fd, 5 if how == "status" else 0) == 0      # replaced, not appended
+        if how == "cleared":
+            assert L.emb_peer_last_words(None, 1, 0) == 0
+        if how == "segv":
+            ctypes.string_at(8)
+        os.abort()
+    """ % ROOT)
+    for how, rc_ok in (("abort", True), ("segv", True), ("status", True), ("cleared", False)):
+        res = subprocess.run([sys.executable, "-c", script, how], capture_output=True, text=True, timeout=120)
+        if rc_ok:
+            assert res.returncode == (5 if how == "status" else 0) and res.stdout == '{"metric": "kept", "value": 2}\n', (how, res.returncode, res.stdout, res.stderr[-500:])
+        else:
+            assert res.returncode != 0 and res.stdout == "", (how, res.returncode, res.stdout)

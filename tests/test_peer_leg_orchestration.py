@@ -54,6 +54,11 @@ def shard_leg(a, peak, c, rep, transport=None):
         return canned("abc") if rank == 0 else None
     if mode == "hang":
         time.sleep(3600)
+    if mode.startswith("abort-rank"):            # what a GPU memory fault ends in: the runtime calls abort()
+        if rank == int(mode[-1]):
+            os.abort()
+        time.sleep(1.0)
+        return canned("abc") if rank == 0 else None
 args = types.SimpleNamespace(steps=4, warmup=2)
 db.peer_leg(args, 64 << 20, result, emit, finish, ctx, shard_leg, 8000.0, True)
 emit(finish(result))
@@ -117,3 +122,14 @@ def test_peer_leg_that_hangs_ends_at_its_deadline_with_the_line_printed(tmp_path
     assert rcs == [0, 0], outs
     assert d["verified"] is True and d["value"] == 1.0
     assert "no result within 2 s" in d["exchange_peer"]["skipped"]
+
+
+@pytest.mark.parametrize("who", [0, 1])
+def test_peer_leg_in_which_a_rank_dies_keeps_the_rccl_numbers(tmp_path, who):
+    """A fatal signal inside the leg (abort(): the runtime's answer to a GPU memory fault) on rank 0 or on another rank: the
+    line with the RCCL leg's numbers is still printed -- by rank 0's signal handler (emb_peer_last_words) or by rank 0 once its
+    collective with the dead rank fails -- and EVERY rank ends with status 0, so the launcher does not tear the job down."""
+    rcs, d, outs = _run("abort-rank%d" % who, tmp_path, {"PIMEMB_PEER_LEG_TIMEOUT": "60"})
+    assert rcs == [0, 0], outs
+    assert d["verified"] is True and d["value"] == 1.0 and "value_exchange_peer" not in d
+    assert "skipped" in d["exchange_peer"] and ("fatal signal" if who == 0 else "left the job") in d["exchange_peer"]["skipped"]
