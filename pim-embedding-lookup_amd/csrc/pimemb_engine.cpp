@@ -1493,7 +1493,10 @@ static int read_verdicts(emb_engine *e, bool wait, unsigned long long *bad_total
             for (int spin = 0; spin < 200000 && ((word = *result) >> 24) != pv.seq; spin++) {
             }
             if ((word >> 24) != pv.seq) {
-                HIP_TRY(hipStreamSynchronize(pv.stream));
+                if (hipStreamSynchronize(pv.stream) != hipSuccess) {     // (the caller may have destroyed the stream since: wait for the device)
+                    (void)hipGetLastError();
+                    HIP_TRY(hipDeviceSynchronize());
+                }
                 if (((word = *result) >> 24) != pv.seq) {
                     resync_validation(e);
                     return fail(EMB_ERR_DEVICE, "validation kernel of checked call %llu did not report", pv.seq);
