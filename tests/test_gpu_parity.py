@@ -2328,3 +2328,94 @@ def test_deferred_verdict_of_checked_calls(pel, oracle):
             torch.cuda.synchronize()
     e.check_report()
     e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("itype", ["u32", "i64"])
+def test_validation_kernel_counts_exactly(pel, itype):
+    """The validation kernel (16-byte loads, two-level tickets that carry the findings, one verdict word) against a numpy count:
+    lengths around every boundary of its layout (the vector width, a workgroup's share, the 32-counter threshold, the cap of
+    1 024 workgroups per descriptor -> the grid-stride loop), arrays that start at ANY element (views: 4- / 8-byte aligned only),
+    descriptors of very different lengths in one launch, bad values at the head, in the remainder, on vector boundaries, in the
+    last bag; broken offsets of every kind.  Device and host buffers."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(77 if itype == "u32" else 78)
+    npt = np.uint32 if itype == "u32" else np.int64
+    tdt = torch.int32 if itype == "u32" else torch.int64
+    e = pel.EmbeddingEngine(device=0, max_tables=8)
+    rows = [50, 1000, 1 << 20, 7]
+    for t, n in enumerate(rows):
+        e.alloc_table(t, n, 16, pel.EMB_F32)
+
+    def want(idx, off, n_rows):
+        i = idx.astype(np.int64) if itype == "i64" else idx.astype(np.uint64)
+        bad = int(((i < 0) | (i >= n_rows)).sum()) if itype == "i64" else int((i >= n_rows).sum())
+        o = off.astype(np.int64) if itype == "i64" else off.astype(np.uint64).astype(np.int64)
+        nxt = np.append(o[1:], len(idx))
+        ou = o.astype(np.uint64) if itype == "i64" else o.astype(np.uint64)
+        nu = nxt.astype(np.uint64)
+        bad += int(((ou > nu) | (nu > np.uint64(len(idx)))).sum())
+        return bad
+
+    def make(n_idx, n_bags, n_rows, spoil):
+        idx = rng.integers(0, n_rows, size=n_idx).astype(npt)
+        cuts = np.sort(rng.integers(0, n_idx + 1, size=n_bags)) if n_bags else np.zeros(0, np.int64)
+        if n_bags:
+            cuts[0] = 0
+        off = cuts.astype(npt)
+        if spoil and n_idx:
+            k = min(n_idx, int(rng.integers(1, 9)))
+            pos = set(int(x) for x in rng.integers(0, n_idx, size=k))
+            pos |= {0, n_idx - 1, (n_idx // 4) * 4 - 1 if n_idx >= 4 else 0, max(0, n_idx - n_idx % 4)}
+            for p in pos:
+                p = min(max(p, 0), n_idx - 1)
+                idx[p] = n_rows + int(rng.integers(0, 5)) if (itype == "u32" or rng.integers(0, 2)) else -1 - int(rng.integers(0, 5))
+        if spoil and n_bags >= 2:
+            for _ in range(int(rng.integers(1, 4))):
+                b = int(rng.integers(0, n_bags))
+                kind = int(rng.integers(0, 3))
+                if kind == 0:
+                    off[b] = n_idx + 1 + int(rng.integers(0, 3))          # beyond the indices
+                elif kind == 1 and itype == "i64":
+                    off[b] = -3
+                else:
+                    off[b] = (int(off[b - 1]) + int(off[b]) + 1) if b else off[b]    # may break monotony
+            off[n_bags - 1] = n_idx + 2                                  # the last bag: its end is n_idx
+        return idx, off
+
+    lengths = [0, 1, 2, 3, 4, 5, 7, 8, 9, 255, 256, 257, 1023, 1024, 1025, 2047, 2048, 2049, 4096 + 3, 33 * 1024 + 1, 70_001, 1024 * 1024 * 2 + 5]
+    checked = 0
+    for spoil in (False, True):
+        for n_idx in lengths:
+            for shift in (0, 1, 3):
+                n_bags = min(n_idx, int(rng.integers(1, 2 + n_idx))) if n_idx else 1
+                idx, off = make(n_idx, n_bags, rows[1], spoil)
+                w = want(idx, off, rows[1])
+                assert spoil or w == 0
+                # device buffers that start `shift` elements into an allocation
+                di = torch.empty(n_idx + shift + 4, dtype=tdt, device=dev)[shift:shift + n_idx]
+                do = torch.empty(n_bags + shift + 4, dtype=tdt, device=dev)[shift:shift + n_bags]
+                di.copy_(torch.from_numpy(idx.view(np.int32) if itype == "u32" else idx))
+                do.copy_(torch.from_numpy(off.view(np.int32) if itype == "u32" else off))
+                got = e.validate([1], [di], [do])
+                assert got == w, (n_idx, n_bags, shift, spoil, got, w)
+                if shift == 0:
+                    got = e.validate([1], [idx], [off])                   # host buffers (staged by the library)
+                    assert got == w, ("host", n_idx, n_bags, spoil, got, w)
+                checked += 1
+    # descriptors of very different lengths in one launch, each with its own findings
+    parts = [make(n, max(1, n // 3), rows[t], True) for t, n in enumerate((5, 40_000, 3_000_000, 17))]
+    total = sum(want(i, o, rows[t]) for t, (i, o) in enumerate(parts))
+    got = e.validate([0, 1, 2, 3], [p[0] for p in parts], [p[1] for p in parts])
+    assert got == total and total > 8
+    as_t = (lambda a: torch.from_numpy(a.view(np.int32)).to(dev)) if itype == "u32" else (lambda a: torch.from_numpy(a).to(dev))
+    d = [(as_t(i), as_t(o)) for i, o in parts]
+    assert e.validate([0, 1, 2, 3], [x[0] for x in d], [x[1] for x in d]) == total
+    # fixed pooling: n_idx must be n_bags * L
+    idx = rng.integers(0, 50, size=96).astype(npt)
+    assert e.validate([0], [idx], [None], fixed_pooling=4) == 0
+    idx[95] = 50
+    assert e.validate([0], [idx], [None], fixed_pooling=4) == 1
+    assert checked > 100
+    e.close()
