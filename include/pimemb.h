@@ -81,7 +81,8 @@ typedef struct emb_config {
                                     per 26-table call at 39 292 bags per table).  The validation kernel still disarms the call's
                                     lookup on the device when it finds something (outputs untouched); the finding is returned --
                                     EMB_ERR_RANGE, emb_last_error naming the call it belongs to -- by the first later checked call
-                                    that finds it arrived (that call's own work has been launched), or by emb_check_report.  Like a
+                                    that finds it arrived -- of any thread, on any stream: verdicts are the engine's -- (that call's own work
+                                    has been launched), or by emb_check_report.  Like a
                                     device-side assert: late, never lost (emb_destroy prints a verdict nobody read).
                                     emb_lookup_batched_checked stays synchronous. */
 

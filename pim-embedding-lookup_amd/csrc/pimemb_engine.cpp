@@ -479,6 +479,11 @@ int resolve(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs, emb_i
             group_idx += descs[i].n_indices;
         }
         g.kind = pimemb::choose_kernel(group_bags, group_idx, g.geom);
+        {   // developer A/B (tools/kernel_choice_probe.py): PIMEMB_FORCE_KERNEL=group | wavebatch overrides the choice where both kernels apply
+            static const char *force = getenv("PIMEMB_FORCE_KERNEL");
+            if (force && g.kind != pimemb::KERNEL_ANYDIM && group_idx <= 2 * group_bags)
+                g.kind = force[0] == 'g' ? pimemb::KERNEL_GROUP : pimemb::KERNEL_WAVEBATCH;
+        }
         g.ranged = row_lo != nullptr;
         if (g.ranged && g.kind == pimemb::KERNEL_GROUP) g.kind = pimemb::KERNEL_WAVEBATCH;    // (small launches too: the predicate lives there)
         if (g.kind == pimemb::KERNEL_GROUP) {   // pooled launch over tables with a hot-row set: LDS-staged kernel
@@ -1532,6 +1537,7 @@ static int read_verdicts(emb_engine *e, bool wait, unsigned long long *bad_total
 static int checked_launch(emb_engine *e, Resolved &r, emb_index_type itype, hipStream_t s, bool launch, uint64_t *n_bad, bool defer) {
     if (n_bad) *n_bad = 0;
     if (r.descs.empty()) return EMB_OK;
+    if (r.descs.size() > 65535u) return fail(EMB_ERR_UNSUPPORTED, "a checked call takes at most 65535 descriptors (%zu given)", r.descs.size());
     std::lock_guard<std::mutex> vlk(e->val_mu);
     unsigned long long seq = 0, earlier_bad = 0, earlier_seq = 0;
     // verdicts of earlier deferred calls: what has arrived (all of them before a slot is reused).  A call that waits for its own

@@ -127,6 +127,15 @@ uint32_t route_meta_piece_word(uint32_t n_tables, uint32_t n_shards);
 hipError_t launch_publish_words(const uint32_t *const src[3], const uint32_t n[3], uint32_t *dst_host,
                                 unsigned long long *flag_host, unsigned long long value, hipStream_t stream);
 hipError_t launch_zero_words(uint32_t *p, uint32_t n, hipStream_t stream);
+// n[i] uint32 words at src[i] -> int64 words at dst[i], for up to kWidenSegs segments in one launch (see widen_words_kernel).
+constexpr uint32_t kWidenSegs = 16;
+struct WidenArgs {
+    const uint32_t *src[kWidenSegs];
+    long long *dst[kWidenSegs];
+    uint64_t n[kWidenSegs];
+    uint32_t n_seg;
+};
+hipError_t launch_widen_words(const WidenArgs &a, hipStream_t stream);
 
 // Record the calling thread's error text (returned by emb_last_error()) and hand `code` back.
 int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));

@@ -1079,6 +1079,37 @@ hipError_t launch_zero_words(uint32_t *p, uint32_t n, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// uint32 words -> int64 words, segment by segment (blockIdx.y): the request pieces of an int64 job's routed step (uint32 local
+// row ids and sub-bag starts, as they travel) widened once, so that they ride in the SAME launch as the job's int64 arrays
+// instead of a small launch of their own (pimemb_shard.cpp, widen_pieces).
+__global__ void __launch_bounds__(kBlock)
+widen_words_kernel(WidenArgs a) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+    typedef long long i64x2 __attribute__((ext_vector_type(2), aligned(8)));
+    const uint32_t *__restrict__ src = a.src[blockIdx.y];
+    long long *__restrict__ dst = a.dst[blockIdx.y];
+    const uint64_t n = a.n[blockIdx.y], quads = n / 4;
+    for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q < quads; q += (uint64_t)gridDim.x * kBlock) {
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(src + 4 * q);
+        i64x2 lo, hi;
+        lo[0] = v[0]; lo[1] = v[1]; hi[0] = v[2]; hi[1] = v[3];
+        *reinterpret_cast<i64x2 *>(dst + 4 * q) = lo;
+        *reinterpret_cast<i64x2 *>(dst + 4 * q + 2) = hi;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < n % 4) dst[quads * 4 + threadIdx.x] = src[quads * 4 + threadIdx.x];
+}
+hipError_t launch_widen_words(const WidenArgs &a, hipStream_t stream) {
+    if (a.n_seg == 0) return hipSuccess;
+    if (a.n_seg > kWidenSegs) return hipErrorInvalidValue;
+    uint64_t most = 0;
+    for (uint32_t i = 0; i < a.n_seg; i++) most = a.n[i] > most ? a.n[i] : most;
+    if (most == 0) return hipSuccess;
+    uint64_t wgs = (most / 4 + kBlock * 2 - 1) / (kBlock * 2);          // ~two 16-byte loads per lane
+    wgs = wgs < 1 ? 1 : (wgs > 1024 ? 1024 : wgs);
+    hipLaunchKernelGGL(widen_words_kernel, dim3((uint32_t)wgs, a.n_seg), dim3(kBlock), 0, stream, a);
+    return hipGetLastError();
+}
+
 int geometry_for(emb_dtype dtype, uint32_t dim, LaunchGeom *g) {
     uint32_t elem = (dtype == EMB_F16) ? 2u : 4u;
     if (dtype != EMB_F32 && dtype != EMB_F16 && dtype != EMB_FIXED32) return EMB_ERR_INVALID;

@@ -120,6 +120,7 @@ struct Batch {
     std::vector<emb_shard_input> in;
     // HBM, grow-only, owned by the slot
     DevBuf req_send, meta, slotmap, counts_in, wc_send, req_recv, ret_send, ret_recv;
+    DevBuf wide;                        // an int64 job's routed step: the request pieces it serves, widened to int64 words (widen_pieces)
     // pinned host
     uint32_t *wc_host = nullptr;        // whole-table counts this rank sends: [sum_p |whole_of[p]|][kWholeWords]
     uint32_t *pc_host = nullptr;        // collective-free exchange: per destination, the constants its mailbox message ends with
@@ -202,6 +203,9 @@ struct emb_shard {
     std::vector<uint32_t *> desc_ctr, local_ctr, rdesc_ctr;
     // ... and the width of each descriptor's index array (routed pieces are uint32 local row ids whatever the caller's width)
     std::vector<uint32_t> desc_it, local_it, rdesc_it;
+    struct PieceRef { uint32_t desc, src; uint64_t off_word, idx_word; };     // a routed piece's descriptor: whose piece, where in it
+    std::vector<PieceRef> piece_refs;
+    bool widen = true;                                 // PIMEMB_SHARD_WIDEN=0: A/B (two launches, as before)
     // EMB_SHARD_DEFER_REPORT with no peer-store peer: the counters of a counted launch go to this rank's own pinned words only, and
     // nobody waits for them inside the call -- so they are not published by a kernel of their own behind every lookup (+4.7 us on a
     // 62-us step) but collected here and carried by ONE kernel every second submit (and before anything that waits for them)
@@ -811,6 +815,40 @@ int stage_request(emb_shard *s, Batch &b) {
 }
 
 // ---- S(b) + T(b) ---------------------------------------------------------------------------------------------------------
+// The request pieces this rank serves for batch b (s->piece_refs: uint32 words at piece_words[source]) widened into b.wide, the
+// piece descriptors pointed there and marked int64.  Source p's piece keeps its place: word w of it is word (words before p) + w.
+int widen_pieces(emb_shard *s, Batch &b, const std::vector<const uint32_t *> &piece_words) {
+    const uint32_t N = (uint32_t)s->N;
+    uint64_t total = 0;
+    for (uint32_t p = 0; p < N; p++) total += b.in_words[p];
+    if (total == 0 || s->piece_refs.empty()) return EMB_OK;
+    EMB_TRY(ensure(s, b.wide, total * 8));
+    long long *wide = static_cast<long long *>(b.wide.p);
+    std::vector<uint64_t> at(N, 0);
+    pimemb::WidenArgs a{};
+    uint64_t run = 0;
+    for (uint32_t p = 0; p < N; p++) {
+        at[p] = run;
+        run += b.in_words[p];
+        if (b.in_words[p] == 0 || !piece_words[p]) continue;
+        a.src[a.n_seg] = piece_words[p];
+        a.dst[a.n_seg] = wide + at[p];
+        a.n[a.n_seg] = b.in_words[p];
+        if (++a.n_seg == pimemb::kWidenSegs) {
+            HIP_TRY(pimemb::launch_widen_words(a, s->cs));
+            a.n_seg = 0;
+        }
+    }
+    HIP_TRY(pimemb::launch_widen_words(a, s->cs));
+    for (const emb_shard::PieceRef &r : s->piece_refs) {
+        emb_lookup_desc &d = s->descs[r.desc];
+        d.offsets = wide + at[r.src] + r.off_word;
+        d.indices = wide + at[r.src] + r.idx_word;
+        s->desc_it[r.desc] = EMB_IDX_I64;
+    }
+    return EMB_OK;
+}
+
 int stage_serve(emb_shard *s, Batch &b) {
     const uint32_t N = (uint32_t)s->N, Kr = s->Kr, M = s->M, dim = s->dim;
     uint32_t *recv = recv_counts(s, b), *rwhole = recv_whole(s, b);
@@ -845,6 +883,8 @@ int stage_serve(emb_shard *s, Batch &b) {
     uint32_t n_piece_descs = 0;
     // row pieces: source s asked for sub-bags of my shard of table k -- an ordinary lookup each
     uint64_t in_at = 0, out_at = 0, served_at = 0, back_at = 0;
+    s->piece_refs.clear();
+    std::vector<const uint32_t *> piece_words(N, nullptr);
     for (uint32_t p = 0; p < N; p++) {
         const Via how = via(s, (int)p);
         // the request piece: where it arrived (RCCL), where it was written (my own), or where it sits in the peer's HBM
@@ -859,6 +899,7 @@ int stage_serve(emb_shard *s, Batch &b) {
         if (how == PEER && (b.in_words[p] || b.rows_served[p]) && (!words || !rows_dst))
             return fail(EMB_ERR_INVALID, "emb_shard: rank %u posted buffer offsets outside its arena", p);
         if (how == PEER) s->st.bytes_to_peers += b.in_words[p] * 4 + b.rows_served[p] * (uint64_t)dim * 4;     // read from / stored into the peer's HBM
+        piece_words[p] = words;
         uint64_t cur = 0, row = 0;
         for (uint32_t k = 0; k < Kr; k++) {
             const uint64_t ns = recv[((size_t)p * (Kr + 1) + k) * 2], ni = recv[((size_t)p * (Kr + 1) + k) * 2 + 1];
@@ -870,6 +911,7 @@ int stage_serve(emb_shard *s, Batch &b) {
                 d.n_indices = ni;
                 d.n_bags = ns;
                 d.pooled = rows_dst + row * dim;
+                s->piece_refs.push_back(emb_shard::PieceRef{(uint32_t)s->descs.size(), p, cur, cur + pad4(ns)});
                 s->descs.push_back(d);
                 s->desc_it.push_back(EMB_IDX_U32);                 // (a routed piece: uint32 local row ids + sub-bag starts, whatever the source handed in)
                 own_width[EMB_IDX_U32] = true;
@@ -887,6 +929,7 @@ int stage_serve(emb_shard *s, Batch &b) {
         served_at += b.rows_served[p];
         back_at += b.rows_back[p];
     }
+    const uint64_t n_sub_pieces = n_sub, n_idx_pieces = n_idx;
     // whole tables owned here: source p's bags exactly as p's caller passed them
     uint64_t win_at = in_w, wrow_at = served;
     for (uint32_t p = 0; p < N; p++) {
@@ -1000,6 +1043,21 @@ int stage_serve(emb_shard *s, Batch &b) {
         if (!s->descs.empty()) {
             EMB_TRY(tick(s, b, 2, false));
             s->refused = 0;
+            // an int64 job: the pieces are the only uint32 arrays of the call, and with about one index per sub-bag a launch of
+            // their own is a SMALL launch (C4's share, one index per bag: 6 x 16 384 sub-bags = the lane-group kernel at 27 us;
+            // riding in the big launch they cost 5) -- widen them once (2.4 MB there) and everything goes out as ONE int64 launch:
+            // 115 -> 95 us per step, uint32 job 91 (tools/ab_widen_pieces.sh).  Pooled pieces stay uint32 and a launch of their own:
+            // at 32 indices per bag they are a big launch anyway, and 8-byte ids cost more than the second launch (612 vs 597 us).
+            if (n_piece_descs && s->widen && n_idx_pieces <= 2 * n_sub_pieces) {
+                bool any64 = false;
+                for (uint32_t it : s->desc_it) any64 = any64 || it == EMB_IDX_I64;
+                if (any64) {
+                    EMB_TRY(widen_pieces(s, b, piece_words));
+                    own_width[0] = own_width[1] = false;
+                    if (local_batch == &b && n_local_descs) own_width[b.itype] = true;
+                    for (size_t i = n_local_descs; i < s->desc_it.size(); i++) own_width[s->desc_it[i]] = true;
+                }
+            }
             EMB_TRY(fused_lookup(s, b, /*cacheable=*/n_piece_descs == 0));      // (row pieces change size with every batch: nothing recurs)
             EMB_TRY(tick(s, b, 2, true));
             // a validating launch that found something gathered nothing: whoever had descriptors in it holds zero rows and says so
@@ -1332,6 +1390,7 @@ int emb_shard_create(emb_engine *e, emb_comm *comm, const emb_shard_config *cfg,
     if (const char *t = getenv("PIMEMB_SHARD_TIMEOUT_S")) s->timeout_s = atof(t) > 0 ? atof(t) : s->timeout_s;
     if (const char *t = getenv("PIMEMB_SHARD_DIRECT")) s->allow_direct = t[0] != '0';
     if (const char *t = getenv("PIMEMB_SHARD_DIRECT_MERGE")) s->merge_direct = t[0] != '0';
+    if (const char *t = getenv("PIMEMB_SHARD_WIDEN")) s->widen = t[0] != '0';
     if (cfg->flags & EMB_SHARD_NO_DIRECT) s->allow_direct = false;
     s->tabs.assign(cfg->tables, cfg->tables + cfg->n_tables);
     s->whole_of.assign((size_t)world, {});
@@ -1616,7 +1675,7 @@ int emb_shard_destroy(emb_shard *s) {
         if (c.plan) (void)emb_plan_destroy(c.plan);
     for (emb_plan *p : s->retired) (void)emb_plan_destroy(p);
     for (Batch &b : s->ring) {
-        DevBuf *bufs[9] = {&b.req_send, &b.meta, &b.slotmap, &b.counts_in, &b.wc_send, &b.req_recv, &b.ret_send, &b.ret_recv, &b.chk_ctr};
+        DevBuf *bufs[10] = {&b.req_send, &b.meta, &b.slotmap, &b.counts_in, &b.wc_send, &b.req_recv, &b.ret_send, &b.ret_recv, &b.chk_ctr, &b.wide};
         for (DevBuf *d : bufs)
             if (d->p && !d->arena) (void)hipFree(d->p);
         if (b.chk_host) (void)hipHostFree(b.chk_host);

@@ -140,7 +140,7 @@ def hbm_budget(plan: ShardPlan, rank: int, bags: int, pooling: int, n_slots: int
                  which the library uses in place) + pooled rows of ALL tables for its own bags (peer stores: carved from the
                  arena instead -- counted there);
       staging    the library's ring of 6 batch slots (pimemb_shard.cpp kRing), grow-only with 25 % headroom: routed requests,
-                 slot maps, what arrives from the peers (request pieces, whole tables' index arrays) and what goes back (partial
+                 slot maps, an int64 job's widened copy of the pieces it serves, what arrives from the peers (request pieces, whole tables' index arrays) and what goes back (partial
                  rows, pooled rows of whole tables owned here) -- the last two only over RCCL: with peer stores the owner gathers
                  and stores in place; batches rotate through ALL six slots whatever the depth, and a slot keeps what it grew to;
       plans      64 cached plans (emb_shard's kPlanCache): descriptors (128 B) + the XCD map (8 B per workgroup);
@@ -181,6 +181,8 @@ def hbm_budget(plan: ShardPlan, rank: int, bags: int, pooling: int, n_slots: int
             recv_idx = int(balance * Kr * B * L)                                                # indices this shard is asked for, all sources
             recv_sub = int(min(balance * Kr * B * sub, recv_idx))
             stg += live * (grow((recv_idx + recv_sub) * 4 + 64 * N * Kr) + grow(recv_sub * dim * 4))     # req_recv, ret_send
+        if ib == 8:                                    # an int64 job widens the pieces it serves once (Batch.wide), whatever carried them
+            stg += live * grow((int(balance * Kr * B * L) + int(min(balance * Kr * B * sub, balance * Kr * B * L))) * 8 + 128 * N * Kr)
     if M and transport != "peer" and N > 1:            # whole tables owned here: the other ranks' index arrays in, their pooled rows out
         stg += live * (grow((N - 1) * M * B * (L + 1) * ib) + grow((N - 1) * M * B * dim * 4))       # (whole tables' arrays travel as they are)
     out["staging"] = stg

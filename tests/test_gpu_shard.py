@@ -190,19 +190,22 @@ def test_shard_bad_index_raises_on_the_serving_rank_and_nobody_hangs(ids, tmp_pa
         assert raised == [0, 0, 1], raised
 
 
-@pytest.mark.parametrize("ids", ["int32", "int64"])
-def test_one_bad_batch_in_a_pipelined_stream_is_reported_once_per_batch_it_spoilt(ids, tmp_path):
+@pytest.mark.parametrize("ids", ["int32", "int64", "int64-two-launches"])
+def test_one_bad_batch_in_a_pipelined_stream_is_reported_once_per_batch_it_spoilt(ids, tmp_path, monkeypatch):
     """Round 5 returned a serving-side finding twice -- by the submit that ran S(b) and again by the one that ran U(b): at depth
     3 two IndexErrors for one bad batch, the second on a clean submit.  Three RCCL ranks, depth 3, eight pipelined submits, ONE
     bad index in batch 2 (rank 0, a row-split table -> served by the last shard, rank 2): the launch that finds it gathers
     nothing, so batch 2 (its pieces) and -- uint32 ids: one fused launch -- the younger batch whose replicated tables rode in it
-    hold zero rows: exactly one IndexError each on rank 2, none anywhere else.  int64 ids: the request pieces (uint32 local row
-    ids) and the callers' int64 arrays are two launches, only the pieces' is refused: exactly one."""
+    hold zero rows: exactly one IndexError each on rank 2, none anywhere else.  int64 ids: the same -- the request pieces
+    (uint32 local row ids, about one per sub-bag here) are widened into the one int64 launch (round 6); with
+    PIMEMB_SHARD_WIDEN=0 they are a launch of their own, as pooled pieces always are, and only that launch is refused: exactly one."""
+    if ids == "int64-two-launches":
+        monkeypatch.setenv("PIMEMB_SHARD_WIDEN", "0")
     cfg = dict(rows=[7, 300, 5000, 64, 2000, 1500], dim=16, rep=64 * 16 * 4, split=3000 * 16 * 4, bags=29, max_len=3,
-               bad_pipeline={"rank": 0, "table": 2}, batches=2, depths=[3], int64=ids == "int64")
+               bad_pipeline={"rank": 0, "table": 2}, batches=2, depths=[3], int64=ids != "int32")
     res = _run(cfg, 3, tmp_path)
     raised = [st["pipeline_raised_depth3"] for st in res]
-    assert raised == [0, 0, 2 if ids == "int32" else 1], raised
+    assert raised == [0, 0, 1 if ids == "int64-two-launches" else 2], raised
 
 
 @pytest.mark.parametrize("table,mode", [(0, "deferred"), (1, "deferred"), (2, "deferred"), (2, "sync"), (0, "int64-negative"), (2, "int64-huge"), (1, "int64-sync")])
