@@ -36,4 +36,8 @@ echo "round 6 -- int64 ids, three ranks, peer stores, CHECKED with the deferred 
 PIMEMB_RCCL_ONE_GPU=1 PIMEMB_VERIFY_EVERY=37 run m python3 "$root/bench.py" --gpus 3 --shard-mode rows --replicate-mb 64 --batch 2003 --steps 3000 --nbatch 7 --exchange peer --checked --ids int64 --no-cpu-baseline
 echo "round 6 -- int64 ids, whole tables over RCCL (index arrays travel at 8 bytes per id), four ranks, pooling 3, verify every 37th step:" >> "$out"
 PIMEMB_RCCL_ONE_GPU=1 PIMEMB_VERIFY_EVERY=37 run n python3 "$root/bench.py" --gpus 4 --shard-mode whole --replicate-mb 400 --pooling 3 --batch 2003 --steps 300 --nbatch 7 --exchange rccl --ids int64 --no-cpu-baseline
+echo "round 6 -- int64 ids, three RCCL ranks, ONE index per bag (routed behind RCCL; the uint32 pieces are widened into the one int64 launch), verify every 37th step:" >> "$out"
+PIMEMB_RCCL_ONE_GPU=1 PIMEMB_VERIFY_EVERY=37 run o python3 "$root/bench.py" --gpus 3 --shard-mode rows --replicate-mb 64 --batch 2003 --steps 600 --nbatch 7 --exchange rccl --ids int64 --no-cpu-baseline
+echo "round 6 -- the same, CHECKED (the serving rank validates the one widened launch):" >> "$out"
+PIMEMB_RCCL_ONE_GPU=1 PIMEMB_VERIFY_EVERY=37 run p python3 "$root/bench.py" --gpus 3 --shard-mode rows --replicate-mb 64 --batch 2003 --steps 600 --nbatch 7 --exchange rccl --ids int64 --checked --no-cpu-baseline
 cat "$out"
