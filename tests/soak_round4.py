@@ -3,7 +3,8 @@
     (empty ones too), ragged bags -> routed, one index per bag -> the direct path (one ranged launch), fixed pooling 3,
     shard objects re-created with a random pipeline depth and checking on / off, waits that lag by a random amount;
   * the request queue (`RequestQueue`): host and device queues, a random number of random small requests per flush;
-  * `emb_lookup_ranged` over whole tables + the shards of row-split tables in one launch, N emulated shards.
+  * `emb_lookup_ranged` over whole tables + the shards of row-split tables in one launch, N emulated shards;
+  * round 6: checked calls of the plain engine (`check=True` / `"deferred"`), two streams, bad values injected.
     python tests/soak_round4.py [seconds [seed]]      (lives under tests/: the oracle is its checker)"""
 import ctypes as C
 import os
@@ -242,10 +243,83 @@ def ranged_phase(seconds):
         e2.close()
 
 
+# ---- round 6: checked calls of the plain engine, the verdict waited for or deferred --------------------------------------------
+# Random multi-table calls on two streams, index width either, ragged bags; one call in seven carries 1..5 bad values (an index
+# out of range, a broken offset).  A refused call leaves its outputs untouched (NaN-filled before), every other call equals the
+# oracle, and every bad call is reported EXACTLY once -- by itself (sync), by a later call, by check_report() (deferred).
+def checked_phase(seconds):
+    global n_bags_checked
+    t0 = time.time()
+    e3 = pel.EmbeddingEngine(device=0, max_tables=8)
+    c_rows = [33, 70_000, 1500, 4096, 9]
+    c_dim = int(rng.choice([8, 16, 64]))
+    c_tabs = [rng.standard_normal((n, c_dim)).astype(np.float32) for n in c_rows]
+    for t, w in enumerate(c_tabs):
+        e3.load_table(t, w)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    while time.time() - t0 < seconds:
+        mode = ["deferred", True][int(rng.integers(0, 2))]
+        idt = [np.int32, np.int64][int(rng.integers(0, 2))]
+        calls, n_bad_calls, n_reports = [], 0, 0
+        for _ in range(int(rng.integers(3, 90))):
+            nt = int(rng.integers(1, len(c_rows) + 1))
+            which = [int(x) for x in rng.choice(len(c_rows), size=nt, replace=False)]
+            nb = int(rng.integers(1, 20_000 if rng.integers(0, 6) == 0 else 600))
+            idx, off = [], []
+            for t in which:
+                o, n = ragged(nb, 3)
+                idx.append(rng.integers(0, c_rows[t], size=n).astype(idt))
+                off.append(o.astype(idt))
+            spoil = rng.integers(0, 7) == 0
+            if spoil:
+                hit = False
+                for _ in range(int(rng.integers(1, 6))):
+                    k = int(rng.integers(0, nt))
+                    if rng.integers(0, 2) and len(idx[k]):
+                        idx[k][int(rng.integers(0, len(idx[k])))] = c_rows[which[k]] + int(rng.integers(0, 3))
+                        hit = True
+                    elif nb >= 2:
+                        off[k][int(rng.integers(1, nb))] = len(idx[k]) + 1 + int(rng.integers(0, 3))
+                        hit = True
+                spoil = hit
+            st = streams[int(rng.integers(0, 2))]
+            with torch.cuda.stream(st):
+                d_i = [torch.from_numpy(i).to(dev) for i in idx]
+                d_o = [torch.from_numpy(o).to(dev) for o in off]
+                outs = [torch.full((nb, c_dim), float("nan"), device=dev) for _ in which]
+                n_bad_calls += int(spoil)
+                try:
+                    e3.lookup_batched(which, d_i, d_o, outs, check=mode)
+                except IndexError:
+                    n_reports += 1
+            calls.append((which, idx, off, outs, spoil, nb))
+        try:
+            e3.check_report()
+        except IndexError:
+            n_reports += 1
+        torch.cuda.synchronize()
+        n_found = 0
+        for which, idx, off, outs, spoil, nb in calls:
+            for k, t in enumerate(which):
+                got = outs[k].cpu().numpy()
+                if spoil:
+                    assert np.isnan(got).all(), ("checked: a refused call wrote rows", mode, t)
+                else:
+                    ii, oo = (idx[k].view(np.uint32), off[k].view(np.uint32)) if idx[k].dtype == np.int32 else (idx[k], off[k])
+                    assert np.array_equal(got, oracle.c_bag_sum(c_tabs[t], ii, oo)), ("checked", mode, t, nb)
+                    n_bags_checked += nb
+            n_found += int(spoil)
+        # deferred: several bad calls may be read in one go (one report for them); never more reports than bad calls, never none
+        assert (n_reports == n_bad_calls) if mode is True else (n_bad_calls == 0) == (n_reports == 0) and n_reports <= n_bad_calls, (mode, n_reports, n_bad_calls)
+        n_calls["checked"] = n_calls.get("checked", 0) + len(calls)
+        n_calls["refused"] = n_calls.get("refused", 0) + n_found
+    e3.close()
+
+
 phase = 0
 while time.time() - t_start < budget:
     slice_s = min(20.0, max(1.0, budget - (time.time() - t_start)))
-    (shard_phase, queue_phase, ranged_phase)[phase % 3](slice_s)
+    (shard_phase, queue_phase, ranged_phase, checked_phase)[phase % 4](slice_s)
     phase += 1
     print("  %4.0f s: %s, %d bags checked" % (time.time() - t_start, n_calls, n_bags_checked), flush=True)
 torch.cuda.synchronize()
