@@ -1528,7 +1528,7 @@ static int read_verdicts(emb_engine *e, bool wait, unsigned long long *bad_total
 
 // Validate the resolved descriptors of a call (device-resident buffers) on stream `s` and -- with `launch` -- enqueue its
 // lookup kernels right behind the validation kernel, over the SAME launch image: a finding zeroes the descriptors' tile
-// counts on the device, so the lookup does nothing.  The host waits for the validation result only (two pinned words the
+// counts on the device, so the lookup does nothing.  The host waits for the validation result only (one pinned word the
 // kernel's last workgroup writes; polled), not for the lookup -- or, `defer`, for nothing at all: the verdict is read by a
 // later checked call (which returns EMB_ERR_RANGE for it, after having launched its own work) or by emb_check_report; the wait
 // inside the call puts the host one launch behind the GPU on every call (21 -> 41 us per 26-table call at 39 292 bags per table).

@@ -69,7 +69,7 @@ hipError_t launch_scatter_column(int32_t *table, const int32_t *column, uint64_t
 // Who is last: returning atomics on ONE address retire at ~20 per microsecond on this chip, a thousand workgroups drawing
 // tickets from one counter would cost more than the checking.  So two levels: workgroup w signs off at sub[w % kValLanes]
 // (each counter on a line of its own, kValStride bytes apart), and the workgroup that completes a sub-counter signs off at
-// `tickets` with the sub-counter's findings; the one that completes THAT reports.  (Rounds 3-6 had a one-thread kernel behind big grids for this: 4.8 us of
+// `tickets` with the sub-counter's findings; the one that completes THAT reports.  (Rounds 3-5 had a one-thread kernel behind big grids for this: 4.8 us of
 // stream time per checked call, two PCIe writes with a system fence between them.)
 #ifndef PIMEMB_VALIDATE_LANES
 #define PIMEMB_VALIDATE_LANES 32

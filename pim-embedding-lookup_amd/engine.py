@@ -855,7 +855,7 @@ class EmbeddingEngine:
             pending = None
             try:
                 self.check_report()                  # a deferred verdict nobody met is raised here, after the engine is gone
-            except IndexError as ex:
+            except (IndexError, _l.PimembError) as ex:
                 pending = ex
             _l.check(self._L.emb_destroy(self._h))   # raises while plans are alive
             self._h = None
