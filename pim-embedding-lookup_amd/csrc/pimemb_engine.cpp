@@ -156,6 +156,8 @@ struct emb_engine {
     std::mutex host_mu;  // serialises host-pointer calls (they share one staging buffer) -- held for the whole call
     pimemb::HostCopier copier;   // packs inputs / unpacks results of host-pointer calls (used under host_mu)
     hipEvent_t pipe_ev[4] = {};  // pipelined zero-copy calls: "tables of part k are done"
+    hipStream_t host_s2 = nullptr;      // big host-pointer calls (under host_mu): the second half's copy-in + kernel run here, next to the first half's copy-out
+    hipEvent_t split_ev[2] = {};
     // Launch images of transient calls: a small POOL of rings, each under its own lock, picked by the calling thread -- a
     // launch holds its ring's lock across image copy + enqueue, so threads of a serving process no longer queue up behind ONE
     // engine-wide mutex (round 3: launch_resolved held `mu`); `mu` is left with the tables, the map cache and the staging
@@ -690,6 +692,13 @@ int ensure_stage(emb_engine *e, size_t h_bytes, size_t d_bytes) {
         size_t cap = d_bytes + d_bytes / 4 + 4096;
         HIP_TRY(hipMalloc((void **)&e->d_stage, cap));
         e->d_stage_cap = cap;
+        // a staging buffer that big belongs to calls that may go out in two parts (lookup_host_split): their second stream and
+        // events are made here, next to an allocation, not inside a call that is being timed (a stream costs milliseconds the first time)
+        if (cap >= (8u << 20) && !e->host_s2) {
+            HIP_TRY(hipStreamCreateWithFlags(&e->host_s2, hipStreamNonBlocking));
+            for (hipEvent_t &ev : e->split_ev)
+                if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        }
     }
     return EMB_OK;
 }
@@ -704,6 +713,7 @@ struct HostStage {
     size_t in_bytes = 0, out_bytes = 0;
     char *h_out = nullptr;  // pinned landing zone for small results (null if not reserved)
     bool zero_copy = false; // the kernel reads/writes the pinned host staging itself (no copies)
+    bool h2d_deferred = false;   // big call with link-speed output pieces: the caller enqueues the copy-in itself, in two parts (lookup_host_split)
 };
 
 // Host-pointer calls up to 40 MB skip both copy-engine transfers: the pinned staging buffer is
@@ -721,8 +731,10 @@ static const size_t kZeroCopyBytes = getenv("PIMEMB_ZERO_COPY_BYTES") ? strtoull
 static const size_t kStagedOutBytes = kZeroCopyBytes > (1u << 20) ? kZeroCopyBytes : (1u << 20);
 static const size_t kFastPieceBytes = getenv("PIMEMB_FAST_PIECE_BYTES") ? strtoull(getenv("PIMEMB_FAST_PIECE_BYTES"), nullptr, 10) : 1500000;   // measured boundary: 1.28 MB pieces slow, 1.536 MB pieces fast
 
+static const size_t kSplitInBytes = getenv("PIMEMB_HOST_SPLIT_BYTES") ? strtoull(getenv("PIMEMB_HOST_SPLIT_BYTES"), nullptr, 10) : (1u << 20);
+
 int stage_host_inputs(emb_engine *e, const emb_lookup_desc *descs, uint32_t n, emb_index_type itype,
-                      hipStream_t s, HostStage *hs, bool with_outputs, bool allow_zero_copy = false) {
+                      hipStream_t s, HostStage *hs, bool with_outputs, bool allow_zero_copy = false, bool allow_split = false) {
     const size_t isz = index_size(itype);
     size_t in_bytes = 0, out_bytes = 0, min_piece = SIZE_MAX;
     for (uint32_t i = 0; i < n; i++) {
@@ -772,7 +784,8 @@ int stage_host_inputs(emb_engine *e, const emb_lookup_desc *descs, uint32_t n, e
     }
     hs->in_bytes = in_bytes;
     hs->out_bytes = out_bytes;
-    if (in_bytes && !hs->zero_copy)
+    hs->h2d_deferred = allow_split && !hs->zero_copy && with_outputs && fast_pieces && n >= 2 && in_bytes >= kSplitInBytes;
+    if (in_bytes && !hs->zero_copy && !hs->h2d_deferred)
         HIP_TRY(hipMemcpyAsync(e->d_stage, e->h_stage, in_bytes, hipMemcpyHostToDevice, s));
     return EMB_OK;
 }
@@ -832,6 +845,63 @@ int lookup_host_pipelined(emb_engine *e, const emb_lookup_desc *descs, uint32_t 
     return EMB_OK;
 }
 
+// Big host-pointer calls whose rows go back table by table at link speed (every table >= 1.5 MB of rows: the Criteo shape at
+// 39 292 bags is 8 MB of indices in, 65 MB of rows out): copy-in, kernel and copy-out in one chain leave the link idle in one
+// direction at a time -- 0.24 ms in, then 1.42 ms out.  Two parts instead: the first eighth of the input bytes goes in and is
+// looked up on the caller's stream; the REST goes in and is looked up on a second stream while the first part's rows are
+// already on their way out (PCIe is full duplex, the two directions have copy engines of their own); the caller's stream waits
+// for the second kernel before it copies that part's rows out.  Everything is enqueued before the first device-to-host copy
+// (those block the host while they run).  emb_host_bench 26 16 1000000 39292 1: 1.77 -> 1.59-1.63 ms per lookup(); 65 536 bags:
+// 2.77 -> 2.56 ms.  PIMEMB_HOST_SPLIT_BYTES: the least input bytes for which a call is split (A/B).
+int lookup_host_split(emb_engine *e, const emb_lookup_desc *descs, uint32_t n, emb_index_type itype, hipStream_t s, const HostStage &hs, double t0) {
+    if (!e->host_s2) HIP_TRY(hipStreamCreateWithFlags(&e->host_s2, hipStreamNonBlocking));
+    for (hipEvent_t &ev : e->split_ev)
+        if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    const char *in_base = e->d_stage;
+    auto in_off = [&](uint32_t i) { return i < n ? (size_t)(static_cast<const char *>(hs.d_indices[i]) - in_base) : hs.in_bytes; };
+    uint32_t m = 1;
+    while (m + 1 < n && in_off(m) * 8 < hs.in_bytes) m++;
+    const uint32_t bounds[3] = {0, m, n};
+    hipStream_t on[2] = {s, e->host_s2};
+    HIP_TRY(hipEventRecord(e->split_ev[0], s));                       // whatever the caller queued on its stream comes first
+    HIP_TRY(hipStreamWaitEvent(e->host_s2, e->split_ev[0], 0));
+    uint64_t bags = 0, idx = 0;
+    for (uint32_t k = 0; k < 2; k++) {
+        const uint32_t lo = bounds[k], cnt = bounds[k + 1] - lo;
+        const size_t b0 = in_off(lo), b1 = in_off(bounds[k + 1]);
+        int rc = EMB_OK;
+        if (b1 > b0 && hipMemcpyAsync(e->d_stage + b0, e->h_stage + b0, b1 - b0, hipMemcpyHostToDevice, on[k]) != hipSuccess)
+            rc = fail(EMB_ERR_DEVICE, "host-pointer call: copy-in of part %u failed: %s", k, hipGetErrorString(hipGetLastError()));
+        std::vector<const void *> di(hs.d_indices.begin() + lo, hs.d_indices.begin() + lo + cnt);
+        std::vector<const void *> dof(hs.d_offsets.begin() + lo, hs.d_offsets.begin() + lo + cnt);
+        std::vector<float *> dout(hs.d_out.begin() + lo, hs.d_out.begin() + lo + cnt);
+        Resolved r;
+        r.stream = on[k];
+        if (rc == EMB_OK) rc = resolve(e, descs + lo, cnt, itype, &di, &dof, &dout, &r, /*cache_maps=*/true);
+        if (rc == EMB_OK) rc = launch_resolved(e, r, itype, on[k], false);
+        if (rc) {
+            (void)hipStreamSynchronize(s);
+            (void)hipStreamSynchronize(e->host_s2);
+            return rc;
+        }
+        bags += r.n_bags;
+        idx += r.n_indices;
+    }
+    HIP_TRY(hipEventRecord(e->split_ev[1], e->host_s2));
+    for (uint32_t k = 0; k < 2; k++) {
+        if (k == 1) HIP_TRY(hipStreamWaitEvent(s, e->split_ev[1], 0));
+        for (uint32_t i = bounds[k]; i < bounds[k + 1]; i++) {
+            const size_t bytes = descs[i].n_bags * (size_t)e->tables[descs[i].table_id].dim * 4;
+            if (bytes) HIP_TRY(hipMemcpyAsync(descs[i].pooled, hs.d_out[i], bytes, hipMemcpyDeviceToHost, s));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    e->us_sync += now_us() - t0;
+    e->n_bags.fetch_add(bags, std::memory_order_relaxed);
+    e->n_indices.fetch_add(idx, std::memory_order_relaxed);
+    return EMB_OK;
+}
+
 // Host-pointer lookup.  Default: ONE enqueue chain (copy-in -> descriptor upload -> kernel ->
 // copy-out) and ONE wait at the end -- the lowest latency.  With stage timing on (emb_config.flags
 // & EMB_FLAG_STAGE_TIMING, emb_trace_enable, or lookup(latency_print=1)) the host waits after every
@@ -846,9 +916,10 @@ int lookup_host(emb_engine *e, const emb_lookup_desc *descs, uint32_t n, emb_ind
     const double t0 = now_us();
     {
         std::lock_guard<std::mutex> lk(e->mu);
-        int rc = stage_host_inputs(e, descs, n, itype, s, &hs, true, /*allow_zero_copy=*/true);
+        int rc = stage_host_inputs(e, descs, n, itype, s, &hs, true, /*allow_zero_copy=*/true, /*allow_split=*/!timed);
         if (rc) return rc;
     }
+    if (hs.h2d_deferred) return lookup_host_split(e, descs, n, itype, s, hs, t0);
     if (timed) HIP_TRY(hipStreamSynchronize(s));
     const double t1 = now_us();
     if (hs.zero_copy && !timed && hs.out_bytes >= kPipelineBytes && n >= 2)
@@ -1016,6 +1087,9 @@ int emb_destroy(emb_engine *e) {
     }
     for (hipEvent_t ev : e->pipe_ev)
         if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : e->split_ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (e->host_s2) (void)hipStreamDestroy(e->host_s2);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
     if (e->d_stage) (void)hipFree(e->d_stage);
     if (e->d_val) (void)hipFree(e->d_val);

@@ -176,6 +176,42 @@ void xmap_cache_shapes() {
     printf("xmap cache under shapes that do not recur ok (%ld device-wide waits in 3 129 launches)\n", pimemb_stub_device_syncs() - syncs0);
 }
 
+// ---- a big host-pointer call: copy-in and lookup in two parts, the second on a stream of the engine's own (lookup_host_split) ---
+// Every table returns >= 1.5 MB of rows and the indices are >= 1 MB: the staging offsets of the two parts, the second stream and
+// its events, the order of the copies -- under the sanitizers; and a stage-timed call of the same shape (one chain, as before).
+void big_host_call() {
+    emb_engine *e = make_engine(0);
+    const uint32_t T = 5, B = 40000;
+    std::vector<std::vector<uint32_t>> idx(T), off(T);
+    std::vector<std::vector<float>> out(T);
+    std::vector<emb_lookup_desc> d(T);
+    Rng rng{0x1234567ull};
+    for (uint32_t t = 0; t < T; t++) {
+        const uint32_t L = t == 2 ? 0u : 1u;                  // one table with explicit (ragged) offsets, the others fixed pooling
+        off[t].resize(B);
+        uint32_t at = 0;
+        for (uint32_t b = 0; b < B; b++) { off[t][b] = at; at += L ? 1u : rng.next() % 3; }
+        idx[t].resize(at);
+        for (auto &v : idx[t]) v = rng.next() % kRows;
+        out[t].assign((size_t)B * kDim, -1.f);
+        d[t] = emb_lookup_desc{t, L, idx[t].data(), L ? nullptr : off[t].data(), idx[t].size(), B, out[t].data()};
+    }
+    for (int it = 0; it < 3; it++) CHECK(emb_lookup_batched(e, d.data(), T, EMB_IDX_U32, EMB_MEM_HOST, nullptr));
+    CHECK(emb_set_stage_timing(e, 1));
+    CHECK(emb_lookup_batched(e, d.data(), T, EMB_IDX_U32, EMB_MEM_HOST, nullptr));
+    CHECK(emb_set_stage_timing(e, 0));
+    void *stream = nullptr;
+    CHECK(emb_stream_create(e, &stream));
+    CHECK(emb_lookup_batched(e, d.data(), T, EMB_IDX_U32, EMB_MEM_HOST, stream));
+    CHECK(emb_lookup_batched(e, d.data(), 2, EMB_IDX_U32, EMB_MEM_HOST, stream));        // two descriptors: one per part
+    CHECK(emb_stream_destroy(e, stream));
+    emb_stats st{};
+    CHECK(emb_get_stats(e, &st));
+    EXPECT(st.n_lookup_calls == 6 && st.n_bags == (uint64_t)B * (5 * T + 2));
+    CHECK(emb_destroy(e));
+    printf("big host-pointer call in two parts ok\n");
+}
+
 // ---- checked calls whose verdict is deferred (EMB_FLAG_DEFER_CHECK / emb_lookup_batched_checked_deferred / emb_check_report) -----
 // The finding of a call is returned by a LATER call or by emb_check_report, once, naming the call; more calls than verdict
 // slots between two reports; a synchronous checked call behind a deferred one reports the earlier finding.
@@ -886,6 +922,7 @@ int main(int argc, char **argv) {
         xmap_cache_shapes();
         learn_hot_rows_check();
         deferred_check();
+        big_host_call();
         queue_threads();
         shard_one_rank(false, false);
         shard_one_rank(false, true);

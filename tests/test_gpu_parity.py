@@ -2419,3 +2419,40 @@ def test_validation_kernel_counts_exactly(pel, itype):
     assert e.validate([0], [idx], [None], fixed_pooling=4) == 1
     assert checked > 100
     e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,bags", [(16, [40_000, 39_292, 65_536, 30_000, 50_000]), (64, [40_000, 30_000]), (128, [20_000, 16_384, 24_000, 16_384])])
+def test_big_host_pointer_call_in_two_parts(pel, oracle, dim, bags):
+    """A host-pointer call whose rows go back table by table at link speed (every table >= 1.5 MB of rows) with >= 1 MB of
+    indices: copy-in + lookup in two parts, the second on the engine's own stream next to the first part's copy-out
+    (lookup_host_split).  Ragged and one-index tables, uint32 and int64, the default stream and a stream of the caller's with
+    work queued on it, the call repeated (the staging buffer and the second stream are reused): the oracle's bits every time."""
+    import torch
+    rng = np.random.default_rng(dim + len(bags))
+    e = pel.EmbeddingEngine(device=0, max_tables=8)
+    tabs = [rng.standard_normal((5000 + 1000 * t, dim)).astype(np.float32) for t in range(len(bags))]
+    for t, w in enumerate(tabs):
+        e.load_table(t, w)
+    ids = list(range(len(bags)))
+    st = torch.cuda.Stream()
+    for rep, itype in enumerate((np.uint32, np.int64, np.uint32)):
+        idx, off = [], []
+        for t, b in enumerate(bags):
+            if t % 2:
+                o, n = pel.workloads.ragged_offsets(rng, b, 12, dtype=itype)
+            else:
+                o, n = np.arange(b).astype(itype) * 6, b * 6
+            off.append(o)
+            idx.append(rng.integers(0, tabs[t].shape[0], size=n).astype(itype))
+        assert sum(i.nbytes + o.nbytes for i, o in zip(idx, off)) >= 1 << 20
+        if rep == 2:           # behind work of the caller's on its own stream
+            with torch.cuda.stream(st):
+                junk = torch.rand((4096, 4096), device="cuda") @ torch.rand((4096, 4096), device="cuda")
+            outs = e.lookup_batched(ids, idx, off, stream=st.cuda_stream)
+            del junk
+        else:
+            outs = e.lookup_batched(ids, idx, off)
+        for t in range(len(bags)):
+            assert np.array_equal(outs[t], oracle.c_bag_sum(tabs[t], idx[t], off[t])), (dim, t, itype)
+    e.close()
