@@ -1169,6 +1169,7 @@ int emb_load_table_column(emb_engine *e, uint32_t table_id, uint32_t col, const 
         return fail(EMB_ERR_INVALID, "table %u: %llu rows > allocated %llu", table_id,
                     (unsigned long long)nr_rows, (unsigned long long)t.nr_rows);
     DeviceGuard g(e->device);
+    std::lock_guard<std::mutex> host_lk(e->host_mu);         // (the staging buffers and the copier are the host-pointer path's)
     std::lock_guard<std::mutex> lk(e->mu);
     if (t.n_hot) {
         HIP_TRY(hipDeviceSynchronize());
@@ -1176,9 +1177,14 @@ int emb_load_table_column(emb_engine *e, uint32_t table_id, uint32_t col, const 
         t.generation = e->next_generation++;
     }
     size_t bytes = nr_rows * sizeof(int32_t);
-    int rc = ensure_stage(e, 0, bytes);
+    // through the pinned staging buffer (a few host threads pack it), not straight out of the caller's pageable column: a
+    // synchronous copy from pageable memory runs at ~6 GB/s on this runtime (0.69 ms for the 4 MB of a million-row column),
+    // pack + copy from pinned memory at the link's rate
+    int rc = ensure_stage(e, bytes, bytes);
     if (rc) return rc;
-    HIP_TRY(hipMemcpy(e->d_stage, column, bytes, hipMemcpyHostToDevice));
+    std::vector<pimemb::CopyPiece> pack{{e->h_stage, column, bytes}};
+    e->copier.copy(pack);
+    HIP_TRY(hipMemcpyAsync(e->d_stage, e->h_stage, bytes, hipMemcpyHostToDevice, nullptr));
     HIP_TRY(pimemb::launch_scatter_column(static_cast<int32_t *>(t.rows),
                                           reinterpret_cast<const int32_t *>(e->d_stage), nr_rows,
                                           t.dim, col, nullptr));
