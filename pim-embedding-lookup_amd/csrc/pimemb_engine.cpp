@@ -698,6 +698,10 @@ int ensure_stage(emb_engine *e, size_t h_bytes, size_t d_bytes) {
             HIP_TRY(hipStreamCreateWithFlags(&e->host_s2, hipStreamNonBlocking));
             for (hipEvent_t &ev : e->split_ev)
                 if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            // ... and used once: the runtime builds a stream's hardware queue at its first launch (8-9 ms, seen as the one slow
+            // call of a loop of lookup()s)
+            HIP_TRY(pimemb::launch_zero_words(reinterpret_cast<uint32_t *>(e->d_stage), 1, e->host_s2));
+            HIP_TRY(hipStreamSynchronize(e->host_s2));
         }
     }
     return EMB_OK;
@@ -847,8 +851,8 @@ int lookup_host_pipelined(emb_engine *e, const emb_lookup_desc *descs, uint32_t 
 
 // Big host-pointer calls whose rows go back table by table at link speed (every table >= 1.5 MB of rows: the Criteo shape at
 // 39 292 bags is 8 MB of indices in, 65 MB of rows out): copy-in, kernel and copy-out in one chain leave the link idle in one
-// direction at a time -- 0.24 ms in, then 1.42 ms out.  Two parts instead: the first eighth of the input bytes goes in and is
-// looked up on the caller's stream; the REST goes in and is looked up on a second stream while the first part's rows are
+// direction at a time -- 0.24 ms in, then 1.42 ms out.  Two parts instead: a first part (about an eighth of the Criteo shape: the cut
+// is estimated from the link's rates) goes in and is looked up on the caller's stream; the REST goes in and is looked up on a second stream while the first part's rows are
 // already on their way out (PCIe is full duplex, the two directions have copy engines of their own); the caller's stream waits
 // for the second kernel before it copies that part's rows out.  Everything is enqueued before the first device-to-host copy
 // (those block the host while they run).  emb_host_bench 26 16 1000000 39292 1: 1.77 -> 1.59-1.63 ms per lookup(); 65 536 bags:
@@ -859,8 +863,24 @@ int lookup_host_split(emb_engine *e, const emb_lookup_desc *descs, uint32_t n, e
         if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     const char *in_base = e->d_stage;
     auto in_off = [&](uint32_t i) { return i < n ? (size_t)(static_cast<const char *>(hs.d_indices[i]) - in_base) : hs.in_bytes; };
+    // where to cut: the first part's input goes in alone (nothing to overlap it with), then the second part's input and kernel
+    // run next to the first part's rows going out, then the second part's rows.  Estimated with the link's measured rates
+    // (profiles/r06/link_probe.log: 53 GB/s in, 46 GB/s out in table-sized copies) and the cut that minimises the sum is taken.
+    auto out_bytes_of = [&](uint32_t i) { return descs[i].n_bags * (double)e->tables[descs[i].table_id].dim * 4.0; };
     uint32_t m = 1;
-    while (m + 1 < n && in_off(m) * 8 < hs.in_bytes) m++;
+    {
+        double best = 1e300, out_a = 0;
+        for (uint32_t c = 1; c < n; c++) {
+            out_a += out_bytes_of(c - 1);
+            const double in_a = (double)in_off(c), in_b = (double)hs.in_bytes - in_a, out_b = (double)hs.out_bytes - out_a;
+            const double second_ready = in_b / 53e3 + 30.0, first_out = out_a / 46e3;              // microseconds
+            const double total = in_a / 53e3 + 20.0 + (first_out > second_ready ? first_out : second_ready) + out_b / 46e3;
+            if (total < best) {
+                best = total;
+                m = c;
+            }
+        }
+    }
     const uint32_t bounds[3] = {0, m, n};
     hipStream_t on[2] = {s, e->host_s2};
     HIP_TRY(hipEventRecord(e->split_ev[0], s));                       // whatever the caller queued on its stream comes first
