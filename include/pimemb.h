@@ -273,7 +273,7 @@ int emb_plan_time(emb_plan *p, void *stream, uint32_t warmup, uint32_t iters, fl
 int emb_validate_inputs(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs,
                         emb_index_type itype, emb_memspace space, uint64_t *n_bad);
 /* The same on a stream of the caller's (emb_validate_inputs uses the default stream): the check is ordered behind
- * whatever produced the indices on `stream`.  One small kernel and one event wait; no allocation, no device-wide
+ * whatever produced the indices on `stream`.  One small kernel whose last workgroup reports into a pinned word the host polls; no event, no allocation, no device-wide
  * synchronize. */
 int emb_validate_inputs_on(emb_engine *e, const emb_lookup_desc *descs, uint32_t n_descs,
                            emb_index_type itype, emb_memspace space, void *stream, uint64_t *n_bad);

@@ -13,12 +13,13 @@ max_norm -- the reference has none of them either.
 Input checking.  The C ABI is as unchecked as the reference (an out-of-range index is a wild read there,
 emb_dpu_lookup.c:113); these modules are what user tensors reach first, so by default every forward goes through
 emb_lookup_batched_checked: indices / offsets are validated on the GPU first and IndexError is raised, like
-nn.EmbeddingBag does, before anything is launched.  That costs one small kernel and one event wait per call (no
+nn.EmbeddingBag does, before anything is launched.  That costs one small kernel (7 us) and a wait for its one-word verdict per call (no
 allocation, no device-wide synchronize); pass `trusted_inputs=True` (constructor or attribute) for the unchecked
 fast path once the producer of the indices is known to be sound, or `deferred_check=True` to keep the check (a bad call's
 lookup is still kept from running, on the GPU) without the wait: the IndexError then comes out of a LATER forward, of
 `engine.check_report()` or of `engine.close()`, naming the call -- the wait inside the call is what a checked forward costs
-(26 tables x 39 292 bags: 41 us checked, 21 us unchecked; deferred: see profiles/r06/py_overhead_deferred_check.log).
+on host-bound shapes (26 tables x 2048 bags: 14.4 us checked, 9.7 deferred, 6.6 unchecked; apply_emb with per-table lists: 31.5 / 20.7 /
+17.5; 26 x 39 292 bags is GPU-bound: 28.8 either way, 20.9 unchecked -- profiles/r06/checked_calls/).
 
 Checkpoints.  `state_dict()` carries `<prefix>weight` read out of HBM and `load_state_dict` uploads it, so a
 DLRM whose `emb_l[k]` were swapped for these modules saves / loads the same keys and shapes as before."""
