@@ -136,6 +136,8 @@ struct WidenArgs {
     uint32_t n_seg;
 };
 hipError_t launch_widen_words(const WidenArgs &a, hipStream_t stream);
+// dst[i][:] = src[d_ids[i]][:], n rows of row_bytes (a multiple of 16) each, ids in device memory (emb_set_hot_rows).
+hipError_t launch_gather_rows(void *dst, const void *src, const unsigned long long *d_ids, uint32_t n, uint32_t row_bytes, hipStream_t stream);
 
 // Record the calling thread's error text (returned by emb_last_error()) and hand `code` back.
 int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));

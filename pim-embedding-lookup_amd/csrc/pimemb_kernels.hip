@@ -1079,6 +1079,25 @@ hipError_t launch_zero_words(uint32_t *p, uint32_t n, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// dst[i][:] = src[ids[i]][:] for n rows of row_bytes (a multiple of 16) each: the hot-row set of a table copied next to its hash
+// in ONE launch (emb_set_hot_rows did one device-to-device copy per row: ~10 us each, a millisecond per table).
+__global__ void __launch_bounds__(kBlock)
+gather_rows_kernel(char *__restrict__ dst, const char *__restrict__ src, const unsigned long long *__restrict__ ids, uint32_t n, uint32_t row_bytes) {
+    const uint32_t chunks = row_bytes / 16;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < (uint64_t)n * chunks; i += (uint64_t)gridDim.x * kBlock) {
+        const uint32_t r = (uint32_t)(i / chunks), c = (uint32_t)(i % chunks);
+        reinterpret_cast<f32x4 *>(dst + (uint64_t)r * row_bytes)[c] = reinterpret_cast<const f32x4 *>(src + ids[r] * row_bytes)[c];
+    }
+}
+hipError_t launch_gather_rows(void *dst, const void *src, const unsigned long long *d_ids, uint32_t n, uint32_t row_bytes, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    if (row_bytes % 16) return hipErrorInvalidValue;
+    uint64_t wgs = ((uint64_t)n * (row_bytes / 16) + kBlock - 1) / kBlock;
+    wgs = wgs > 4096 ? 4096 : wgs;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((uint32_t)wgs), dim3(kBlock), 0, stream, static_cast<char *>(dst), static_cast<const char *>(src), d_ids, n, row_bytes);
+    return hipGetLastError();
+}
+
 // uint32 words -> int64 words, segment by segment (blockIdx.y): the request pieces of an int64 job's routed step (uint32 local
 // row ids and sub-bag starts, as they travel) widened once, so that they ride in the SAME launch as the job's int64 arrays
 // instead of a small launch of their own (pimemb_shard.cpp, widen_pieces).
