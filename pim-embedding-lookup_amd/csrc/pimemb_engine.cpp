@@ -192,6 +192,7 @@ struct emb_engine {
     };
     std::deque<PendingVerdict> val_pending;                         // deferred verdicts not read yet, oldest first (under val_mu)
     bool defer_check = false;                                       // EMB_FLAG_DEFER_CHECK
+    unsigned long long val_owed_bad = 0, val_owed_first = 0;        // findings of deferred calls read but not yet handed to a caller (under val_mu)
     std::mutex val_mu;          // checked calls take turns (their findings are read as deltas of one device counter); `mu` is
                                 // held only while such a call enqueues, not while it waits for its result
     volatile unsigned long long *val_result = nullptr;   // [kValSlots] pinned, device-visible words the validation kernels report into (validate_word)
@@ -884,7 +885,7 @@ int lookup_host_split(emb_engine *e, const emb_lookup_desc *descs, uint32_t n, e
     const uint32_t bounds[3] = {0, m, n};
     hipStream_t on[2] = {s, e->host_s2};
     HIP_TRY(hipEventRecord(e->split_ev[0], s));                       // whatever the caller queued on its stream comes first
-    HIP_TRY(hipStreamWaitEvent(e->host_s2, e->split_ev[0], 0));
+    HIP_TRY(hipStreamWaitEvent(e->host_s2, e->split_ev[0], 0));       // (nothing of this call is enqueued yet: a failure here leaves nothing behind)
     uint64_t bags = 0, idx = 0;
     for (uint32_t k = 0; k < 2; k++) {
         const uint32_t lo = bounds[k], cnt = bounds[k + 1] - lo;
@@ -907,15 +908,20 @@ int lookup_host_split(emb_engine *e, const emb_lookup_desc *descs, uint32_t n, e
         bags += r.n_bags;
         idx += r.n_indices;
     }
-    HIP_TRY(hipEventRecord(e->split_ev[1], e->host_s2));
-    for (uint32_t k = 0; k < 2; k++) {
-        if (k == 1) HIP_TRY(hipStreamWaitEvent(s, e->split_ev[1], 0));
-        for (uint32_t i = bounds[k]; i < bounds[k + 1]; i++) {
+    hipError_t err = hipEventRecord(e->split_ev[1], e->host_s2);
+    for (uint32_t k = 0; k < 2 && err == hipSuccess; k++) {
+        if (k == 1) err = hipStreamWaitEvent(s, e->split_ev[1], 0);
+        for (uint32_t i = bounds[k]; i < bounds[k + 1] && err == hipSuccess; i++) {
             const size_t bytes = descs[i].n_bags * (size_t)e->tables[descs[i].table_id].dim * 4;
-            if (bytes) HIP_TRY(hipMemcpyAsync(descs[i].pooled, hs.d_out[i], bytes, hipMemcpyDeviceToHost, s));
+            if (bytes) err = hipMemcpyAsync(descs[i].pooled, hs.d_out[i], bytes, hipMemcpyDeviceToHost, s);
         }
     }
-    HIP_TRY(hipStreamSynchronize(s));
+    if (err == hipSuccess) err = hipStreamSynchronize(s);
+    if (err != hipSuccess) {          // nothing of this call may still be running when the staging buffers are handed to the next one
+        (void)hipStreamSynchronize(e->host_s2);
+        (void)hipStreamSynchronize(s);
+        return fail(EMB_ERR_DEVICE, "host-pointer call (two parts): %s", hipGetErrorString(err));
+    }
     e->us_sync += now_us() - t0;
     e->n_bags.fetch_add(bags, std::memory_order_relaxed);
     e->n_indices.fetch_add(idx, std::memory_order_relaxed);
@@ -1073,8 +1079,7 @@ int emb_create(const emb_config *cfg, emb_engine **out) {
     return EMB_OK;
 }
 
-static int read_verdicts(emb_engine *e, bool wait, unsigned long long *bad_total, unsigned long long *first_seq,
-                         unsigned long long own_seq = 0, unsigned long long *own_bad = nullptr);
+static int read_verdicts(emb_engine *e, bool wait, unsigned long long own_seq = 0, unsigned long long *own_bad = nullptr);
 
 int emb_destroy(emb_engine *e) {
     if (!e) return EMB_OK;
@@ -1085,9 +1090,10 @@ int emb_destroy(emb_engine *e) {
     (void)hipDeviceSynchronize();
     {       // a deferred verdict nobody read is never lost silently
         std::lock_guard<std::mutex> vlk(e->val_mu);
-        unsigned long long bad = 0, first = 0;
-        if (!e->val_pending.empty() && read_verdicts(e, true, &bad, &first) == EMB_OK && bad)
-            fprintf(stderr, "[pimemb] emb_destroy: an unread verdict: %llu out-of-range indices / broken offsets in checked call number %llu\n", bad, first);
+        if (!e->val_pending.empty()) (void)read_verdicts(e, true);
+        if (e->val_owed_bad)
+            fprintf(stderr, "[pimemb] emb_destroy: an unread verdict: %llu out-of-range indices / broken offsets in checked call number %llu\n",
+                    e->val_owed_bad, e->val_owed_first);
     }
     if (g_prof.on && g_prof.calls) {
         const double n = (double)g_prof.calls;
@@ -1586,13 +1592,12 @@ static void resync_validation(emb_engine *e) {
 }
 
 // Read the verdicts of deferred checked calls, oldest first (caller holds val_mu).  wait = false: only those that have arrived;
-// wait = true: all of them (a spin, then the call's stream).  *bad_total / *first_seq: offending values found and the sequence
-// number of the first call they belong to.  A refused call's lookup kernels were disarmed on the device: they are taken out of
-// the launch statistics here.  own_seq / own_bad: the finding of THAT call is returned apart (not in *bad_total).
-static int read_verdicts(emb_engine *e, bool wait, unsigned long long *bad_total, unsigned long long *first_seq,
-                         unsigned long long own_seq, unsigned long long *own_bad) {
-    *bad_total = 0;
-    *first_seq = 0;
+// wait = true: all of them (a spin, then the call's stream).  What they found is ADDED to e->val_owed_bad (val_owed_first: the
+// sequence number of the first call it belongs to) and stays owed until a caller hands it over (take_owed) -- a call that fails
+// for a reason of its own between reading a verdict and returning does not lose it.  A refused call's lookup kernels were
+// disarmed on the device: they are taken out of the launch statistics here.  own_seq / own_bad: the finding of THAT call is
+// returned apart (not owed to anybody else).
+static int read_verdicts(emb_engine *e, bool wait, unsigned long long own_seq, unsigned long long *own_bad) {
     if (own_bad) *own_bad = 0;
     while (!e->val_pending.empty()) {
         const emb_engine::PendingVerdict pv = e->val_pending.front();
@@ -1620,8 +1625,8 @@ static int read_verdicts(emb_engine *e, bool wait, unsigned long long *bad_total
             if (own_bad && pv.seq == own_seq) {
                 *own_bad = bad;
             } else {
-                if (!*bad_total) *first_seq = pv.seq;
-                *bad_total += bad;
+                if (!e->val_owed_bad) e->val_owed_first = pv.seq;
+                e->val_owed_bad += bad;
             }
             if (pv.launched) {
                 e->n_kernel_launches.fetch_sub(pv.n_groups, std::memory_order_relaxed);
@@ -1645,17 +1650,11 @@ static int checked_launch(emb_engine *e, Resolved &r, emb_index_type itype, hipS
     if (r.descs.empty()) return EMB_OK;
     if (r.descs.size() > 65535u) return fail(EMB_ERR_UNSUPPORTED, "a checked call takes at most 65535 descriptors (%zu given)", r.descs.size());
     std::lock_guard<std::mutex> vlk(e->val_mu);
-    unsigned long long seq = 0, earlier_bad = 0, earlier_seq = 0;
+    unsigned long long seq = 0;
     // verdicts of earlier deferred calls: what has arrived (all of them before a slot is reused).  A call that waits for its own
     // verdict reads them behind its launch, in one wait.
-    if (defer && !e->val_pending.empty())
-        EMB_TRY(read_verdicts(e, /*wait=*/false, &earlier_bad, &earlier_seq));
-    if (e->val_pending.size() + 1 >= emb_engine::kValSlots) {
-        unsigned long long more = 0, more_seq = 0;
-        EMB_TRY(read_verdicts(e, /*wait=*/true, &more, &more_seq));
-        if (more && !earlier_bad) earlier_seq = more_seq;
-        earlier_bad += more;
-    }
+    if (defer && !e->val_pending.empty()) EMB_TRY(read_verdicts(e, /*wait=*/false));
+    if (e->val_pending.size() + 1 >= emb_engine::kValSlots) EMB_TRY(read_verdicts(e, /*wait=*/true));
     volatile unsigned long long *result = nullptr;
     uint32_t slot = 0;
     {
@@ -1707,12 +1706,9 @@ static int checked_launch(emb_engine *e, Resolved &r, emb_index_type itype, hipS
         e->val_pending.push_back(pv);
     }
     unsigned long long bad = 0;
-    if (!defer) {              // this call's own verdict, and whatever was still outstanding in front of it
-        unsigned long long more = 0, more_seq = 0;
-        EMB_TRY(read_verdicts(e, /*wait=*/true, &more, &more_seq, seq, &bad));
-        if (more && !earlier_bad) earlier_seq = more_seq;
-        earlier_bad += more;
-    }
+    if (!defer) EMB_TRY(read_verdicts(e, /*wait=*/true, seq, &bad));      // this call's own verdict, and whatever was still outstanding in front of it
+    const unsigned long long earlier_bad = e->val_owed_bad, earlier_seq = e->val_owed_first;      // handed over now
+    e->val_owed_bad = e->val_owed_first = 0;
     if (n_bad) *n_bad = bad + earlier_bad;
     if (bad) {
         if (earlier_bad)
@@ -1769,8 +1765,9 @@ int emb_check_report(emb_engine *e, uint64_t *n_bad) {
     if (!e) return fail(EMB_ERR_INVALID, "engine is NULL");
     DeviceGuard g(e->device);
     std::lock_guard<std::mutex> vlk(e->val_mu);
-    unsigned long long bad = 0, first = 0;
-    EMB_TRY(read_verdicts(e, /*wait=*/true, &bad, &first));
+    EMB_TRY(read_verdicts(e, /*wait=*/true));
+    const unsigned long long bad = e->val_owed_bad, first = e->val_owed_first;
+    e->val_owed_bad = e->val_owed_first = 0;
     if (n_bad) *n_bad = bad;
     if (bad)
         return fail(EMB_ERR_RANGE, "%llu out-of-range indices / broken offsets in checked call number %llu of this engine (its lookup was "

@@ -300,14 +300,18 @@ validate_kernel(DevDesc *__restrict__ descs, uint32_t n_descs, ValidateCtl *__re
         const unsigned long long lane_wgs = total_wgs / kValLanes + (lane < total_wgs % kValLanes ? 1ull : 0ull);
         const unsigned long long got = __hip_atomic_fetch_add(&ctl->sub[lane].done, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + mine;
         if ((got & kValTicketMask) != lane_wgs) return;
-        __hip_atomic_store(&ctl->sub[lane].done, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (nobody else touches it any more)
         mine = 1ull + (got & ~kValTicketMask);
         top_target = kValLanes;
     }
     const unsigned long long got = __hip_atomic_fetch_add(&ctl->tickets, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + mine;
     if ((got & kValTicketMask) != top_target) return;
+    // the last one out: every other workgroup has made its last access to the counters (its sign-off IS that access), so THIS
+    // thread zeroes them all -- its own stores, which its own fence below orders -- for whoever the host gives this ValidateCtl
+    // next (it may be on another stream) ...
+    if (total_wgs > kValLanes)
+        for (uint32_t l = 0; l < kValLanes; l++) __hip_atomic_store(&ctl->sub[l].done, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&ctl->tickets, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence();                                       // the counters are zero for whoever the host gives this ValidateCtl next (it may be on another stream) ...
+    __threadfence();
     *result = validate_word(seq, got >> kValTicketBits);   // ... before the host can know that this call is done with it
 }
 
