@@ -497,7 +497,7 @@ int emb_peer_barrier(emb_peer *p);   /* host barrier of the group through the sh
 int emb_peer_destroy(emb_peer *p);   /* call emb_peer_barrier first: a peer may still be reading this rank's arena */
 /* A last word for a process that may die inside code nobody has run across real links yet (bench.py's peer-store leg, run
  * AFTER the RCCL leg's numbers are in hand): while `line` is set, a fatal signal (SIGABRT -- what the runtime raises on a GPU
- * memory fault --, SIGSEGV, SIGBUS) writes it to file descriptor `fd` and ends the process with `status` instead of a core dump, so the
+ * memory fault --, SIGSEGV, SIGBUS; and SIGTERM: what a launcher sends the surviving ranks when another rank died) writes it to file descriptor `fd` and ends the process with `status` instead of a core dump, so the
  * numbers measured before survive.  line = "" : just end with `status` (the ranks that print nothing).  line = NULL: take the
  * handlers out again.  The text is copied.  Async-signal-safe: write(2) and _exit(2), nothing else. */
 int emb_peer_last_words(const char *line, int fd, int status);

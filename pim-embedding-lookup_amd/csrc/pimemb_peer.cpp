@@ -424,8 +424,9 @@ char *g_last_words = nullptr;                  // malloc'd, never freed while th
 size_t g_last_words_len = 0;
 int g_last_words_fd = 1, g_last_words_status = 0;
 bool g_last_words_in = false;
-struct sigaction g_last_words_old[3];
-const int kLastWordSignals[3] = {SIGABRT, SIGSEGV, SIGBUS};
+struct sigaction g_last_words_old[4];
+// (SIGTERM: what a launcher sends the surviving ranks when ANOTHER rank died -- the line belongs on stdout all the same)
+const int kLastWordSignals[4] = {SIGABRT, SIGSEGV, SIGBUS, SIGTERM};
 
 void last_words_handler(int) {
     size_t off = 0;
@@ -442,7 +443,7 @@ int emb_peer_last_words(const char *line, int fd, int status) {
     static std::mutex mu;
     std::lock_guard<std::mutex> lk(mu);
     if (g_last_words_in) {                     // take the handlers out first: nothing reads the old text after this
-        for (int i = 0; i < 3; i++) (void)sigaction(kLastWordSignals[i], &g_last_words_old[i], nullptr);
+        for (int i = 0; i < 4; i++) (void)sigaction(kLastWordSignals[i], &g_last_words_old[i], nullptr);
         g_last_words_in = false;
     }
     free(g_last_words);
@@ -461,7 +462,7 @@ int emb_peer_last_words(const char *line, int fd, int status) {
     memset(&sa, 0, sizeof sa);
     sa.sa_handler = last_words_handler;
     sigemptyset(&sa.sa_mask);
-    for (int i = 0; i < 3; i++)
+    for (int i = 0; i < 4; i++)
         if (sigaction(kLastWordSignals[i], &sa, &g_last_words_old[i]) != 0) return fail(EMB_ERR_DEVICE, "emb_peer_last_words: sigaction failed");
     g_last_words_in = true;
     return EMB_OK;

@@ -194,9 +194,13 @@ def test_last_words_survive_a_fatal_signal(tmp_path):
             assert L.emb_peer_last_words(None, 1, 0) == 0
         if how == "segv":
             ctypes.string_at(8)
+        if how == "term":
+            import signal
+            os.kill(os.getpid(), signal.SIGTERM)
+            signal.pause()
         os.abort()
     """ % ROOT)
-    for how, rc_ok in (("abort", True), ("segv", True), ("status", True), ("cleared", False)):
+    for how, rc_ok in (("abort", True), ("segv", True), ("term", True), ("status", True), ("cleared", False)):
         res = subprocess.run([sys.executable, "-c", script, how], capture_output=True, text=True, timeout=120)
         if rc_ok:
             assert res.returncode == (5 if how == "status" else 0) and res.stdout == '{"metric": "kept", "value": 2}\n', (how, res.returncode, res.stdout, res.stderr[-500:])
