@@ -988,6 +988,8 @@ def peer_leg(args, rep_bytes, result, emit, finish, ctx, shard_leg, hbm_peak_gbs
         last = json.dumps(finish(snap))
     sys.stdout.flush()
     _lib.load().emb_peer_last_words(last.encode(), int(ctx.get("json_fd", 1)), 0)
+    if os.environ.get("PIMEMB_BENCH_TEST_ABORT") == "peer:%d" % rank:       # (test hook: what a GPU memory fault in this leg ends in)
+        os.abort()
     a3 = copy.copy(args)
     if secondary:            # the same W / K as the RCCL leg it is compared with (the digest is over the slot the loop ends on)
         a3.steps, a3.warmup = min(args.steps, 400), min(args.warmup, 40)

@@ -816,3 +816,20 @@ def test_peer_leg_that_cannot_come_up_is_skipped_not_failed(how):
     assert "skipped" in d["exchange_peer"] and "value_exchange_peer" not in d
     assert d["config"]["exchange_peer_skipped"] == d["exchange_peer"]["skipped"] and "exchange_peer_value" not in d["config"]
     assert ("no result within" in d["exchange_peer"]["skipped"]) == (how == "deadline"), d["exchange_peer"]
+
+
+@pytest.mark.parametrize("who", [0, 1])
+def test_a_rank_that_dies_in_the_peer_leg_keeps_the_rccl_numbers(who):
+    """The real thing behind tests/test_peer_leg_orchestration.py: two RCCL ranks on the one GPU, `--exchange both`, and rank
+    `who` calls abort() at the start of its peer-store leg (PIMEMB_BENCH_TEST_ABORT: what the runtime does on a GPU memory
+    fault) -- with HIP, RCCL and torch loaded in the process.  The launcher must see status 0, stdout ONE JSON line with the
+    RCCL leg's verified numbers and exchange_peer = {"skipped": ...}."""
+    import json
+    env = {"PIMEMB_BENCH_TEST_ABORT": "peer:%d" % who, "PIMEMB_PEER_LEG_TIMEOUT": "45", "PIMEMB_PEER_LEG_WAIT_S": "10", "PIMEMB_TEARDOWN_TIMEOUT": "10"}
+    res, lines = _bench_rccl_ranks(2, ["--steps", "6", "--warmup", "3", "--nbatch", "4", "--batch", "4099"], env_extra=env, timeout=400)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["verified"] is True and d["value_exchange"] > 0 and d["config"]["exchange"]["verified"] is True
+    assert "skipped" in d["exchange_peer"] and "value_exchange_peer" not in d
+    assert ("fatal signal" in d["exchange_peer"]["skipped"]) == (who == 0), d["exchange_peer"]
