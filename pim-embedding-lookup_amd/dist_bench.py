@@ -908,6 +908,8 @@ def run(args, hbm_peak_gbs: float) -> None:
                 snap["verified"] = False
                 sys.stdout.flush()
                 _lib.load().emb_peer_last_words(json.dumps(finish(snap)).encode(), json_fd, 5)
+            if os.environ.get("PIMEMB_BENCH_TEST_ABORT") == "rccl:%d" % rank:       # (test hook: a rank dies in the sharded leg)
+                os.abort()
             try:
                 sec = shard_leg(args, hbm_peak_gbs, ctx, 64 << 20)
             except BaseException as ex:  # noqa: BLE001 -- SystemExit from a leg included

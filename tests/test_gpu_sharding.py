@@ -833,3 +833,19 @@ def test_a_rank_that_dies_in_the_peer_leg_keeps_the_rccl_numbers(who):
     assert d["verified"] is True and d["value_exchange"] > 0 and d["config"]["exchange"]["verified"] is True
     assert "skipped" in d["exchange_peer"] and "value_exchange_peer" not in d
     assert ("fatal signal" in d["exchange_peer"]["skipped"]) == (who == 0), d["exchange_peer"]
+
+
+@pytest.mark.parametrize("who", [0, 1])
+def test_a_rank_that_dies_in_the_rccl_leg_leaves_the_replica_line(who):
+    """... and in the sharded RCCL leg itself (whose failure FAILS the run): rank `who` calls abort() before
+    the leg (PIMEMB_BENCH_TEST_ABORT=rccl:<rank>).  Rank 0 leaves the replica leg's line with the failure noted -- written by
+    its fatal-signal handler when it dies itself, or when the launcher ends it (SIGTERM) after the other rank died -- and the
+    job's status is not 0."""
+    import json
+    env = {"PIMEMB_BENCH_TEST_ABORT": "rccl:%d" % who, "PIMEMB_LAUNCH_GRACE": "3", "PIMEMB_EXCHANGE_TIMEOUT": "120"}
+    res, lines = _bench_rccl_ranks(2, ["--steps", "6", "--warmup", "3", "--nbatch", "4", "--batch", "4099"], env_extra=env, timeout=400)
+    assert res.returncode != 0, res.stdout[-2000:]
+    assert len(lines) == 1, (lines, res.stderr[-3000:])
+    d = json.loads(lines[0])
+    assert d["verified"] is False and d["value"] > 0 and "fatal signal" in d["headline"] and d["headline"].startswith("replica")
+    assert d["config"]["exchange"]["verified"] is False and "failed" in d["config"]["exchange"]
