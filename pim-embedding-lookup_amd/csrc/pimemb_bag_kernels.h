@@ -553,6 +553,10 @@ bag_sum_anydim_vec_kernel(const DevDesc *__restrict__ descs, uint32_t dim, uint3
 #ifndef PIMEMB_LPR64_ONEHOT_INFLIGHT
 #define PIMEMB_LPR64_ONEHOT_INFLIGHT 4
 #endif
+// ... and for 512-byte rows (LPR = 32: dim 128 fp32, the Terabyte shape): tools/onehot_inflight_sweep.sh
+#ifndef PIMEMB_LPR32_ONEHOT_INFLIGHT
+#define PIMEMB_LPR32_ONEHOT_INFLIGHT 8
+#endif
 
 // ---- v2: wave batches of 64 bags, coalesced bounds, shuffle-distributed, one-hot fast path -------
 // RANGED (the sharded lookup's direct path, pimemb_shard.cpp): one index per bag, and a descriptor serves only the bags
@@ -573,7 +577,7 @@ bag_sum_wavebatch_kernel(const DevDesc *__restrict__ descs, uint32_t chunks_arg,
     constexpr int U = Cfg::kUnroll;
     // (1-KiB rows, LPR = 64: eight rounds in flight = 8 KiB per wavefront and two registers more than the 64-VGPR cap of the
     // fp32 configurations holds -- 12 bytes of scratch per lane; PIMEMB_LPR64_ONEHOT_INFLIGHT picks the depth for that row width)
-    constexpr uint32_t kInFlight = (LPR == 64) ? (uint32_t)PIMEMB_LPR64_ONEHOT_INFLIGHT : (uint32_t)Cfg::kOneHot;
+    constexpr uint32_t kInFlight = (LPR == 64) ? (uint32_t)PIMEMB_LPR64_ONEHOT_INFLIGHT : (LPR == 32) ? (uint32_t)PIMEMB_LPR32_ONEHOT_INFLIGHT : (uint32_t)Cfg::kOneHot;
     constexpr uint32_t RU = (ROUNDS < kInFlight) ? ROUNDS : kInFlight;
 
     uint32_t desc_i, tile;

@@ -54,15 +54,18 @@ void launch_one(const DevDesc *d, uint32_t n, uint32_t max_tiles, const LaunchGe
     struct { uint32_t chunks; } g{g_in.chunks | ((xmap && xdirect) ? kXmapDirect : 0u)};
     using One = typename WaveCfgOf<DT>::One;
     using Two = typename WaveCfgOf<DT>::Two;
+    // developer A/B (tools/onehot_occupancy_sweep.sh): bytes of dynamic LDS per workgroup of the one-batch wave-batch launch -- LDS the
+    // kernel never touches, reserved to CAP how many of its wavefronts a CU holds at once (160 KB per CU)
+    static const uint32_t lds_pad = getenv("PIMEMB_WAVEBATCH_LDS_PAD") ? (uint32_t)atoi(getenv("PIMEMB_WAVEBATCH_LDS_PAD")) : 0u;
     if (ranged) {      // launch_bag_sum lets the two wave-batch kinds through only (uint32 and int64 indices alike)
         if (kind == KERNEL_WAVEBATCH)
-            hipLaunchKernelGGL((bag_sum_wavebatch_kernel<IdxT, DT, L, One, true>), grid, dim3(One::kBlock), 0, s, d, g.chunks, xmap);
+            hipLaunchKernelGGL((bag_sum_wavebatch_kernel<IdxT, DT, L, One, true>), grid, dim3(One::kBlock), lds_pad, s, d, g.chunks, xmap);
         else if constexpr (L <= 4)
             hipLaunchKernelGGL((bag_sum_wavebatch_kernel<IdxT, DT, L, Two, true>), grid, dim3(Two::kBlock), 0, s, d, g.chunks, xmap);
         return;
     }
     if (kind == KERNEL_WAVEBATCH) {
-        hipLaunchKernelGGL((bag_sum_wavebatch_kernel<IdxT, DT, L, One>), grid, dim3(One::kBlock), 0, s, d, g.chunks, xmap);
+        hipLaunchKernelGGL((bag_sum_wavebatch_kernel<IdxT, DT, L, One>), grid, dim3(One::kBlock), lds_pad, s, d, g.chunks, xmap);
     } else if (kind == KERNEL_WAVEBATCH2) {
         // choose_kernel hands out the two-batch geometry for <= 4 lanes per row only; wider rows are not
         // instantiated (they would spill under the 64-VGPR cap and are never launched)
